@@ -1,0 +1,69 @@
+"""ctypes binding of libdmcnet_hip.so (the C ABI declared in include/dmcnet_hip.h).
+
+There is no CPU fallback: if the shared library is missing or an entry point fails, the
+caller gets an exception.
+"""
+import ctypes
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libdmcnet_hip.so")
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+_Z = ctypes.c_size_t
+
+#: name -> (restype, argtypes); must list every symbol include/dmcnet_hip.h declares
+SIGNATURES = {
+    "dmc_version": (_I, []),
+    "dmc_last_error": (ctypes.c_char_p, []),
+    "dmc_gen_tiny_workspace_bytes": (_Z, []),
+    "dmc_gen_tiny_saved_bytes": (_Z, [_I, _I, _I]),
+    "dmc_gen_tiny_gbuf_bytes": (_Z, [_I, _I, _I]),
+    "dmc_gen_tiny_partials_bytes": (_Z, [_I, _I, _I]),
+    "dmc_gen_tiny_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dmc_gen_tiny_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "dmc_flow_mse_partials_bytes": (_Z, []),
+    "dmc_flow_mse_fwd": (_I, [_P, _P, _P, _P, _Z, _P]),
+    "dmc_flow_mse_bwd": (_I, [_P, _P, _P, _P, _Z, _P]),
+    "dmc_consensus_ce_fwd_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "dmc_disc_tail_stats_bytes": (_Z, [_I]),
+    "dmc_disc_tail_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
+    "dmc_disc_tail_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+}
+
+_lib = None
+
+
+class DmcHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once; raises if it has not been built (``python -m dmcnet_amd.build``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DmcHipError(
+                "%s is missing: the DMC-Net hot path has no CPU fallback. Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'`." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)     # AttributeError if the .so does not export it
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise DmcHipError("%s failed (%d): %s" % (what, rc, load().dmc_last_error().decode()))
+
+
+def ptr(t):
+    return _P(t.data_ptr()) if t is not None else _P(0)
+
+
+def ptr_array(tensors):
+    return (_P * len(tensors))(*[t.data_ptr() for t in tensors])

@@ -1,0 +1,48 @@
+"""Build recipe for libdmcnet_hip.so (gfx950 only, hipcc cross-compiles without a GPU)."""
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libdmcnet_hip.so")
+SOURCES = ["gen_tiny.hip", "gen_tiny_fused.hip", "losses.hip", "disc_tail.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + \
+           [os.path.join(ROOT, "include", "dmcnet_hip.h"), os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=False):
+    """Compile every HIP source into dmc-net_amd/libdmcnet_hip.so; returns the path."""
+    if not force and not _stale():
+        return LIB
+    objs = []
+    for src in SOURCES:
+        path = os.path.join(CSRC, src)
+        if not os.path.exists(path):
+            continue
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        cmd = [HIPCC] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,88 @@
+// Shared host/device helpers for libdmcnet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "dmcnet_hip.h"
+
+namespace dmc {
+
+// ---- error reporting (thread-local, no global mutable state shared between threads) --------
+inline char* err_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+inline int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(DMC_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return DMC_OK;
+}
+
+// ---- EstimatorDenseNetTiny geometry (code/dmcnet/model.py:172-194) --------------------------
+// Physical channel order used by every kernel: [mv0 mv1 r0 r1 r2 | y0(8) | y1(8) | y2(6) | y3(4)
+// | y4(2)] -- features are APPENDED, so layer k reads physical channels [0, CIN[k]).  The
+// reference PREPENDS (torch.cat((conv(x), x), 1)); the weight repack maps between the two.
+constexpr int NL = 6;
+__host__ __device__ constexpr int cin_of(int k) {
+    return k == 0 ? 5 : k == 1 ? 13 : k == 2 ? 21 : k == 3 ? 27 : k == 4 ? 31 : 33;
+}
+__host__ __device__ constexpr int cout_of(int k) {
+    return k == 0 ? 8 : k == 1 ? 8 : k == 2 ? 6 : k == 3 ? 4 : 2;
+}
+// first physical channel of y_k (k = 0..4); yoff(5) = 33
+__host__ __device__ constexpr int yoff(int k) { return cin_of(k); }
+constexpr int NFEAT = 28;   // y0..y4 channels kept in the `saved` / `gbuf` buffers
+constexpr int NIN = 5;
+
+// packed parameter block (floats):  WF | BF | WB
+//   WF[k][p][tap][co]   forward weights, p = physical input channel           (4554)
+//   BF[k][co]                                                                  (30)
+//   WB[k][cg][tap][cd]  k = 1..5, data-gradient weights: conv from g_k (cg) to the features
+//                       cd in [0, CIN[k]-5), taps already flipped              (3204)
+__host__ __device__ constexpr int wf_off(int k) {
+    int o = 0;
+    for (int i = 0; i < k; ++i) o += cin_of(i) * 9 * cout_of(i);
+    return o;
+}
+constexpr int WF_TOTAL = wf_off(6);   // 4554
+__host__ __device__ constexpr int bf_off(int k) {
+    int o = WF_TOTAL;
+    for (int i = 0; i < k; ++i) o += cout_of(i);
+    return o;
+}
+constexpr int NPARAM = bf_off(6);     // 4584
+__host__ __device__ constexpr int wb_off(int k) {
+    int o = NPARAM;
+    for (int i = 1; i < k; ++i) o += cout_of(i) * 9 * (cin_of(i) - NIN);
+    return o;
+}
+constexpr int PACKED_TOTAL = wb_off(6);   // 7788
+
+// logical (reference, prepend order) input-channel index of physical channel p in layer k
+__host__ __device__ inline int logical_of(int k, int p) {
+    if (p < NIN) return (cin_of(k) - NIN) + p;
+    int j = 0;
+    while (p >= yoff(j) + cout_of(j)) ++j;
+    int l = 0;
+    for (int i = j + 1; i < k; ++i) l += cout_of(i);
+    return l + (p - yoff(j));
+}
+
+struct ParamPtrs {
+    const float* w[NL];
+    const float* b[NL];
+};
+struct GradPtrs {
+    float* w[NL];
+    float* b[NL];
+};
+
+}  // namespace dmc

@@ -1,0 +1,199 @@
+"""torch.autograd bindings of the HIP kernels (device memory and streams are PyTorch's; the
+arithmetic is libdmcnet_hip.so's).  Every op requires contiguous fp32 CUDA tensors and raises
+otherwise -- there is no CPU path."""
+import torch
+
+from . import _lib
+
+__all__ = ["gen_tiny", "flow_mse", "consensus_ce", "disc_tail"]
+
+
+def _stream():
+    return _lib._P(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.DmcHipError("the DMC-Net hot path runs on the HIP extension only: got a %s "
+                                   "tensor (no CPU fallback)" % t.device)
+        if t.dtype not in (torch.float32, torch.int64):
+            raise _lib.DmcHipError("expected fp32 tensors, got %s" % t.dtype)
+
+
+def _floats(nbytes, device):
+    return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+
+
+class _GenTiny(torch.autograd.Function):
+    """EstimatorDenseNetTiny(cat(mv, res)) [+ mv]; reference code/dmcnet/model.py:187-194,341-346."""
+
+    @staticmethod
+    def forward(ctx, mv, res, add_mv, *params):
+        lib = _lib.load()
+        _need_cuda(mv, res, *params)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            raise NotImplementedError("gradients w.r.t. the MV/residual inputs are not produced "
+                                      "(the reference never requests them)")
+        mv, res = mv.contiguous(), res.contiguous()
+        ws, bs = [p.contiguous() for p in params[:6]], [p.contiguous() for p in params[6:]]
+        n, _, h, w = mv.shape
+        out = torch.empty((n, 2, h, w), dtype=torch.float32, device=mv.device)
+        saved = _floats(lib.dmc_gen_tiny_saved_bytes(n, h, w), mv.device)
+        work = _floats(lib.dmc_gen_tiny_workspace_bytes(), mv.device)
+        _lib.check(lib.dmc_gen_tiny_fwd(_lib.ptr(mv), _lib.ptr(res), _lib.ptr_array(ws),
+                                        _lib.ptr_array(bs), _lib.ptr(out), _lib.ptr(saved),
+                                        _lib.ptr(work), n, h, w, int(add_mv), _stream()),
+                   "dmc_gen_tiny_fwd")
+        ctx.save_for_backward(mv, res, saved, *ws)
+        ctx.bias_like = [(b.shape, b.dtype) for b in bs]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        mv, res, saved = ctx.saved_tensors[:3]
+        ws = list(ctx.saved_tensors[3:])
+        grad_out = grad_out.contiguous()
+        n, _, h, w = mv.shape
+        dws = [torch.empty_like(x) for x in ws]
+        dbs = [torch.empty(s, dtype=d, device=mv.device) for s, d in ctx.bias_like]
+        gbuf = _floats(lib.dmc_gen_tiny_gbuf_bytes(n, h, w), mv.device)
+        partials = _floats(lib.dmc_gen_tiny_partials_bytes(n, h, w), mv.device)
+        work = _floats(lib.dmc_gen_tiny_workspace_bytes(), mv.device)
+        _lib.check(lib.dmc_gen_tiny_bwd(_lib.ptr(mv), _lib.ptr(res), _lib.ptr_array(ws),
+                                        _lib.ptr(saved), _lib.ptr(grad_out), _lib.ptr_array(dws),
+                                        _lib.ptr_array(dbs), _lib.ptr(gbuf), _lib.ptr(partials),
+                                        _lib.ptr(work), n, h, w, _stream()),
+                   "dmc_gen_tiny_bwd")
+        return (None, None, None) + tuple(dws) + tuple(dbs)
+
+
+def gen_tiny(mv, res, weights, biases, add_mv=False):
+    """mv [N,2,H,W], res [N,3,H,W], 6 weights + 6 biases (reference layout) -> [N,2,H,W]."""
+    return _GenTiny.apply(mv, res, bool(add_mv), *weights, *biases)
+
+
+class _FlowMSE(torch.autograd.Function):
+    """nn.MSELoss()(gen_flow, input_flow); reference code/dmcnet/train.py:167,245."""
+
+    @staticmethod
+    def forward(ctx, gen_flow, flow):
+        lib = _lib.load()
+        _need_cuda(gen_flow, flow)
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError("no gradient w.r.t. the flow target")
+        if gen_flow.shape != flow.shape:
+            raise ValueError("shape mismatch %s vs %s" % (tuple(gen_flow.shape), tuple(flow.shape)))
+        gen_flow, flow = gen_flow.contiguous(), flow.contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=gen_flow.device)
+        partials = _floats(lib.dmc_flow_mse_partials_bytes(), gen_flow.device)
+        _lib.check(lib.dmc_flow_mse_fwd(_lib.ptr(gen_flow), _lib.ptr(flow), _lib.ptr(loss),
+                                        _lib.ptr(partials), gen_flow.numel(), _stream()),
+                   "dmc_flow_mse_fwd")
+        ctx.save_for_backward(gen_flow, flow)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        lib = _lib.load()
+        gen_flow, flow = ctx.saved_tensors
+        grad_loss = grad_loss.contiguous().float()
+        grad = torch.empty_like(gen_flow)
+        _lib.check(lib.dmc_flow_mse_bwd(_lib.ptr(gen_flow), _lib.ptr(flow), _lib.ptr(grad_loss),
+                                        _lib.ptr(grad), gen_flow.numel(), _stream()),
+                   "dmc_flow_mse_bwd")
+        return grad, None
+
+
+def flow_mse(gen_flow, flow):
+    return _FlowMSE.apply(gen_flow, flow)
+
+
+class _ConsensusCE(torch.autograd.Function):
+    """view(-1,S,C).mean(1) + CrossEntropyLoss; reference code/dmcnet/train.py:239-241."""
+
+    @staticmethod
+    def forward(ctx, logits, target, num_segments):
+        lib = _lib.load()
+        _need_cuda(logits, target)
+        logits, target = logits.contiguous(), target.contiguous()
+        n, c = logits.shape
+        if n % num_segments != 0 or target.numel() * num_segments != n:
+            raise ValueError("logits %s do not match %d targets x %d segments"
+                             % (tuple(logits.shape), target.numel(), num_segments))
+        b = n // num_segments
+        consensus = torch.empty((b, c), dtype=torch.float32, device=logits.device)
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        grad = torch.empty_like(logits) if ctx.needs_input_grad[0] else None
+        _lib.check(lib.dmc_consensus_ce_fwd_bwd(_lib.ptr(logits), _lib.ptr(target),
+                                                _lib.ptr(consensus), _lib.ptr(loss), _lib.ptr(grad),
+                                                b, num_segments, c, _stream()),
+                   "dmc_consensus_ce_fwd_bwd")
+        ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(consensus)
+        return loss, consensus
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_consensus):
+        (grad,) = ctx.saved_tensors
+        return grad * grad_loss, None, None
+
+
+def consensus_ce(logits, target, num_segments):
+    """Returns (loss, consensus logits [B, C])."""
+    return _ConsensusCE.apply(logits, target, num_segments)
+
+
+class _DiscTail(torch.autograd.Function):
+    """LeakyReLU(0.2) -> Dropout2d keep-mask -> BatchNorm2d; reference
+    code/dmcnet_GAN/model.py:254-279."""
+
+    @staticmethod
+    def forward(ctx, x, keep, gamma, beta, running_mean, running_var, training, eps, momentum):
+        lib = _lib.load()
+        _need_cuda(x, keep, gamma, beta)
+        x = x.contiguous()
+        n, c, h, w = x.shape
+        use_bn = gamma is not None
+        keep = keep.contiguous() if keep is not None else None
+        y = torch.empty_like(x)
+        stats = _floats(lib.dmc_disc_tail_stats_bytes(c), x.device) if use_bn else None
+        _lib.check(lib.dmc_disc_tail_fwd(_lib.ptr(x), _lib.ptr(keep), _lib.ptr(gamma), _lib.ptr(beta),
+                                         _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(y),
+                                         _lib.ptr(stats), n, c, h, w, int(use_bn), int(training),
+                                         float(eps), float(momentum), _stream()),
+                   "dmc_disc_tail_fwd")
+        ctx.save_for_backward(x, keep, gamma, stats)
+        ctx.use_bn = use_bn
+        ctx.training = bool(training)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, keep, gamma, stats = ctx.saved_tensors
+        if ctx.use_bn and not ctx.training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not implemented")
+        dy = dy.contiguous()
+        n, c, h, w = x.shape
+        dx = torch.empty_like(x)
+        dgamma = torch.empty_like(gamma) if ctx.use_bn else None
+        dbeta = torch.empty_like(gamma) if ctx.use_bn else None
+        _lib.check(lib.dmc_disc_tail_bwd(_lib.ptr(x), _lib.ptr(keep), _lib.ptr(gamma), _lib.ptr(stats),
+                                         _lib.ptr(dy), _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta),
+                                         n, c, h, w, int(ctx.use_bn), _stream()),
+                   "dmc_disc_tail_bwd")
+        return dx, None, dgamma, dbeta, None, None, None, None, None
+
+
+def disc_tail(x, keep, bn, training):
+    """x: conv output; keep: [N,C] mask/(1-p) or None; bn: nn.BatchNorm2d or None."""
+    if bn is None:
+        return _DiscTail.apply(x, keep, None, None, None, None, training, 0.0, 0.0)
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _DiscTail.apply(x, keep, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
+                           bn.eps, bn.momentum)

@@ -1,0 +1,87 @@
+"""ResNet backbones for the classifier over the DMC cue.
+
+The reference takes them from torchvision (``getattr(torchvision.models, base_model)``,
+code/dmcnet/model.py:305), which is not available here; the published architecture is restated
+with the same attribute names, so ``base_model.*`` state-dict keys match torchvision's.  The
+convolutions run on PyTorch-ROCm (MIOpen); BASELINE.json config 2 scopes them that way.
+"""
+import torch
+from torch import nn
+
+_CFG = {
+    "resnet18": ("basic", (2, 2, 2, 2)),
+    "resnet34": ("basic", (3, 4, 6, 3)),
+    "resnet50": ("bottleneck", (3, 4, 6, 3)),
+    "resnet101": ("bottleneck", (3, 4, 23, 3)),
+    "resnet152": ("bottleneck", (3, 8, 36, 3)),
+}
+
+
+def _conv(cin, cout, k, stride=1):
+    return nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=False)
+
+
+class ResidualUnit(nn.Module):
+    """BasicBlock (two 3x3) or Bottleneck (1x1, 3x3, 1x1 with 4x expansion)."""
+
+    def __init__(self, kind, cin, planes, stride):
+        super().__init__()
+        self.kind = kind
+        cout = planes * (4 if kind == "bottleneck" else 1)
+        if kind == "basic":
+            self.conv1, self.bn1 = _conv(cin, planes, 3, stride), nn.BatchNorm2d(planes)
+            self.conv2, self.bn2 = _conv(planes, planes, 3), nn.BatchNorm2d(planes)
+        else:
+            self.conv1, self.bn1 = _conv(cin, planes, 1), nn.BatchNorm2d(planes)
+            self.conv2, self.bn2 = _conv(planes, planes, 3, stride), nn.BatchNorm2d(planes)
+            self.conv3, self.bn3 = _conv(planes, cout, 1), nn.BatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(_conv(cin, cout, 1, stride), nn.BatchNorm2d(cout))
+        self.out_channels = cout
+
+    def forward(self, x):
+        shortcut = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        if self.kind == "basic":
+            y = self.bn2(self.conv2(y))
+        else:
+            y = self.relu(self.bn2(self.conv2(y)))
+            y = self.bn3(self.conv3(y))
+        y += shortcut
+        return self.relu(y)
+
+
+class ResNet(nn.Module):
+    def __init__(self, kind, depths, num_classes=1000):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        width = 64
+        for stage, (planes, count) in enumerate(zip((64, 128, 256, 512), depths)):
+            units = []
+            for j in range(count):
+                unit = ResidualUnit(kind, width, planes, 2 if (stage > 0 and j == 0) else 1)
+                width = unit.out_channels
+                units.append(unit)
+            setattr(self, "layer%d" % (stage + 1), nn.Sequential(*units))
+        self.avgpool = nn.AvgPool2d(7, stride=1)
+        self.fc = nn.Linear(width, num_classes)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
+            x = stage(x)
+        return self.fc(torch.flatten(self.avgpool(x), 1))
+
+
+def build(name, pretrained=False):
+    """``pretrained`` mirrors the reference's call; ImageNet weights are not obtainable offline,
+    so it only emits a note -- load a checkpoint with ``--weights`` semantics instead."""
+    if name not in _CFG:
+        raise ValueError("Unknown base model: {}".format(name))
+    kind, depths = _CFG[name]
+    return ResNet(kind, depths)

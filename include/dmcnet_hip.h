@@ -1,0 +1,140 @@
+/*
+ * dmcnet_hip.h -- C ABI of libdmcnet_hip.so: the MI355X (gfx950) kernels behind the DMC-Net
+ * training hot path.
+ *
+ * The reference (facebookresearch/dmc-net) has NO FFI seam on this path: its hot path is stock
+ * torch.nn modules driven from Python.  Each entry point below therefore
+ * names the reference Python it replaces (paths relative to the reference root); the binding a
+ * maintainer adds on the reference side is the ctypes stub in INTEGRATION.md.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes, no torch types; every pointer is a DEVICE pointer unless it
+ *     says "host";
+ *   - the caller owns every buffer, workspaces included; nothing here allocates, frees or
+ *     synchronises; every launch is asynchronous on `stream` (a hipStream_t; NULL = the
+ *     null stream);
+ *   - tensors are contiguous NCHW fp32; weights are in PyTorch's native [Cout][Cin][3][3]
+ *     layout with the reference's prepend-concat input-channel order
+ *     (code/dmcnet/model.py:187-194: layer k sees [y_{k-1}, ..., y_0, mv(2), residual(3)]);
+ *   - return value: DMC_OK (0) or a negative DMC_E_* code; dmc_last_error() gives the text
+ *     (thread-local);
+ *   - no global mutable state: safe from several host threads on distinct streams.
+ */
+#ifndef DMCNET_HIP_H
+#define DMCNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMC_OK 0
+#define DMC_E_INVALID (-1) /* bad argument (null pointer, non-positive size, ...) */
+#define DMC_E_LAUNCH (-2)  /* hipLaunch / hipGetLastError failure                */
+
+typedef void* dmc_stream_t; /* hipStream_t */
+
+/* Library version: major*10000 + minor*100 + patch. */
+int dmc_version(void);
+/* Text of the last error on this host thread ("" if none). */
+const char* dmc_last_error(void);
+
+/* ---- EstimatorDenseNetTiny (the DMC generator every shipped recipe uses) ----------------
+ * Replaces: EstimatorDenseNetTiny.forward            code/dmcnet/model.py:187-194
+ *           + torch.cat((mv, residual), 1)            code/dmcnet/model.py:341
+ *           + torch.add(gen_flow, input_mv)           code/dmcnet/model.py:345-346
+ * Layer widths 5->8, 13->8, 21->6, 27->4, 31->2, 33->2 (last one without LeakyReLU(0.1)).
+ *
+ * w[6], b[6] (host arrays of device pointers): conv_0..conv_4 `.0.weight/.0.bias`, then
+ * predict_flow.weight/.bias.
+ */
+
+/* Bytes of `workspace` the generator entry points need (repacked weights). */
+size_t dmc_gen_tiny_workspace_bytes(void);
+/* Bytes of the saved-activation buffer for N frames of H x W (28 channels fp32). */
+size_t dmc_gen_tiny_saved_bytes(int N, int H, int W);
+
+/*
+ * Forward.  mv [N,2,H,W], res [N,3,H,W] -> out [N,2,H,W].
+ * saved: NULL for inference; for training a buffer of dmc_gen_tiny_saved_bytes() that
+ * receives y0..y4 (the post-LeakyReLU features) for the backward pass.
+ * If `saved` is NULL, `scratch` must still provide the same number of bytes (intermediate
+ * features of the unfused fallback path); pass the same pointer in both cases if convenient.
+ * add_mv_delta != 0 adds input_mv to the result (gen_flow_or_delta == 1).
+ */
+int dmc_gen_tiny_fwd(const float* mv, const float* res, const float* const* w,
+                     const float* const* b, float* out, float* saved, float* workspace, int N,
+                     int H, int W, int add_mv_delta, dmc_stream_t stream);
+
+/* Bytes of the gradient-feature buffer (`gbuf`) and of the per-workgroup weight-gradient
+ * partials (`partials`) that the backward needs. */
+size_t dmc_gen_tiny_gbuf_bytes(int N, int H, int W);
+size_t dmc_gen_tiny_partials_bytes(int N, int H, int W);
+
+/*
+ * Backward (autograd of the stack above; replaces loss.backward() through
+ * code/dmcnet/model.py:187-194).  grad_out [N,2,H,W] is dL/d(out).
+ * Writes dw[6], db[6] (host arrays of device pointers, same shapes as w, b; overwritten, not
+ * accumulated).  Gradients w.r.t. mv/res through the convolutions are not produced (the
+ * reference never asks for them); in delta mode dL/d(mv) through the skip is grad_out itself.
+ */
+int dmc_gen_tiny_bwd(const float* mv, const float* res, const float* const* w,
+                     const float* saved, const float* grad_out, float* const* dw,
+                     float* const* db, float* gbuf, float* partials, float* workspace, int N,
+                     int H, int W, dmc_stream_t stream);
+
+/* ---- flow reconstruction loss --------------------------------------------------------------
+ * Replaces: nn.MSELoss()(gen_flow, input_flow)        code/dmcnet/train.py:167,245
+ * (mean over all `numel` elements).  partials: workspace of dmc_flow_mse_partials_bytes().
+ * loss_out: one float on the device.
+ */
+size_t dmc_flow_mse_partials_bytes(void);
+int dmc_flow_mse_fwd(const float* gen_flow, const float* flow, float* loss_out, float* partials,
+                     size_t numel, dmc_stream_t stream);
+/* grad_gen = 2 (gen - flow) / numel * (*grad_loss) ; grad_loss is a device scalar. */
+int dmc_flow_mse_bwd(const float* gen_flow, const float* flow, const float* grad_loss,
+                     float* grad_gen, size_t numel, dmc_stream_t stream);
+
+/* ---- TSN segment consensus + cross entropy ---------------------------------------------------
+ * Replaces: output.view(-1, S, C).mean(dim=1); CrossEntropyLoss()(output, target)
+ *           code/dmcnet/train.py:239-241   (also the adversarial CE with S = 1,
+ *           code/dmcnet_GAN/train.py:274,346)
+ * logits [B*S, C] fp32, target [B] int64 ->
+ *   consensus [B, C] (the averaged logits, what accuracy() consumes),
+ *   loss_out  one float: mean over B of -log softmax(consensus)[target],
+ *   grad_logits [B*S, C] = (softmax - onehot) / (B*S), i.e. dloss/dlogits for upstream grad 1
+ *   (may be NULL to skip).
+ */
+int dmc_consensus_ce_fwd_bwd(const float* logits, const int64_t* target, float* consensus,
+                             float* loss_out, float* grad_logits, int B, int S, int C,
+                             dmc_stream_t stream);
+
+/* ---- discriminator block tail ----------------------------------------------------------------
+ * Replaces the three modules that follow the Conv2d of discriminator_block /
+ * discriminator_block2:  LeakyReLU(0.2) -> Dropout2d(0.25) -> BatchNorm2d(C, eps=0.8)
+ *           code/dmcnet_GAN/model.py:254-279
+ * x [N,C,H,W] is the conv output.  keep [N,C] holds the Dropout2d keep-mask ALREADY divided by
+ * (1-p) (0 or 1/0.75) -- the caller draws it, so CPU and GPU runs can share one.
+ * Training-mode BatchNorm: batch statistics (biased variance for normalisation), running stats
+ * updated with momentum (unbiased variance), as torch.nn.BatchNorm2d does.
+ * use_bn == 0 (first block): y = keep * lrelu(x) only; gamma..running_var ignored.
+ * stats: workspace of dmc_disc_tail_stats_bytes(C) bytes; its first 2*C floats receive
+ * (mean, invstd) for the backward pass, the rest is reduction scratch.
+ */
+size_t dmc_disc_tail_stats_bytes(int C);
+int dmc_disc_tail_fwd(const float* x, const float* keep, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, float* y, float* stats, int N,
+                      int C, int H, int W, int use_bn, int training, float eps, float momentum,
+                      dmc_stream_t stream);
+/* Backward of the above in training mode: given dy -> dx, dgamma, dbeta (overwritten).
+ * `stats` is the buffer the forward filled (its scratch part is reused). */
+int dmc_disc_tail_bwd(const float* x, const float* keep, const float* gamma, float* stats,
+                      const float* dy, float* dx, float* dgamma, float* dbeta, int N, int C, int H,
+                      int W, int use_bn, dmc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMCNET_HIP_H */
