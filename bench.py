@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Headline benchmark: clips/sec of one full DMC-Net training step (DMC generator + ResNet-18 +
+flow-MSE + consensus CE, backward, two Adam steps), 3 segments x 224x224 per clip, 40 clips per
+GPU (weak scaling), synthetic MV/residual/flow already resident in HBM.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").  The `roofline` object is for the
+dominant hand-written kernel, the generator forward, timed with HIP events on its stream inside
+the timed region; the `cpu_baseline` object is the CPU oracle (a port of the reference's CPU
+path, validated against it by tests/golden) timed on this box's host cores, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: fp32 vector == fp32 matrix peak
+HBM_PEAK_GBS = 8000.0
+GEN_FLOP_PER_PX = 9108         # 4,554 MAC, SURVEY.md 8(d)
+GEN_BYTES_PER_PX = 28          # read 5 ch + write 2 ch fp32 (fused, inference-style)
+
+HP = dict(lr=0.01, weight_decay=1e-4, lr_cls_mult=0.01, lr_mse_mult=1.0)
+
+
+def usable_cores():
+    """Cores this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))     # beyond ~64 threads torch's CPU convs stop scaling
+
+
+def cpu_baseline(batch, num_segments, num_class, budget_s=20.0):
+    """The oracle's dmcnet train step on the host cores (kind 'port')."""
+    from oracle import dmc_oracle as O
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    kw = dict(base_model="resnet18", use_databn=0, gen_flow_or_delta=1, arch_estimator="DenseNetTiny")
+    m = O.OracleModel(num_class, num_segments, "mv", **kw).train()
+    oc, og = O.make_optimizers(m, **HP)
+    # bounded sample: probe with 2 clips, then size the timed batch for ~budget_s of CPU work
+    probe = O.synthetic_batch(1234, 2, num_segments, num_class, flow_ds_factor=16)
+    O.dmcnet_train_step(m, oc, og, probe, num_segments, 1.0, 10.0)      # warm-up (allocator, oneDNN)
+    t0 = time.time()
+    O.dmcnet_train_step(m, oc, og, probe, num_segments, 1.0, 10.0)
+    per_clip = (time.time() - t0) / 2
+    b = int(max(2, min(batch, budget_s / 2 / max(per_clip, 1e-6))))
+    data = O.synthetic_batch(1234, b, num_segments, num_class, flow_ds_factor=16)
+    times = []
+    for _ in range(2):
+        t0 = time.time()
+        O.dmcnet_train_step(m, oc, og, data, num_segments, 1.0, 10.0)
+        times.append(time.time() - t0)
+    dt = min(times)
+    return {"value": round(b / dt, 3), "unit": "clips/sec", "cores": cores, "kind": "port",
+            "sample": "oracle dmcnet train step (torch CPU fp32, %d threads), %d clips x %d segments x "
+                      "224x224 per step (the B=%d workload cut to fit ~%ds), best of 2 timed steps after "
+                      "warm-up" % (cores, b, num_segments, batch, int(budget_s))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=40, help="clips per GPU")
+    ap.add_argument("--num-class", type=int, default=51)
+    ap.add_argument("--config", default="dmcnet", choices=["dmcnet", "gan"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--miopen-find", type=int, default=0,
+                    help="1 = torch.backends.cudnn.benchmark (MIOpen exhaustive find during warm-up)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=dev)
+
+    import dmcnet_amd
+    from dmcnet_amd import dataset, ddp, ops, train
+    S = 3
+    torch.manual_seed(0)
+    gan = args.config == "gan"
+    model = dmcnet_amd.Model(args.num_class, S, "mv", base_model="resnet18", use_databn=0,
+                             gen_flow_or_delta=1, arch_estimator="DenseNetTiny",
+                             arch_d="Discriminator3" if gan else None).to(dev).train()
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+    reducer = ddp.GradBucketReducer(list(model.parameters())) if world > 1 else None
+    if gan:
+        stepper = train.GanTrainStep(model, S, 1.0, 1.0, 0.01, 10.0, lr_d_mult=1.0, reducer=reducer, **HP)
+    else:
+        stepper = train.DmcnetTrainStep(model, S, 1.0, 10.0, reducer=reducer, **HP)
+    batch = dataset.synthetic_batch_on_device(1234 + rank, args.batch, S, args.num_class, dev,
+                                              flow_ds_factor=0 if gan else 16)
+
+    def one(i):
+        return stepper.step(batch, i) if gan else stepper.step(batch)
+
+    for i in range(args.warmup):
+        one(i)
+    probe = ops.EventProbe()
+    ops.PROBE = probe
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = one(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.PROBE = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss = float(out["loss"])
+    spans = probe.summary()
+
+    if rank == 0:
+        n_frames = args.batch * S
+        px = n_frames * 224 * 224
+        fwd_ms, _ = spans["gen_tiny_fwd"]
+        tf = px * GEN_FLOP_PER_PX / (fwd_ms * 1e-3) / 1e12
+        gbs = px * GEN_BYTES_PER_PX / (fwd_ms * 1e-3) / 1e9
+        line = {
+            "metric": "clips/sec (3-seg 224x224) DMC-gen+ResNet-18 train step",
+            "value": round(world * args.batch * args.steps / elapsed, 3), "unit": "clips/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("dmcnet_GAN HMDB-51 split1 (Discriminator3, alternating D/G)" if gan else
+                                    "HMDB-51 split1 dmcnet (no GAN), 3 segments, ResNet-18, DenseNetTiny "
+                                    "generator, delta mode, MSE x10") +
+                                   ", batch %d clips/GPU, random-init weights" % args.batch,
+                       "global_batch": world * args.batch, "num_class": args.num_class,
+                       "parallelism": "dp%d" % world, "final_loss": round(loss, 6)},
+            "roofline": {
+                "kernel": "dmc_gen_tiny_fwd (EstimatorDenseNetTiny forward, %d frames)" % n_frames,
+                # the fused fp32 generator is FMA-bound (325 FLOP/B >> ridge 20 FLOP/B): the binding
+                # roof is the fp32 vector/matrix peak, reported in the "mfma" slot of the schema
+                "bound": "mfma", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                "launch_ms": round(fwd_ms, 4),
+                "hbm": {"achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 5)}},
+            "kernels_ms": {k: round(v[0], 4) for k, v in spans.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline and not gan:
+            line["cpu_baseline"] = cpu_baseline(args.batch, S, args.num_class)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

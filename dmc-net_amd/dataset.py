@@ -1,0 +1,216 @@
+"""Data side of the hot path: the integer segment-index sampling of the reference's
+``CoviarDataSet`` (bit-exact), its tensor contract, and synthetic clips with that contract.
+
+Reference: code/dmcnet/dataset.py (paths relative to the reference root) --
+``get_seg_range`` :46-60, ``get_gop_pos`` :63-73, ``_get_train_frame_index`` :130-137,
+``_get_test_frame_index`` :139-149, flow frame number :178, blockified flow :229-246,
+normalisation :251-263, returned tuple :278.  Decoding (``coviar`` = FFmpeg MPEG-4) and the
+TV-L1 flow JPEGs are outside the path: ``CoviarDataSet`` keeps the constructor and the sampling
+and needs ``coviar`` only when a real video is read.
+"""
+import os
+import random
+
+import numpy as np
+import torch
+import torch.utils.data as data
+
+GOP_SIZE = 12
+_MOTION = ("residual", "mv", "flow")
+_STD = (0.229, 0.224, 0.225)
+STD_MEAN = float(torch.tensor(_STD, dtype=torch.float32).mean())   # what torch.mean(_input_std) gives
+
+
+def get_seg_range(n, num_segments, seg, representation):
+    """[begin, end) of segment ``seg``; P-frame representations skip frame 0 (an I-frame)."""
+    shift = 1 if representation in _MOTION else 0
+    n -= shift
+    seg_size = float(n - 1) / num_segments
+    begin = int(np.round(seg_size * seg))            # np.round: half to even, on float64
+    end = int(np.round(seg_size * (seg + 1)))
+    if end == begin:
+        end = begin + 1
+    return begin + shift, end + shift
+
+
+def get_gop_pos(frame_idx, representation, gop_size=None):
+    gop = GOP_SIZE if gop_size is None else gop_size
+    index, pos = divmod(frame_idx, gop)
+    if representation in _MOTION:
+        if pos == 0:                                  # borrow the previous GOP's last P-frame
+            index, pos = index - 1, gop - 1
+    else:
+        pos = 0
+    return index, pos
+
+
+def train_frame_index(num_frames, seg, num_segments, representation, rng=random):
+    begin, end = get_seg_range(num_frames, num_segments, seg, representation)
+    return get_gop_pos(rng.randint(begin, end - 1), representation)
+
+
+def test_frame_index(num_frames, seg, num_segments, representation):
+    shift = 1 if representation in _MOTION else 0
+    num_frames -= shift
+    v = int(np.round(float(num_frames - 1) / num_segments * (seg + 0.5))) + shift
+    return get_gop_pos(v, representation)
+
+
+test_frame_index.__test__ = False
+
+
+def flow_frame_number(gop_index, gop_pos, gop_size=None):
+    return gop_index * (GOP_SIZE if gop_size is None else gop_size) + gop_pos + 1
+
+
+def blockify(flow, factor):
+    """Mean over factor x factor blocks (ragged edges zero-padded, as skimage's block_reduce),
+    repeated back to the input size.  ``flow`` [..., H, W] numpy."""
+    h, w = flow.shape[-2:]
+    ph, pw = (-h) % factor, (-w) % factor
+    pad = [(0, 0)] * (flow.ndim - 2) + [(0, ph), (0, pw)]
+    x = np.pad(flow.astype(np.float64), pad)
+    lead = x.shape[:-2]
+    x = x.reshape(lead + ((h + ph) // factor, factor, (w + pw) // factor, factor)).mean(axis=(-3, -1))
+    return x.repeat(factor, axis=-2).repeat(factor, axis=-1)[..., :h, :w]
+
+
+def to_tensors(frames, flow_ds_factor=0):
+    """``frames`` [S,7,H,W] (uint8 or int) = [flow2, mv2, res3] -> the reference's
+    (input_flow, input_mv, input_residual) fp32 tensors for representation 'mv'."""
+    flow, mv, res = frames[:, 0:2], frames[:, 2:4], frames[:, 4:]
+    if flow_ds_factor != 0:
+        flow = blockify(flow, flow_ds_factor)
+    std = torch.tensor(_STD, dtype=torch.float32).reshape(1, 3, 1, 1)
+    f = torch.from_numpy(np.ascontiguousarray(flow)).float() / 255.0
+    m = torch.from_numpy(np.ascontiguousarray(mv)).float() / 255.0
+    r = torch.from_numpy(np.ascontiguousarray(res)).float() / 255.0
+    return (f - 0.5) / torch.mean(std), (m - 0.5) / torch.mean(std), (r - 0.5) / std
+
+
+def synthetic_clip_u8(rs, num_segments, size=224):
+    """One clip of uint8 frames [S,7,H,W]: MV constant per 16x16 macroblock (sigma 6 px on the
+    +-20 -> +-127.5 scale), residual sigma 12, flow sigma 10 around 128."""
+    mb = (size + 15) // 16
+    mv = np.clip(128 + np.round(rs.normal(0, 6, (num_segments, 2, mb, mb)) * 127.5 / 20), 0, 255)
+    mv = mv.repeat(16, axis=2).repeat(16, axis=3)[..., :size, :size]
+    res = np.clip(128 + np.round(rs.normal(0, 12, (num_segments, 3, size, size))), 0, 255)
+    flow = np.clip(128 + np.round(rs.normal(0, 10, (num_segments, 2, size, size))), 0, 255)
+    return np.concatenate((flow, mv, res), axis=1).astype(np.uint8)
+
+
+class SyntheticCoviarDataSet(data.Dataset):
+    """Same item contract as ``CoviarDataSet`` (input_flow, input_mv, input_residual, label) on
+    seeded synthetic frames; no files."""
+
+    def __init__(self, length, num_class, num_segments=3, flow_ds_factor=0, size=224, seed=1234):
+        self.length, self.num_class, self.num_segments = length, num_class, num_segments
+        self.flow_ds_factor, self.size, self.seed = flow_ds_factor, size, seed
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, index):
+        rs = np.random.RandomState(self.seed + index)
+        frames = synthetic_clip_u8(rs, self.num_segments, self.size)
+        flow, mv, res = to_tensors(frames, self.flow_ds_factor)
+        return flow, mv, res, int(rs.randint(0, self.num_class))
+
+
+def synthetic_batch_on_device(seed, batch, num_segments, num_class, device, size=224,
+                              flow_ds_factor=0):
+    """A batch with the dataset's value distribution, generated directly in HBM (bench input)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    mb = (size + 15) // 16
+
+    def u8(sigma, shape, scale=1.0):
+        x = torch.randn(shape, generator=g, device=device) * sigma * scale
+        return torch.clamp(128 + torch.round(x), 0, 255)
+
+    mv = u8(6, (batch, num_segments, 2, mb, mb), 127.5 / 20)
+    mv = mv.repeat_interleave(16, -2).repeat_interleave(16, -1)[..., :size, :size]
+    res = u8(12, (batch, num_segments, 3, size, size))
+    flow = u8(10, (batch, num_segments, 2, size, size))
+    if flow_ds_factor:
+        f = flow_ds_factor
+        flow = torch.nn.functional.avg_pool2d(flow.flatten(0, 1), f).repeat_interleave(f, -2) \
+            .repeat_interleave(f, -1).reshape(batch, num_segments, 2, size, size)
+    std = torch.tensor(_STD, device=device).reshape(1, 1, 3, 1, 1)
+    flow = ((flow / 255.0 - 0.5) / STD_MEAN).contiguous()
+    mv = ((mv / 255.0 - 0.5) / STD_MEAN).contiguous()
+    res = ((res / 255.0 - 0.5) / std).contiguous()
+    target = torch.randint(0, num_class, (batch,), generator=g, device=device)
+    return flow, mv, res, target
+
+
+class CoviarDataSet(data.Dataset):
+    """Constructor and sampling of the reference's dataset (code/dmcnet/dataset.py:76-281).
+    Reading real videos needs the ``coviar`` extension and PIL, imported on first use."""
+
+    def __init__(self, data_root, flow_root, data_name, video_list, representation, new_length,
+                 flow_ds_factor, upsample_interp, transform, num_segments, is_train, accumulate,
+                 gop, mv_minmaxnorm=0, viz=False, flow_folder="tvl1"):
+        global GOP_SIZE
+        GOP_SIZE = gop
+        self._data_root, self._flow_root, self._data_name = data_root, flow_root, data_name
+        self._representation, self._new_length = representation, new_length
+        self._flow_ds_factor, self._upsample_interp = flow_ds_factor, upsample_interp
+        self._transform, self._num_segments, self._is_train = transform, num_segments, is_train
+        self._accumulate, self._mv_minmaxnorm, self._viz = accumulate, mv_minmaxnorm, viz
+        self._flow_folder = flow_folder
+        if upsample_interp:
+            raise NotImplementedError("upsample_interp=True is not used by any shipped recipe")
+        self._video_list = []
+        self._load_list(video_list)
+
+    @staticmethod
+    def _flow_dir(flow_root, video_path):
+        parts = video_path.split("/")
+        return os.path.join(flow_root, parts[-2], parts[-1][:-4])
+
+    def _load_list(self, video_list):
+        from coviar import get_num_frames
+        with open(video_list, "r") as f:
+            for line in f:
+                video, _, label = line.strip().split()
+                path = os.path.join(self._data_root, video[:-4] + ".mp4")
+                n_flow = len(os.listdir(self._flow_dir(self._flow_root, path))) / 3
+                self._video_list.append((path, int(label), min(get_num_frames(path), n_flow)))
+
+    def _get_train_frame_index(self, num_frames, seg):
+        return train_frame_index(num_frames, seg, self._num_segments, self._representation)
+
+    def _get_test_frame_index(self, num_frames, seg):
+        return test_frame_index(num_frames, seg, self._num_segments, self._representation)
+
+    def __len__(self):
+        return len(self._video_list)
+
+    def __getitem__(self, index):
+        from coviar import load
+        from PIL import Image
+        if self._representation != "mv":
+            raise NotImplementedError("the DMC-Net recipes use representation 'mv'")
+        path, label, num_frames = random.choice(self._video_list) if self._is_train \
+            else self._video_list[index]
+        flow_dir = self._flow_dir(self._flow_root, path)
+        frames = []
+        for seg in range(self._num_segments):
+            pick = self._get_train_frame_index if self._is_train else self._get_test_frame_index
+            gop_index, gop_pos = pick(num_frames, seg)
+            idx = flow_frame_number(gop_index, gop_pos)
+            flow = np.stack([np.array(Image.open(os.path.join(
+                flow_dir, "flow_%s_%05d.jpg" % (axis, idx))).convert("L")) for axis in "xy"], -1)
+            mv = load(path, gop_index, gop_pos, 1, self._accumulate)
+            if mv is None:
+                mv = np.zeros((256, 256, 2))
+            else:
+                mv = mv.astype(np.float64)
+                if self._mv_minmaxnorm == 1:
+                    mv *= 127.5 / 20
+                mv = np.clip(mv + 128, 0, 255).astype(np.uint8)
+            res = np.clip(load(path, gop_index, gop_pos, 2, self._accumulate) + 128, 0, 255)
+            frames.append(np.concatenate((flow, mv, res.astype(np.uint8)), axis=2))
+        frames = np.transpose(np.array(self._transform(frames)), (0, 3, 1, 2))
+        flow, mv, res = to_tensors(frames, self._flow_ds_factor)
+        return flow, mv, res, label

@@ -8,6 +8,52 @@ from . import _lib
 __all__ = ["gen_tiny", "flow_mse", "consensus_ce", "disc_tail"]
 
 
+class EventProbe(object):
+    """HIP-event timing of individual C-ABI calls on the stream they are launched on (PyTorch's
+    current stream).  bench.py installs one over the timed region to obtain the generator
+    kernels' average duration; ``summary()`` synchronises."""
+
+    def __init__(self):
+        self.pairs = {}
+
+    def span(self, name):
+        return _Span(self, name)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        return {k: (sum(a.elapsed_time(b) for a, b in v) / len(v), len(v))
+                for k, v in self.pairs.items() if v}
+
+
+class _Span(object):
+    def __init__(self, probe, name):
+        self.probe, self.name = probe, name
+
+    def __enter__(self):
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.b = torch.cuda.Event(enable_timing=True)
+        self.a.record()
+
+    def __exit__(self, *exc):
+        self.b.record()
+        self.probe.pairs.setdefault(self.name, []).append((self.a, self.b))
+
+
+class _NoSpan(object):
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+PROBE = None          # set to an EventProbe to time the calls below
+
+
+def _span(name):
+    return PROBE.span(name) if PROBE is not None else _NoSpan()
+
+
 def _stream():
     return _lib._P(torch.cuda.current_stream().cuda_stream)
 
@@ -43,10 +89,11 @@ class _GenTiny(torch.autograd.Function):
         out = torch.empty((n, 2, h, w), dtype=torch.float32, device=mv.device)
         saved = _floats(lib.dmc_gen_tiny_saved_bytes(n, h, w), mv.device)
         work = _floats(lib.dmc_gen_tiny_workspace_bytes(), mv.device)
-        _lib.check(lib.dmc_gen_tiny_fwd(_lib.ptr(mv), _lib.ptr(res), _lib.ptr_array(ws),
-                                        _lib.ptr_array(bs), _lib.ptr(out), _lib.ptr(saved),
-                                        _lib.ptr(work), n, h, w, int(add_mv), _stream()),
-                   "dmc_gen_tiny_fwd")
+        with _span("gen_tiny_fwd"):
+            _lib.check(lib.dmc_gen_tiny_fwd(_lib.ptr(mv), _lib.ptr(res), _lib.ptr_array(ws),
+                                            _lib.ptr_array(bs), _lib.ptr(out), _lib.ptr(saved),
+                                            _lib.ptr(work), n, h, w, int(add_mv), _stream()),
+                       "dmc_gen_tiny_fwd")
         ctx.save_for_backward(mv, res, saved, *ws)
         ctx.bias_like = [(b.shape, b.dtype) for b in bs]
         return out
@@ -63,11 +110,12 @@ class _GenTiny(torch.autograd.Function):
         gbuf = _floats(lib.dmc_gen_tiny_gbuf_bytes(n, h, w), mv.device)
         partials = _floats(lib.dmc_gen_tiny_partials_bytes(n, h, w), mv.device)
         work = _floats(lib.dmc_gen_tiny_workspace_bytes(), mv.device)
-        _lib.check(lib.dmc_gen_tiny_bwd(_lib.ptr(mv), _lib.ptr(res), _lib.ptr_array(ws),
-                                        _lib.ptr(saved), _lib.ptr(grad_out), _lib.ptr_array(dws),
-                                        _lib.ptr_array(dbs), _lib.ptr(gbuf), _lib.ptr(partials),
-                                        _lib.ptr(work), n, h, w, _stream()),
-                   "dmc_gen_tiny_bwd")
+        with _span("gen_tiny_bwd"):
+            _lib.check(lib.dmc_gen_tiny_bwd(_lib.ptr(mv), _lib.ptr(res), _lib.ptr_array(ws),
+                                            _lib.ptr(saved), _lib.ptr(grad_out), _lib.ptr_array(dws),
+                                            _lib.ptr_array(dbs), _lib.ptr(gbuf), _lib.ptr(partials),
+                                            _lib.ptr(work), n, h, w, _stream()),
+                       "dmc_gen_tiny_bwd")
         return (None, None, None) + tuple(dws) + tuple(dbs)
 
 
@@ -90,9 +138,10 @@ class _FlowMSE(torch.autograd.Function):
         gen_flow, flow = gen_flow.contiguous(), flow.contiguous()
         loss = torch.empty((), dtype=torch.float32, device=gen_flow.device)
         partials = _floats(lib.dmc_flow_mse_partials_bytes(), gen_flow.device)
-        _lib.check(lib.dmc_flow_mse_fwd(_lib.ptr(gen_flow), _lib.ptr(flow), _lib.ptr(loss),
-                                        _lib.ptr(partials), gen_flow.numel(), _stream()),
-                   "dmc_flow_mse_fwd")
+        with _span("flow_mse_fwd"):
+            _lib.check(lib.dmc_flow_mse_fwd(_lib.ptr(gen_flow), _lib.ptr(flow), _lib.ptr(loss),
+                                            _lib.ptr(partials), gen_flow.numel(), _stream()),
+                       "dmc_flow_mse_fwd")
         ctx.save_for_backward(gen_flow, flow)
         return loss
 
@@ -102,9 +151,10 @@ class _FlowMSE(torch.autograd.Function):
         gen_flow, flow = ctx.saved_tensors
         grad_loss = grad_loss.contiguous().float()
         grad = torch.empty_like(gen_flow)
-        _lib.check(lib.dmc_flow_mse_bwd(_lib.ptr(gen_flow), _lib.ptr(flow), _lib.ptr(grad_loss),
-                                        _lib.ptr(grad), gen_flow.numel(), _stream()),
-                   "dmc_flow_mse_bwd")
+        with _span("flow_mse_bwd"):
+            _lib.check(lib.dmc_flow_mse_bwd(_lib.ptr(gen_flow), _lib.ptr(flow), _lib.ptr(grad_loss),
+                                            _lib.ptr(grad), gen_flow.numel(), _stream()),
+                       "dmc_flow_mse_bwd")
         return grad, None
 
 
