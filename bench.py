@@ -124,9 +124,11 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    ops.profile_mark()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = one(i)
+    ops.profile_mark()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

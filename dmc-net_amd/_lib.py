@@ -18,6 +18,7 @@ _Z = ctypes.c_size_t
 SIGNATURES = {
     "dmc_version": (_I, []),
     "dmc_last_error": (ctypes.c_char_p, []),
+    "dmc_profile_mark": (_I, [_P]),
     "dmc_gen_tiny_workspace_bytes": (_Z, []),
     "dmc_gen_tiny_saved_bytes": (_Z, [_I, _I, _I]),
     "dmc_gen_tiny_gbuf_bytes": (_Z, [_I, _I, _I]),

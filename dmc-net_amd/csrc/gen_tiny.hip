@@ -41,30 +41,6 @@ __global__ void pack_params_kernel(ParamPtrs P, float* __restrict__ pk) {
     }
 }
 
-// Loads the 3x6 neighbourhood (rows y-1..y+1, cols x0-1..x0+4) of one plane, zero outside.
-template <bool VEC4>
-__device__ __forceinline__ void load_patch(const float* __restrict__ plane, int y, int x0, int H,
-                                           int W, float (&xv)[3][6]) {
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int yy = y + ky - 1;
-        const bool rowok = (yy >= 0) && (yy < H);
-        const float* row = plane + (size_t)(rowok ? yy : 0) * W;
-        if (VEC4 && rowok && x0 + 4 < W && x0 > 0) {
-            const float4 c = *reinterpret_cast<const float4*>(row + x0);
-            xv[ky][0] = row[x0 - 1];
-            xv[ky][1] = c.x; xv[ky][2] = c.y; xv[ky][3] = c.z; xv[ky][4] = c.w;
-            xv[ky][5] = row[x0 + 4];
-        } else {
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int xx = x0 - 1 + j;
-                xv[ky][j] = (rowok && xx >= 0 && xx < W) ? row[xx] : 0.f;
-            }
-        }
-    }
-}
-
 __device__ __forceinline__ const float* in_plane(const float* mv, const float* res,
                                                  const float* feat, int n, int p, size_t HW) {
     return p < 2 ? mv + ((size_t)n * 2 + p) * HW
@@ -73,48 +49,135 @@ __device__ __forceinline__ const float* in_plane(const float* mv, const float* r
 }
 
 // ------------------------------------------------------------------------------------------
-// forward, one layer: thread = 4 horizontally adjacent pixels x all COUT channels.
-// Weights are wave-uniform -> scalar loads, FMAs take them as SGPR operands.
-// block (64, 4): x = strip, y = row
+// One 3x3 layer over a 32x32-pixel tile per workgroup (256 threads).
+//
+//   lane = (row r of the tile, 4-pixel strip s); it produces 4 pixels x ALL output channels, so
+//   every input value fetched from LDS feeds 3*COUT FMAs and the weights are wave-uniform:
+//   they arrive through scalar loads and enter the FMAs as SGPR operands.
+//   Input planes are staged in chunks of 8 channels, branch-free (clamped addresses, values
+//   zeroed by a select), as [34 rows][32] interior + two compact halo-column arrays, so the
+//   lane's reads are one conflict-free ds_read_b128 and two conflict-free ds_read_b32 per row.
+//   52 KB of LDS per workgroup -> 3 workgroups (12 waves) per CU; another workgroup's FMAs
+//   cover this one's staging.
+//
+// MODE 0: forward hidden layer K   (inputs mv/res/feat[0..), output LeakyReLU(0.1) -> feat)
+// MODE 1: forward last layer       (output -> out, optionally + mv)
+// MODE 2: data-gradient of layer K (inputs g_K, output accumulated into gbuf[0..D), the
+//         channels of y_{K-1} finalised with LeakyReLU'(y_{K-1}))
 // ------------------------------------------------------------------------------------------
-template <int K, bool VEC4>
-__global__ __launch_bounds__(256) void gen_layer_fwd_kernel(
-    const float* __restrict__ mv, const float* __restrict__ res, float* feat,
-    const float* __restrict__ pk, float* __restrict__ out, int H, int W, int add_mv) {
-    constexpr int CIN = cin_of(K), COUT = cout_of(K);
-    const int n = blockIdx.z;
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    if (y >= H || x0 >= W) return;
+constexpr int LT = 32;                       // tile edge (pixels)
+constexpr int LCH = 8;                       // channels per staged chunk
+constexpr int LROWS = LT + 2;
+constexpr int L_MAIN = LROWS * LT;           // 1088 floats
+constexpr int L_HALO = LROWS * 8;            // per side
+constexpr int L_PLANE = L_MAIN + 2 * L_HALO; // 1632 floats per channel
+constexpr int L_LDS = LCH * L_PLANE;         // 13056 floats = 52,224 B
+
+struct LayerArgs {
+    const float* mv;      // [N,2,H,W]
+    const float* res;     // [N,3,H,W]
+    const float* feat;    // [N,28,H,W] features y0..y4 (read)
+    float* feat_out;      // same buffer (written by MODE 0)
+    const float* gout;    // [N,2,H,W]  dL/d(out)            (MODE 2)
+    float* gbuf;          // [N,28,H,W] feature gradients     (MODE 2)
+    const float* pk;      // packed parameters
+    float* out;           // [N,2,H,W]                        (MODE 1)
+    int H, W, add_mv;
+};
+
+template <int MODE, int K>
+__device__ __forceinline__ const float* layer_in_plane(const LayerArgs& a, int n, int c, size_t HW) {
+    if (MODE == 2)
+        return K == 5 ? a.gout + ((size_t)n * 2 + c) * HW
+                      : a.gbuf + ((size_t)n * NFEAT + (yoff(K) - NIN) + c) * HW;
+    return in_plane(a.mv, a.res, a.feat, n, c, HW);
+}
+
+template <int MODE, int K, bool VEC4>
+__global__ __launch_bounds__(256) void gen_layer_kernel(LayerArgs a) {
+    constexpr int CIN = MODE == 2 ? cout_of(K) : cin_of(K);
+    constexpr int COUT = MODE == 2 ? cin_of(K) - NIN : cout_of(K);
+    __shared__ __attribute__((aligned(16))) float lds[L_LDS];
+    const int n = blockIdx.z, ty0 = blockIdx.y * LT, tx0 = blockIdx.x * LT;
+    const int H = a.H, W = a.W;
     const size_t HW = (size_t)H * W;
+    const int tid = threadIdx.x, r = tid >> 3, s = tid & 7;
 
     float acc[COUT][4];
 #pragma unroll
     for (int co = 0; co < COUT; ++co) {
-        const float bv = pk[bf_off(K) + co];
+        const float bv = MODE == 2 ? 0.f : a.pk[bf_off(K) + co];
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[co][j] = bv;
     }
-    const float* wk = pk + wf_off(K);
+    const float* wbase = a.pk + (MODE == 2 ? wb_off(K) : wf_off(K));
+
 #pragma unroll 1
-    for (int p = 0; p < CIN; ++p) {
-        float xv[3][6];
-        load_patch<VEC4>(in_plane(mv, res, feat, n, p, HW), y, x0, H, W, xv);
-        const float* wp = wk + p * 9 * COUT;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                for (int co = 0; co < COUT; ++co) {
-                    const float wv = wp[(ky * 3 + kx) * COUT + co];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[co][j] = fmaf(xv[ky][j + kx], wv, acc[co][j]);
+    for (int c0 = 0; c0 < CIN; c0 += LCH) {
+        const int nch = (CIN - c0) < LCH ? (CIN - c0) : LCH;
+        if (c0 > 0) __syncthreads();
+        // ---- stage nch planes: rows ty0-1..ty0+32, interior cols tx0..tx0+31, halo cols ----
+        {
+            const int q = tid & 7, xx = tx0 + 4 * q;
+            for (int rr = tid >> 3; rr < nch * LROWS; rr += 32) {
+                const int c = rr / LROWS, row = rr - c * LROWS;
+                const int yy = ty0 - 1 + row;
+                const bool rowok = (yy >= 0) && (yy < H);
+                const float* src = layer_in_plane<MODE, K>(a, n, c0 + c, HW) + (size_t)(rowok ? yy : 0) * W;
+                float4 v;
+                if (VEC4) {
+                    const bool ok = rowok && xx < W;
+                    v = *reinterpret_cast<const float4*>(src + (ok ? xx : 0));
+                    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    v.x = (rowok && xx + 0 < W) ? src[xx + 0 < W ? xx + 0 : 0] : 0.f;
+                    v.y = (rowok && xx + 1 < W) ? src[xx + 1 < W ? xx + 1 : 0] : 0.f;
+                    v.z = (rowok && xx + 2 < W) ? src[xx + 2 < W ? xx + 2 : 0] : 0.f;
+                    v.w = (rowok && xx + 3 < W) ? src[xx + 3 < W ? xx + 3 : 0] : 0.f;
                 }
+                *reinterpret_cast<float4*>(lds + c * L_PLANE + row * LT + 4 * q) = v;
+                // halo columns of strip q: left = col 4q-1, right = col 4q+4 (tile-relative)
+                const int xl = xx - 1, xr = xx + 4;
+                const bool okl = rowok && xl >= 0 && xl < W, okr = rowok && xr < W;
+                const float hl = src[okl ? xl : 0], hr = src[okr ? xr : 0];
+                lds[c * L_PLANE + L_MAIN + row * 8 + q] = okl ? hl : 0.f;
+                lds[c * L_PLANE + L_MAIN + L_HALO + row * 8 + q] = okr ? hr : 0.f;
+            }
+        }
+        __syncthreads();
+        // ---- accumulate ----
+#pragma unroll 1
+        for (int c = 0; c < nch; ++c) {
+            const float* pl = lds + c * L_PLANE;
+            float xv[3][6];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int row = r + ky;
+                const float4 m = *reinterpret_cast<const float4*>(pl + row * LT + 4 * s);
+                xv[ky][0] = pl[L_MAIN + row * 8 + s];
+                xv[ky][1] = m.x; xv[ky][2] = m.y; xv[ky][3] = m.z; xv[ky][4] = m.w;
+                xv[ky][5] = pl[L_MAIN + L_HALO + row * 8 + s];
+            }
+            const float* wp = wbase + (c0 + c) * 9 * COUT;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) {
+                        const float wv = wp[(ky * 3 + kx) * COUT + co];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[co][j] = fmaf(xv[ky][j + kx], wv, acc[co][j]);
+                    }
+        }
     }
+
+    // ---- epilogue ----
+    const int y = ty0 + r, x0 = tx0 + 4 * s;
+    if (y >= H || x0 >= W) return;
     const size_t pix = (size_t)y * W + x0;
-    if (K < 5) {
-        float* dst = feat + ((size_t)n * NFEAT + (yoff(K) - NIN)) * HW + pix;
+    if (MODE == 0) {
+        float* dst = a.feat_out + ((size_t)n * NFEAT + (yoff(K) - NIN)) * HW + pix;
 #pragma unroll
         for (int co = 0; co < COUT; ++co) {
             float v[4];
@@ -128,159 +191,61 @@ __global__ __launch_bounds__(256) void gen_layer_fwd_kernel(
                     if (x0 + j < W) dst[co * HW + j] = v[j];
             }
         }
-    } else {
+    } else if (MODE == 1) {
 #pragma unroll
         for (int co = 0; co < COUT; ++co) {
-            float* dst = out + ((size_t)n * 2 + co) * HW + pix;
-            const float* m = mv + ((size_t)n * 2 + co) * HW + pix;
+            float* dst = a.out + ((size_t)n * 2 + co) * HW + pix;
+            const float* m = a.mv + ((size_t)n * 2 + co) * HW + pix;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (VEC4 || x0 + j < W) dst[j] = acc[co][j] + (add_mv ? m[j] : 0.f);
+                if (VEC4 || x0 + j < W) dst[j] = acc[co][j] + (a.add_mv ? m[j] : 0.f);
         }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// backward, data path of layer K (K = 5..1): correlation of g_K (COUT[K] channels) with the
-// flipped weights into the gradient of every feature channel below it, accumulated in gbuf.
-// After layer K's contribution the channels of y_{K-1} are complete (all their consumers
-// K..5 are done), so they are turned into g_{K-1} = dL/dy_{K-1} * LeakyReLU'(.) right here.
-// ------------------------------------------------------------------------------------------
-template <int K, bool VEC4>
-__global__ __launch_bounds__(256) void gen_layer_bwd_data_kernel(
-    const float* __restrict__ gout, const float* __restrict__ feat, float* gbuf,
-    const float* __restrict__ pk, int H, int W) {
-    constexpr int G = cout_of(K), D = cin_of(K) - NIN, TOP0 = D - cout_of(K - 1);
-    const int n = blockIdx.z;
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    if (y >= H || x0 >= W) return;
-    const size_t HW = (size_t)H * W;
-
-    float acc[D][4];
+    } else {
+        constexpr int TOP0 = COUT - cout_of(K - 1 < 0 ? 0 : K - 1);
 #pragma unroll
-    for (int cd = 0; cd < D; ++cd)
+        for (int cd = 0; cd < COUT; ++cd) {
+            float* dst = a.gbuf + ((size_t)n * NFEAT + cd) * HW + pix;
+            const float* f = a.feat + ((size_t)n * NFEAT + cd) * HW + pix;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[cd][j] = 0.f;
-#pragma unroll 1
-    for (int cg = 0; cg < G; ++cg) {
-        const float* plane = (K == 5) ? gout + ((size_t)n * 2 + cg) * HW
-                                      : gbuf + ((size_t)n * NFEAT + (yoff(K) - NIN) + cg) * HW;
-        float xv[3][6];
-        load_patch<VEC4>(plane, y, x0, H, W, xv);
-        const float* wp = pk + wb_off(K) + cg * 9 * D;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                for (int cd = 0; cd < D; ++cd) {
-                    const float wv = wp[(ky * 3 + kx) * D + cd];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[cd][j] = fmaf(xv[ky][j + kx], wv, acc[cd][j]);
+            for (int j = 0; j < 4; ++j) {
+                if (VEC4 || x0 + j < W) {
+                    float v = acc[cd][j];
+                    if (K != 5) v += dst[j];
+                    if (cd >= TOP0) v *= (f[j] > 0.f ? 1.f : 0.1f);
+                    dst[j] = v;
                 }
-    }
-    const size_t pix = (size_t)y * W + x0;
-#pragma unroll
-    for (int cd = 0; cd < D; ++cd) {
-        float* dst = gbuf + ((size_t)n * NFEAT + cd) * HW + pix;
-        const float* a = feat + ((size_t)n * NFEAT + cd) * HW + pix;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (VEC4 || x0 + j < W) {
-                float v = acc[cd][j];
-                if (K != 5) v += dst[j];
-                if (cd >= TOP0) v *= (a[j] > 0.f ? 1.f : 0.1f);
-                dst[j] = v;
             }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// backward, weight path.  Persistent workgroups; each stages an 8x32-pixel tile of all 33
-// input/feature planes (halo 1) in LDS.  A LANE owns one (layer, input channel, ky) triple and
-// keeps its 3 x COUT partial sums in registers for the whole launch; the pixel loop is
-// wave-uniform, so dL/dy values come in through scalar loads and feed the FMAs as SGPR
-// operands.  One extra lane per layer has x == 1 and thereby accumulates the bias gradient.
-// Per-workgroup partials are reduced by a second kernel in a fixed order (deterministic).
+// backward, weight path: one fp32-MFMA GEMM over pixels.
+//
+//   dW[(k,co)][(ci,tap)] = sum_px g_k[co][px] * x[ci][px + tap]
+//
+// Rows M = the 30 (layer, cout) pairs of all six layers, split in two 16-row tiles
+//   tile A = g0(8) g1(8)            tile B = g2(6) g3(4) g4(2) g5(2) + 2 zero rows
+// columns N = (physical input channel, tap) = 33*9 = 297 (+ column 297 == 1 for the bias
+// gradient), in 19 tiles of 16; K = pixels, 4 per v_mfma_f32_16x16x4_f32.  Tile A only needs
+// input channels < 13 (N tiles 0..7) plus the bias tile: 28 MFMAs per 4 pixels, 66 % of them
+// useful -- exact fp32 (an fmaf chain per accumulator) at the matrix-core rate, the VALU stays
+// free for addressing.  Persistent workgroups stage an 8x32-pixel tile of the 33 input/feature
+// planes (halo 1) and of the 30 gradient planes in LDS; the 28 accumulator tiles (112
+// registers) live in registers for the whole launch and are reduced across waves (fixed
+// order) and across workgroups (second kernel, fixed order): deterministic.
 // ------------------------------------------------------------------------------------------
-constexpr int WT_H = 8, WT_W = 32, WT_ROWS = WT_H + 2, WT_PITCH = 40, WT_COL0 = 3;
-constexpr int WT_LDS = 33 * WT_ROWS * WT_PITCH;
-constexpr int WGRAD_MAX_GROUPS = 768;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int K, int CHUNK>
-struct WTask {
-    static constexpr int CIN = cin_of(K), COUT = cout_of(K), NIT = CIN * 3;
-    float acc[3][COUT];
-    int ci, ky;
-    bool active, isbias;
-
-    __device__ __forceinline__ void init(int lane) {
-        const int item = CHUNK * 64 + lane;
-        isbias = (item == NIT);
-        active = (item <= NIT);
-        const int it = item < NIT ? item : NIT - 1;
-        ci = it / 3;
-        ky = it % 3;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-            for (int co = 0; co < COUT; ++co) acc[kx][co] = 0.f;
-    }
-
-    // gk: plane of g_K channel 0 of this frame; (ty0, tx0): tile origin; th x tw valid pixels
-    __device__ __forceinline__ void tile(const float* lds, const float* __restrict__ gk, size_t HW,
-                                         int W, int ty0, int tx0, int th, int tw) {
-        const float* xbase = lds + (ci * WT_ROWS + ky) * WT_PITCH + WT_COL0;
-        for (int r = 0; r < th; ++r) {
-            const float* xr = xbase + r * WT_PITCH;
-            const float* grow = gk + (size_t)(ty0 + r) * W + tx0;
-            for (int s = 0; s * 4 < tw; ++s) {
-                float x[6];
-                const float4 c = *reinterpret_cast<const float4*>(xr + 4 * s + 1);
-                x[0] = xr[4 * s];
-                x[1] = c.x; x[2] = c.y; x[3] = c.z; x[4] = c.w;
-                x[5] = xr[4 * s + 5];
-                if (isbias) {
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) x[j] = 1.f;
-                }
-                const bool full = (4 * s + 3 < tw);
-#pragma unroll
-                for (int co = 0; co < COUT; ++co) {
-                    float g[4];
-                    const float* gp = grow + co * HW + 4 * s;
-                    if (full) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) g[j] = gp[j];
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) g[j] = (4 * s + j < tw) ? gp[j] : 0.f;
-                    }
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[kx][co] = fmaf(x[j + kx], g[j], acc[kx][co]);
-                }
-            }
-        }
-    }
-
-    __device__ __forceinline__ void store(float* __restrict__ part) const {
-        if (!active) return;
-        if (isbias) {
-#pragma unroll
-            for (int co = 0; co < COUT; ++co) part[bf_off(K) + co] = acc[1][co];
-        } else {
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                for (int co = 0; co < COUT; ++co)
-                    part[wf_off(K) + ((ci * 3 + ky) * 3 + kx) * COUT + co] = acc[kx][co];
-        }
-    }
-};
+constexpr int WT_H = 8, WT_W = 32;
+constexpr int WX_PITCH = 36, WX_PLANE = 364;           // plane % 32 == 12: conflict-light gathers
+constexpr int WG_PLANE = WT_H * WT_W + 2;              // 258: conflict-free A-fragment reads
+constexpr int WX_FLOATS = 33 * WX_PLANE, WG_FLOATS = 32 * WG_PLANE;
+constexpr int WT_LDS = WX_FLOATS + WG_FLOATS;          // 20268 floats = 81,072 B -> 2 WG / CU
+constexpr int NT_A = 9, NT_B = 19, NT_ALL = NT_A + NT_B;   // accumulator tiles per wave
+constexpr int WPART = NT_ALL * 256;                    // floats per workgroup partial
+constexpr int WGRAD_MAX_GROUPS = 512;
+constexpr int BIAS_COL = 297;
 
 struct WgradArgs {
     const float* mv;
@@ -292,86 +257,188 @@ struct WgradArgs {
     int N, H, W, tiles_x, tiles_y;
 };
 
-__device__ __forceinline__ const float* g_plane(const WgradArgs& a, int k, int n, size_t HW) {
-    return k == 5 ? a.gout + (size_t)n * 2 * HW
-                  : a.gbuf + ((size_t)n * NFEAT + (yoff(k) - NIN)) * HW;
-}
-
-__device__ __forceinline__ void wgrad_stage_tile(const WgradArgs& a, float* lds, int n, int ty0,
-                                                 int tx0, size_t HW) {
-    constexpr int COLS = WT_W + 2;
-    for (int i = threadIdx.x; i < 33 * WT_ROWS * COLS; i += 256) {
-        const int c = i / (WT_ROWS * COLS);
-        const int rem = i - c * (WT_ROWS * COLS);
+// Generic (any W) staging: one bounds-checked element per thread-iteration.
+__device__ __forceinline__ void wgrad_stage_tile_generic(const WgradArgs& a, float* lds, int n,
+                                                         int ty0, int tx0, size_t HW) {
+    constexpr int COLS = WT_W + 2, ROWS = WT_H + 2;
+    for (int i = threadIdx.x; i < 33 * ROWS * COLS; i += 256) {
+        const int c = i / (ROWS * COLS);
+        const int rem = i - c * (ROWS * COLS);
         const int row = rem / COLS, col = rem - row * COLS;
         const int yy = ty0 - 1 + row, xx = tx0 - 1 + col;
         float v = 0.f;
         if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
             v = in_plane(a.mv, a.res, a.feat, n, c, HW)[(size_t)yy * a.W + xx];
-        lds[(c * WT_ROWS + row) * WT_PITCH + WT_COL0 + col] = v;
+        lds[c * WX_PLANE + row * WX_PITCH + col] = v;
+    }
+    float* gl = lds + WX_FLOATS;
+    for (int i = threadIdx.x; i < 30 * WT_H * WT_W; i += 256) {
+        const int c = i / (WT_H * WT_W);
+        const int rem = i - c * (WT_H * WT_W);
+        const int row = rem / WT_W, col = rem - row * WT_W;
+        const int yy = ty0 + row, xx = tx0 + col;
+        float v = 0.f;
+        if (yy < a.H && xx < a.W) {
+            const float* src = c < NFEAT ? a.gbuf + ((size_t)n * NFEAT + c) * HW
+                                         : a.gout + ((size_t)n * 2 + (c - NFEAT)) * HW;
+            v = src[(size_t)yy * a.W + xx];
+        }
+        gl[c * WG_PLANE + rem] = v;
     }
 }
 
-// The tile loop, run by every wave with its own task set (T1 [, T2 [, T3]]).
-template <class T1, int K1, class T2, int K2, class T3, int K3>
-__device__ __forceinline__ void wgrad_wave_loop(const WgradArgs& a, float* lds, int lane) {
-    T1 t1; T2 t2; T3 t3;
-    t1.init(lane); t2.init(lane); t3.init(lane);
+// W % 4 == 0: 16-byte global loads, 8 lanes per 32-pixel row, all loads of a thread independent.
+//   x planes: rows ty0-1 .. ty0+8, cols tx0-1 .. tx0+32 (LDS col 0 / 33 = halo), zero outside
+//   gradient planes 0..27 = g0..g4 (gbuf), 28..29 = g5 (grad_out)
+__device__ __forceinline__ void wgrad_stage_tile_vec(const WgradArgs& a, float* lds, int n, int ty0,
+                                                     int tx0, size_t HW) {
+    const int q = threadIdx.x & 7, xx = tx0 + 4 * q;
+    const bool colok = xx < a.W;                       // W % 4 == 0 -> the whole quad is in or out
+#pragma unroll 2
+    for (int rr = threadIdx.x >> 3; rr < 33 * (WT_H + 2); rr += 32) {
+        const int c = rr / (WT_H + 2), row = rr - c * (WT_H + 2);
+        const int yy = ty0 - 1 + row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (colok && yy >= 0 && yy < a.H)
+            v = *reinterpret_cast<const float4*>(in_plane(a.mv, a.res, a.feat, n, c, HW) + (size_t)yy * a.W + xx);
+        float* d = lds + c * WX_PLANE + row * WX_PITCH + 1 + 4 * q;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    for (int i = threadIdx.x; i < 33 * (WT_H + 2) * 2; i += 256) {
+        const int rr = i >> 1, side = i & 1;
+        const int c = rr / (WT_H + 2), row = rr - c * (WT_H + 2);
+        const int yy = ty0 - 1 + row, xh = side ? tx0 + WT_W : tx0 - 1;
+        float v = 0.f;
+        if (yy >= 0 && yy < a.H && xh >= 0 && xh < a.W)
+            v = in_plane(a.mv, a.res, a.feat, n, c, HW)[(size_t)yy * a.W + xh];
+        lds[c * WX_PLANE + row * WX_PITCH + (side ? WT_W + 1 : 0)] = v;
+    }
+    float* gl = lds + WX_FLOATS;
+#pragma unroll 2
+    for (int rr = threadIdx.x >> 3; rr < 30 * WT_H; rr += 32) {
+        const int c = rr / WT_H, row = rr - c * WT_H;
+        const int yy = ty0 + row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (colok && yy < a.H) {
+            const float* src = c < NFEAT ? a.gbuf + ((size_t)n * NFEAT + c) * HW
+                                         : a.gout + ((size_t)n * 2 + (c - NFEAT)) * HW;
+            v = *reinterpret_cast<const float4*>(src + (size_t)yy * a.W + xx);
+        }
+        float* d = gl + c * WG_PLANE + row * WT_W + 4 * q;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(256, 2) void gen_bwd_weight_kernel(WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[WT_LDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kq = lane >> 4;          // column / pixel-in-group of this lane
+    float* gl = lds + WX_FLOATS;
+    for (int i = threadIdx.x; i < 2 * WG_PLANE; i += 256) gl[30 * WG_PLANE + i] = 0.f;
+
+    // per-lane gather offsets of the B fragments (x[(ci,tap)][pixel kq of the group])
+    int offB[NT_B];
+#pragma unroll
+    for (int t = 0; t < NT_B; ++t) {
+        int nn = 16 * t + j;
+        nn = nn < 297 ? nn : 296;
+        const int ci = nn / 9, tap = nn - ci * 9;
+        offB[t] = ci * WX_PLANE + (tap / 3) * WX_PITCH + (tap % 3) + kq;
+    }
+    const bool ones = (16 * 18 + j) == BIAS_COL;      // bias column lives in N tile 18
+    // A fragments: row j of the M tile, pixel kq
+    const int offA0 = j * WG_PLANE + kq;              // tile A: planes 0..15
+    const int offA1 = (16 + j) * WG_PLANE + kq;       // tile B: planes 16..29 (+2 zero planes)
+
+    f32x4 accA[NT_A], accB[NT_B];
+#pragma unroll
+    for (int t = 0; t < NT_A; ++t) accA[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT_B; ++t) accB[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
     const size_t HW = (size_t)a.H * a.W;
     const int per_frame = a.tiles_x * a.tiles_y;
     const int ntiles = a.N * per_frame;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int n = t / per_frame, r = t - n * per_frame;
-        const int ty0 = (r / a.tiles_x) * WT_H, tx0 = (r % a.tiles_x) * WT_W;
-        const int th = min(WT_H, a.H - ty0), tw = min(WT_W, a.W - tx0);
-        __syncthreads();   // previous tile fully consumed
-        wgrad_stage_tile(a, lds, n, ty0, tx0, HW);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n = tile / per_frame, r0 = tile - n * per_frame;
+        const int ty0 = (r0 / a.tiles_x) * WT_H, tx0 = (r0 % a.tiles_x) * WT_W;
         __syncthreads();
-        t1.tile(lds, g_plane(a, K1, n, HW), HW, a.W, ty0, tx0, th, tw);
-        if (K2 >= 0) t2.tile(lds, g_plane(a, K2 < 0 ? 0 : K2, n, HW), HW, a.W, ty0, tx0, th, tw);
-        if (K3 >= 0) t3.tile(lds, g_plane(a, K3 < 0 ? 0 : K3, n, HW), HW, a.W, ty0, tx0, th, tw);
+        if (VEC4) wgrad_stage_tile_vec(a, lds, n, ty0, tx0, HW);
+        else wgrad_stage_tile_generic(a, lds, n, ty0, tx0, HW);
+        __syncthreads();
+        // 64 groups of 4 pixels per tile, 16 per wave: wave w takes rows 2w, 2w+1
+#pragma unroll 1
+        for (int g = 0; g < 16; ++g) {
+            const int r = wave * 2 + (g >> 3), c0 = (g & 7) * 4;
+            const int xb = r * WX_PITCH + c0, gb = r * WT_W + c0;
+            const float a0 = gl[offA0 + gb], a1 = gl[offA1 + gb];
+            float b[NT_B];
+#pragma unroll
+            for (int t = 0; t < NT_B; ++t) b[t] = lds[offB[t] + xb];
+            if (ones) b[18] = 1.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                accA[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[t], accA[t], 0, 0, 0);
+            accA[8] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[18], accA[8], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT_B; ++t)
+                accB[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[t], accB[t], 0, 0, 0);
+        }
     }
-    float* part = a.partials + (size_t)blockIdx.x * NPARAM;
-    t1.store(part);
-    if (K2 >= 0) t2.store(part);
-    if (K3 >= 0) t3.store(part);
+    // cross-wave reduction in LDS, fixed order (wave 0 stores, waves 1..3 add in turn)
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < NT_ALL; ++t) {
+                const f32x4 v = t < NT_A ? accA[t < NT_A ? t : 0] : accB[t >= NT_A ? t - NT_A : 0];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int idx = t * 256 + (kq * 4 + q) * 16 + j;   // C row = kq*4+q, col = j
+                    lds[idx] = (w == 0 ? 0.f : lds[idx]) + v[q];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* part = a.partials + (size_t)blockIdx.x * WPART;
+    for (int i = threadIdx.x; i < WPART; i += 256) part[i] = lds[i];
 }
 
-__global__ __launch_bounds__(256) void gen_bwd_weight_kernel(WgradArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[WT_LDS];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63;
-    // cost per pixel of a task = 3 * COUT; the four waves carry 30 / 30 / 30 / 24
-    if (wave == 0) {
-        wgrad_wave_loop<WTask<1, 0>, 1, WTask<5, 0>, 5, WTask<5, 0>, -1>(a, lds, lane);
-    } else if (wave == 1) {
-        wgrad_wave_loop<WTask<0, 0>, 0, WTask<5, 1>, 5, WTask<5, 1>, -1>(a, lds, lane);
-    } else if (wave == 2) {
-        wgrad_wave_loop<WTask<2, 0>, 2, WTask<3, 0>, 3, WTask<3, 0>, -1>(a, lds, lane);
-    } else {
-        wgrad_wave_loop<WTask<3, 1>, 3, WTask<4, 0>, 4, WTask<4, 1>, 4>(a, lds, lane);
-    }
-}
-
-// partials [groups][NPARAM] (packed order) -> the 12 gradient tensors in PyTorch layout
+// partials [groups][28 tiles][16][16] -> the 12 gradient tensors in PyTorch layout
 __global__ void gen_bwd_weight_reduce_kernel(const float* __restrict__ partials, int groups,
                                              GradPtrs G) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= NPARAM) return;
-    float s = 0.f;
-    for (int g = 0; g < groups; ++g) s += partials[(size_t)g * NPARAM + i];
+    int k = 0, co, col, p = 0, tap = 0;
     if (i < WF_TOTAL) {
-        int k = 0;
         while (k < NL - 1 && i >= wf_off(k + 1)) ++k;
-        const int cin = cin_of(k), cout = cout_of(k);
+        const int cout = cout_of(k);
         const int r = i - wf_off(k);
-        const int co = r % cout, tap = (r / cout) % 9, p = r / (cout * 9);
-        G.w[k][(co * cin + logical_of(k, p)) * 9 + tap] = s;
+        co = r % cout; tap = (r / cout) % 9; p = r / (cout * 9);
+        col = p * 9 + tap;
     } else {
-        int k = 0;
         while (k < NL - 1 && i >= bf_off(k + 1)) ++k;
-        G.b[k][i - bf_off(k)] = s;
+        co = i - bf_off(k);
+        col = BIAS_COL;
     }
+    const int nt = col >> 4, jj = col & 15;
+    int slot, row;
+    if (k < 2) {                      // tile A: g0 rows 0..7, g1 rows 8..15
+        row = k * 8 + co;
+        slot = nt == 18 ? 8 : nt;
+    } else {                          // tile B: g2 0..5, g3 6..9, g4 10..11, g5 12..13
+        row = (k == 2 ? 0 : k == 3 ? 6 : k == 4 ? 10 : 12) + co;
+        slot = NT_A + nt;
+    }
+    const size_t off = (size_t)slot * 256 + row * 16 + jj;
+    float s = 0.f;
+    for (int g = 0; g < groups; ++g) s += partials[(size_t)g * WPART + off];
+    if (i < WF_TOTAL)
+        G.w[k][(co * cin_of(k) + logical_of(k, p)) * 9 + tap] = s;
+    else
+        G.b[k][co] = s;
 }
 
 int wgrad_groups(int N, int H, int W) {
@@ -379,26 +446,12 @@ int wgrad_groups(int N, int H, int W) {
     return (int)(tiles < WGRAD_MAX_GROUPS ? tiles : WGRAD_MAX_GROUPS);
 }
 
-template <int K>
-int launch_fwd_layer(const float* mv, const float* res, float* feat, const float* pk, float* out,
-                     int N, int H, int W, int add_mv, hipStream_t s) {
-    const dim3 block(64, 4), grid((W + 255) / 256, (H + 3) / 4, N);
-    if (W % 4 == 0)
-        gen_layer_fwd_kernel<K, true><<<grid, block, 0, s>>>(mv, res, feat, pk, out, H, W, add_mv);
-    else
-        gen_layer_fwd_kernel<K, false><<<grid, block, 0, s>>>(mv, res, feat, pk, out, H, W, add_mv);
-    return check_launch("gen_layer_fwd");
-}
-
-template <int K>
-int launch_bwd_data_layer(const float* gout, const float* feat, float* gbuf, const float* pk, int N,
-                          int H, int W, hipStream_t s) {
-    const dim3 block(64, 4), grid((W + 255) / 256, (H + 3) / 4, N);
-    if (W % 4 == 0)
-        gen_layer_bwd_data_kernel<K, true><<<grid, block, 0, s>>>(gout, feat, gbuf, pk, H, W);
-    else
-        gen_layer_bwd_data_kernel<K, false><<<grid, block, 0, s>>>(gout, feat, gbuf, pk, H, W);
-    return check_launch("gen_layer_bwd_data");
+template <int MODE, int K>
+int launch_layer(const LayerArgs& a, int N, hipStream_t s) {
+    const dim3 grid((a.W + LT - 1) / LT, (a.H + LT - 1) / LT, N);
+    if (a.W % 4 == 0) gen_layer_kernel<MODE, K, true><<<grid, 256, 0, s>>>(a);
+    else gen_layer_kernel<MODE, K, false><<<grid, 256, 0, s>>>(a);
+    return check_launch("gen_layer");
 }
 
 int pack(const float* const* w, const float* const* b, float* pk, hipStream_t s) {
@@ -423,7 +476,7 @@ size_t dmc_gen_tiny_saved_bytes(int N, int H, int W) {
 }
 size_t dmc_gen_tiny_gbuf_bytes(int N, int H, int W) { return dmc_gen_tiny_saved_bytes(N, H, W); }
 size_t dmc_gen_tiny_partials_bytes(int N, int H, int W) {
-    return (size_t)wgrad_groups(N, H, W) * NPARAM * sizeof(float);
+    return (size_t)wgrad_groups(N, H, W) * WPART * sizeof(float);
 }
 
 int dmc_gen_tiny_fwd(const float* mv, const float* res, const float* const* w,
@@ -435,12 +488,15 @@ int dmc_gen_tiny_fwd(const float* mv, const float* res, const float* const* w,
     hipStream_t s = (hipStream_t)stream;
     int rc = pack(w, b, workspace, s);
     if (rc) return rc;
-    if ((rc = launch_fwd_layer<0>(mv, res, saved, workspace, out, N, H, W, add_mv_delta, s))) return rc;
-    if ((rc = launch_fwd_layer<1>(mv, res, saved, workspace, out, N, H, W, add_mv_delta, s))) return rc;
-    if ((rc = launch_fwd_layer<2>(mv, res, saved, workspace, out, N, H, W, add_mv_delta, s))) return rc;
-    if ((rc = launch_fwd_layer<3>(mv, res, saved, workspace, out, N, H, W, add_mv_delta, s))) return rc;
-    if ((rc = launch_fwd_layer<4>(mv, res, saved, workspace, out, N, H, W, add_mv_delta, s))) return rc;
-    return launch_fwd_layer<5>(mv, res, saved, workspace, out, N, H, W, add_mv_delta, s);
+    LayerArgs a;
+    a.mv = mv; a.res = res; a.feat = saved; a.feat_out = saved; a.gout = nullptr; a.gbuf = nullptr;
+    a.pk = workspace; a.out = out; a.H = H; a.W = W; a.add_mv = add_mv_delta;
+    if ((rc = launch_layer<0, 0>(a, N, s))) return rc;
+    if ((rc = launch_layer<0, 1>(a, N, s))) return rc;
+    if ((rc = launch_layer<0, 2>(a, N, s))) return rc;
+    if ((rc = launch_layer<0, 3>(a, N, s))) return rc;
+    if ((rc = launch_layer<0, 4>(a, N, s))) return rc;
+    return launch_layer<1, 5>(a, N, s);
 }
 
 int dmc_gen_tiny_bwd(const float* mv, const float* res, const float* const* w, const float* saved,
@@ -458,11 +514,14 @@ int dmc_gen_tiny_bwd(const float* mv, const float* res, const float* const* w, c
     }
     int rc = pack(w, nullptr, workspace, s);
     if (rc) return rc;
-    if ((rc = launch_bwd_data_layer<5>(grad_out, saved, gbuf, workspace, N, H, W, s))) return rc;
-    if ((rc = launch_bwd_data_layer<4>(grad_out, saved, gbuf, workspace, N, H, W, s))) return rc;
-    if ((rc = launch_bwd_data_layer<3>(grad_out, saved, gbuf, workspace, N, H, W, s))) return rc;
-    if ((rc = launch_bwd_data_layer<2>(grad_out, saved, gbuf, workspace, N, H, W, s))) return rc;
-    if ((rc = launch_bwd_data_layer<1>(grad_out, saved, gbuf, workspace, N, H, W, s))) return rc;
+    LayerArgs la;
+    la.mv = mv; la.res = res; la.feat = saved; la.feat_out = nullptr; la.gout = grad_out; la.gbuf = gbuf;
+    la.pk = workspace; la.out = nullptr; la.H = H; la.W = W; la.add_mv = 0;
+    if ((rc = launch_layer<2, 5>(la, N, s))) return rc;
+    if ((rc = launch_layer<2, 4>(la, N, s))) return rc;
+    if ((rc = launch_layer<2, 3>(la, N, s))) return rc;
+    if ((rc = launch_layer<2, 2>(la, N, s))) return rc;
+    if ((rc = launch_layer<2, 1>(la, N, s))) return rc;
 
     WgradArgs a;
     a.mv = mv; a.res = res; a.feat = saved; a.gout = grad_out; a.gbuf = gbuf; a.partials = partials;
@@ -470,7 +529,8 @@ int dmc_gen_tiny_bwd(const float* mv, const float* res, const float* const* w, c
     a.tiles_x = (W + WT_W - 1) / WT_W;
     a.tiles_y = (H + WT_H - 1) / WT_H;
     const int groups = wgrad_groups(N, H, W);
-    gen_bwd_weight_kernel<<<groups, 256, 0, s>>>(a);
+    if (W % 4 == 0) gen_bwd_weight_kernel<true><<<groups, 256, 0, s>>>(a);
+    else gen_bwd_weight_kernel<false><<<groups, 256, 0, s>>>(a);
     if ((rc = check_launch("gen_bwd_weight"))) return rc;
     gen_bwd_weight_reduce_kernel<<<(NPARAM + 127) / 128, 128, 0, s>>>(partials, groups, G);
     return check_launch("gen_bwd_weight_reduce");

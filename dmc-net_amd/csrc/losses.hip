@@ -137,6 +137,10 @@ __global__ __launch_bounds__(1024) void consensus_ce_kernel(const float* __restr
 
 }  // namespace
 
+// Empty kernel with a recognisable name: bench.py brackets its timed region with it so that a
+// rocprofv3 kernel trace can be cut to that region (tools/rocprof_region.py).
+__global__ void dmc_profile_mark_kernel() {}
+
 extern "C" {
 
 size_t dmc_flow_mse_partials_bytes(void) { return (size_t)MSE_BLOCKS * sizeof(double); }
@@ -174,6 +178,11 @@ int dmc_consensus_ce_fwd_bwd(const float* logits, const int64_t* target, float* 
     consensus_ce_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(logits, target, consensus, loss_out,
                                                               grad_logits, B, S, C);
     return check_launch("consensus_ce");
+}
+
+int dmc_profile_mark(dmc_stream_t stream) {
+    dmc_profile_mark_kernel<<<1, 64, 0, (hipStream_t)stream>>>();
+    return check_launch("dmc_profile_mark");
 }
 
 int dmc_version(void) { return 100; }   // 0.1.0

@@ -58,6 +58,11 @@ def _stream():
     return _lib._P(torch.cuda.current_stream().cuda_stream)
 
 
+def profile_mark():
+    """Bracket a region in a rocprofv3 kernel trace (see tools/rocprof_region.py)."""
+    _lib.check(_lib.load().dmc_profile_mark(_stream()), "dmc_profile_mark")
+
+
 def _need_cuda(*tensors):
     for t in tensors:
         if t is None:

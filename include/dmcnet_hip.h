@@ -40,6 +40,9 @@ typedef void* dmc_stream_t; /* hipStream_t */
 int dmc_version(void);
 /* Text of the last error on this host thread ("" if none). */
 const char* dmc_last_error(void);
+/* Launches an empty kernel named dmc_profile_mark_kernel on `stream`: a marker that brackets
+ * a region of interest in a rocprofv3 kernel trace (no reference counterpart; tooling only). */
+int dmc_profile_mark(dmc_stream_t stream);
 
 /* ---- EstimatorDenseNetTiny (the DMC generator every shipped recipe uses) ----------------
  * Replaces: EstimatorDenseNetTiny.forward            code/dmcnet/model.py:187-194
