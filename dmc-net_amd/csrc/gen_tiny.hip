@@ -7,6 +7,8 @@
 // This file holds the "layerwise" path: one launch per layer, features kept in a
 // [N][28][H][W] buffer in physical (append) channel order.  It handles any H, W and is the
 // path the backward pass reads its saved activations from.
+#include <stdlib.h>
+
 #include "dmc_common.h"
 
 using namespace dmc;
@@ -446,8 +448,28 @@ int wgrad_groups(int N, int H, int W) {
     return (int)(tiles < WGRAD_MAX_GROUPS ? tiles : WGRAD_MAX_GROUPS);
 }
 
+// Frames are processed in chunks small enough for a chunk's planes (inputs + 28 features, or
+// 28 features + 28 gradients) to stay resident in the 256 MiB Infinity Cache between layers.
+int frames_per_pass(int N, int H, int W) {
+    static const long budget = [] {
+        const char* e = getenv("DMC_GEN_CACHE_MB");
+        return (e ? atol(e) : (1L << 20)) << 20;   // default: one pass (chunking measured slower)
+    }();
+    const long per_frame = (long)(NIN + 2 * NFEAT) * H * W * sizeof(float);
+    long f = budget / (per_frame > 0 ? per_frame : 1);
+    return (int)(f < 1 ? 1 : (f > N ? N : f));
+}
+
 template <int MODE, int K>
-int launch_layer(const LayerArgs& a, int N, hipStream_t s) {
+int launch_layer(LayerArgs a, int n0, int N, hipStream_t s) {
+    const size_t HW = (size_t)a.H * a.W;
+    a.mv = a.mv ? a.mv + (size_t)n0 * 2 * HW : nullptr;
+    a.res = a.res ? a.res + (size_t)n0 * 3 * HW : nullptr;
+    a.feat = a.feat ? a.feat + (size_t)n0 * NFEAT * HW : nullptr;
+    a.feat_out = a.feat_out ? a.feat_out + (size_t)n0 * NFEAT * HW : nullptr;
+    a.gout = a.gout ? a.gout + (size_t)n0 * 2 * HW : nullptr;
+    a.gbuf = a.gbuf ? a.gbuf + (size_t)n0 * NFEAT * HW : nullptr;
+    a.out = a.out ? a.out + (size_t)n0 * 2 * HW : nullptr;
     const dim3 grid((a.W + LT - 1) / LT, (a.H + LT - 1) / LT, N);
     if (a.W % 4 == 0) gen_layer_kernel<MODE, K, true><<<grid, 256, 0, s>>>(a);
     else gen_layer_kernel<MODE, K, false><<<grid, 256, 0, s>>>(a);
@@ -491,12 +513,17 @@ int dmc_gen_tiny_fwd(const float* mv, const float* res, const float* const* w,
     LayerArgs a;
     a.mv = mv; a.res = res; a.feat = saved; a.feat_out = saved; a.gout = nullptr; a.gbuf = nullptr;
     a.pk = workspace; a.out = out; a.H = H; a.W = W; a.add_mv = add_mv_delta;
-    if ((rc = launch_layer<0, 0>(a, N, s))) return rc;
-    if ((rc = launch_layer<0, 1>(a, N, s))) return rc;
-    if ((rc = launch_layer<0, 2>(a, N, s))) return rc;
-    if ((rc = launch_layer<0, 3>(a, N, s))) return rc;
-    if ((rc = launch_layer<0, 4>(a, N, s))) return rc;
-    return launch_layer<1, 5>(a, N, s);
+    const int step = frames_per_pass(N, H, W);
+    for (int n0 = 0; n0 < N; n0 += step) {
+        const int nn = (N - n0) < step ? (N - n0) : step;
+        if ((rc = launch_layer<0, 0>(a, n0, nn, s))) return rc;
+        if ((rc = launch_layer<0, 1>(a, n0, nn, s))) return rc;
+        if ((rc = launch_layer<0, 2>(a, n0, nn, s))) return rc;
+        if ((rc = launch_layer<0, 3>(a, n0, nn, s))) return rc;
+        if ((rc = launch_layer<0, 4>(a, n0, nn, s))) return rc;
+        if ((rc = launch_layer<1, 5>(a, n0, nn, s))) return rc;
+    }
+    return DMC_OK;
 }
 
 int dmc_gen_tiny_bwd(const float* mv, const float* res, const float* const* w, const float* saved,
@@ -517,11 +544,15 @@ int dmc_gen_tiny_bwd(const float* mv, const float* res, const float* const* w, c
     LayerArgs la;
     la.mv = mv; la.res = res; la.feat = saved; la.feat_out = nullptr; la.gout = grad_out; la.gbuf = gbuf;
     la.pk = workspace; la.out = nullptr; la.H = H; la.W = W; la.add_mv = 0;
-    if ((rc = launch_layer<2, 5>(la, N, s))) return rc;
-    if ((rc = launch_layer<2, 4>(la, N, s))) return rc;
-    if ((rc = launch_layer<2, 3>(la, N, s))) return rc;
-    if ((rc = launch_layer<2, 2>(la, N, s))) return rc;
-    if ((rc = launch_layer<2, 1>(la, N, s))) return rc;
+    const int step = frames_per_pass(N, H, W);
+    for (int n0 = 0; n0 < N; n0 += step) {
+        const int nn = (N - n0) < step ? (N - n0) : step;
+        if ((rc = launch_layer<2, 5>(la, n0, nn, s))) return rc;
+        if ((rc = launch_layer<2, 4>(la, n0, nn, s))) return rc;
+        if ((rc = launch_layer<2, 3>(la, n0, nn, s))) return rc;
+        if ((rc = launch_layer<2, 2>(la, n0, nn, s))) return rc;
+        if ((rc = launch_layer<2, 1>(la, n0, nn, s))) return rc;
+    }
 
     WgradArgs a;
     a.mv = mv; a.res = res; a.feat = saved; a.gout = grad_out; a.gbuf = gbuf; a.partials = partials;

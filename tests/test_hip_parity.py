@@ -140,13 +140,23 @@ def test_discriminator_train_mode_vs_oracle(golden, arch):
     so, sm = o.state_dict(), m.state_dict()
     for k in so:
         assert rel_err(sm[k].float(), so[k].float()) < 1e-4, k
-    po, pm = dict(o.named_parameters()), dict(m.named_parameters())
-    errs = {k: rel_err(pm[k].grad, po[k].grad) for k in po}
-    errs["input"] = rel_err(xg.grad, xo.grad)
-    print({k: "%.1e" % e for k, e in errs.items()})
-    # the convolutions run on MIOpen, whose fp32 backward algorithms are not bit-faithful to the
-    # CPU's; the chain of up to 12 conv backwards is looser than the unit test of the HIP tail
-    assert max(errs.values()) < 3e-2, errs
+    # Gradients through a chain of BatchNorm(eps=0.8) backwards are ill-conditioned in fp32
+    # (dy - mean(dy) - zhat*mean(dy*zhat) cancels): the reference's own fp32 CPU path is only
+    # accurate to ~1e-2 there.  Criterion: against an fp64 evaluation of the same graph, the HIP
+    # path must be as accurate as the reference's fp32 CPU path (within 4x), or within 1e-4.
+    o64 = O.seeded_state_fill(O.OracleDiscriminator(arch), seed=31).double().train()
+    o64.forced_masks = {k: v.double() for k, v in masks.items()}
+    x64 = xin.double().requires_grad_(True)
+    F.cross_entropy(o64(x64), tgt).backward()
+    po, pm, p64 = dict(o.named_parameters()), dict(m.named_parameters()), dict(o64.named_parameters())
+    worst = 0.0
+    for k in list(po) + ["input"]:
+        t64 = x64.grad if k == "input" else p64[k].grad
+        e_hip = rel_err(xg.grad if k == "input" else pm[k].grad, t64)
+        e_cpu = rel_err(xo.grad if k == "input" else po[k].grad, t64)
+        worst = max(worst, e_hip)
+        assert e_hip <= max(4 * e_cpu, 1e-4), (k, e_hip, e_cpu)
+    print("worst HIP-vs-fp64 gradient error %.1e" % worst)
     if arch == "Discriminator3":
         g = golden("g3_disc_train")
         assert rel_err(v, g["validity"]) < 1e-4
@@ -227,3 +237,101 @@ def test_disc_tail_unit(shape, use_bn):
         with torch.no_grad():
             ye = ops.disc_tail(x.to(DEV), None, bn_m, False)
             assert rel_err(ye, bn_o(F.leaky_relu(x, 0.2))) < 1e-5
+
+
+# ------------------------------------------------------------------ whole training steps
+from tests.golden.make_golden import HP, WATCH, WATCH_D   # noqa: E402
+from dmcnet_amd import train as T                          # noqa: E402
+
+
+def _watch(model, keys):
+    sd = model.state_dict()
+    return {k: (sd[k] if sd[k].numel() <= 4096 else sd[k].reshape(-1)[:4096]) for k in keys}
+
+
+@pytest.mark.parametrize("tag,freeze", [("dmcnet", False), ("dmcnet_frozen", True)])
+def test_dmcnet_train_step_vs_reference_golden(golden, tag, freeze):
+    """One iteration of the reference's own train() (golden G4) reproduced by the HIP path:
+    losses / consensus logits within 1e-4 relative, post-step weights close."""
+    g = golden("g4_train_steps")
+    _, m = _product(False, 41)
+    m.train()
+    batch = O.synthetic_batch(seed=42, batch=2, num_segments=3, num_class=51, flow_ds_factor=16)
+    step = T.DmcnetTrainStep(m, 3, HP["lr_cls"], HP["lr_mse"], HP["lr"], HP["weight_decay"],
+                             HP["lr_cls_mult"], HP["lr_mse_mult"])
+    T.adjust_learning_rate(step.optimizer_cls, 0, [20, 35, 45], 0.1, HP["lr"], HP["weight_decay"],
+                           freeze=True, epoch_thre=1 if freeze else 0)
+    T.adjust_learning_rate(step.optimizer_gf, 0, [20, 35, 45], 0.1, HP["lr"], HP["weight_decay"])
+    r = step.step(tuple(t.to(DEV) for t in batch), freeze=freeze)
+    for k in ("loss", "loss_cls", "loss_mse", "output"):
+        assert rel_err(r[k], g["%s_%s" % (tag, k)]) < 1e-4, k
+    np.testing.assert_allclose(checksum(r["gen_flow"].cpu()), g[tag + "_genflow_checksum"], rtol=1e-5)
+    for k, v in _watch(m, WATCH).items():
+        # Adam normalises the update: a weight moves by ~lr whatever its gradient's size, so the
+        # comparison is absolute, at a small fraction of the step (lr * lr_mult <= 1e-2)
+        ref = torch.as_tensor(g["%s_post_%s" % (tag, k)])
+        assert float((v.cpu() - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max())), k
+
+
+def test_gan_train_steps_vs_reference_golden(golden):
+    """D step then G step of the reference's own train() (golden G4).  Losses, logits and
+    validity within 2e-4 relative.  Post-step weights: the gradients that reach them pass the
+    ill-conditioned BatchNorm(eps=0.8) chain (see the discriminator test) and Adam(eps=1e-3)
+    normalises small gradients, so the criterion is accuracy against an fp64 run of the same two
+    steps: the HIP path may be at most 4x further from it than the reference's fp32 CPU result
+    (the golden) is, or within 2e-5 absolute."""
+    g = golden("g4_train_steps")
+    o, m = _product(True, 43)
+    m.train()
+    o64 = o.double().train()
+    b0 = O.synthetic_batch(seed=44, batch=2, num_segments=3, num_class=51)
+    b1 = O.synthetic_batch(seed=45, batch=2, num_segments=3, num_class=51)
+    md = O.seeded_dropout_masks(46, o.discriminator, 12)
+    mg = O.seeded_dropout_masks(47, o.discriminator, 6)
+    step = T.GanTrainStep(m, 3, HP["lr_cls"], HP["lr_adv_g"], HP["lr_adv_d"], HP["lr_mse"], HP["lr"],
+                          HP["weight_decay"], HP["lr_cls_mult"], HP["lr_mse_mult"], HP["lr_d_mult"])
+    opts64 = O.make_optimizers(o64, HP["lr"], HP["weight_decay"], HP["lr_cls_mult"], HP["lr_mse_mult"],
+                               HP["lr_d_mult"])
+    for o_ in opts64:
+        O.adjust_learning_rate(o_, 0, [20, 35, 45], 0.1, HP["lr"], HP["weight_decay"])
+    for i, (b, masks, tag) in enumerate(((b0, md, "gan_D"), (b1, mg, "gan_G"))):
+        m.discriminator.forced_masks = masks
+        o64.discriminator.forced_masks = {k: v.double() for k, v in masks.items()}
+        r = step.step(tuple(t.to(DEV) for t in b), i)
+        b64 = tuple(t.double() if t.is_floating_point() else t for t in b)
+        O.gan_train_step(o64, opts64[0], opts64[1], opts64[2], b64, i, 3, HP["lr_cls"], HP["lr_adv_g"],
+                         HP["lr_adv_d"], HP["lr_mse"])
+        for k in ("loss", "loss_cls", "loss_adv", "output", "validity") + (("loss_mse",) if i else ()):
+            assert rel_err(r[k], g["%s_%s" % (tag, k)]) < 2e-4, (tag, k)
+        w64 = _watch(o64, WATCH + WATCH_D)
+        for k, v in _watch(m, WATCH + WATCH_D).items():
+            ref32 = torch.as_tensor(g["%s_post_%s" % (tag, k)]).double()
+            e_hip = float((v.double().cpu() - w64[k]).abs().max())
+            e_ref = float((ref32 - w64[k]).abs().max())
+            assert e_hip <= max(4 * e_ref, 2e-5), (tag, k, e_hip, e_ref)
+
+
+def test_reducer_single_rank_nccl_is_transparent():
+    """world_size 1 over RCCL: the bucketed path must leave gradients untouched."""
+    import os
+    import torch.distributed as dist
+    from dmcnet_amd import ddp
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        _, m = _product(False, 41)
+        m.train()
+        batch = tuple(t.to(DEV) for t in O.synthetic_batch(seed=42, batch=2, num_segments=3, num_class=51))
+        kw = dict(lr=0.01, weight_decay=1e-4, lr_cls_mult=0.01, lr_mse_mult=1.0)
+        a = T.DmcnetTrainStep(m, 3, 1.0, 10.0, **kw)
+        ra = a.step(batch)
+        _, m2 = _product(False, 41)
+        m2.train()
+        b = T.DmcnetTrainStep(m2, 3, 1.0, 10.0, reducer=ddp.GradBucketReducer(list(m2.parameters())), **kw)
+        rb = b.step(batch)
+        assert torch.equal(ra["loss"], rb["loss"])
+        for (k, p), (_, q) in zip(m.named_parameters(), m2.named_parameters()):
+            assert torch.equal(p, q), k
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,196 @@
+"""CPU tests of the host logic: index sampling (bit-exact vs the reference's vectors), tensor
+contract, LR policy / optimiser grouping, transforms, and the gradient-bucket reducer on a
+2-rank gloo group."""
+import os
+import random
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import dmcnet_amd
+from dmcnet_amd import dataset, ddp, train, transforms
+from oracle import dmc_oracle as O
+
+
+def test_index_sampling_bit_exact_vs_reference_vectors(golden):
+    g = golden("g5_index_sampling")
+    for n in (13, 14, 25, 50, 121, 300, 1000):
+        for S in (3, 25):
+            got = np.array([dataset.get_seg_range(n, S, s, "mv") for s in range(S)], dtype=np.int64)
+            assert np.array_equal(got, g["range_n%d_s%d" % (n, S)])
+            got = np.array([dataset.test_frame_index(n, s, S, "mv") for s in range(S)], dtype=np.int64)
+            assert np.array_equal(got, g["test_n%d_s%d" % (n, S)])
+            for seed in (0, 1, 2):
+                random.seed(seed)
+                got = np.array([dataset.train_frame_index(n, s, S, "mv") for s in range(S)], dtype=np.int64)
+                assert np.array_equal(got, g["train_n%d_s%d_seed%d" % (n, S, seed)])
+    assert np.array_equal(np.array([dataset.get_gop_pos(v, "mv") for v in range(1, 61)]), g["gop_pos_mv"])
+    assert np.array_equal(np.array([dataset.get_gop_pos(v, "iframe") for v in range(60)]), g["gop_pos_iframe"])
+    assert np.array_equal(np.array([dataset.get_seg_range(121, 3, s, "iframe") for s in range(3)]),
+                          g["range_iframe_n121_s3"])
+    assert dataset.flow_frame_number(2, 5) == 30
+
+
+def test_tensor_contract_matches_oracle():
+    frames = O.synthetic_frames_u8(3, 2, 3, size=50)       # ragged: 50 is not a multiple of 16
+    for f in (0, 16):
+        a = dataset.to_tensors(frames[0], f)
+        b = O.normalize_sample(frames[0], f)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    ds = dataset.SyntheticCoviarDataSet(4, 51, num_segments=3, flow_ds_factor=16, size=32)
+    flow, mv, res, label = ds[1]
+    assert flow.shape == (3, 2, 32, 32) and mv.shape == (3, 2, 32, 32) and res.shape == (3, 3, 32, 32)
+    assert 0 <= label < 51 and len(ds) == 4
+    blocks = flow.reshape(3, 2, 2, 16, 2, 16)
+    assert torch.equal(blocks, blocks[..., :1, :, :1].expand_as(blocks))    # blockified flow
+
+
+def test_lr_schedule_and_param_groups(golden):
+    table = golden("g6_lr_schedule")["table"]
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = train.GroupedAdam([{"params": p, "lr": 0.01, "lr_mult": 0.01, "decay_mult": 1.0}],
+                            weight_decay=1e-4, eps=1e-3)
+    for epoch, freeze, thre, lr, glr, gwd in table:
+        got = train.adjust_learning_rate(opt, int(epoch), [20, 35, 45], 0.1, 0.01, 1e-4,
+                                         freeze=bool(freeze), epoch_thre=int(thre))
+        assert got == lr and opt.param_groups[0]["lr"] == glr and opt.param_groups[0]["weight_decay"] == gwd
+    m = dmcnet_amd.Model(51, 3, "mv", base_model="resnet18", use_databn=0, gen_flow_or_delta=1,
+                         arch_estimator="DenseNetTiny", arch_d="Discriminator3")
+    oc, og, od = train.make_optimizers(m, 0.01, 1e-4, 0.01, 1.0, 1.0)
+    assert (len(oc.param_groups), len(og.param_groups), len(od.param_groups)) == (62, 12, 48)
+    ro = O.make_optimizers(O.OracleModel(51, 3, "mv", base_model="resnet18", use_databn=0,
+                                         gen_flow_or_delta=1, arch_estimator="DenseNetTiny",
+                                         arch_d="Discriminator3"), 0.01, 1e-4, 0.01, 1.0, 1.0)
+    for mine, ref in zip((oc, og, od), ro):
+        for a, b in zip(mine.param_groups, ref.param_groups):
+            assert a["lr_mult"] == b["lr_mult"] and a["decay_mult"] == b["decay_mult"]
+            assert a["eps"] == b["eps"] == 1e-3 and a["params"][0].shape == b["params"][0].shape
+
+
+def test_grouped_adam_equals_torch_adam():
+    torch.manual_seed(0)
+    ws = [torch.randn(5, 3), torch.randn(7), torch.randn(2, 2, 3, 3)]
+    a = [torch.nn.Parameter(w.clone()) for w in ws]
+    b = [torch.nn.Parameter(w.clone()) for w in ws]
+    mk = lambda ps: [{"params": p, "lr": 0.01 * (1 + i), "weight_decay": 1e-4 * (i % 2)} for i, p in enumerate(ps)]
+    oa, ob = train.GroupedAdam(mk(a), eps=1e-3), torch.optim.Adam(mk(b), eps=1e-3)
+    for step in range(4):
+        for pa, pb in zip(a, b):
+            g = torch.randn_like(pa)
+            pa.grad, pb.grad = g.clone(), g.clone()
+        oa.step(); ob.step()
+    for pa, pb in zip(a, b):
+        torch.testing.assert_close(pa, pb, rtol=1e-6, atol=1e-7)
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert len(sa["param_groups"]) == len(sb["param_groups"]) == 3
+    assert set(sa["state"][0].keys()) == set(sb["state"][0].keys())
+
+
+def test_accuracy_and_meters():
+    out = torch.tensor([[0.1, 0.9, 0.0], [0.8, 0.1, 0.1], [0.2, 0.3, 0.5]])
+    tgt = torch.tensor([1, 2, 2])
+    p1, p2 = train.accuracy(out, tgt, topk=(1, 2))
+    q1, q2 = O.accuracy(out, tgt, topk=(1, 2))
+    assert float(p1) == float(q1) and float(p2) == float(q2)
+    m = train.AverageMeter()
+    m.update(2.0, 2); m.update(4.0, 2)
+    assert m.avg == 3.0 and m.val == 4.0
+
+
+def test_transforms_contract():
+    random.seed(0)
+    frames = [np.random.RandomState(i).randint(0, 256, (256, 340, 7)).astype(np.uint8) for i in range(3)]
+    aug = transforms.Compose([transforms.GroupMultiScaleCrop(224, [1, .875, .75]),
+                              transforms.GroupRandomHorizontalFlip()])
+    out = aug(frames)
+    assert len(out) == 3 and all(o.shape == (224, 224, 7) for o in out)
+    f = transforms.flip_with_x_negation(frames[0])
+    assert np.array_equal(f[:, :, 1], frames[0][:, ::-1, 1].astype(np.int32))          # flow y kept
+    assert np.array_equal(f[:, :, 0], 256 - frames[0][:, ::-1, 0].astype(np.int32))    # flow x negated
+    assert np.array_equal(f[:, :, 2], 256 - frames[0][:, ::-1, 2].astype(np.int32))    # mv x negated
+    val = transforms.Compose([transforms.GroupScale(256), transforms.GroupCenterCrop(224)])(frames)
+    assert all(o.shape == (224, 224, 7) for o in val)
+    ident = transforms.resize_bilinear(frames[0], 256, 340)
+    assert ident is frames[0]
+
+
+def test_checkpoint_key_layout(tmp_path):
+    m = dmcnet_amd.Model(51, 3, "mv", base_model="resnet18", use_databn=0, arch_estimator="DenseNetTiny")
+    sd = train.reference_state_dict(m)
+    assert all(k.startswith("module.") for k in sd)
+    assert "module.gen_flow_model.conv_0.0.weight" in sd and "module.base_model.fc.bias" in sd
+    m2 = dmcnet_amd.Model(51, 3, "mv", base_model="resnet18", use_databn=0, arch_estimator="DenseNetTiny")
+    res = train.load_reference_weights(m2, sd)
+    assert not res.missing_keys and not res.unexpected_keys
+    os.chdir(tmp_path)
+    name = train.save_checkpoint({"epoch": 1, "arch": "resnet18", "state_dict": sd, "best_prec1": 0.0},
+                                 True, "model", "mv")
+    assert os.path.exists(name) and os.path.exists("model_mv_model_best.pth.tar")
+
+
+# ----------------------------------------------------------------------------- 2-rank gloo
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _ddp_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)          # different init per rank: the reducer must broadcast
+    net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.ReLU(), torch.nn.Linear(8, 4),
+                              torch.nn.ReLU(), torch.nn.Linear(4, 3))
+    red = ddp.GradBucketReducer(list(net.parameters()), bucket_bytes=128)    # several buckets
+    torch.manual_seed(7)
+    x, t = torch.randn(8, 6), torch.randint(0, 3, (8,))
+    shard = slice(rank * 4, rank * 4 + 4)
+    for p in net.parameters():
+        p.grad = None
+    red.begin()
+    torch.nn.functional.cross_entropy(net(x[shard]), t[shard]).backward()
+    red.finish()
+    # second step with one layer frozen out of the graph (unused parameters keep grad None)
+    for p in net.parameters():
+        p.grad = None
+    net[4].weight.requires_grad_(False)
+    red.begin()
+    torch.nn.functional.cross_entropy(net(x[shard]), t[shard]).backward()
+    red.finish()
+    torch.save({"params": [p.detach().clone() for p in net.parameters()],
+                "grads": [None if p.grad is None else p.grad.clone() for p in net.parameters()],
+                "x": x, "t": t, "nbuckets": len(red.buckets)}, os.path.join(out_dir, "r%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_grad_bucket_reducer_two_ranks_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp_path, "r%d.pt" % r)) for r in (0, 1))
+    assert r0["nbuckets"] > 1
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b)                      # broadcast from rank 0
+    for a, b in zip(r0["grads"], r1["grads"]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b)                  # identical after the all-reduce
+    # equal to the single-process gradient of the mean loss over the whole batch
+    net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.ReLU(), torch.nn.Linear(8, 4),
+                              torch.nn.ReLU(), torch.nn.Linear(4, 3))
+    with torch.no_grad():
+        for p, v in zip(net.parameters(), r0["params"]):
+            p.copy_(v)
+    net[4].weight.requires_grad_(False)
+    torch.nn.functional.cross_entropy(net(r0["x"]), r0["t"]).backward()
+    for p, g in zip(net.parameters(), r0["grads"]):
+        if p.grad is None:
+            assert g is None
+        else:
+            torch.testing.assert_close(g, p.grad, rtol=1e-5, atol=1e-7)
