@@ -106,6 +106,8 @@ def main():
                              gen_flow_or_delta=1, arch_estimator="DenseNetTiny",
                              arch_d="Discriminator3" if gan else None).to(dev).train()
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
+    if os.environ.get("DMC_CHANNELS_LAST") == "0":
+        model.base_model.to(memory_format=torch.contiguous_format)
     reducer = ddp.GradBucketReducer(list(model.parameters())) if world > 1 else None
     if gan:
         stepper = train.GanTrainStep(model, S, 1.0, 1.0, 0.01, 10.0, lr_d_mult=1.0, reducer=reducer, **HP)

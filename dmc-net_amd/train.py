@@ -8,6 +8,7 @@ reference's one-group-per-tensor layout (so optimiser state dicts are interchang
 update is issued as a few multi-tensor launches instead of one per tensor; backward segments
 whose results the reference discards at the next ``zero_grad`` are skipped.
 """
+import contextlib
 import importlib
 import shutil
 
@@ -128,6 +129,21 @@ def load_reference_weights(model, state_dict, strict=False):
     return model.load_state_dict(stripped, strict=strict)
 
 
+@contextlib.contextmanager
+def _without_param_grads(*modules):
+    """Build the graph with these modules' parameters as constants: their weight gradients --
+    which the reference computes and then discards at the next zero_grad -- are never computed;
+    gradients still flow THROUGH the modules to their inputs."""
+    ps = [p for m in modules for p in m.parameters() if p.requires_grad]
+    for p in ps:
+        p.requires_grad_(False)
+    try:
+        yield
+    finally:
+        for p in ps:
+            p.requires_grad_(True)
+
+
 class DmcnetTrainStep(object):
     """One iteration of code/dmcnet/train.py:221-266."""
 
@@ -185,7 +201,10 @@ class GanTrainStep(object):
             o.zero_grad(set_to_none=True)
         out = {}
         if i % 2 == 0:
-            output, validity, gen_flow = self.model(input_mv, input_residual, flow)
+            # only optimizer_cls and optimizer_d step (GAN train.py:301-302): the generator's
+            # gradients would be thrown away
+            with _without_param_grads(self.model.gen_flow_model):
+                output, validity, gen_flow = self.model(input_mv, input_residual, flow)
             loss_cls, consensus = ops.consensus_ce(output, target, self.num_segments)
             loss_adv, _ = ops.consensus_ce(validity, torch.cat((fake, valid), 0), 1)
             loss = loss_cls * self.lr_cls + loss_adv * self.lr_adv_d
@@ -193,7 +212,10 @@ class GanTrainStep(object):
             self.optimizer_cls.step()
             self.optimizer_d.step()
         else:
-            output, validity, gen_flow = self.model(input_mv, input_residual)
+            # only optimizer_gf steps (GAN train.py:371): classifier / discriminator weight
+            # gradients would be thrown away; their BatchNorm running statistics still update
+            with _without_param_grads(self.model.base_model, self.model.discriminator):
+                output, validity, gen_flow = self.model(input_mv, input_residual)
             loss_cls, consensus = ops.consensus_ce(output, target, self.num_segments)
             loss_adv, _ = ops.consensus_ce(validity, valid, 1)
             loss_mse = ops.flow_mse(gen_flow, flow)
