@@ -7,7 +7,7 @@ import ctypes
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libdmcnet_hip.so")
+LIB_PATH = os.environ.get("DMC_HIP_LIB", os.path.join(PKG, "libdmcnet_hip.so"))   # override: A/B builds
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int

@@ -20,8 +20,10 @@ namespace {
 // ------------------------------------------------------------------------------------------
 __global__ void pack_params_kernel(ParamPtrs P, float* __restrict__ pk) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= PACKED_TOTAL) return;
-    if (i < WF_TOTAL) {
+    if (i >= PACKED_TOTAL + ZERO_PAD) return;
+    if (i >= PACKED_TOTAL) {
+        pk[i] = 0.f;                         // zero words: source of out-of-image LDS-DMA lanes
+    } else if (i < WF_TOTAL) {
         int k = 0;
         while (k < NL - 1 && i >= wf_off(k + 1)) ++k;
         const int cin = cin_of(k), cout = cout_of(k);
@@ -241,12 +243,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WT_H = 8, WT_W = 32;
 constexpr int WX_PITCH = 36, WX_PLANE = 364;           // plane % 32 == 12: conflict-light gathers
-constexpr int WG_PLANE = WT_H * WT_W + 2;              // 258: conflict-free A-fragment reads
-constexpr int WX_FLOATS = 33 * WX_PLANE, WG_FLOATS = 32 * WG_PLANE;
-constexpr int WT_LDS = WX_FLOATS + WG_FLOATS;          // 20268 floats = 81,072 B -> 2 WG / CU
+constexpr int WX_FLOATS = 33 * WX_PLANE;
+constexpr int WT_CHUNKS = (WX_FLOATS + 63) / 64;       // 188 DMA wave-instructions per tile
+constexpr int WT_LDS = WT_CHUNKS * 64;                 // 12032 floats; x2 buffers = 96,256 B
 constexpr int NT_A = 9, NT_B = 19, NT_ALL = NT_A + NT_B;   // accumulator tiles per wave
 constexpr int WPART = NT_ALL * 256;                    // floats per workgroup partial
-constexpr int WGRAD_MAX_GROUPS = 512;
+constexpr int WGRAD_MAX_GROUPS = 256;
 constexpr int BIAS_COL = 297;
 
 struct WgradArgs {
@@ -259,86 +261,64 @@ struct WgradArgs {
     int N, H, W, tiles_x, tiles_y;
 };
 
-// Generic (any W) staging: one bounds-checked element per thread-iteration.
-__device__ __forceinline__ void wgrad_stage_tile_generic(const WgradArgs& a, float* lds, int n,
-                                                         int ty0, int tx0, size_t HW) {
-    constexpr int COLS = WT_W + 2, ROWS = WT_H + 2;
-    for (int i = threadIdx.x; i < 33 * ROWS * COLS; i += 256) {
-        const int c = i / (ROWS * COLS);
-        const int rem = i - c * (ROWS * COLS);
-        const int row = rem / COLS, col = rem - row * COLS;
+// Producer side: one wave-instruction of LDS-DMA (global_load_lds_dword) fills 64 consecutive
+// floats of the tile image; every lane supplies its own source address (or the address of a zero
+// word for pixels outside the image and for padding), so the padded / halo'd layout costs nothing
+// and no VGPRs are tied up by data in flight.
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void wgrad_dma_tile(const WgradArgs& a, float* buf, int tile,
+                                               int per_frame, size_t HW, int pw, int lane,
+                                               const float* zero) {
+    const int n = tile / per_frame, r0 = tile - n * per_frame;
+    const int ty0 = (r0 / a.tiles_x) * WT_H, tx0 = (r0 % a.tiles_x) * WT_W;
+    const float* mvp = a.mv + (size_t)n * 2 * HW;
+    const float* rsp = a.res + (size_t)n * 3 * HW;
+    const float* ftp = a.feat + (size_t)n * NFEAT * HW;
+#pragma unroll 1
+    for (int m = pw; m < WT_CHUNKS; m += 8) {
+        const int L = 64 * m + lane;
+        const int plane = L / WX_PLANE, rem = L - plane * WX_PLANE;
+        const int row = rem / WX_PITCH, col = rem - row * WX_PITCH;
         const int yy = ty0 - 1 + row, xx = tx0 - 1 + col;
-        float v = 0.f;
-        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
-            v = in_plane(a.mv, a.res, a.feat, n, c, HW)[(size_t)yy * a.W + xx];
-        lds[c * WX_PLANE + row * WX_PITCH + col] = v;
-    }
-    float* gl = lds + WX_FLOATS;
-    for (int i = threadIdx.x; i < 30 * WT_H * WT_W; i += 256) {
-        const int c = i / (WT_H * WT_W);
-        const int rem = i - c * (WT_H * WT_W);
-        const int row = rem / WT_W, col = rem - row * WT_W;
-        const int yy = ty0 + row, xx = tx0 + col;
-        float v = 0.f;
-        if (yy < a.H && xx < a.W) {
-            const float* src = c < NFEAT ? a.gbuf + ((size_t)n * NFEAT + c) * HW
-                                         : a.gout + ((size_t)n * 2 + (c - NFEAT)) * HW;
-            v = src[(size_t)yy * a.W + xx];
-        }
-        gl[c * WG_PLANE + rem] = v;
+        const bool ok = plane < 33 && row < WT_H + 2 && col < WT_W + 2 && yy >= 0 && yy < a.H &&
+                        xx >= 0 && xx < a.W;
+        const float* base = plane < 2 ? mvp + (size_t)plane * HW
+                          : plane < NIN ? rsp + (size_t)(plane - 2) * HW
+                                        : ftp + (size_t)(plane - NIN) * HW;
+        const float* src = ok ? base + (size_t)yy * a.W + xx : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + 64 * m), 4, 0, 0);
     }
 }
 
-// W % 4 == 0: 16-byte global loads, 8 lanes per 32-pixel row, all loads of a thread independent.
-//   x planes: rows ty0-1 .. ty0+8, cols tx0-1 .. tx0+32 (LDS col 0 / 33 = halo), zero outside
-//   gradient planes 0..27 = g0..g4 (gbuf), 28..29 = g5 (grad_out)
-__device__ __forceinline__ void wgrad_stage_tile_vec(const WgradArgs& a, float* lds, int n, int ty0,
-                                                     int tx0, size_t HW) {
-    const int q = threadIdx.x & 7, xx = tx0 + 4 * q;
-    const bool colok = xx < a.W;                       // W % 4 == 0 -> the whole quad is in or out
-#pragma unroll 2
-    for (int rr = threadIdx.x >> 3; rr < 33 * (WT_H + 2); rr += 32) {
-        const int c = rr / (WT_H + 2), row = rr - c * (WT_H + 2);
-        const int yy = ty0 - 1 + row;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (colok && yy >= 0 && yy < a.H)
-            v = *reinterpret_cast<const float4*>(in_plane(a.mv, a.res, a.feat, n, c, HW) + (size_t)yy * a.W + xx);
-        float* d = lds + c * WX_PLANE + row * WX_PITCH + 1 + 4 * q;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
-    for (int i = threadIdx.x; i < 33 * (WT_H + 2) * 2; i += 256) {
-        const int rr = i >> 1, side = i & 1;
-        const int c = rr / (WT_H + 2), row = rr - c * (WT_H + 2);
-        const int yy = ty0 - 1 + row, xh = side ? tx0 + WT_W : tx0 - 1;
-        float v = 0.f;
-        if (yy >= 0 && yy < a.H && xh >= 0 && xh < a.W)
-            v = in_plane(a.mv, a.res, a.feat, n, c, HW)[(size_t)yy * a.W + xh];
-        lds[c * WX_PLANE + row * WX_PITCH + (side ? WT_W + 1 : 0)] = v;
-    }
-    float* gl = lds + WX_FLOATS;
-#pragma unroll 2
-    for (int rr = threadIdx.x >> 3; rr < 30 * WT_H; rr += 32) {
-        const int c = rr / WT_H, row = rr - c * WT_H;
-        const int yy = ty0 + row;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (colok && yy < a.H) {
-            const float* src = c < NFEAT ? a.gbuf + ((size_t)n * NFEAT + c) * HW
-                                         : a.gout + ((size_t)n * 2 + (c - NFEAT)) * HW;
-            v = *reinterpret_cast<const float4*>(src + (size_t)yy * a.W + xx);
-        }
-        float* d = gl + c * WG_PLANE + row * WT_W + 4 * q;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
-}
-
-template <bool VEC4>
-__global__ __launch_bounds__(256, 2) void gen_bwd_weight_kernel(WgradArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[WT_LDS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// 512 threads per workgroup, one workgroup per CU, two LDS buffers.  Per tile every wave first
+// issues its share of the LDS-DMA for the NEXT tile (asynchronous, no VGPRs), then runs the MFMAs
+// of one row (8 groups of 4 pixels) of the CURRENT tile; two MFMA waves per SIMD cover each
+// other's LDS gathers (one wave per SIMD measured 50 % matrix-pipe utilisation).
+__global__ __launch_bounds__(512, 2) void gen_bwd_weight_kernel(WgradArgs a, const float* zero) {
+    __shared__ __attribute__((aligned(16))) float lds2[2 * WT_LDS];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int j = lane & 15, kq = lane >> 4;          // column / pixel-in-group of this lane
-    float* gl = lds + WX_FLOATS;
-    for (int i = threadIdx.x; i < 2 * WG_PLANE; i += 256) gl[30 * WG_PLANE + i] = 0.f;
+    const bool ones = (16 * 18 + j) == BIAS_COL;      // bias column lives in N tile 18
+    const size_t HW = (size_t)a.H * a.W;
+    // A fragments (gradient rows) come straight from global memory: lane (j, kq) needs row j of
+    // each M tile at pixel kq of the group -- 2 loads per 28 MFMAs, requested one tile ahead.
+    //   tile A rows 0..15 = gbuf channels 0..15 (g0, g1)
+    //   tile B rows 0..11 = gbuf channels 16..27 (g2, g3, g4), rows 12,13 = grad_out, 14,15 = 0
+    const bool rowB = j < 14;
+    const size_t chanA = (size_t)j * HW;
+    const size_t chanB = (j < 12 ? (size_t)(16 + j) : j < 14 ? (size_t)(j - 12) : (size_t)0) * HW;
 
+    f32x4 accA[NT_A], accB[NT_B];
+#pragma unroll
+    for (int t = 0; t < NT_A; ++t) accA[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT_B; ++t) accB[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int per_frame = a.tiles_x * a.tiles_y;
+    const int ntiles = a.N * per_frame;
     // per-lane gather offsets of the B fragments (x[(ci,tap)][pixel kq of the group])
     int offB[NT_B];
 #pragma unroll
@@ -348,33 +328,47 @@ __global__ __launch_bounds__(256, 2) void gen_bwd_weight_kernel(WgradArgs a) {
         const int ci = nn / 9, tap = nn - ci * 9;
         offB[t] = ci * WX_PLANE + (tap / 3) * WX_PITCH + (tap % 3) + kq;
     }
-    const bool ones = (16 * 18 + j) == BIAS_COL;      // bias column lives in N tile 18
-    // A fragments: row j of the M tile, pixel kq
-    const int offA0 = j * WG_PLANE + kq;              // tile A: planes 0..15
-    const int offA1 = (16 + j) * WG_PLANE + kq;       // tile B: planes 16..29 (+2 zero planes)
-
-    f32x4 accA[NT_A], accB[NT_B];
-#pragma unroll
-    for (int t = 0; t < NT_A; ++t) accA[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < NT_B; ++t) accB[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const size_t HW = (size_t)a.H * a.W;
-    const int per_frame = a.tiles_x * a.tiles_y;
-    const int ntiles = a.N * per_frame;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    float cur0[8], cur1[8], nxt0[8], nxt1[8];
+    auto request_row = [&](int tile, float (&v0)[8], float (&v1)[8]) {
         const int n = tile / per_frame, r0 = tile - n * per_frame;
         const int ty0 = (r0 / a.tiles_x) * WT_H, tx0 = (r0 % a.tiles_x) * WT_W;
-        __syncthreads();
-        if (VEC4) wgrad_stage_tile_vec(a, lds, n, ty0, tx0, HW);
-        else wgrad_stage_tile_generic(a, lds, n, ty0, tx0, HW);
-        __syncthreads();
-        // 64 groups of 4 pixels per tile, 16 per wave: wave w takes rows 2w, 2w+1
-#pragma unroll 1
-        for (int g = 0; g < 16; ++g) {
-            const int r = wave * 2 + (g >> 3), c0 = (g & 7) * 4;
-            const int xb = r * WX_PITCH + c0, gb = r * WT_W + c0;
-            const float a0 = gl[offA0 + gb], a1 = gl[offA1 + gb];
+        const float* gA = a.gbuf + (size_t)n * NFEAT * HW + chanA;
+        const float* gB = (j < 12 ? a.gbuf + (size_t)n * NFEAT * HW : a.gout + (size_t)n * 2 * HW) + chanB;
+        int yy = ty0 + wave;
+        yy = yy < a.H ? yy : a.H - 1;                 // clamped: masked to zero when used
+        const size_t rowoff = (size_t)yy * a.W;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            int xx = tx0 + g * 4 + kq;
+            xx = xx < a.W ? xx : a.W - 1;
+            v0[g] = gA[rowoff + xx];
+            v1[g] = gB[rowoff + xx];
+        }
+    };
+    int it = 0;
+    if ((int)blockIdx.x < ntiles) {
+        wgrad_dma_tile(a, lds2, blockIdx.x, per_frame, HW, wave, lane, zero);
+        request_row(blockIdx.x, cur0, cur1);
+    }
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+        const float* lds = lds2 + (it & 1) * WT_LDS;
+        const bool more = tile + (int)gridDim.x < ntiles;
+        if (more) {
+            wgrad_dma_tile(a, lds2 + ((it + 1) & 1) * WT_LDS, tile + gridDim.x, per_frame, HW, wave,
+                           lane, zero);
+            request_row(tile + gridDim.x, nxt0, nxt1);
+        }
+        const int r0 = tile % per_frame;
+        const int ty0 = (r0 / a.tiles_x) * WT_H, tx0 = (r0 % a.tiles_x) * WT_W;
+        const bool rowok = ty0 + wave < a.H;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int c0 = g * 4;
+            const bool ok = rowok && (tx0 + c0 + kq < a.W);
+            const float a0 = ok ? cur0[g] : 0.f;
+            const float a1 = (ok && rowB) ? cur1[g] : 0.f;
+            const int xb = wave * WX_PITCH + c0;
             float b[NT_B];
 #pragma unroll
             for (int t = 0; t < NT_B; ++t) b[t] = lds[offB[t] + xb];
@@ -387,10 +381,13 @@ __global__ __launch_bounds__(256, 2) void gen_bwd_weight_kernel(WgradArgs a) {
             for (int t = 0; t < NT_B; ++t)
                 accB[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[t], accB[t], 0, 0, 0);
         }
+        __syncthreads();                               // DMA of the next tile has landed
+#pragma unroll
+        for (int g = 0; g < 8; ++g) { cur0[g] = nxt0[g]; cur1[g] = nxt1[g]; }
     }
-    // cross-wave reduction in LDS, fixed order (wave 0 stores, waves 1..3 add in turn)
-    __syncthreads();
-    for (int w = 0; w < 4; ++w) {
+    // cross-wave reduction in LDS, fixed order (wave 0 stores, waves 1..7 add in turn)
+    float* lds = lds2;
+    for (int w = 0; w < 8; ++w) {
         if (wave == w) {
 #pragma unroll
             for (int t = 0; t < NT_ALL; ++t) {
@@ -405,10 +402,24 @@ __global__ __launch_bounds__(256, 2) void gen_bwd_weight_kernel(WgradArgs a) {
         __syncthreads();
     }
     float* part = a.partials + (size_t)blockIdx.x * WPART;
-    for (int i = threadIdx.x; i < WPART; i += 256) part[i] = lds[i];
+    for (int i = threadIdx.x; i < WPART; i += 512) part[i] = lds[i];
 }
 
-// partials [groups][28 tiles][16][16] -> the 12 gradient tensors in PyTorch layout
+// Stage 1 of the cross-workgroup reduction: partials [groups][WPART] -> [RED_CHUNKS][WPART],
+// coalesced over the WPART axis, fixed summation order.
+constexpr int RED_CHUNKS = 16;
+__global__ __launch_bounds__(256) void gen_bwd_weight_reduce1_kernel(float* __restrict__ partials,
+                                                                     int groups) {
+    const int i = blockIdx.x * 256 + threadIdx.x;          // < WPART (7168 = 28 * 256)
+    const int per = (groups + RED_CHUNKS - 1) / RED_CHUNKS;
+    const int g0 = blockIdx.y * per, g1 = (g0 + per < groups) ? g0 + per : groups;
+    float s = 0.f;
+    for (int g = g0; g < g1; ++g) s += partials[(size_t)g * WPART + i];
+    // results are written behind the raw partials (the buffer is sized for groups + RED_CHUNKS)
+    partials[(size_t)(groups + blockIdx.y) * WPART + i] = s;
+}
+
+// Stage 2: [RED_CHUNKS][28 tiles][16][16] -> the 12 gradient tensors in PyTorch layout
 __global__ void gen_bwd_weight_reduce_kernel(const float* __restrict__ partials, int groups,
                                              GradPtrs G) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -436,7 +447,7 @@ __global__ void gen_bwd_weight_reduce_kernel(const float* __restrict__ partials,
     }
     const size_t off = (size_t)slot * 256 + row * 16 + jj;
     float s = 0.f;
-    for (int g = 0; g < groups; ++g) s += partials[(size_t)g * WPART + off];
+    for (int c = 0; c < RED_CHUNKS; ++c) s += partials[(size_t)(groups + c) * WPART + off];
     if (i < WF_TOTAL)
         G.w[k][(co * cin_of(k) + logical_of(k, p)) * 9 + tap] = s;
     else
@@ -483,7 +494,7 @@ int pack(const float* const* w, const float* const* b, float* pk, hipStream_t s)
         P.w[k] = w[k];
         P.b[k] = b ? b[k] : w[k];   // bias slots are unused by the backward pass
     }
-    pack_params_kernel<<<(PACKED_TOTAL + 255) / 256, 256, 0, s>>>(P, pk);
+    pack_params_kernel<<<(PACKED_TOTAL + ZERO_PAD + 255) / 256, 256, 0, s>>>(P, pk);
     return check_launch("pack_params");
 }
 
@@ -491,14 +502,14 @@ int pack(const float* const* w, const float* const* b, float* pk, hipStream_t s)
 
 extern "C" {
 
-size_t dmc_gen_tiny_workspace_bytes(void) { return (size_t)PACKED_TOTAL * sizeof(float); }
+size_t dmc_gen_tiny_workspace_bytes(void) { return (size_t)(PACKED_TOTAL + ZERO_PAD) * sizeof(float); }
 
 size_t dmc_gen_tiny_saved_bytes(int N, int H, int W) {
     return (size_t)N * NFEAT * H * W * sizeof(float);
 }
 size_t dmc_gen_tiny_gbuf_bytes(int N, int H, int W) { return dmc_gen_tiny_saved_bytes(N, H, W); }
 size_t dmc_gen_tiny_partials_bytes(int N, int H, int W) {
-    return (size_t)wgrad_groups(N, H, W) * WPART * sizeof(float);
+    return (size_t)(wgrad_groups(N, H, W) + RED_CHUNKS) * WPART * sizeof(float);
 }
 
 int dmc_gen_tiny_fwd(const float* mv, const float* res, const float* const* w,
@@ -560,9 +571,10 @@ int dmc_gen_tiny_bwd(const float* mv, const float* res, const float* const* w, c
     a.tiles_x = (W + WT_W - 1) / WT_W;
     a.tiles_y = (H + WT_H - 1) / WT_H;
     const int groups = wgrad_groups(N, H, W);
-    if (W % 4 == 0) gen_bwd_weight_kernel<true><<<groups, 256, 0, s>>>(a);
-    else gen_bwd_weight_kernel<false><<<groups, 256, 0, s>>>(a);
+    gen_bwd_weight_kernel<<<groups, 512, 0, s>>>(a, workspace + PACKED_TOTAL);
     if ((rc = check_launch("gen_bwd_weight"))) return rc;
+    gen_bwd_weight_reduce1_kernel<<<dim3(WPART / 256, RED_CHUNKS), 256, 0, s>>>(partials, groups);
+    if ((rc = check_launch("gen_bwd_weight_reduce1"))) return rc;
     gen_bwd_weight_reduce_kernel<<<(NPARAM + 127) / 128, 128, 0, s>>>(partials, groups, G);
     return check_launch("gen_bwd_weight_reduce");
 }
