@@ -45,8 +45,9 @@ constexpr int NIN = 5;
 // packed parameter block (floats):  WF | BF | WB
 //   WF[k][p][tap][co]   forward weights, p = physical input channel           (4554)
 //   BF[k][co]                                                                  (30)
-//   WB[k][cg][tap][cd]  k = 1..5, data-gradient weights: conv from g_k (cg) to the features
-//                       cd in [0, CIN[k]-5), taps already flipped              (3204)
+//   WB[j][c][tap][cd]   j = 0..4, data-gradient weights BY OUTPUT GROUP: the gradient of feature
+//                       group y_j (cd in [0, COUT[j])) gathers from every later layer's g:
+//                       input channel c runs over [g_{j+1} .. g_4, g_5], taps flipped  (3204)
 __host__ __device__ constexpr int wf_off(int k) {
     int o = 0;
     for (int i = 0; i < k; ++i) o += cin_of(i) * 9 * cout_of(i);
@@ -59,12 +60,14 @@ __host__ __device__ constexpr int bf_off(int k) {
     return o;
 }
 constexpr int NPARAM = bf_off(6);     // 4584
-__host__ __device__ constexpr int wb_off(int k) {
+// number of gradient channels feeding feature group j: all g_k with k > j (30 - yoff(j+1) + 5)
+__host__ __device__ constexpr int gin_of(int j) { return 35 - yoff(j + 1); }
+__host__ __device__ constexpr int wb_off(int j) {
     int o = NPARAM;
-    for (int i = 1; i < k; ++i) o += cout_of(i) * 9 * (cin_of(i) - NIN);
+    for (int i = 0; i < j; ++i) o += gin_of(i) * 9 * cout_of(i);
     return o;
 }
-constexpr int PACKED_TOTAL = wb_off(6);   // 7788
+constexpr int PACKED_TOTAL = wb_off(5);   // 7788
 constexpr int ZERO_PAD = 16;              // zero words kept behind the packed parameters
 
 // logical (reference, prepend order) input-channel index of physical channel p in layer k

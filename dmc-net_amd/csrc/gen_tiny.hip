@@ -35,13 +35,17 @@ __global__ void pack_params_kernel(ParamPtrs P, float* __restrict__ pk) {
         while (k < NL - 1 && i >= bf_off(k + 1)) ++k;
         pk[i] = P.b[k][i - bf_off(k)];
     } else {
-        int k = 1;
-        while (k < NL - 1 && i >= wb_off(k + 1)) ++k;
-        const int cin = cin_of(k), D = cin - NIN;
-        const int r = i - wb_off(k);
-        const int cd = r % D, tap = (r / D) % 9, cg = r / (D * 9);
+        int j = 0;
+        while (j < 4 && i >= wb_off(j + 1)) ++j;
+        const int D = cout_of(j);
+        const int r = i - wb_off(j);
+        const int cd = r % D, tap = (r / D) % 9, c = r / (D * 9);
+        // input channel c of group j -> (layer k > j, its output channel cg): the gradient
+        // channels are ordered g_{j+1}, ..., g_5
+        int k = j + 1, cg = c;
+        while (cg >= cout_of(k)) { cg -= cout_of(k); ++k; }
         // d/dx of a correlation is a correlation with the flipped kernel: tap -> 8 - tap
-        pk[i] = P.w[k][(cg * cin + logical_of(k, cd + NIN)) * 9 + (8 - tap)];
+        pk[i] = P.w[k][(cg * cin_of(k) + logical_of(k, yoff(j) + cd)) * 9 + (8 - tap)];
     }
 }
 
@@ -66,8 +70,9 @@ __device__ __forceinline__ const float* in_plane(const float* mv, const float* r
 //
 // MODE 0: forward hidden layer K   (inputs mv/res/feat[0..), output LeakyReLU(0.1) -> feat)
 // MODE 1: forward last layer       (output -> out, optionally + mv)
-// MODE 2: data-gradient of layer K (inputs g_K, output accumulated into gbuf[0..D), the
-//         channels of y_{K-1} finalised with LeakyReLU'(y_{K-1}))
+// MODE 2: data gradient of feature group y_K (K = 4..0): gathers from every later layer's
+//         gradient g_{K+1..5} in one pass and writes g_K = dL/dy_K * LeakyReLU'(y_K) once (no
+//         read-modify-write of the gradient buffer)
 // ------------------------------------------------------------------------------------------
 constexpr int LT = 32;                       // tile edge (pixels)
 constexpr int LCH = 8;                       // channels per staged chunk
@@ -91,16 +96,18 @@ struct LayerArgs {
 
 template <int MODE, int K>
 __device__ __forceinline__ const float* layer_in_plane(const LayerArgs& a, int n, int c, size_t HW) {
-    if (MODE == 2)
-        return K == 5 ? a.gout + ((size_t)n * 2 + c) * HW
-                      : a.gbuf + ((size_t)n * NFEAT + (yoff(K) - NIN) + c) * HW;
+    if (MODE == 2) {
+        constexpr int NG = gin_of(K) - 2;           // channels that live in gbuf; then grad_out
+        return c < NG ? a.gbuf + ((size_t)n * NFEAT + (yoff(K + 1) - NIN) + c) * HW
+                      : a.gout + ((size_t)n * 2 + (c - NG)) * HW;
+    }
     return in_plane(a.mv, a.res, a.feat, n, c, HW);
 }
 
 template <int MODE, int K, bool VEC4>
 __global__ __launch_bounds__(256) void gen_layer_kernel(LayerArgs a) {
-    constexpr int CIN = MODE == 2 ? cout_of(K) : cin_of(K);
-    constexpr int COUT = MODE == 2 ? cin_of(K) - NIN : cout_of(K);
+    constexpr int CIN = MODE == 2 ? gin_of(K) : cin_of(K);
+    constexpr int COUT = cout_of(K);
     __shared__ __attribute__((aligned(16))) float lds[L_LDS];
     const int n = blockIdx.z, ty0 = blockIdx.y * LT, tx0 = blockIdx.x * LT;
     const int H = a.H, W = a.W;
@@ -205,20 +212,14 @@ __global__ __launch_bounds__(256) void gen_layer_kernel(LayerArgs a) {
                 if (VEC4 || x0 + j < W) dst[j] = acc[co][j] + (a.add_mv ? m[j] : 0.f);
         }
     } else {
-        constexpr int TOP0 = COUT - cout_of(K - 1 < 0 ? 0 : K - 1);
+        float* dst = a.gbuf + ((size_t)n * NFEAT + (yoff(K) - NIN)) * HW + pix;
+        const float* f = a.feat + ((size_t)n * NFEAT + (yoff(K) - NIN)) * HW + pix;
 #pragma unroll
         for (int cd = 0; cd < COUT; ++cd) {
-            float* dst = a.gbuf + ((size_t)n * NFEAT + cd) * HW + pix;
-            const float* f = a.feat + ((size_t)n * NFEAT + cd) * HW + pix;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (VEC4 || x0 + j < W) {
-                    float v = acc[cd][j];
-                    if (K != 5) v += dst[j];
-                    if (cd >= TOP0) v *= (f[j] > 0.f ? 1.f : 0.1f);
-                    dst[j] = v;
-                }
-            }
+            for (int j = 0; j < 4; ++j)
+                if (VEC4 || x0 + j < W)
+                    dst[cd * HW + j] = acc[cd][j] * (f[cd * HW + j] > 0.f ? 1.f : 0.1f);
         }
     }
 }
@@ -558,11 +559,11 @@ int dmc_gen_tiny_bwd(const float* mv, const float* res, const float* const* w, c
     const int step = frames_per_pass(N, H, W);
     for (int n0 = 0; n0 < N; n0 += step) {
         const int nn = (N - n0) < step ? (N - n0) : step;
-        if ((rc = launch_layer<2, 5>(la, n0, nn, s))) return rc;
         if ((rc = launch_layer<2, 4>(la, n0, nn, s))) return rc;
         if ((rc = launch_layer<2, 3>(la, n0, nn, s))) return rc;
         if ((rc = launch_layer<2, 2>(la, n0, nn, s))) return rc;
         if ((rc = launch_layer<2, 1>(la, n0, nn, s))) return rc;
+        if ((rc = launch_layer<2, 0>(la, n0, nn, s))) return rc;
     }
 
     WgradArgs a;
