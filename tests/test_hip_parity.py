@@ -330,7 +330,7 @@ def test_reducer_single_rank_nccl_is_transparent():
         m2.train()
         b = T.DmcnetTrainStep(m2, 3, 1.0, 10.0, reducer=ddp.GradBucketReducer(list(m2.parameters())), **kw)
         rb = b.step(batch)
-        assert torch.equal(ra["loss"], rb["loss"])
+        assert rel_err(ra["loss"], rb["loss"]) < 1e-5
         # MIOpen's NHWC weight-gradient kernels split K with atomics, so two runs of the same
         # step differ in the last bits; the reducer itself adds nothing (generator grads, which
         # come from the deterministic HIP path, must match exactly); MIOpen may also pick a
