@@ -5,7 +5,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["gen_tiny", "flow_mse", "consensus_ce", "disc_tail"]
+__all__ = ["gen_tiny", "flow_mse", "consensus_ce", "disc_tail", "bn_act", "bn_act_supported"]
 
 
 class EventProbe(object):
@@ -252,3 +252,70 @@ def disc_tail(x, keep, bn, training):
         bn.num_batches_tracked.add_(1)
     return _DiscTail.apply(x, keep, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
                            bn.eps, bn.momentum)
+
+
+class _BnAct(torch.autograd.Function):
+    """act(BatchNorm2d(x) [+ residual]) on channels_last tensors; reference: the BatchNorm /
+    ReLU / residual-add modules of torchvision's ResNet (code/dmcnet/model.py:305,352)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, relu, training, eps,
+                momentum):
+        lib = _lib.load()
+        _need_cuda(x, residual, gamma, beta)
+        n, c, h, w = x.shape
+        m = n * h * w
+        y = torch.empty_like(x)           # keeps the channels_last strides
+        stats = _floats(lib.dmc_bn_act_stats_bytes(c), x.device)
+        with _span("bn_act_fwd"):
+            _lib.check(lib.dmc_bn_act_fwd(_lib.ptr(x), _lib.ptr(residual), _lib.ptr(gamma),
+                                          _lib.ptr(beta), _lib.ptr(running_mean),
+                                          _lib.ptr(running_var), _lib.ptr(y), _lib.ptr(stats), m, c,
+                                          int(relu), int(training), float(eps), float(momentum),
+                                          _stream()), "dmc_bn_act_fwd")
+        ctx.save_for_backward(x, residual if relu else None, gamma, beta, stats)
+        ctx.relu, ctx.training, ctx.has_res = bool(relu), bool(training), residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, residual, gamma, beta, stats = ctx.saved_tensors
+        if not ctx.training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not implemented")
+        n, c, h, w = x.shape
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(x)
+        want_dres = ctx.has_res and ctx.needs_input_grad[1]
+        # without ReLU the residual's gradient is dy itself
+        dres = torch.empty_like(x) if (want_dres and ctx.relu) else None
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        with _span("bn_act_bwd"):
+            _lib.check(lib.dmc_bn_act_bwd(_lib.ptr(x), _lib.ptr(residual), _lib.ptr(gamma),
+                                          _lib.ptr(beta), _lib.ptr(stats), _lib.ptr(dy), _lib.ptr(dx),
+                                          _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta),
+                                          n * h * w, c, int(ctx.relu), _stream()), "dmc_bn_act_bwd")
+        if want_dres and not ctx.relu:
+            dres = dy
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None
+
+
+def bn_act_supported(x):
+    """True if the fused NHWC kernel handles this activation (else use the stock modules)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+        return False
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        return False
+    n, c, h, w = x.shape
+    return bool(_lib.load().dmc_bn_act_supported(n * h * w, c))
+
+
+def bn_act(x, bn, residual=None, relu=True):
+    """relu?(bn(x) [+ residual]) for a channels_last ``x`` and an ``nn.BatchNorm2d`` ``bn``."""
+    training = bn.training
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    if residual is not None:
+        residual = residual.contiguous(memory_format=torch.channels_last)
+    return _BnAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, relu,
+                        training, bn.eps, bn.momentum if bn.momentum is not None else 0.1)

@@ -8,6 +8,20 @@ convolutions run on PyTorch-ROCm (MIOpen); BASELINE.json config 2 scopes them th
 import torch
 from torch import nn
 
+from . import ops
+
+
+def _bn_act(bn, x, residual=None, relu=True):
+    """relu?(bn(x) [+ residual]): the fused NHWC HIP kernel when the activation qualifies
+    (channels_last fp32 on the GPU, train or eval), the stock modules otherwise."""
+    if x.is_cuda and bn.track_running_stats and (bn.training or not torch.is_grad_enabled()) \
+            and ops.bn_act_supported(x):
+        return ops.bn_act(x, bn, residual, relu)
+    y = bn(x)
+    if residual is not None:
+        y = y + residual
+    return torch.relu(y) if relu else y
+
 _CFG = {
     "resnet18": ("basic", (2, 2, 2, 2)),
     "resnet34": ("basic", (3, 4, 6, 3)),
@@ -42,15 +56,15 @@ class ResidualUnit(nn.Module):
         self.out_channels = cout
 
     def forward(self, x):
-        shortcut = x if self.downsample is None else self.downsample(x)
-        y = self.relu(self.bn1(self.conv1(x)))
-        if self.kind == "basic":
-            y = self.bn2(self.conv2(y))
+        if self.downsample is None:
+            shortcut = x
         else:
-            y = self.relu(self.bn2(self.conv2(y)))
-            y = self.bn3(self.conv3(y))
-        y += shortcut
-        return self.relu(y)
+            shortcut = _bn_act(self.downsample[1], self.downsample[0](x), relu=False)
+        y = _bn_act(self.bn1, self.conv1(x))
+        if self.kind == "basic":
+            return _bn_act(self.bn2, self.conv2(y), residual=shortcut)
+        y = _bn_act(self.bn2, self.conv2(y))
+        return _bn_act(self.bn3, self.conv3(y), residual=shortcut)
 
 
 class ResNet(nn.Module):
@@ -72,7 +86,7 @@ class ResNet(nn.Module):
         self.fc = nn.Linear(width, num_classes)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(_bn_act(self.bn1, self.conv1(x)))
         for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
             x = stage(x)
         return self.fc(torch.flatten(self.avgpool(x), 1))

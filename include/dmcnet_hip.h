@@ -137,6 +137,27 @@ int dmc_disc_tail_bwd(const float* x, const float* keep, const float* gamma, flo
                       const float* dy, float* dx, float* dgamma, float* dbeta, int N, int C, int H,
                       int W, int use_bn, dmc_stream_t stream);
 
+/* ---- classifier BatchNorm [+ residual] [+ ReLU], NHWC -------------------------------------------
+ * Replaces, inside the torchvision ResNet the reference builds at code/dmcnet/model.py:305 and
+ * runs at :352 (GAN: code/dmcnet_GAN/model.py:560): nn.BatchNorm2d followed by the residual
+ * addition and the in-place nn.ReLU of the stem and of every BasicBlock / Bottleneck:
+ *     y = act( BN(x) [+ residual] ),  act = ReLU if relu != 0 else identity.
+ * x, residual, y, dy, dx, dresidual: [M][C] row-major, M = N*H*W (the memory of a channels_last
+ * tensor).  Training mode uses batch statistics and updates running_mean / running_var exactly
+ * as nn.BatchNorm2d does.  dmc_bn_act_supported() tells whether (M, C) is handled
+ * (C % 4 == 0, C/4 <= 256, 256 % (C/4) == 0); callers use the stock op otherwise.
+ * stats: workspace of dmc_bn_act_stats_bytes(C); the forward leaves (mean, invstd) in its first
+ * 2*C floats for the backward.  The backward recomputes the ReLU mask from x (and residual).
+ */
+int dmc_bn_act_supported(int M, int C);
+size_t dmc_bn_act_stats_bytes(int C);
+int dmc_bn_act_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float* y, float* stats, int M, int C,
+                   int relu, int training, float eps, float momentum, dmc_stream_t stream);
+int dmc_bn_act_bwd(const float* x, const float* residual, const float* gamma, const float* beta,
+                   float* stats, const float* dy, float* dx, float* dresidual, float* dgamma,
+                   float* dbeta, int M, int C, int relu, dmc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

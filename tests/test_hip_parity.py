@@ -342,3 +342,40 @@ def test_reducer_single_rank_nccl_is_transparent():
                 assert float((p - q).abs().max()) < 1e-4, k      # one Adam step = lr * lr_mult = 1e-4
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shape,res,relu", [((4, 64, 56, 56), False, True), ((4, 64, 56, 56), True, True),
+                                             ((3, 128, 7, 9), True, True), ((2, 512, 7, 7), False, False),
+                                             ((6, 256, 14, 14), True, False)])
+def test_bn_act_unit(shape, res, relu):
+    """Fused NHWC BatchNorm(+residual)(+ReLU) against the stock modules, forward and backward."""
+    c = shape[1]
+    x, r, go = rnd(51, shape), rnd(52, shape), rnd(53, shape)
+    bn_o = torch.nn.BatchNorm2d(c)
+    O.seeded_state_fill(bn_o, 54)
+    bn_m = torch.nn.BatchNorm2d(c)
+    bn_m.load_state_dict(bn_o.state_dict())
+    bn_m.to(DEV)
+    xo, ro = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    yo = bn_o(xo) + (ro if res else 0)
+    yo = torch.relu(yo) if relu else yo
+    (yo * go).sum().backward()
+    xg = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    rg = r.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert ops.bn_act_supported(xg)
+    y = ops.bn_act(xg, bn_m, rg if res else None, relu)
+    (y * go.to(DEV)).sum().backward()
+    assert rel_err(y, yo) < 1e-5
+    assert rel_err(xg.grad, xo.grad) < 1e-4
+    if res:
+        assert rel_err(rg.grad, ro.grad) < 1e-5
+    assert rel_err(bn_m.weight.grad, bn_o.weight.grad) < 1e-4
+    assert rel_err(bn_m.bias.grad, bn_o.bias.grad) < 1e-4
+    assert rel_err(bn_m.running_mean, bn_o.running_mean) < 1e-5
+    assert rel_err(bn_m.running_var, bn_o.running_var) < 1e-5
+    assert int(bn_m.num_batches_tracked) == 1
+    bn_o.eval(); bn_m.eval()
+    with torch.no_grad():
+        ye = ops.bn_act(xg, bn_m, rg if res else None, relu)
+        yr = bn_o(x) + (r if res else 0)
+        assert rel_err(ye, torch.relu(yr) if relu else yr) < 1e-5
