@@ -32,6 +32,8 @@ SIGNATURES = {
     "dmc_disc_tail_stats_bytes": (_Z, [_I]),
     "dmc_disc_tail_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
     "dmc_disc_tail_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dmc_prepare_inputs_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "dmc_prepare_inputs": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "dmc_bn_act_supported": (_I, [_I, _I]),
     "dmc_bn_act_stats_bytes": (_Z, [_I]),
     "dmc_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),

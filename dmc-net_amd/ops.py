@@ -5,7 +5,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["gen_tiny", "flow_mse", "consensus_ce", "disc_tail", "bn_act", "bn_act_supported"]
+__all__ = ["gen_tiny", "flow_mse", "consensus_ce", "disc_tail", "bn_act", "bn_act_supported", "prepare_inputs"]
 
 
 class EventProbe(object):
@@ -319,3 +319,34 @@ def bn_act(x, bn, residual=None, relu=True):
         residual = residual.contiguous(memory_format=torch.channels_last)
     return _BnAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, relu,
                         training, bn.eps, bn.momentum if bn.momentum is not None else 0.1)
+
+
+_STD = (0.229, 0.224, 0.225)
+
+
+def prepare_inputs(frames_u8, flip=None, flow_ds_factor=0):
+    """uint8 [N,H,W,7] HWC frames (+ optional [N] flip flags) on the GPU -> (input_flow [N,2,H,W],
+    input_mv [N,2,H,W], input_residual [N,3,H,W]) exactly as the reference's dataset produces them
+    (code/dmcnet/dataset.py:215-263, transforms.py:47-58)."""
+    import ctypes
+    lib = _lib.load()
+    if not frames_u8.is_cuda or frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 \
+            or frames_u8.shape[-1] != 7:
+        raise _lib.DmcHipError("prepare_inputs expects a CUDA uint8 tensor [N,H,W,7]")
+    frames_u8 = frames_u8.contiguous()
+    n, h, w, _ = frames_u8.shape
+    dev = frames_u8.device
+    if flip is not None:
+        flip = flip.to(dev, torch.uint8).contiguous()
+    flow = torch.empty((n, 2, h, w), dtype=torch.float32, device=dev)
+    mv = torch.empty((n, 2, h, w), dtype=torch.float32, device=dev)
+    res = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev)
+    work = _floats(lib.dmc_prepare_inputs_workspace_bytes(n, h, w, int(flow_ds_factor)), dev)
+    std = torch.tensor(_STD, dtype=torch.float64).float()
+    std4 = (ctypes.c_float * 4)(float(torch.mean(std)), float(std[0]), float(std[1]), float(std[2]))
+    with _span("prepare_inputs"):
+        _lib.check(lib.dmc_prepare_inputs(_lib.ptr(frames_u8), _lib.ptr(flip), _lib.ptr(flow),
+                                          _lib.ptr(mv), _lib.ptr(res), _lib.ptr(work), n, h, w,
+                                          int(flow_ds_factor), ctypes.cast(std4, ctypes.c_void_p),
+                                          _stream()), "dmc_prepare_inputs")
+    return flow, mv, res

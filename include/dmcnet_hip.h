@@ -158,6 +158,21 @@ int dmc_bn_act_bwd(const float* x, const float* residual, const float* gamma, co
                    float* stats, const float* dy, float* dx, float* dresidual, float* dgamma,
                    float* dbeta, int M, int C, int relu, dmc_stream_t stream);
 
+/* ---- GPU-side input preparation -----------------------------------------------------------------
+ * Replaces the tensor side of CoviarDataSet.__getitem__, code/dmcnet/dataset.py:215-263 (channel
+ * split, flow block_reduce(mean)+repeat when flow_ds_factor != 0, /255, (x-0.5)/std) and the
+ * horizontal flip of code/dmcnet/transforms.py:47-58, bit-identically.
+ * frames_u8 [N,H,W,7] uint8 HWC = [flow_x flow_y mv_x mv_y r g b] (already cropped/resized);
+ * flip [N] bytes or NULL (non-zero: mirror the frame, x components of flow and MV -> 256 - v);
+ * outputs input_flow [N,2,H,W], input_mv [N,2,H,W], input_residual [N,3,H,W] fp32.
+ * std4_host: HOST array {mean(std), std_r, std_g, std_b} as fp32 (what torch computes from
+ * [0.229, 0.224, 0.225]).  workspace: dmc_prepare_inputs_workspace_bytes() bytes.
+ */
+size_t dmc_prepare_inputs_workspace_bytes(int N, int H, int W, int flow_ds_factor);
+int dmc_prepare_inputs(const unsigned char* frames_u8, const unsigned char* flip, float* out_flow,
+                       float* out_mv, float* out_res, float* workspace, int N, int H, int W,
+                       int flow_ds_factor, const float* std4_host, dmc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

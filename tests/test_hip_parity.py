@@ -379,3 +379,38 @@ def test_bn_act_unit(shape, res, relu):
         ye = ops.bn_act(xg, bn_m, rg if res else None, relu)
         yr = bn_o(x) + (r if res else 0)
         assert rel_err(ye, torch.relu(yr) if relu else yr) < 1e-5
+
+
+def test_eval_path_25_segments_vs_oracle():
+    """test.py-style scoring: 25 segments per video, consensus mean, eval mode."""
+    from dmcnet_amd import evaluate
+    o, m = _product(False, 61)
+    o.eval(); m.eval()
+    flow, mv, res, _ = O.synthetic_batch(seed=62, batch=1, num_segments=25, num_class=51)
+    with torch.no_grad():
+        ref = o(mv, res)[0].view(1, 25, 51).mean(1).numpy()
+    got = evaluate.forward_video(m, mv.to(DEV), res.to(DEV), 25, 1)
+    assert got.shape == (1, 51) and rel_err(torch.from_numpy(got), ref) < 1e-4
+    loader = [(flow, mv, res, torch.tensor([7]))]
+    out, acc = evaluate.evaluate(m, loader, 25, 1, DEV)
+    assert len(out) == 1 and out[0][1] == 7 and acc in (0.0, 100.0)
+
+
+@pytest.mark.parametrize("size,factor", [(224, 0), (224, 16), (50, 16), (37, 0)])
+def test_prepare_inputs_bit_exact(size, factor):
+    """GPU input preparation == the reference dataset's tensors, bit for bit, incl. the flip."""
+    from dmcnet_amd import transforms
+    frames = O.synthetic_frames_u8(71, 2, 3, size=size)                # [B,S,7,H,W] u8
+    hwc = np.ascontiguousarray(frames.reshape(6, 7, size, size).transpose(0, 2, 3, 1))
+    flip = np.array([0, 0, 0, 1, 1, 1], dtype=np.uint8)                # second clip mirrored
+    ref = []
+    for i in range(6):
+        img = hwc[i]
+        if flip[i]:
+            img = transforms.flip_with_x_negation(img)                 # int32, as the reference
+        ref.append(np.transpose(np.asarray(img), (2, 0, 1)))
+    ref = np.stack(ref)                                                # [6,7,H,W]
+    f0, m0, r0 = O.normalize_sample(ref, factor)
+    f, m, r = ops.prepare_inputs(torch.from_numpy(hwc).to(DEV), torch.from_numpy(flip), factor)
+    assert torch.equal(m.cpu(), m0) and torch.equal(r.cpu(), r0)
+    assert torch.equal(f.cpu(), f0)

@@ -194,3 +194,29 @@ def test_grad_bucket_reducer_two_ranks_gloo(tmp_path):
             assert g is None
         else:
             torch.testing.assert_close(g, p.grad, rtol=1e-5, atol=1e-7)
+
+
+def test_score_fusion_matches_reference_combine(golden, tmp_path):
+    """combine() on the reference's shipped HMDB-51 split-1 score files reproduces the accuracy the
+    reference's own combine.py prints for them (fixture g7)."""
+    from dmcnet_amd import evaluate
+    g = golden("g7_score_fusion")
+    exp = dict(zip(g["expected_names"].tolist(), g["expected_acc"].tolist()))
+    part = lambda t: (g["hmdb51_split1_" + t].astype(np.float64), g["hmdb51_split1_labels_" + t])
+    for tag, name in (("dmc", "hmdb51/gen_flow/split1"), ("dmc_gan", "hmdb51/gan/split1")):
+        acc, comb = evaluate.combine(part("iframe"), part("mv"), part("residual"), part(tag))
+        assert abs(acc - exp[name]) < 1e-6 and comb.shape == (1530, 51)
+    assert abs(exp["hmdb51/gen_flow/split1"] - 0.639216) < 1e-6       # SURVEY section 4: 63.92 %
+    # weights matter: the I-frame stream carries weight 2
+    acc_eq, _ = evaluate.combine(part("iframe"), part("mv"), part("residual"), part("dmc"), wi=1.0)
+    assert acc_eq != exp["hmdb51/gen_flow/split1"]
+    # dump / load round trip in the reference's layout (sorted by name)
+    names = ["b.avi", "a.avi", "c.avi"]
+    output = [(np.full((1, 51), i, np.float32), i) for i in range(3)]
+    p = str(tmp_path / "s.npz")
+    evaluate.save_scores(p, output, names)
+    s, l, n = evaluate.load_scores(p)
+    assert n.tolist() == ["a.avi", "b.avi", "c.avi"] and l.tolist() == [1, 0, 2]
+    assert s.shape == (3, 51) and s[0, 0] == 1.0
+    with pytest.raises(ValueError):
+        evaluate.combine((s, l), (s, l[::-1].copy()), (s, l))
