@@ -57,16 +57,19 @@ __device__ __forceinline__ const float* in_plane(const float* mv, const float* r
 }
 
 // ------------------------------------------------------------------------------------------
-// One 3x3 layer over a 32x32-pixel tile per workgroup (256 threads).
+// One 3x3 layer over a full-width row band per workgroup: 256 x 8 pixels, 512 threads.
 //
 //   lane = (row r of the tile, 4-pixel strip s); it produces 4 pixels x ALL output channels, so
 //   every input value fetched from LDS feeds 3*COUT FMAs and the weights are wave-uniform:
 //   they arrive through scalar loads and enter the FMAs as SGPR operands.
-//   Input planes are staged in chunks of 8 channels, branch-free (clamped addresses, values
-//   zeroed by a select), as [34 rows][32] interior + two compact halo-column arrays, so the
+//   The tile spans the whole image width (224 <= 256), so there is NO horizontal halo to fetch:
+//   with 32-pixel-wide tiles every 128-byte row segment dragged in two more cache lines for its
+//   halo columns and the layer kernels ran at the HBM roof (PMC: 1,648 B/px forward, 5.7 TB/s).
+//   Input planes are staged 4 channels at a time, branch-free (clamped addresses, values
+//   zeroed by a select), as [10 rows][256] interior + two compact halo-column arrays, so the
 //   lane's reads are one conflict-free ds_read_b128 and two conflict-free ds_read_b32 per row.
-//   52 KB of LDS per workgroup -> 3 workgroups (12 waves) per CU; another workgroup's FMAs
-//   cover this one's staging.
+//   61 KB of LDS per workgroup -> 2 workgroups (16 waves) per CU; one workgroup's FMAs cover the
+//   other's staging.
 //
 // MODE 0: forward hidden layer K   (inputs mv/res/feat[0..), output LeakyReLU(0.1) -> feat)
 // MODE 1: forward last layer       (output -> out, optionally + mv)
@@ -74,13 +77,15 @@ __device__ __forceinline__ const float* in_plane(const float* mv, const float* r
 //         gradient g_{K+1..5} in one pass and writes g_K = dL/dy_K * LeakyReLU'(y_K) once (no
 //         read-modify-write of the gradient buffer)
 // ------------------------------------------------------------------------------------------
-constexpr int LT = 32;                       // tile edge (pixels)
-constexpr int LCH = 8;                       // channels per staged chunk
-constexpr int LROWS = LT + 2;
-constexpr int L_MAIN = LROWS * LT;           // 1088 floats
-constexpr int L_HALO = LROWS * 8;            // per side
-constexpr int L_PLANE = L_MAIN + 2 * L_HALO; // 1632 floats per channel
-constexpr int L_LDS = LCH * L_PLANE;         // 13056 floats = 52,224 B
+constexpr int LTW = 256, LTH = 8;            // tile width / height (pixels)
+constexpr int LNS = LTW / 4;                 // 64 strips per row = one wave per tile row
+constexpr int LTHREADS = LNS * LTH;          // 512
+constexpr int LCH = 4;                       // channels per staged chunk
+constexpr int LROWS = LTH + 2;
+constexpr int L_MAIN = LROWS * LTW;          // 2560 floats
+constexpr int L_HALO = LROWS * LNS;          // 640 per side
+constexpr int L_PLANE = L_MAIN + 2 * L_HALO; // 3840 floats per channel
+constexpr int L_LDS = LCH * L_PLANE;         // 15360 floats = 61,440 B
 
 struct LayerArgs {
     const float* mv;      // [N,2,H,W]
@@ -105,14 +110,15 @@ __device__ __forceinline__ const float* layer_in_plane(const LayerArgs& a, int n
 }
 
 template <int MODE, int K, bool VEC4>
-__global__ __launch_bounds__(256) void gen_layer_kernel(LayerArgs a) {
+__global__ __launch_bounds__(LTHREADS, 4) void gen_layer_kernel(LayerArgs a) {   // 2 WG/CU -> <= 128 VGPRs
     constexpr int CIN = MODE == 2 ? gin_of(K) : cin_of(K);
     constexpr int COUT = cout_of(K);
     __shared__ __attribute__((aligned(16))) float lds[L_LDS];
-    const int n = blockIdx.z, ty0 = blockIdx.y * LT, tx0 = blockIdx.x * LT;
+    const int n = blockIdx.z, ty0 = blockIdx.y * LTH, tx0 = blockIdx.x * LTW;
     const int H = a.H, W = a.W;
     const size_t HW = (size_t)H * W;
-    const int tid = threadIdx.x, r = tid >> 3, s = tid & 7;
+    const int tid = threadIdx.x, s = tid % LNS;
+    const int r = __builtin_amdgcn_readfirstlane(tid / LNS);       // tile row == wave index
 
     float acc[COUT][4];
 #pragma unroll
@@ -123,39 +129,83 @@ __global__ __launch_bounds__(256) void gen_layer_kernel(LayerArgs a) {
     }
     const float* wbase = a.pk + (MODE == 2 ? wb_off(K) : wf_off(K));
 
+    // Staging is software-pipelined through registers: the global loads of chunk c+1 are issued
+    // before the FMAs of chunk c and written to LDS after them, so HBM/L2 latency overlaps
+    // compute (PMC before this: waves parked 68 % of their cycles at s_waitcnt / s_barrier).
+    // Wave w owns tile row w (waves 0,1 also rows 8,9): row, validity and plane base are
+    // wave-uniform (scalar); only the column offset is per lane.
+    const int xx = tx0 + 4 * s;
+    const bool colok = xx < W;
+    const int xl = xx - 1, xr = xx + 4;
+    const bool okl = xl >= 0 && xl < W, okr = xr < W;
+    const int ol = okl ? xl : 0, orr = okr ? xr : 0, oc = colok ? xx : 0;
+    float4 sv[LCH][2];
+    float shl[LCH][2], shr[LCH][2];
+
+    auto load_chunk = [&](int c0) {
+#pragma unroll
+        for (int c = 0; c < LCH; ++c) {
+            if (c0 + c < CIN) {
+                const float* plane = layer_in_plane<MODE, K>(a, n, c0 + c, HW);
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int row = r + pass * LTH;
+                    if (row < LROWS) {                       // wave-uniform
+                        int yy = ty0 - 1 + row;
+                        yy = yy < 0 ? 0 : (yy < H ? yy : H - 1);
+                        const float* src = plane + (size_t)yy * W;
+                        if (VEC4) {
+                            sv[c][pass] = *reinterpret_cast<const float4*>(src + oc);
+                        } else {
+                            sv[c][pass].x = src[xx + 0 < W ? xx + 0 : 0];
+                            sv[c][pass].y = src[xx + 1 < W ? xx + 1 : 0];
+                            sv[c][pass].z = src[xx + 2 < W ? xx + 2 : 0];
+                            sv[c][pass].w = src[xx + 3 < W ? xx + 3 : 0];
+                        }
+                        shl[c][pass] = src[ol];
+                        shr[c][pass] = src[orr];
+                    }
+                }
+            }
+        }
+    };
+    auto store_chunk = [&](int c0) {
+#pragma unroll
+        for (int c = 0; c < LCH; ++c) {
+            if (c0 + c < CIN) {
+                float* dl = lds + c * L_PLANE;
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int row = r + pass * LTH;
+                    if (row < LROWS) {
+                        const int yy = ty0 - 1 + row;
+                        const bool rowok = (yy >= 0) && (yy < H);
+                        float4 v = sv[c][pass];
+                        if (VEC4) {
+                            if (!(rowok && colok)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        } else {
+                            v.x = (rowok && xx + 0 < W) ? v.x : 0.f;
+                            v.y = (rowok && xx + 1 < W) ? v.y : 0.f;
+                            v.z = (rowok && xx + 2 < W) ? v.z : 0.f;
+                            v.w = (rowok && xx + 3 < W) ? v.w : 0.f;
+                        }
+                        *reinterpret_cast<float4*>(dl + row * LTW + 4 * s) = v;
+                        dl[L_MAIN + row * LNS + s] = (rowok && okl) ? shl[c][pass] : 0.f;
+                        dl[L_MAIN + L_HALO + row * LNS + s] = (rowok && okr) ? shr[c][pass] : 0.f;
+                    }
+                }
+            }
+        }
+    };
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
 #pragma unroll 1
     for (int c0 = 0; c0 < CIN; c0 += LCH) {
         const int nch = (CIN - c0) < LCH ? (CIN - c0) : LCH;
-        if (c0 > 0) __syncthreads();
-        // ---- stage nch planes: rows ty0-1..ty0+32, interior cols tx0..tx0+31, halo cols ----
-        {
-            const int q = tid & 7, xx = tx0 + 4 * q;
-            for (int rr = tid >> 3; rr < nch * LROWS; rr += 32) {
-                const int c = rr / LROWS, row = rr - c * LROWS;
-                const int yy = ty0 - 1 + row;
-                const bool rowok = (yy >= 0) && (yy < H);
-                const float* src = layer_in_plane<MODE, K>(a, n, c0 + c, HW) + (size_t)(rowok ? yy : 0) * W;
-                float4 v;
-                if (VEC4) {
-                    const bool ok = rowok && xx < W;
-                    v = *reinterpret_cast<const float4*>(src + (ok ? xx : 0));
-                    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                } else {
-                    v.x = (rowok && xx + 0 < W) ? src[xx + 0 < W ? xx + 0 : 0] : 0.f;
-                    v.y = (rowok && xx + 1 < W) ? src[xx + 1 < W ? xx + 1 : 0] : 0.f;
-                    v.z = (rowok && xx + 2 < W) ? src[xx + 2 < W ? xx + 2 : 0] : 0.f;
-                    v.w = (rowok && xx + 3 < W) ? src[xx + 3 < W ? xx + 3 : 0] : 0.f;
-                }
-                *reinterpret_cast<float4*>(lds + c * L_PLANE + row * LT + 4 * q) = v;
-                // halo columns of strip q: left = col 4q-1, right = col 4q+4 (tile-relative)
-                const int xl = xx - 1, xr = xx + 4;
-                const bool okl = rowok && xl >= 0 && xl < W, okr = rowok && xr < W;
-                const float hl = src[okl ? xl : 0], hr = src[okr ? xr : 0];
-                lds[c * L_PLANE + L_MAIN + row * 8 + q] = okl ? hl : 0.f;
-                lds[c * L_PLANE + L_MAIN + L_HALO + row * 8 + q] = okr ? hr : 0.f;
-            }
-        }
-        __syncthreads();
+        const bool more = c0 + LCH < CIN;
+        if (more) load_chunk(c0 + LCH);                      // in flight during the FMAs below
         // ---- accumulate ----
 #pragma unroll 1
         for (int c = 0; c < nch; ++c) {
@@ -164,10 +214,10 @@ __global__ __launch_bounds__(256) void gen_layer_kernel(LayerArgs a) {
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int row = r + ky;
-                const float4 m = *reinterpret_cast<const float4*>(pl + row * LT + 4 * s);
-                xv[ky][0] = pl[L_MAIN + row * 8 + s];
+                const float4 m = *reinterpret_cast<const float4*>(pl + row * LTW + 4 * s);
+                xv[ky][0] = pl[L_MAIN + row * LNS + s];
                 xv[ky][1] = m.x; xv[ky][2] = m.y; xv[ky][3] = m.z; xv[ky][4] = m.w;
-                xv[ky][5] = pl[L_MAIN + L_HALO + row * 8 + s];
+                xv[ky][5] = pl[L_MAIN + L_HALO + row * LNS + s];
             }
             const float* wp = wbase + (c0 + c) * 9 * COUT;
 #pragma unroll
@@ -180,6 +230,11 @@ __global__ __launch_bounds__(256) void gen_layer_kernel(LayerArgs a) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) acc[co][j] = fmaf(xv[ky][j + kx], wv, acc[co][j]);
                     }
+        }
+        if (more) {
+            __syncthreads();                                 // everyone is done reading this chunk
+            store_chunk(c0 + LCH);
+            __syncthreads();
         }
     }
 
@@ -482,9 +537,9 @@ int launch_layer(LayerArgs a, int n0, int N, hipStream_t s) {
     a.gout = a.gout ? a.gout + (size_t)n0 * 2 * HW : nullptr;
     a.gbuf = a.gbuf ? a.gbuf + (size_t)n0 * NFEAT * HW : nullptr;
     a.out = a.out ? a.out + (size_t)n0 * 2 * HW : nullptr;
-    const dim3 grid((a.W + LT - 1) / LT, (a.H + LT - 1) / LT, N);
-    if (a.W % 4 == 0) gen_layer_kernel<MODE, K, true><<<grid, 256, 0, s>>>(a);
-    else gen_layer_kernel<MODE, K, false><<<grid, 256, 0, s>>>(a);
+    const dim3 grid((a.W + LTW - 1) / LTW, (a.H + LTH - 1) / LTH, N);
+    if (a.W % 4 == 0) gen_layer_kernel<MODE, K, true><<<grid, LTHREADS, 0, s>>>(a);
+    else gen_layer_kernel<MODE, K, false><<<grid, LTHREADS, 0, s>>>(a);
     return check_launch("gen_layer");
 }
 
