@@ -39,7 +39,7 @@ def main():
         if not any(t in k for t in ("gen_", "flow_mse", "pack_params")):
             continue
         f, w = fetch.get(k, 0.0), write.get(k, 0.0)
-        name = k.split("(")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+        name = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         print("%s,%.2f,%.2f,%.2f,%.2f,%.1f" % (name, f / 1e6, w / 1e6, f * kr / 1e6, w * kw / 1e6,
                                              (f * kr + w * kw) / px))
         grp = "fwd" if ("gen_layer_kernel<0" in k or "gen_layer_kernel<1" in k) else \
@@ -49,6 +49,13 @@ def main():
     for g, v in tot.items():
         print("# generator %s total: %.1f MB calibrated = %.1f B/px (algorithmic: fwd 28 B/px fused, "
               "140 B/px with saved features)" % (g, v / 1e6, v / px))
+    if len(sys.argv) > 4:
+        import json
+        json.dump({"frames": n, "fetch_scale": kr, "write_scale": kw,
+                   "gen_fwd_bytes_per_px": tot["fwd"] / px, "gen_bwd_bytes_per_px": tot["bwd"] / px,
+                   "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
+                             "tools/gen_microbench.py, calibrated on flow_mse kernels of known traffic"},
+                  open(sys.argv[4], "w"), indent=1)
 
 
 if __name__ == "__main__":
