@@ -149,6 +149,12 @@ def main():
         fwd_ms, _ = spans["gen_tiny_fwd"]
         tf = px * GEN_FLOP_PER_PX / (fwd_ms * 1e-3) / 1e12
         gbs = px * GEN_BYTES_PER_PX / (fwd_ms * 1e-3) / 1e9
+        # HBM bytes per forward call from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, calibrated;
+        # collected offline with tools/pmc_traffic.py, see profiles/r1_gen_traffic.csv)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1_gen_traffic.json")
+        if os.path.exists(tpath):
+            traffic = int(json.load(open(tpath))["gen_fwd_bytes_per_px"] * px)
         line = {
             "metric": "clips/sec (3-seg 224x224) DMC-gen+ResNet-18 train step",
             "value": round(world * args.batch * args.steps / elapsed, 3), "unit": "clips/sec",
@@ -166,10 +172,12 @@ def main():
                 # the fused fp32 generator is FMA-bound (325 FLOP/B >> ridge 20 FLOP/B): the binding
                 # roof is the fp32 vector/matrix peak, reported in the "mfma" slot of the schema
                 "bound": "mfma", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
                 "launch_ms": round(fwd_ms, 4),
                 "hbm": {"achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(gbs / HBM_PEAK_GBS, 5)}},
+                        "frac": round(gbs / HBM_PEAK_GBS, 5),
+                        "note": "algorithmic 28 B/px; 'traffic' = measured HBM bytes of the 6 layer launches",
+                        "traffic_gbs": None if traffic is None else round(traffic / (fwd_ms * 1e-3) / 1e9, 1)}},
             "kernels_ms": {k: round(v[0], 4) for k, v in spans.items()},
         }
         if world == 1 and not args.no_cpu_baseline and not gan:
