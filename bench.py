@@ -73,6 +73,62 @@ def cpu_baseline(batch, num_segments, num_class, budget_s=20.0):
                       "warm-up" % (cores, b, num_segments, batch, int(budget_s))}
 
 
+def bench_i3d(args, rank, world, dev):
+    """BASELINE config 5: I3D over the per-frame DMC generator; micro-batch of 3 clips x T frames,
+    trunk under bf16 autocast, generator fp32; D and G phases alternate (iter_size 1)."""
+    from dmcnet_amd import ddp, i3d, ops
+    torch.manual_seed(0)
+    b = 3 if args.batch == 40 else args.batch
+    net = i3d.I3D(args.num_class, modality="flow+mp4", dropout_prob=0.85, arch_estimator="DenseNetTiny",
+                  arch_d="Discriminator").to(dev).train()
+    net.trunk_dtype = torch.bfloat16
+    stepper = i3d.I3DTrainStep(net, iter_size=1)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    data = torch.randn((b, 7, args.clip_length, 224, 224), generator=g, device=dev)
+    target = torch.randint(0, args.num_class, (b,), generator=g, device=dev)
+    reducer = ddp.GradBucketReducer(list(net.parameters())) if world > 1 else None
+
+    def one():
+        if reducer is not None:
+            reducer.begin()
+        out = stepper.step(data, target)
+        if reducer is not None:
+            reducer.finish()
+        return out
+
+    if reducer is not None:
+        raise SystemExit("i3d config: gradient exchange must sit between backward and step; "
+                         "multi-GPU I3D is not wired this round")
+    for _ in range(args.warmup):
+        one()
+    probe = ops.EventProbe()
+    ops.PROBE = probe
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, losses, _ = one()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.PROBE = None
+    spans = probe.summary()
+    px = b * args.clip_length * 224 * 224
+    fwd_ms = spans["gen_tiny_fwd"][0]
+    tf = px * GEN_FLOP_PER_PX / (fwd_ms * 1e-3) / 1e12
+    print(json.dumps({
+        "metric": "clips/sec (%d-frame 224x224 clips) dmcnet_I3D train micro-step" % args.clip_length,
+        "value": round(b * args.steps / elapsed, 3), "unit": "clips/sec", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 trunk / f32 generator",
+        "data": "synthetic",
+        "config": {"workload": "dmcnet_I3D HMDB-51, DenseNetTiny generator per frame + I3D trunk + Discriminator, "
+                               "micro-batch %d clips x %d frames, alternating D/G phases" % (b, args.clip_length),
+                   "final_losses": [round(float(l), 5) for l in losses]},
+        "roofline": {"kernel": "dmc_gen_tiny_fwd (%d frames)" % (b * args.clip_length), "bound": "mfma",
+                     "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": None, "launch_ms": round(fwd_ms, 4)},
+        "kernels_ms": {k: round(v[0], 4) for k, v in spans.items()}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,7 +136,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=40, help="clips per GPU")
     ap.add_argument("--num-class", type=int, default=51)
-    ap.add_argument("--config", default="dmcnet", choices=["dmcnet", "gan"])
+    ap.add_argument("--config", default="dmcnet", choices=["dmcnet", "gan", "i3d"])
+    ap.add_argument("--clip-length", type=int, default=64, help="frames per clip (i3d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--miopen-find", type=int, default=0,
                     help="1 = torch.backends.cudnn.benchmark (MIOpen exhaustive find during warm-up)")
@@ -99,6 +156,8 @@ def main():
 
     import dmcnet_amd
     from dmcnet_amd import dataset, ddp, ops, train
+    if args.config == "i3d":
+        return bench_i3d(args, rank, world, dev)
     S = 3
     torch.manual_seed(0)
     gan = args.config == "gan"

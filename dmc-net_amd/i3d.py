@@ -1,0 +1,248 @@
+"""I3D variant (BASELINE config 5): the DMC generator applied per frame, an Inception-v1 I3D trunk
+over the resulting cue, optional discriminator node.
+
+Same module/attribute names and state-dict keys as the reference's
+``code/dmcnet_I3D/network/i3d.py`` (``Unit3Dpy`` :328-403, ``MaxPool3dTFPadding`` :406-418,
+``Mixed`` :421-455, ``I3D`` :458-601) and the loss assembly of
+``code/dmcnet_I3D/train/model.py:135-188``.  The per-frame generator is the HIP path
+(``EstimatorDenseNetTiny``); the 3-D convolutions run on PyTorch-ROCm (MIOpen), optionally under
+bf16 autocast (the generator stays fp32).
+"""
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from . import model as _m
+
+
+def _same_pad(kernel, stride):
+    """TF 'SAME' padding per dimension (d, h, w) -> (front, back) pairs."""
+    out = []
+    for k, s in zip(kernel, stride):
+        total = max(k - s, 0)
+        out.append((total // 2, total - total // 2))
+    return out
+
+
+class Unit3Dpy(nn.Module):
+    """Conv3d [+ BatchNorm3d] [+ ReLU] with TF-SAME padding; optional squeeze(H,W) + mean(T)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=(1, 1, 1), stride=(1, 1, 1),
+                 activation="relu", padding="SAME", use_bias=False, use_bn=True, squeeze=False,
+                 mean=False):
+        super().__init__()
+        if padding not in ("SAME", "VALID"):
+            raise ValueError("padding should be in [VALID|SAME] but got {}".format(padding))
+        self.squeeze, self.mean, self.relu = squeeze, mean, activation is not None
+        pad = 0
+        self.pad = None
+        if padding == "SAME":
+            pads = _same_pad(kernel_size, stride)
+            if all(p == pads[0] and p[0] == p[1] for p in pads):
+                pad = pads[0][0]
+            else:   # ConstantPad3d order: (w_l, w_r, h_t, h_b, d_f, d_b)
+                self.pad = nn.ConstantPad3d(pads[2] + pads[1] + pads[0], 0)
+        self.conv3d = nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride, padding=pad,
+                                bias=use_bias)
+        if use_bn:
+            self.batch3d = nn.BatchNorm3d(out_channels)
+        self.use_bn = use_bn
+
+    def forward(self, x):
+        if self.pad is not None:
+            x = self.pad(x)
+        x = self.conv3d(x)
+        if self.use_bn:
+            x = self.batch3d(x)
+        if self.relu:
+            x = F.relu(x)
+        if self.squeeze:
+            x = x.squeeze(3).squeeze(3)
+            if self.mean:
+                x = x.mean(2)
+        return x
+
+
+class MaxPool3dTFPadding(nn.Module):
+    def __init__(self, kernel_size, stride=None, padding="SAME"):
+        super().__init__()
+        pads = _same_pad(kernel_size, stride)
+        self.pad = nn.ConstantPad3d(pads[2] + pads[1] + pads[0], 0)
+        self.pool = nn.MaxPool3d(kernel_size, stride, ceil_mode=True)
+
+    def forward(self, x):
+        return self.pool(self.pad(x))
+
+
+class Mixed(nn.Module):
+    """Inception block: 1x1 | 1x1-3x3 | 1x1-3x3 | pool-1x1, concatenated."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        o = out_channels
+        self.branch_0 = Unit3Dpy(in_channels, o[0])
+        self.branch_1 = nn.Sequential(Unit3Dpy(in_channels, o[1]), Unit3Dpy(o[1], o[2], (3, 3, 3)))
+        self.branch_2 = nn.Sequential(Unit3Dpy(in_channels, o[3]), Unit3Dpy(o[3], o[4], (3, 3, 3)))
+        self.branch_3 = nn.Sequential(MaxPool3dTFPadding((3, 3, 3), (1, 1, 1)),
+                                      Unit3Dpy(in_channels, o[5]))
+
+    def forward(self, x):
+        return torch.cat((self.branch_0(x), self.branch_1(x), self.branch_2(x), self.branch_3(x)), 1)
+
+
+_MIXED = (("mixed_3b", 192, (64, 96, 128, 16, 32, 32)), ("mixed_3c", 256, (128, 128, 192, 32, 96, 64)),
+          ("mixed_4b", 480, (192, 96, 208, 16, 48, 64)), ("mixed_4c", 512, (160, 112, 224, 24, 64, 64)),
+          ("mixed_4d", 512, (128, 128, 256, 24, 64, 64)), ("mixed_4e", 512, (112, 144, 288, 32, 64, 64)),
+          ("mixed_4f", 528, (256, 160, 320, 32, 128, 128)), ("mixed_5b", 832, (256, 160, 320, 32, 128, 128)),
+          ("mixed_5c", 832, (384, 192, 384, 48, 128, 128)))
+
+
+class I3D(nn.Module):
+    def __init__(self, num_classes, modality="rgb", dropout_prob=0, arch_estimator=None, arch_d=None,
+                 name="inception", **kwargs):
+        super().__init__()
+        self.name, self.num_classes, self.modality = name, num_classes, modality
+        in_channels = 2 if modality in ("flow", "mv", "flow+mp4") else 3
+        self.arch_estimator, self.arch_d = arch_estimator, arch_d
+        if arch_estimator in ("DenseNet", "DenseNetSmall", "DenseNetTiny"):
+            self.gen_flow_model = _m._ESTIMATORS[arch_estimator](5)
+        if arch_d is not None:
+            if arch_d not in _m._DISCRIMINATORS:
+                raise ValueError("Unknown discriminator: {}".format(arch_d))
+            self.discriminator = _m._DISCRIMINATORS[arch_d](2)
+        self.conv3d_1a_7x7 = Unit3Dpy(in_channels, 64, (7, 7, 7), (2, 2, 2))
+        self.maxPool3d_2a_3x3 = MaxPool3dTFPadding((1, 3, 3), (1, 2, 2))
+        self.conv3d_2b_1x1 = Unit3Dpy(64, 64)
+        self.conv3d_2c_3x3 = Unit3Dpy(64, 192, (3, 3, 3))
+        self.maxPool3d_3a_3x3 = MaxPool3dTFPadding((1, 3, 3), (1, 2, 2))
+        for nm, cin, outs in _MIXED[:2]:
+            setattr(self, nm, Mixed(cin, outs))
+        self.maxPool3d_4a_3x3 = MaxPool3dTFPadding((3, 3, 3), (2, 2, 2))
+        for nm, cin, outs in _MIXED[2:7]:
+            setattr(self, nm, Mixed(cin, outs))
+        self.maxPool3d_5a_2x2 = MaxPool3dTFPadding((2, 2, 2), (2, 2, 2))
+        for nm, cin, outs in _MIXED[7:]:
+            setattr(self, nm, Mixed(cin, outs))
+        self.avg_pool = nn.AvgPool3d((2, 7, 7), (1, 1, 1))
+        self.dropout = nn.Dropout(dropout_prob)
+        self.conv3d_0c_1x1 = Unit3Dpy(1024, 400, activation=None, use_bias=True, use_bn=False,
+                                      squeeze=True, mean=True)
+        self.classifier = nn.Linear(400, num_classes)
+        self.softmax = nn.Softmax(1)
+        #: dtype the trunk runs in (torch.bfloat16 = autocast, as BASELINE config 5 asks)
+        self.trunk_dtype = None
+
+    _ORDER = ("conv3d_1a_7x7", "maxPool3d_2a_3x3", "conv3d_2b_1x1", "conv3d_2c_3x3",
+              "maxPool3d_3a_3x3", "mixed_3b", "mixed_3c", "maxPool3d_4a_3x3", "mixed_4b", "mixed_4c",
+              "mixed_4d", "mixed_4e", "mixed_4f", "maxPool3d_5a_2x2", "mixed_5b", "mixed_5c",
+              "avg_pool", "conv3d_0c_1x1")
+
+    def generate(self, inp):
+        """[b,5,T,H,W] -> the DMC cue [b,2,T,H,W] (generator applied to every frame)."""
+        b, c, t, h, w = inp.shape
+        frames = inp.transpose(1, 2).reshape(-1, c, h, w)
+        if isinstance(self.gen_flow_model, _m.EstimatorDenseNetTiny):
+            g = self.gen_flow_model.forward_mv_res(frames[:, :2].contiguous(), frames[:, 2:].contiguous())
+        else:
+            g = self.gen_flow_model(frames)
+        return g.reshape(b, t, 2, h, w).transpose(1, 2)
+
+    def forward(self, inp, node="logit", detach=False):
+        if node == "D":
+            return self.discriminator(inp)
+        if self.arch_estimator in ("DenseNet", "DenseNetSmall", "DenseNetTiny"):
+            inp = self.generate(inp)
+        x = inp.detach() if detach else inp
+        if self.trunk_dtype is not None and x.is_cuda:
+            with torch.autocast("cuda", dtype=self.trunk_dtype):
+                for nm in self._ORDER:
+                    x = getattr(self, nm)(x)
+            x = x.float()
+        else:
+            for nm in self._ORDER:
+                x = getattr(self, nm)(x)
+        out = self.classifier(self.dropout(x))
+        if node == "flow+logit":
+            return out, inp
+        if node == "gen_flow":
+            return inp
+        return out
+
+
+def i3d_losses(net, data, target, stage=None, detach=False):
+    """Loss assembly of the reference's ``static_model.forward`` in training mode
+    (code/dmcnet_I3D/train/model.py:135-188), 'flow+logit' node.  ``data`` [b,7,T,H,W].
+
+    As written in the reference: channels [:5] feed the generator and channels [5:7] are the flow
+    target, although its loader packs [flow2, mv2, res3] -- kept, not "fixed".
+    Returns (logits, [loss_cls, mse] or [loss_cls, mse, loss_adv])."""
+    output, flow = net(data[:, :5], node="flow+logit", detach=detach)
+    losses = [F.cross_entropy(output, target), F.mse_loss(flow, data[:, 5:7])]
+    if stage is not None:
+        t = flow.size(2)
+        h, w = flow.shape[-2:]
+        valid = torch.ones(target.numel() * t, dtype=torch.int64, device=target.device)
+        fake = torch.zeros_like(valid)
+        d_in = torch.cat((flow.transpose(1, 2).reshape(-1, 2, h, w),
+                          data[:, 5:7].transpose(1, 2).reshape(-1, 2, h, w)), 0)
+        losses.append(F.cross_entropy(net(d_in, node="D"), torch.cat((fake, valid), 0)))
+    return output, losses
+
+
+class I3DTrainStep(object):
+    """Micro-batch accumulation of ``model.fit`` (code/dmcnet_I3D/train/model.py:354-491):
+    ``iter_size`` D-phase micro-batches (loss_cls + adv*loss_adv; trunk + discriminator step) then
+    ``iter_size`` G-phase micro-batches (loss_cls + mse + adv*loss_adv; generator step), gradients
+    divided by ``iter_size`` before each step.  Optimisers: Adam over the trunk, Adam(eps=1e-3)
+    over the discriminator and the generator (code/dmcnet_I3D/train_model.py:122-168)."""
+
+    def __init__(self, net, lr_base=4e-4, lr_d=2e-3, weight_decay=1e-4, adv=1.0, iter_size=1,
+                 detach=True):
+        self.net, self.adv, self.iter_size, self.detach = net, adv, iter_size, detach
+        trunk = [p for k, p in net.named_parameters()
+                 if not k.startswith("gen_flow_model") and not k.startswith("discriminator")]
+        self.optimizer = torch.optim.Adam(trunk, lr=lr_base, weight_decay=weight_decay)
+        self.optimizer_mse = torch.optim.Adam(net.gen_flow_model.parameters(), lr=lr_base,
+                                              weight_decay=weight_decay, eps=1e-3)
+        self.optimizer_d = None
+        if getattr(net, "arch_d", None) is not None and adv > 0:
+            self.optimizer_d = torch.optim.Adam(net.discriminator.parameters(), lr=lr_d,
+                                                weight_decay=weight_decay, eps=1e-3)
+        self.i_batch = 0
+        for o in (self.optimizer, self.optimizer_mse, self.optimizer_d):
+            if o is not None:
+                o.zero_grad(set_to_none=True)
+
+    def _finish(self, opts):
+        for o in opts:
+            if self.iter_size != 1:
+                for g in o.param_groups:
+                    for p in g["params"]:
+                        if p.grad is not None:
+                            p.grad /= self.iter_size
+            o.step()
+            o.zero_grad(set_to_none=True)
+
+    def step(self, data, target):
+        """One micro-batch; returns (logits, losses, phase)."""
+        gan = self.optimizer_d is not None
+        d_phase = gan and (self.i_batch % (2 * self.iter_size)) < self.iter_size
+        out, losses = i3d_losses(self.net, data, target, stage="D" if gan else None,
+                                 detach=self.detach)
+        if d_phase:
+            (losses[0] + self.adv * losses[2]).backward()
+        elif gan:
+            (losses[0] + losses[1] + self.adv * losses[2]).backward()
+        else:
+            (losses[0] + losses[1]).backward()
+        self.i_batch += 1
+        if self.i_batch % self.iter_size == 0:
+            if d_phase:
+                self._finish([self.optimizer, self.optimizer_d])
+                self.optimizer_mse.zero_grad(set_to_none=True)
+            else:
+                self._finish(([] if gan else [self.optimizer]) + [self.optimizer_mse])
+                self.optimizer.zero_grad(set_to_none=True)
+                if gan:
+                    self.optimizer_d.zero_grad(set_to_none=True)
+        return out.detach(), [l.detach() for l in losses], ("D" if d_phase else "G")

@@ -414,3 +414,48 @@ def test_prepare_inputs_bit_exact(size, factor):
     f, m, r = ops.prepare_inputs(torch.from_numpy(hwc).to(DEV), torch.from_numpy(flip), factor)
     assert torch.equal(m.cpu(), m0) and torch.equal(r.cpu(), r0)
     assert torch.equal(f.cpu(), f0)
+
+
+def test_i3d_forward_vs_reference_golden(golden):
+    """BASELINE config 5: I3D trunk over the per-frame HIP generator, eval mode, against the
+    reference's own i3d.py (golden G8); bf16-autocast trunk sanity."""
+    from dmcnet_amd import i3d
+    g = golden("g8_i3d_eval")
+    ref = O.build_estimator("DenseNetTiny")      # only to reuse seeded_state_fill's key-based fill
+    net = i3d.I3D(51, modality="flow+mp4", dropout_prob=0, arch_estimator="DenseNetTiny",
+                  arch_d="Discriminator")
+    assert list(net.state_dict().keys()) == g["keys"].tolist()
+    O.seeded_state_fill(net, seed=81)
+    net.to(DEV).eval()
+    data = rnd(82, (1, 7, 16, 224, 224)).to(DEV)
+    with torch.no_grad():
+        logits, flow = net(data[:, :5], node="flow+logit")
+        validity = net(flow.transpose(1, 2).reshape(-1, 2, 224, 224)[:4], node="D")
+    assert rel_err(logits, g["logits"]) < 1e-4
+    np.testing.assert_allclose(checksum(flow.cpu()), g["flow_checksum"], rtol=1e-5)
+    assert rel_err(flow[0, :, 3, 100:104, 50:66], g["flow_slice"]) < 1e-5
+    assert rel_err(validity, g["validity"]) < 1e-4
+    net.trunk_dtype = torch.bfloat16
+    with torch.no_grad():
+        lb = net(data[:, :5])
+    assert rel_err(lb, g["logits"]) < 5e-2            # bf16 trunk: loose sanity only
+
+
+def test_i3d_train_step_phases():
+    from dmcnet_amd import i3d
+    torch.manual_seed(0)
+    net = i3d.I3D(51, modality="flow+mp4", dropout_prob=0, arch_estimator="DenseNetTiny",
+                  arch_d="Discriminator").to(DEV).train()
+    step = i3d.I3DTrainStep(net, iter_size=1)
+    data, tgt = rnd(83, (1, 7, 16, 224, 224)).to(DEV), torch.tensor([3], device=DEV)
+    w_gen = net.gen_flow_model.predict_flow.weight.detach().clone()
+    w_d = net.discriminator.adv_layer.weight.detach().clone()
+    _, losses, phase = step.step(data, tgt)
+    assert phase == "D" and len(losses) == 3 and all(torch.isfinite(l) for l in losses)
+    assert torch.equal(net.gen_flow_model.predict_flow.weight, w_gen)      # D phase: G untouched
+    assert not torch.equal(net.discriminator.adv_layer.weight, w_d)
+    w_d = net.discriminator.adv_layer.weight.detach().clone()
+    _, _, phase = step.step(data, tgt)
+    assert phase == "G"
+    assert not torch.equal(net.gen_flow_model.predict_flow.weight, w_gen)
+    assert torch.equal(net.discriminator.adv_layer.weight, w_d)
