@@ -148,11 +148,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    # test hooks: DMC_FORCE_DEVICE / DMC_DIST_BACKEND=gloo let two ranks share one GPU so the N>1
+    # code path can be exercised on a 1-GPU box (never set by the driver)
+    if "DMC_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["DMC_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=dev)
+        backend = os.environ.get("DMC_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import dmcnet_amd
     from dmcnet_amd import dataset, ddp, ops, train
