@@ -54,18 +54,20 @@ int dmc_profile_mark(dmc_stream_t stream);
  * predict_flow.weight/.bias.
  */
 
-/* Bytes of `workspace` the generator entry points need (repacked weights). */
+/* Bytes of `workspace` the generator entry points need (repacked weights, zero words). */
 size_t dmc_gen_tiny_workspace_bytes(void);
 /* Bytes of the saved-activation buffer for N frames of H x W (28 channels fp32). */
 size_t dmc_gen_tiny_saved_bytes(int N, int H, int W);
 
 /*
  * Forward.  mv [N,2,H,W], res [N,3,H,W] -> out [N,2,H,W].
- * saved: NULL for inference; for training a buffer of dmc_gen_tiny_saved_bytes() that
- * receives y0..y4 (the post-LeakyReLU features) for the backward pass.
- * If `saved` is NULL, `scratch` must still provide the same number of bytes (intermediate
- * features of the unfused fallback path); pass the same pointer in both cases if convenient.
+ * saved: REQUIRED buffer of dmc_gen_tiny_saved_bytes(); it receives y0..y4 (the post-LeakyReLU
+ * features, physical channel order) -- the later layers read them from it and the backward pass
+ * needs them.  Inference callers may release it as soon as the call has been enqueued on a
+ * stream-ordered allocator.
+ * workspace: dmc_gen_tiny_workspace_bytes() (repacked weights + 16 zero words).
  * add_mv_delta != 0 adds input_mv to the result (gen_flow_or_delta == 1).
+ * Any H, W >= 1; W % 4 == 0 takes the vectorised path.
  */
 int dmc_gen_tiny_fwd(const float* mv, const float* res, const float* const* w,
                      const float* const* b, float* out, float* saved, float* workspace, int N,
