@@ -298,10 +298,13 @@ __global__ __launch_bounds__(LTHREADS, 4) void gen_layer_kernel(LayerArgs a) {  
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WT_H = 8, WT_W = 32;
-constexpr int WX_PITCH = 36, WX_PLANE = 364;           // plane % 32 == 12: conflict-light gathers
-constexpr int WX_FLOATS = 33 * WX_PLANE;
-constexpr int WT_CHUNKS = (WX_FLOATS + 63) / 64;       // 188 DMA wave-instructions per tile
-constexpr int WT_LDS = WT_CHUNKS * 64;                 // 12032 floats; x2 buffers = 96,256 B
+// tile image: [33 planes][10 rows][40 floats]; a row holds image columns tx0-4 .. tx0+35 (the tile,
+// its halo column on each side and 3+3 unused), i.e. ten 16-byte chunks that are each entirely
+// inside or outside the image when W % 4 == 0 -> one 16-byte LDS-DMA lane per chunk
+constexpr int WX_PITCH = 40, WX_COL0 = 3;              // LDS column of image column tx0-1
+constexpr int WX_PLANE = (WT_H + 2) * WX_PITCH + 4;    // 404: plane % 32 == 20, conflict-light gathers
+constexpr int WX_FLOATS = 33 * WX_PLANE;               // 13332
+constexpr int WT_LDS = (WX_FLOATS + 63) / 64 * 64;     // 13376 floats; x2 buffers = 107,008 B
 constexpr int NT_A = 9, NT_B = 19, NT_ALL = NT_A + NT_B;   // accumulator tiles per wave
 constexpr int WPART = NT_ALL * 256;                    // floats per workgroup partial
 constexpr int WGRAD_MAX_GROUPS = 256;
@@ -324,6 +327,11 @@ struct WgradArgs {
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// LDS-DMA of one tile (W % 4 == 0): one dwordx4 instruction moves half a plane (5 rows x 10
+// chunks = 50 lanes x 16 B), so the plane base is wave-uniform and a lane only contributes its
+// fixed (row, chunk): 66 instructions per tile, ~8 per wave, ~10 vector integer ops each.
+// (Issue cost matters: ~100 cycles per LDS-DMA instruction, and decoding a flat 64-float chunk per
+// lane cost ~25 vector ops each and held the MFMA rate at 70 % -- tools/ubench/mfma_f32_issue.hip.)
 __device__ __forceinline__ void wgrad_dma_tile(const WgradArgs& a, float* buf, int tile,
                                                int per_frame, size_t HW, int pw, int lane,
                                                const float* zero) {
@@ -332,19 +340,44 @@ __device__ __forceinline__ void wgrad_dma_tile(const WgradArgs& a, float* buf, i
     const float* mvp = a.mv + (size_t)n * 2 * HW;
     const float* rsp = a.res + (size_t)n * 3 * HW;
     const float* ftp = a.feat + (size_t)n * NFEAT * HW;
+    const int lrow = lane / 10, chunk = lane - lrow * 10;      // lanes 0..49
+    const int xx = tx0 - 4 + 4 * chunk;
+    const bool colok = xx >= 0 && xx < a.W;
+    if (lane < 50) {
 #pragma unroll 1
-    for (int m = pw; m < WT_CHUNKS; m += 8) {
-        const int L = 64 * m + lane;
-        const int plane = L / WX_PLANE, rem = L - plane * WX_PLANE;
-        const int row = rem / WX_PITCH, col = rem - row * WX_PITCH;
-        const int yy = ty0 - 1 + row, xx = tx0 - 1 + col;
-        const bool ok = plane < 33 && row < WT_H + 2 && col < WT_W + 2 && yy >= 0 && yy < a.H &&
-                        xx >= 0 && xx < a.W;
-        const float* base = plane < 2 ? mvp + (size_t)plane * HW
-                          : plane < NIN ? rsp + (size_t)(plane - 2) * HW
-                                        : ftp + (size_t)(plane - NIN) * HW;
-        const float* src = ok ? base + (size_t)yy * a.W + xx : zero;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + 64 * m), 4, 0, 0);
+        for (int hp = pw; hp < 66; hp += 8) {                   // half-planes, wave-uniform
+            const int plane = hp >> 1, row = (hp & 1) * 5 + lrow;
+            const int yy = ty0 - 1 + row;
+            const float* base = plane < 2 ? mvp + (size_t)plane * HW
+                              : plane < NIN ? rsp + (size_t)(plane - 2) * HW
+                                            : ftp + (size_t)(plane - NIN) * HW;
+            const float* src = (colok && yy >= 0 && yy < a.H) ? base + (size_t)yy * a.W + xx : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src,
+                                             (lptr_t)(buf + plane * WX_PLANE + (hp & 1) * 5 * WX_PITCH),
+                                             16, 0, 0);
+        }
+    }
+}
+
+// Any W: dword granularity, one instruction per (plane, row), 34 lanes.
+__device__ __forceinline__ void wgrad_dma_tile_generic(const WgradArgs& a, float* buf, int tile,
+                                                       int per_frame, size_t HW, int pw, int lane,
+                                                       const float* zero) {
+    const int n = tile / per_frame, r0 = tile - n * per_frame;
+    const int ty0 = (r0 / a.tiles_x) * WT_H, tx0 = (r0 % a.tiles_x) * WT_W;
+    const int xx = tx0 - 1 + lane;
+    const bool colok = lane < WT_W + 2 && xx >= 0 && xx < a.W;
+    if (lane < WT_W + 2) {
+#pragma unroll 1
+        for (int rr = pw; rr < 33 * (WT_H + 2); rr += 8) {
+            const int plane = rr / (WT_H + 2), row = rr - plane * (WT_H + 2);
+            const int yy = ty0 - 1 + row;
+            const float* base = in_plane(a.mv, a.res, a.feat, n, plane, HW);
+            const float* src = (colok && yy >= 0 && yy < a.H) ? base + (size_t)yy * a.W + xx : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src,
+                                             (lptr_t)(buf + plane * WX_PLANE + row * WX_PITCH + WX_COL0),
+                                             4, 0, 0);
+        }
     }
 }
 
@@ -352,6 +385,7 @@ __device__ __forceinline__ void wgrad_dma_tile(const WgradArgs& a, float* buf, i
 // issues its share of the LDS-DMA for the NEXT tile (asynchronous, no VGPRs), then runs the MFMAs
 // of one row (8 groups of 4 pixels) of the CURRENT tile; two MFMA waves per SIMD cover each
 // other's LDS gathers (one wave per SIMD measured 50 % matrix-pipe utilisation).
+template <bool VEC4>
 __global__ __launch_bounds__(512, 2) void gen_bwd_weight_kernel(WgradArgs a, const float* zero) {
     __shared__ __attribute__((aligned(16))) float lds2[2 * WT_LDS];
     const int lane = threadIdx.x & 63;
@@ -382,7 +416,7 @@ __global__ __launch_bounds__(512, 2) void gen_bwd_weight_kernel(WgradArgs a, con
         int nn = 16 * t + j;
         nn = nn < 297 ? nn : 296;
         const int ci = nn / 9, tap = nn - ci * 9;
-        offB[t] = ci * WX_PLANE + (tap / 3) * WX_PITCH + (tap % 3) + kq;
+        offB[t] = ci * WX_PLANE + (tap / 3) * WX_PITCH + (tap % 3) + kq + WX_COL0;
     }
     float cur0[8], cur1[8], nxt0[8], nxt1[8];
     auto request_row = [&](int tile, float (&v0)[8], float (&v1)[8]) {
@@ -403,7 +437,8 @@ __global__ __launch_bounds__(512, 2) void gen_bwd_weight_kernel(WgradArgs a, con
     };
     int it = 0;
     if ((int)blockIdx.x < ntiles) {
-        wgrad_dma_tile(a, lds2, blockIdx.x, per_frame, HW, wave, lane, zero);
+        if (VEC4) wgrad_dma_tile(a, lds2, blockIdx.x, per_frame, HW, wave, lane, zero);
+        else wgrad_dma_tile_generic(a, lds2, blockIdx.x, per_frame, HW, wave, lane, zero);
         request_row(blockIdx.x, cur0, cur1);
     }
     __syncthreads();
@@ -411,8 +446,8 @@ __global__ __launch_bounds__(512, 2) void gen_bwd_weight_kernel(WgradArgs a, con
         const float* lds = lds2 + (it & 1) * WT_LDS;
         const bool more = tile + (int)gridDim.x < ntiles;
         if (more) {
-            wgrad_dma_tile(a, lds2 + ((it + 1) & 1) * WT_LDS, tile + gridDim.x, per_frame, HW, wave,
-                           lane, zero);
+            if (VEC4) wgrad_dma_tile(a, lds2 + ((it + 1) & 1) * WT_LDS, tile + gridDim.x, per_frame, HW, wave, lane, zero);
+            else wgrad_dma_tile_generic(a, lds2 + ((it + 1) & 1) * WT_LDS, tile + gridDim.x, per_frame, HW, wave, lane, zero);
             request_row(tile + gridDim.x, nxt0, nxt1);
         }
         const int r0 = tile % per_frame;
@@ -627,7 +662,8 @@ int dmc_gen_tiny_bwd(const float* mv, const float* res, const float* const* w, c
     a.tiles_x = (W + WT_W - 1) / WT_W;
     a.tiles_y = (H + WT_H - 1) / WT_H;
     const int groups = wgrad_groups(N, H, W);
-    gen_bwd_weight_kernel<<<groups, 512, 0, s>>>(a, workspace + PACKED_TOTAL);
+    if (W % 4 == 0) gen_bwd_weight_kernel<true><<<groups, 512, 0, s>>>(a, workspace + PACKED_TOTAL);
+    else gen_bwd_weight_kernel<false><<<groups, 512, 0, s>>>(a, workspace + PACKED_TOTAL);
     if ((rc = check_launch("gen_bwd_weight"))) return rc;
     gen_bwd_weight_reduce1_kernel<<<dim3(WPART / 256, RED_CHUNKS), 256, 0, s>>>(partials, groups);
     if ((rc = check_launch("gen_bwd_weight_reduce1"))) return rc;
