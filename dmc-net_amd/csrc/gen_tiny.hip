@@ -280,6 +280,139 @@ __global__ __launch_bounds__(LTHREADS, 4) void gen_layer_kernel(LayerArgs a) {  
 }
 
 // ------------------------------------------------------------------------------------------
+// Fast path of the same layer for W % 4 == 0 and W <= 256 (one tile spans the image width):
+//   * input planes arrive by LDS-DMA: one 16-byte-per-lane instruction moves one whole row
+//     (wave-uniform plane / row / validity, a lane only adds its column; lanes right of the image
+//     read a zero word), 4 channels per chunk, double-buffered -- chunk c+1 is in flight while the
+//     FMAs of chunk c run; no VGPRs hold data in flight, one barrier per chunk;
+//   * no halo columns are fetched or stored at all: a lane's left / right neighbour pixels are
+//     its neighbour LANES' quads, obtained with DPP wave_shr:1 / wave_shl:1 (zero shifted in at
+//     the image border, which is exactly the convolution's zero padding).
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int D_PLANE = LROWS * LTW;               // 2560 floats per channel
+constexpr int D_BUF = LCH * D_PLANE;               // 10240 floats = 40,960 B; x2 = 81,920 B
+
+template <int MODE, int K>
+__device__ __forceinline__ void layer_dma_chunk(const LayerArgs& a, float* buf, int n, int c0, int nch,
+                                                int ty0, size_t HW, int wave, int lane,
+                                                const float* zero) {
+    const bool colok = 4 * lane < a.W;
+#pragma unroll 1
+    for (int rr = wave; rr < nch * LROWS; rr += LTH) {          // wave-uniform
+        const int c = rr / LROWS, row = rr - c * LROWS;
+        const int yy = ty0 - 1 + row;
+        const float* plane = layer_in_plane<MODE, K>(a, n, c0 + c, HW);
+        const float* src = (colok && yy >= 0 && yy < a.H) ? plane + (size_t)yy * a.W + 4 * lane : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + rr * LTW), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ float dpp_from_left(float v) {     // lane i <- lane i-1, lane 0 <- 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_from_right(float v) {    // lane i <- lane i+1, lane 63 <- 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+
+template <int MODE, int K>
+__global__ __launch_bounds__(LTHREADS, 4) void gen_layer_dma_kernel(LayerArgs a) {
+    constexpr int CIN = MODE == 2 ? gin_of(K) : cin_of(K);
+    constexpr int COUT = cout_of(K);
+    constexpr int NCHUNK = (CIN + LCH - 1) / LCH;
+    __shared__ __attribute__((aligned(16))) float lds[2 * D_BUF];
+    const int n = blockIdx.z, ty0 = blockIdx.y * LTH;
+    const size_t HW = (size_t)a.H * a.W;
+    const int tid = threadIdx.x, s = tid & 63;
+    const int r = __builtin_amdgcn_readfirstlane(tid >> 6);       // tile row == wave index
+    const float* zero = a.pk + PACKED_TOTAL;
+
+    layer_dma_chunk<MODE, K>(a, lds, n, 0, CIN < LCH ? CIN : LCH, ty0, HW, r, s, zero);
+
+    float acc[COUT][4];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+        const float bv = MODE == 2 ? 0.f : a.pk[bf_off(K) + co];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[co][j] = bv;
+    }
+    const float* wbase = a.pk + (MODE == 2 ? wb_off(K) : wf_off(K));
+    __syncthreads();
+
+#pragma unroll 1
+    for (int ch = 0; ch < NCHUNK; ++ch) {
+        const int c0 = ch * LCH;
+        const int nch = (CIN - c0) < LCH ? (CIN - c0) : LCH;
+        const float* buf = lds + (ch & 1) * D_BUF;
+        if (ch + 1 < NCHUNK) {
+            const int c1 = c0 + LCH;
+            layer_dma_chunk<MODE, K>(a, lds + ((ch + 1) & 1) * D_BUF, n, c1,
+                                     (CIN - c1) < LCH ? (CIN - c1) : LCH, ty0, HW, r, s, zero);
+        }
+#pragma unroll 1
+        for (int c = 0; c < nch; ++c) {
+            const float* pl = buf + c * D_PLANE;
+            float xv[3][6];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float4 m = *reinterpret_cast<const float4*>(pl + (r + ky) * LTW + 4 * s);
+                xv[ky][0] = dpp_from_left(m.w);
+                xv[ky][1] = m.x; xv[ky][2] = m.y; xv[ky][3] = m.z; xv[ky][4] = m.w;
+                xv[ky][5] = dpp_from_right(m.x);
+            }
+            const float* wp = wbase + (c0 + c) * 9 * COUT;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) {
+                        const float wv = wp[(ky * 3 + kx) * COUT + co];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[co][j] = fmaf(xv[ky][j + kx], wv, acc[co][j]);
+                    }
+        }
+        __syncthreads();     // next chunk's DMA has landed; this chunk's buffer may be refilled
+    }
+
+    const int y = ty0 + r, x0 = 4 * s;
+    if (y >= a.H || x0 >= a.W) return;
+    const size_t pix = (size_t)y * a.W + x0;
+    if (MODE == 0) {
+        float* dst = a.feat_out + ((size_t)n * NFEAT + (yoff(K) - NIN)) * HW + pix;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[co][j] > 0.f ? acc[co][j] : 0.1f * acc[co][j];
+            *reinterpret_cast<float4*>(dst + co * HW) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    } else if (MODE == 1) {
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            float4 v = make_float4(acc[co][0], acc[co][1], acc[co][2], acc[co][3]);
+            if (a.add_mv) {
+                const float4 m = *reinterpret_cast<const float4*>(a.mv + ((size_t)n * 2 + co) * HW + pix);
+                v.x += m.x; v.y += m.y; v.z += m.z; v.w += m.w;
+            }
+            *reinterpret_cast<float4*>(a.out + ((size_t)n * 2 + co) * HW + pix) = v;
+        }
+    } else {
+        float* dst = a.gbuf + ((size_t)n * NFEAT + (yoff(K) - NIN)) * HW + pix;
+        const float* f = a.feat + ((size_t)n * NFEAT + (yoff(K) - NIN)) * HW + pix;
+#pragma unroll
+        for (int cd = 0; cd < COUT; ++cd) {
+            const float4 fv = *reinterpret_cast<const float4*>(f + cd * HW);
+            *reinterpret_cast<float4*>(dst + cd * HW) =
+                make_float4(acc[cd][0] * (fv.x > 0.f ? 1.f : 0.1f), acc[cd][1] * (fv.y > 0.f ? 1.f : 0.1f),
+                            acc[cd][2] * (fv.z > 0.f ? 1.f : 0.1f), acc[cd][3] * (fv.w > 0.f ? 1.f : 0.1f));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // backward, weight path: one fp32-MFMA GEMM over pixels.
 //
 //   dW[(k,co)][(ci,tap)] = sum_px g_k[co][px] * x[ci][px + tap]
@@ -324,9 +457,6 @@ struct WgradArgs {
 // floats of the tile image; every lane supplies its own source address (or the address of a zero
 // word for pixels outside the image and for padding), so the padded / halo'd layout costs nothing
 // and no VGPRs are tied up by data in flight.
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
 // LDS-DMA of one tile (W % 4 == 0): one dwordx4 instruction moves half a plane (5 rows x 10
 // chunks = 50 lanes x 16 B), so the plane base is wave-uniform and a lane only contributes its
 // fixed (row, chunk): 66 instructions per tile, ~8 per wave, ~10 vector integer ops each.
@@ -573,7 +703,12 @@ int launch_layer(LayerArgs a, int n0, int N, hipStream_t s) {
     a.gbuf = a.gbuf ? a.gbuf + (size_t)n0 * NFEAT * HW : nullptr;
     a.out = a.out ? a.out + (size_t)n0 * 2 * HW : nullptr;
     const dim3 grid((a.W + LTW - 1) / LTW, (a.H + LTH - 1) / LTH, N);
-    if (a.W % 4 == 0) gen_layer_kernel<MODE, K, true><<<grid, LTHREADS, 0, s>>>(a);
+    // measured per layer (N=120, 224x224): the LDS-DMA + DPP kernel wins where little arithmetic
+    // rides on each staged channel (Cout 2: layers 4, 5; gradient groups 2, 3, 4), the
+    // register-pipelined kernel wins for the Cout 8 / 6 / 4 layers
+    constexpr bool DMA_WINS = (MODE != 2 && K >= 4) || (MODE == 2 && K >= 2);
+    if (DMA_WINS && a.W % 4 == 0 && a.W <= LTW) gen_layer_dma_kernel<MODE, K><<<grid, LTHREADS, 0, s>>>(a);
+    else if (a.W % 4 == 0) gen_layer_kernel<MODE, K, true><<<grid, LTHREADS, 0, s>>>(a);
     else gen_layer_kernel<MODE, K, false><<<grid, LTHREADS, 0, s>>>(a);
     return check_launch("gen_layer");
 }
