@@ -459,3 +459,25 @@ def test_i3d_train_step_phases():
     assert phase == "G"
     assert not torch.equal(net.gen_flow_model.predict_flow.weight, w_gen)
     assert torch.equal(net.discriminator.adv_layer.weight, w_d)
+
+
+@pytest.mark.parametrize("kw", [dict(arch_estimator="DenseNetTiny", gen_flow_ds_factor=16, gen_flow_or_delta=1),
+                                dict(arch_estimator="ContextNetwork", att=1),
+                                dict(arch_estimator="DenseNetSmall", gen_flow_or_delta=1, arch_d="Discriminator4"),
+                                dict(arch_estimator="DenseNetTinyEarlyFusionSum", arch_d="Discriminator")])
+def test_model_variants_forward_vs_oracle(kw):
+    """API-only variants (other estimators, down-sampled generator, attention head, other
+    discriminators): same outputs as the oracle model in eval mode."""
+    gan = kw.get("arch_d") is not None
+    o = O.OracleModel(51, 3, "mv", base_model="resnet18", use_databn=0, **kw)
+    O.seeded_state_fill(o, 91)
+    m = dmcnet_amd.Model(51, 3, "mv", base_model="resnet18", use_databn=0, **kw)
+    m.load_state_dict(o.state_dict())
+    o.eval(); m.to(DEV).eval()
+    flow, mv, res, _ = O.synthetic_batch(seed=92, batch=1, num_segments=3, num_class=51)
+    with torch.no_grad():
+        ro = o(mv, res, flow) if gan else o(mv, res)
+        rm = m(mv.to(DEV), res.to(DEV), flow.to(DEV)) if gan else m(mv.to(DEV), res.to(DEV))
+    assert len(ro) == len(rm)
+    for a, b in zip(rm, ro):
+        assert a.shape == b.shape and rel_err(a, b) < 2e-4
