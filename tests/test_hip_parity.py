@@ -481,3 +481,32 @@ def test_model_variants_forward_vs_oracle(kw):
     assert len(ro) == len(rm)
     for a, b in zip(rm, ro):
         assert a.shape == b.shape and rel_err(a, b) < 2e-4
+
+
+def test_driver_fit_epochs_and_checkpoint(tmp_path):
+    """Two tiny epochs through the epoch driver: freeze schedule, validation, checkpoint in the
+    reference's layout; the MSE loss must go down on a fixed synthetic set."""
+    import os
+    from dmcnet_amd import dataset, driver
+    torch.manual_seed(0)
+    m = dmcnet_amd.Model(51, 3, "mv", base_model="resnet18", use_databn=0, gen_flow_or_delta=1,
+                         arch_estimator="DenseNetTiny").to(DEV)
+    ds = dataset.SyntheticCoviarDataSet(8, 51, num_segments=3, flow_ds_factor=16, size=224)
+    loader = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False)
+    step = T.DmcnetTrainStep(m, 3, 1.0, 10.0, lr=0.01, weight_decay=1e-4, lr_cls_mult=0.01, lr_mse_mult=1.0)
+    w_cls = m.base_model.fc.weight.detach().clone()
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        hist, best = driver.fit(m, step, loader, loader, epochs=3, lr=0.01, weight_decay=1e-4,
+                                lr_steps=[20, 35, 45], epoch_thre=1, eval_freq=1, log=None,
+                                model_prefix="t", device=DEV)
+    finally:
+        os.chdir(cwd)
+    assert len(hist) == 3 and all("val" in h for h in hist)
+    assert hist[2]["train"]["loss_mse"] < hist[0]["train"]["loss_mse"]
+    assert os.path.exists(os.path.join(tmp_path, "t_mv_checkpoint.pth.tar"))
+    ck = torch.load(os.path.join(tmp_path, "t_mv_checkpoint.pth.tar"), map_location="cpu")
+    assert set(ck) >= {"epoch", "arch", "state_dict", "best_prec1", "optimizer_cls", "optimizer_gf"}
+    assert all(k.startswith("module.") for k in ck["state_dict"])
+    assert not torch.equal(m.base_model.fc.weight.detach(), w_cls)   # unfrozen after epoch_thre
