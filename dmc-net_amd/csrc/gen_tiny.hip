@@ -413,6 +413,300 @@ __global__ __launch_bounds__(LTHREADS, 4) void gen_layer_dma_kernel(LayerArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
+// Matrix-core path of the same layer (W % 4 == 0, W <= 256): v_mfma_f32_4x4x1_16b_f32.
+//
+// The layers have 2..8 output channels, far too few to fill a 16- or 32-row MFMA tile.  The
+// 4x4x1 instruction is 16 independent 4x4 outer products; seen across the wave it is
+//     D[i][lane] += A[4*(lane/4) + i] * B[lane]          (i = 0..3, one K step)
+// i.e. "4 output rows x 64 pixels, one pixel per lane", at the same 256 MAC / 8 cycles as the big
+// shapes.  Mapping (one wave = one 256-pixel image row, 4 segments of 64 pixels):
+//   * B = one staged input value per lane:  in[ci][y + dy - 1][x]      (a conflict-free ds_read_b32)
+//   * K = (ci, dy): the vertical taps are GATHERED by reading the row above / below;
+//   * rows rho = dx * COUT + co, 3*COUT of them in NT = ceil(3*COUT/4) row tiles: the horizontal
+//     taps are PUSHED -- row (dx, co) accumulates  P_dx[co][x] = sum_{ci,dy} w[co][ci][dy][dx] *
+//     in[ci][y+dy-1][x]  at the INPUT column, and the epilogue forms
+//         out[co][x] = P_0[x-1] + P_1[x] + P_2[x+1]
+//     with two DPP lane shifts per channel (wave_shr / wave_shl; the lane at a segment edge takes
+//     the neighbour segment's edge lane through v_readlane).  Columns >= W hold zeros in LDS, so
+//     image borders need no special case.
+//   MAC efficiency of the tiles: COUT 8 -> 24/24 rows, 6 -> 18/20, 4 -> 12/12, 2 -> 6/8.
+//
+// Workgroup = 7 consumer waves (one tile row each) + 1 producer wave, persistent over a contiguous
+// run of (tile, 4-channel chunk) items.  The producer stages chunks into a 3-deep LDS ring with
+// LDS-DMA and is the only wave that ever blocks on the memory pipe; the consumers only see
+// barriers.  (With every wave issuing its share of the DMA, all of them stalled at issue whenever
+// the CU's miss queue was full, and staging and MFMA time simply added up.)
+// ------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float dpp_shr_fill(float cur, float lane0_value) {   // lane i <- cur[i-1]; lane 0 <- lane0_value
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, lane0_value),
+                                                                 __builtin_bit_cast(int, cur), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_shl_fill(float cur, float lane63_value) {  // lane i <- cur[i+1]; lane 63 <- lane63_value
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, lane63_value),
+                                                                 __builtin_bit_cast(int, cur), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+constexpr int M_SEGS = LTW / 64;                    // 4 segments of 64 pixels per tile row
+constexpr int PT_H = 7;                             // tile rows = consumer waves
+constexpr int P_ROWS = PT_H + 2;                    // staged rows per channel
+constexpr int P_PLANE = P_ROWS * LTW;               // 2304 floats
+constexpr int P_BUF = LCH * P_PLANE;                // 9216 floats = 36,864 B per chunk
+constexpr int RING = 3;                             // chunk buffers: one computing, two in flight
+constexpr int RING_DMA = LCH * P_ROWS;              // 36 row transfers per chunk, all by the producer
+static_assert(RING_DMA <= 63, "vmcnt is a 6-bit counter");
+
+template <int MODE, int K>
+struct MfmaGeom {
+    static constexpr int CIN = MODE == 2 ? gin_of(K) : cin_of(K);
+    static constexpr int COUT = cout_of(K);
+    static constexpr int NROW = 3 * COUT;
+    static constexpr int NT = (NROW + 3) / 4;
+    static constexpr int NTP = NT <= 2 ? 2 : NT <= 4 ? 4 : 8;     // padded tile count (vector loads)
+    static constexpr int NCHUNK = (CIN + LCH - 1) / LCH;
+    static constexpr int WL = NCHUNK * LCH * 3 * 4 * NTP;          // LDS weight copy, zero rows for channels >= CIN
+};
+
+// LDS-DMA issued through inline assembly: the compiler does not see an LDS write, so it inserts
+// no s_waitcnt vmcnt(0) in front of the consumers' ds_reads (with the builtin it does, which
+// serialises every prefetch with the compute it was meant to overlap).  Completion is tracked
+// by hand with s_waitcnt vmcnt(RING_DMA): "everything but the newest chunk has landed".
+__device__ __forceinline__ void dma_row16(unsigned long long src, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(src), "s"(lds_byte_addr) : "memory", "m0");
+}
+
+struct RingArgs {
+    LayerArgs a;
+    int tiles_y, ntiles;                              // row bands per frame, tiles in this launch
+};
+
+// producer: stage chunk c of tile (n, ty0) -- 4 channels x 9 rows, one 1 KB row per instruction.
+// Channels >= CIN, rows outside the image and columns >= W come from the zero words.  Address
+// arithmetic is branch-free scalar code (selects by multiplication with 0/1).
+template <int MODE, int K>
+__device__ __forceinline__ void ring_stage(const LayerArgs& a, unsigned slot_byte, int n, int ty0, int c,
+                                           size_t HW, int lane, const float* zero) {
+    constexpr int CIN = MfmaGeom<MODE, K>::CIN;
+    const unsigned long long zaddr = (unsigned long long)zero;
+    const bool colok = 4 * lane < a.W;
+    const unsigned long long loff = (unsigned long long)lane * 16;
+    const unsigned long long vstride = colok ? (unsigned long long)a.W * 4 : 0;   // lanes right of the image stay on the zero words
+    const bool interior = ty0 >= 1 && ty0 + PT_H < a.H;                            // rows ty0-1 .. ty0+PT_H all inside
+#pragma unroll
+    for (int cc = 0; cc < LCH; ++cc) {
+        const int ch = c * LCH + cc;
+        unsigned long long base;
+        long pidx;
+        if (MODE == 2) {
+            constexpr int NG = gin_of(K) - 2;
+            const long s1 = ch >= NG;                                  // 0: gbuf plane, 1: grad_out plane
+            base = (unsigned long long)a.gbuf + s1 * ((unsigned long long)a.gout - (unsigned long long)a.gbuf);
+            pidx = (long)n * (NFEAT - s1 * (NFEAT - 2)) + ch + (1 - s1) * (yoff(K + 1) - NIN) - s1 * NG;
+        } else {
+            const long s1 = ch >= 2, s2 = ch >= NIN;                   // mv | res | feat
+            base = (unsigned long long)a.mv + s1 * ((unsigned long long)a.res - (unsigned long long)a.mv) +
+                   s2 * ((unsigned long long)a.feat - (unsigned long long)a.res);
+            pidx = (long)n * (2 + s1 + s2 * (NFEAT - 3)) + ch - s1 * 2 - s2 * (NIN - 2);
+        }
+        const bool chok = ch < CIN;                                    // scalar
+        // this lane's pointer into row ty0-1 (never dereferenced while that row is outside the image)
+        const unsigned long long row0 = base + (unsigned long long)((pidx * (long)HW + (long)(ty0 - 1) * a.W) * 4);
+        unsigned long long vptr = (chok && colok) ? row0 + loff : zaddr;
+        const unsigned long long vs = chok ? vstride : 0;
+        const unsigned dst = slot_byte + (unsigned)(cc * P_ROWS) * (LTW * 4);
+        if (interior) {
+#pragma unroll
+            for (int row = 0; row < P_ROWS; ++row) {
+                dma_row16(vptr, dst + row * (LTW * 4));
+                vptr += vs;
+            }
+        } else {
+#pragma unroll
+            for (int row = 0; row < P_ROWS; ++row) {
+                const int yy = ty0 - 1 + row;
+                dma_row16((yy >= 0 && yy < a.H) ? vptr : zaddr, dst + row * (LTW * 4));
+                vptr += vs;
+            }
+        }
+    }
+}
+
+// consumer: one staged chunk = LCH stages of 3 K-steps (dy) x 4 segments x NT row tiles.  The LDS
+// operands of stage cc+1 are requested before the MFMAs of stage cc (register double buffer);
+// sched_barriers keep the compiler from hoisting every load of the chunk to the top.
+template <int MODE, int K, int NT_>
+__device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[M_SEGS][NT_], const float* buf, const float* wl,
+                                           int c0, int r, int lane) {
+    using G = MfmaGeom<MODE, K>;
+    float w[2][3][G::NTP], b[2][3][M_SEGS];
+    auto load_stage = [&](int cc, int sel) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const float* p = wl + (((c0 + cc) * 3 + dy) * 4 + (lane & 3)) * G::NTP;
+            if (G::NTP == 2) {
+                const float2 v = *reinterpret_cast<const float2*>(p);
+                w[sel][dy][0] = v.x; w[sel][dy][1] = v.y;
+            } else {
+#pragma unroll
+                for (int q = 0; q < G::NTP / 4; ++q) {
+                    if (q * 4 < G::NT) {
+                        const float4 v = *reinterpret_cast<const float4*>(p + 4 * q);
+                        w[sel][dy][4 * q + 0] = v.x; w[sel][dy][4 * q + 1] = v.y;
+                        w[sel][dy][4 * q + 2] = v.z; w[sel][dy][4 * q + 3] = v.w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < M_SEGS; ++s) b[sel][dy][s] = buf[cc * P_PLANE + (r + dy) * LTW + s * 64 + lane];
+        }
+    };
+    load_stage(0, 0);
+#pragma unroll
+    for (int cc = 0; cc < LCH; ++cc) {
+        if (cc + 1 < LCH) load_stage(cc + 1, (cc + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int s = 0; s < M_SEGS; ++s)
+#pragma unroll
+                for (int t = 0; t < G::NT; ++t)
+                    acc[s][t] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[cc & 1][dy][t], b[cc & 1][dy][s], acc[s][t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int MODE, int K>
+__global__ __launch_bounds__(LTHREADS, 2) void gen_layer_mfma_kernel(RingArgs ra) {
+    using G = MfmaGeom<MODE, K>;
+    constexpr int CIN = G::CIN, COUT = G::COUT, NT = G::NT, NTP = G::NTP, NCHUNK = G::NCHUNK;
+    __shared__ __attribute__((aligned(16))) float lds[RING * P_BUF + G::WL];
+    const LayerArgs& a = ra.a;
+    float* wl = lds + RING * P_BUF;
+    const size_t HW = (size_t)a.H * a.W;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int r = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave: 0..6 = tile row, 7 = producer
+    const float* zero = a.pk + PACKED_TOTAL;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds;          // LDS byte address of the ring
+
+    // this workgroup's contiguous run of tiles (vertically adjacent bands follow each other)
+    const int t_begin = (int)((long)blockIdx.x * ra.ntiles / gridDim.x);
+    const int t_end = (int)((long)(blockIdx.x + 1) * ra.ntiles / gridDim.x);
+    const int nitems = (t_end - t_begin) * NCHUNK;
+    if (nitems == 0) return;
+
+    // weights -> LDS as [ci][dy][i][NTP]: element (ci, dy, rho = 4*t + i), rho = dx*COUT + co
+    const float* wbase = a.pk + (MODE == 2 ? wb_off(K) : wf_off(K));
+    for (int idx = tid; idx < G::WL; idx += LTHREADS) {
+        const int t = idx % NTP, i = (idx / NTP) % 4, dy = (idx / (4 * NTP)) % 3, ci = idx / (12 * NTP);
+        const int rho = 4 * t + i;
+        wl[idx] = (t < NT && rho < G::NROW && ci < CIN) ? wbase[(ci * 9 + dy * 3 + rho / COUT) * COUT + rho % COUT] : 0.f;
+    }
+    __syncthreads();
+
+    if (r == PT_H) {
+        // ------------------------------ producer wave ------------------------------
+#pragma unroll 1
+        for (int pre = 0; pre < 2 && pre < nitems; ++pre) {
+            const int tile = t_begin + pre / NCHUNK, n = tile / ra.tiles_y;
+            ring_stage<MODE, K>(a, lds0 + pre * (P_BUF * 4), n, (tile - n * ra.tiles_y) * PT_H, pre % NCHUNK, HW, lane, zero);
+        }
+        int tile = t_begin, c = 0, slot = 0;
+#pragma unroll 1
+        for (int q = 0; q < nitems; ++q) {
+            // chunk q has landed (only chunk q+1 may still be in flight); consumers are done with q-1
+            if (q + 1 < nitems) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(RING_DMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (q + 2 < nitems) {
+                const int c2 = c + 2, tile2 = tile + c2 / NCHUNK, n2 = tile2 / ra.tiles_y;
+                int slot2 = slot + 2; slot2 = slot2 >= RING ? slot2 - RING : slot2;
+                ring_stage<MODE, K>(a, lds0 + (unsigned)slot2 * (P_BUF * 4), n2, (tile2 - n2 * ra.tiles_y) * PT_H,
+                                    c2 % NCHUNK, HW, lane, zero);
+            }
+            slot = slot + 1 == RING ? 0 : slot + 1;
+            if (++c == NCHUNK) { c = 0; ++tile; }
+        }
+        return;
+    }
+
+    // ------------------------------ consumer waves ------------------------------
+    f32x4 acc[M_SEGS][NT];
+#pragma unroll
+    for (int s = 0; s < M_SEGS; ++s)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[s][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int tile = t_begin, c = 0, slot = 0;
+#pragma unroll 1
+    for (int q = 0; q < nitems; ++q) {
+        asm volatile("s_barrier" ::: "memory");
+        mfma_chunk<MODE, K, NT>(acc, lds + slot * P_BUF, wl, c * LCH, r, lane);
+        slot = slot + 1 == RING ? 0 : slot + 1;
+        if (++c < NCHUNK) continue;
+        c = 0;
+
+        // ---- epilogue: horizontal taps by lane shifts, then bias / activation / store ----
+        const int n = tile / ra.tiles_y, ty0 = (tile - n * ra.tiles_y) * PT_H;
+        const int y = ty0 + r;
+        float extra[M_SEGS][COUT];       // MODE 1: mv (delta add), MODE 2: y_K (LeakyReLU'): one batch of loads
+        if (MODE != 0) {
+#pragma unroll
+            for (int s = 0; s < M_SEGS; ++s) {
+                const int x = s * 64 + lane;
+                const size_t pix = (y < a.H && x < a.W) ? (size_t)y * a.W + x : 0;
+#pragma unroll
+                for (int co = 0; co < COUT; ++co)
+                    extra[s][co] = MODE == 1 ? (a.add_mv ? a.mv[((size_t)n * 2 + co) * HW + pix] : 0.f)
+                                             : a.feat[((size_t)n * NFEAT + (yoff(K) - NIN) + co) * HW + pix];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < M_SEGS; ++s) {
+            const int x = s * 64 + lane;
+            const size_t pix = (size_t)y * a.W + x;
+            float v[COUT];
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                const int r0 = co, r1 = COUT + co, r2 = 2 * COUT + co;
+                const float p0 = acc[s][r0 / 4][r0 % 4];
+                const float p1 = acc[s][r1 / 4][r1 % 4];
+                const float p2 = acc[s][r2 / 4][r2 % 4];
+                const float edge_l = s > 0 ? lane_bcast(acc[s > 0 ? s - 1 : 0][r0 / 4][r0 % 4], 63) : 0.f;
+                const float edge_r = s + 1 < M_SEGS ? lane_bcast(acc[s + 1 < M_SEGS ? s + 1 : s][r2 / 4][r2 % 4], 0) : 0.f;
+                v[co] = p1 + dpp_shr_fill(p0, edge_l) + dpp_shl_fill(p2, edge_r);
+                if (MODE == 0) {
+                    v[co] += a.pk[bf_off(K) + co];
+                    v[co] = v[co] > 0.f ? v[co] : 0.1f * v[co];
+                } else if (MODE == 1) {
+                    v[co] += a.pk[bf_off(K) + co];
+                    v[co] += extra[s][co];
+                } else {
+                    v[co] *= extra[s][co] > 0.f ? 1.f : 0.1f;
+                }
+            }
+            if (y < a.H && x < a.W) {
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) {
+                    if (MODE == 0) a.feat_out[((size_t)n * NFEAT + (yoff(K) - NIN) + co) * HW + pix] = v[co];
+                    else if (MODE == 1) a.out[((size_t)n * 2 + co) * HW + pix] = v[co];
+                    else a.gbuf[((size_t)n * NFEAT + (yoff(K) - NIN) + co) * HW + pix] = v[co];
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < M_SEGS; ++s)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[s][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        ++tile;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // backward, weight path: one fp32-MFMA GEMM over pixels.
 //
 //   dW[(k,co)][(ci,tap)] = sum_px g_k[co][px] * x[ci][px + tap]
@@ -692,6 +986,17 @@ int frames_per_pass(int N, int H, int W) {
     return (int)(f < 1 ? 1 : (f > N ? N : f));
 }
 
+int num_cus() {
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        return cus;
+    }();
+    return n;
+}
+
 template <int MODE, int K>
 int launch_layer(LayerArgs a, int n0, int N, hipStream_t s) {
     const size_t HW = (size_t)a.H * a.W;
@@ -707,7 +1012,16 @@ int launch_layer(LayerArgs a, int n0, int N, hipStream_t s) {
     // rides on each staged channel (Cout 2: layers 4, 5; gradient groups 2, 3, 4), the
     // register-pipelined kernel wins for the Cout 8 / 6 / 4 layers
     constexpr bool DMA_WINS = (MODE != 2 && K >= 4) || (MODE == 2 && K >= 2);
-    if (DMA_WINS && a.W % 4 == 0 && a.W <= LTW) gen_layer_dma_kernel<MODE, K><<<grid, LTHREADS, 0, s>>>(a);
+    static const int path = [] { const char* e = getenv("DMC_GEN_LAYER_PATH"); return e ? atoi(e) : 1; }();
+    if (path == 1 && a.W % 4 == 0 && a.W <= LTW) {
+        RingArgs ra;
+        ra.a = a;
+        ra.tiles_y = (a.H + PT_H - 1) / PT_H;
+        ra.ntiles = ra.tiles_y * N;
+        const int wgs = ra.ntiles < num_cus() ? ra.ntiles : num_cus();
+        gen_layer_mfma_kernel<MODE, K><<<wgs, LTHREADS, 0, s>>>(ra);
+    }
+    else if (DMA_WINS && a.W % 4 == 0 && a.W <= LTW) gen_layer_dma_kernel<MODE, K><<<grid, LTHREADS, 0, s>>>(a);
     else if (a.W % 4 == 0) gen_layer_kernel<MODE, K, true><<<grid, LTHREADS, 0, s>>>(a);
     else gen_layer_kernel<MODE, K, false><<<grid, LTHREADS, 0, s>>>(a);
     return check_launch("gen_layer");

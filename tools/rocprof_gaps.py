@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Idle gaps between consecutive kernels inside bench.py's timed region (kernel trace CSV):
+where the GPU waits for the host.  python tools/rocprof_gaps.py <trace.csv> [steps]"""
+import csv, sys
+from collections import defaultdict
+rows = []
+with open(sys.argv[1], newline="") as f:
+    for r in csv.DictReader(f):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+rows.sort()
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+marks = [i for i, r in enumerate(rows) if "dmc_profile_mark_kernel" in r[2]]
+region = rows[marks[0] + 1:marks[-1]]
+gaps = defaultdict(lambda: [0, 0])
+end = region[0][1]
+total = 0
+for s, e, name in region[1:]:
+    g = s - end
+    if g > 2000:
+        key = name[:70]
+        gaps[key][0] += g; gaps[key][1] += 1
+        total += g
+    end = max(end, e)
+print("total idle (gaps > 2us): %.3f ms/step" % (total / steps / 1e6))
+for k, (g, n) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:25]:
+    print("%-72s %8.1f us/step in %5.1f gaps/step (before this kernel)" % (k, g / steps / 1e3, n / steps))
