@@ -68,7 +68,7 @@ __host__ __device__ constexpr int wb_off(int j) {
     return o;
 }
 constexpr int PACKED_TOTAL = wb_off(5);   // 7788
-constexpr int ZERO_PAD = 16;              // zero words kept behind the packed parameters
+constexpr int ZERO_PAD = 256;             // zero words (1 KB: one LDS-DMA row) kept behind the packed parameters
 
 // logical (reference, prepend order) input-channel index of physical channel p in layer k
 __host__ __device__ inline int logical_of(int k, int p) {

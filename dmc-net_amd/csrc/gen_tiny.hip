@@ -452,12 +452,14 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
 }
 
 constexpr int M_SEGS = LTW / 64;                    // 4 segments of 64 pixels per tile row
-constexpr int PT_H = 7;                             // tile rows = consumer waves
+constexpr int PT_H = 8;                             // tile rows
+constexpr int P_CONS = 7;                           // consumer waves; wave 7 is the producer
+constexpr int P_MAXW = P_CONS * M_SEGS * 64 / PT_H; // 224: widest image the 7 x 256 pixel slots cover
 constexpr int P_ROWS = PT_H + 2;                    // staged rows per channel
-constexpr int P_PLANE = P_ROWS * LTW;               // 2304 floats
-constexpr int P_BUF = LCH * P_PLANE;                // 9216 floats = 36,864 B per chunk
+constexpr int P_PLANE = P_ROWS * LTW;               // 2560 floats
+constexpr int P_BUF = LCH * P_PLANE;                // 10240 floats = 40,960 B per chunk
 constexpr int RING = 3;                             // chunk buffers: one computing, two in flight
-constexpr int RING_DMA = LCH * P_ROWS;              // 36 row transfers per chunk, all by the producer
+constexpr int RING_DMA = LCH * P_ROWS;              // 40 row transfers per chunk, all by the producer
 static_assert(RING_DMA <= 63, "vmcnt is a 6-bit counter");
 
 template <int MODE, int K>
@@ -477,7 +479,19 @@ struct MfmaGeom {
 // by hand with s_waitcnt vmcnt(RING_DMA): "everything but the newest chunk has landed".
 __device__ __forceinline__ void dma_row16(unsigned long long src, unsigned lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                 :: "v"(src), "s"(lds_byte_addr) : "memory", "m0");
+                 :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)) : "memory", "m0");
+}
+
+__device__ __forceinline__ void dma_row4(unsigned long long src, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
+                 :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)) : "memory", "m0");
+}
+
+// scalar row base + per-lane byte offset: the producer's address arithmetic is all SALU, it never
+// competes with the consumers' MFMAs for the vector issue port
+__device__ __forceinline__ void dma_row16_s(unsigned long long sbase, unsigned voff, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory", "m0");
 }
 
 struct RingArgs {
@@ -485,17 +499,15 @@ struct RingArgs {
     int tiles_y, ntiles;                              // row bands per frame, tiles in this launch
 };
 
-// producer: stage chunk c of tile (n, ty0) -- 4 channels x 9 rows, one 1 KB row per instruction.
-// Channels >= CIN, rows outside the image and columns >= W come from the zero words.  Address
-// arithmetic is branch-free scalar code (selects by multiplication with 0/1).
+// producer: stage chunk c of tile (n, ty0) -- 4 channels x 10 rows, one 1 KB row per instruction.
+// Only lanes left of the image's right edge are active (EXEC is restricted by the caller; the
+// consumers never read staged columns >= W).  Channels >= CIN and rows outside the image come
+// from the 1 KB of zero words behind the packed parameters.  All address arithmetic is scalar.
 template <int MODE, int K>
 __device__ __forceinline__ void ring_stage(const LayerArgs& a, unsigned slot_byte, int n, int ty0, int c,
-                                           size_t HW, int lane, const float* zero) {
+                                           size_t HW, unsigned voff, const float* zero) {
     constexpr int CIN = MfmaGeom<MODE, K>::CIN;
     const unsigned long long zaddr = (unsigned long long)zero;
-    const bool colok = 4 * lane < a.W;
-    const unsigned long long loff = (unsigned long long)lane * 16;
-    const unsigned long long vstride = colok ? (unsigned long long)a.W * 4 : 0;   // lanes right of the image stay on the zero words
     const bool interior = ty0 >= 1 && ty0 + PT_H < a.H;                            // rows ty0-1 .. ty0+PT_H all inside
 #pragma unroll
     for (int cc = 0; cc < LCH; ++cc) {
@@ -513,24 +525,24 @@ __device__ __forceinline__ void ring_stage(const LayerArgs& a, unsigned slot_byt
                    s2 * ((unsigned long long)a.feat - (unsigned long long)a.res);
             pidx = (long)n * (2 + s1 + s2 * (NFEAT - 3)) + ch - s1 * 2 - s2 * (NIN - 2);
         }
-        const bool chok = ch < CIN;                                    // scalar
-        // this lane's pointer into row ty0-1 (never dereferenced while that row is outside the image)
+        const bool chok = ch < CIN;
+        // scalar pointer to row ty0-1 of the plane (never dereferenced while that row is outside the image)
         const unsigned long long row0 = base + (unsigned long long)((pidx * (long)HW + (long)(ty0 - 1) * a.W) * 4);
-        unsigned long long vptr = (chok && colok) ? row0 + loff : zaddr;
-        const unsigned long long vs = chok ? vstride : 0;
+        unsigned long long sptr = chok ? row0 : zaddr;
+        const unsigned long long sstride = chok ? (unsigned long long)a.W * 4 : 0;
         const unsigned dst = slot_byte + (unsigned)(cc * P_ROWS) * (LTW * 4);
         if (interior) {
 #pragma unroll
             for (int row = 0; row < P_ROWS; ++row) {
-                dma_row16(vptr, dst + row * (LTW * 4));
-                vptr += vs;
+                dma_row16_s(sptr, voff, dst + row * (LTW * 4));
+                sptr += sstride;
             }
         } else {
 #pragma unroll
             for (int row = 0; row < P_ROWS; ++row) {
                 const int yy = ty0 - 1 + row;
-                dma_row16((yy >= 0 && yy < a.H) ? vptr : zaddr, dst + row * (LTW * 4));
-                vptr += vs;
+                dma_row16_s((yy >= 0 && yy < a.H) ? sptr : zaddr, voff, dst + row * (LTW * 4));
+                sptr += sstride;
             }
         }
     }
@@ -541,7 +553,7 @@ __device__ __forceinline__ void ring_stage(const LayerArgs& a, unsigned slot_byt
 // sched_barriers keep the compiler from hoisting every load of the chunk to the top.
 template <int MODE, int K, int NT_>
 __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[M_SEGS][NT_], const float* buf, const float* wl,
-                                           int c0, int r, int lane) {
+                                           int c0, const int (&boff)[M_SEGS], int lane) {
     using G = MfmaGeom<MODE, K>;
     float w[2][3][G::NTP], b[2][3][M_SEGS];
     auto load_stage = [&](int cc, int sel) {
@@ -562,7 +574,7 @@ __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[M_SEGS][NT_], const floa
                 }
             }
 #pragma unroll
-            for (int s = 0; s < M_SEGS; ++s) b[sel][dy][s] = buf[cc * P_PLANE + (r + dy) * LTW + s * 64 + lane];
+            for (int s = 0; s < M_SEGS; ++s) b[sel][dy][s] = buf[cc * P_PLANE + dy * LTW + boff[s]];
         }
     };
     load_stage(0, 0);
@@ -585,12 +597,13 @@ template <int MODE, int K>
 __global__ __launch_bounds__(LTHREADS, 2) void gen_layer_mfma_kernel(RingArgs ra) {
     using G = MfmaGeom<MODE, K>;
     constexpr int CIN = G::CIN, COUT = G::COUT, NT = G::NT, NTP = G::NTP, NCHUNK = G::NCHUNK;
-    __shared__ __attribute__((aligned(16))) float lds[RING * P_BUF + G::WL];
+    __shared__ __attribute__((aligned(16))) float lds[RING * P_BUF + G::WL + P_CONS * 2 * 8];
     const LayerArgs& a = ra.a;
     float* wl = lds + RING * P_BUF;
+    float* xchg = wl + G::WL;                                      // [wave][first P_2 | last P_0][co]
     const size_t HW = (size_t)a.H * a.W;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int r = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave: 0..6 = tile row, 7 = producer
+    const int r = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave: 0..6 = consumers, 7 = producer
     const float* zero = a.pk + PACKED_TOTAL;
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds;          // LDS byte address of the ring
 
@@ -609,12 +622,14 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_layer_mfma_kernel(RingArgs ra
     }
     __syncthreads();
 
-    if (r == PT_H) {
+    if (r == P_CONS) {
         // ------------------------------ producer wave ------------------------------
+        if (4 * lane >= a.W) return;                                   // EXEC = lanes that hold image columns
+        const unsigned voff = (unsigned)lane * 16;
 #pragma unroll 1
         for (int pre = 0; pre < 2 && pre < nitems; ++pre) {
             const int tile = t_begin + pre / NCHUNK, n = tile / ra.tiles_y;
-            ring_stage<MODE, K>(a, lds0 + pre * (P_BUF * 4), n, (tile - n * ra.tiles_y) * PT_H, pre % NCHUNK, HW, lane, zero);
+            ring_stage<MODE, K>(a, lds0 + pre * (P_BUF * 4), n, (tile - n * ra.tiles_y) * PT_H, pre % NCHUNK, HW, voff, zero);
         }
         int tile = t_begin, c = 0, slot = 0;
 #pragma unroll 1
@@ -626,15 +641,32 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_layer_mfma_kernel(RingArgs ra
                 const int c2 = c + 2, tile2 = tile + c2 / NCHUNK, n2 = tile2 / ra.tiles_y;
                 int slot2 = slot + 2; slot2 = slot2 >= RING ? slot2 - RING : slot2;
                 ring_stage<MODE, K>(a, lds0 + (unsigned)slot2 * (P_BUF * 4), n2, (tile2 - n2 * ra.tiles_y) * PT_H,
-                                    c2 % NCHUNK, HW, lane, zero);
+                                    c2 % NCHUNK, HW, voff, zero);
             }
             slot = slot + 1 == RING ? 0 : slot + 1;
-            if (++c == NCHUNK) { c = 0; ++tile; }
+            if (++c == NCHUNK) {
+                c = 0; ++tile;
+                asm volatile("s_barrier" ::: "memory");           // the consumers' edge exchange of this tile
+            }
         }
         return;
     }
 
     // ------------------------------ consumer waves ------------------------------
+    // The tile's PT_H x W pixels are numbered row-major, p = y*W + x; consumer wave r owns pixels
+    // [256 r, 256 r + 256) as 4 segments of 64, one pixel per lane.  A 224-wide row is 3.5 segments,
+    // so segments straddle rows: nothing is wasted on columns >= W, and output addresses are simply
+    // ty0*W + p (every store instruction writes 256 contiguous bytes).
+    int boff[M_SEGS];                 // LDS offset of the lane's pixel in staged row 0 (the row above it)
+    bool at_left[M_SEGS], at_right[M_SEGS];
+#pragma unroll
+    for (int s = 0; s < M_SEGS; ++s) {
+        const int p = r * (M_SEGS * 64) + s * 64 + lane;
+        const int yl = p / a.W, x = p - yl * a.W;
+        boff[s] = p < PT_H * a.W ? yl * LTW + x : 0;
+        at_left[s] = x == 0;
+        at_right[s] = x == a.W - 1;
+    }
     f32x4 acc[M_SEGS][NT];
 #pragma unroll
     for (int s = 0; s < M_SEGS; ++s)
@@ -645,20 +677,38 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_layer_mfma_kernel(RingArgs ra
 #pragma unroll 1
     for (int q = 0; q < nitems; ++q) {
         asm volatile("s_barrier" ::: "memory");
-        mfma_chunk<MODE, K, NT>(acc, lds + slot * P_BUF, wl, c * LCH, r, lane);
+        mfma_chunk<MODE, K, NT>(acc, lds + slot * P_BUF, wl, c * LCH, boff, lane);
         slot = slot + 1 == RING ? 0 : slot + 1;
         if (++c < NCHUNK) continue;
         c = 0;
 
         // ---- epilogue: horizontal taps by lane shifts, then bias / activation / store ----
         const int n = tile / ra.tiles_y, ty0 = (tile - n * ra.tiles_y) * PT_H;
-        const int y = ty0 + r;
+        const int pmax = (a.H - ty0 < PT_H ? a.H - ty0 : PT_H) * a.W;      // pixels of this tile inside the image
+        const size_t tile_pix = (size_t)ty0 * a.W;
+        // the pixel left of this wave's first one / right of its last one belongs to the neighbour
+        // wave: exchange those two partial sums per channel through LDS
+        float nb_l[COUT], nb_r[COUT];
+        {
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                const int r0 = co, r2 = 2 * COUT + co;
+                if (lane == 0) xchg[(r * 2 + 0) * 8 + co] = acc[0][r2 / 4][r2 % 4];
+                if (lane == 63) xchg[(r * 2 + 1) * 8 + co] = acc[M_SEGS - 1][r0 / 4][r0 % 4];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                nb_l[co] = r > 0 ? xchg[((r - 1) * 2 + 1) * 8 + co] : 0.f;
+                nb_r[co] = r + 1 < P_CONS ? xchg[((r + 1) * 2 + 0) * 8 + co] : 0.f;
+            }
+        }
         float extra[M_SEGS][COUT];       // MODE 1: mv (delta add), MODE 2: y_K (LeakyReLU'): one batch of loads
         if (MODE != 0) {
 #pragma unroll
             for (int s = 0; s < M_SEGS; ++s) {
-                const int x = s * 64 + lane;
-                const size_t pix = (y < a.H && x < a.W) ? (size_t)y * a.W + x : 0;
+                const int p = r * (M_SEGS * 64) + s * 64 + lane;
+                const size_t pix = p < pmax ? tile_pix + p : 0;
 #pragma unroll
                 for (int co = 0; co < COUT; ++co)
                     extra[s][co] = MODE == 1 ? (a.add_mv ? a.mv[((size_t)n * 2 + co) * HW + pix] : 0.f)
@@ -667,8 +717,8 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_layer_mfma_kernel(RingArgs ra
         }
 #pragma unroll
         for (int s = 0; s < M_SEGS; ++s) {
-            const int x = s * 64 + lane;
-            const size_t pix = (size_t)y * a.W + x;
+            const int p = r * (M_SEGS * 64) + s * 64 + lane;
+            const size_t pix = tile_pix + p;
             float v[COUT];
 #pragma unroll
             for (int co = 0; co < COUT; ++co) {
@@ -676,9 +726,16 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_layer_mfma_kernel(RingArgs ra
                 const float p0 = acc[s][r0 / 4][r0 % 4];
                 const float p1 = acc[s][r1 / 4][r1 % 4];
                 const float p2 = acc[s][r2 / 4][r2 % 4];
-                const float edge_l = s > 0 ? lane_bcast(acc[s > 0 ? s - 1 : 0][r0 / 4][r0 % 4], 63) : 0.f;
-                const float edge_r = s + 1 < M_SEGS ? lane_bcast(acc[s + 1 < M_SEGS ? s + 1 : s][r2 / 4][r2 % 4], 0) : 0.f;
-                v[co] = p1 + dpp_shr_fill(p0, edge_l) + dpp_shl_fill(p2, edge_r);
+                // neighbour pixels are neighbour lanes (the previous / next segment's edge lane at the
+                // segment ends); at the image's left / right border the neighbour is zero padding
+                const float edge_l = s > 0 ? lane_bcast(acc[s > 0 ? s - 1 : 0][r0 / 4][r0 % 4], 63) : nb_l[co];
+                const float edge_r = s + 1 < M_SEGS ? lane_bcast(acc[s + 1 < M_SEGS ? s + 1 : s][r2 / 4][r2 % 4], 0) : nb_r[co];
+                // (the shifts run with all lanes active -- a DPP read from an inactive lane is invalid --
+                // and only then are the border lanes masked)
+                const float sh_l = dpp_shr_fill(p0, edge_l), sh_r = dpp_shl_fill(p2, edge_r);
+                const float from_l = at_left[s] ? 0.f : sh_l;
+                const float from_r = at_right[s] ? 0.f : sh_r;
+                v[co] = p1 + from_l + from_r;
                 if (MODE == 0) {
                     v[co] += a.pk[bf_off(K) + co];
                     v[co] = v[co] > 0.f ? v[co] : 0.1f * v[co];
@@ -689,7 +746,7 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_layer_mfma_kernel(RingArgs ra
                     v[co] *= extra[s][co] > 0.f ? 1.f : 0.1f;
                 }
             }
-            if (y < a.H && x < a.W) {
+            if (p < pmax) {
 #pragma unroll
                 for (int co = 0; co < COUT; ++co) {
                     if (MODE == 0) a.feat_out[((size_t)n * NFEAT + (yoff(K) - NIN) + co) * HW + pix] = v[co];
@@ -776,9 +833,8 @@ __device__ __forceinline__ void wgrad_dma_tile(const WgradArgs& a, float* buf, i
                               : plane < NIN ? rsp + (size_t)(plane - 2) * HW
                                             : ftp + (size_t)(plane - NIN) * HW;
             const float* src = (colok && yy >= 0 && yy < a.H) ? base + (size_t)yy * a.W + xx : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src,
-                                             (lptr_t)(buf + plane * WX_PLANE + (hp & 1) * 5 * WX_PITCH),
-                                             16, 0, 0);
+            dma_row16((unsigned long long)src,
+                      (unsigned)(size_t)(lptr_t)(buf + plane * WX_PLANE + (hp & 1) * 5 * WX_PITCH));
         }
     }
 }
@@ -798,9 +854,8 @@ __device__ __forceinline__ void wgrad_dma_tile_generic(const WgradArgs& a, float
             const int yy = ty0 - 1 + row;
             const float* base = in_plane(a.mv, a.res, a.feat, n, plane, HW);
             const float* src = (colok && yy >= 0 && yy < a.H) ? base + (size_t)yy * a.W + xx : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src,
-                                             (lptr_t)(buf + plane * WX_PLANE + row * WX_PITCH + WX_COL0),
-                                             4, 0, 0);
+            dma_row4((unsigned long long)src,
+                     (unsigned)(size_t)(lptr_t)(buf + plane * WX_PLANE + row * WX_PITCH + WX_COL0));
         }
     }
 }
@@ -865,6 +920,7 @@ __global__ __launch_bounds__(512, 2) void gen_bwd_weight_kernel(WgradArgs a, con
         else wgrad_dma_tile_generic(a, lds2, blockIdx.x, per_frame, HW, wave, lane, zero);
         request_row(blockIdx.x, cur0, cur1);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the inline-asm LDS-DMA is invisible to the compiler
     __syncthreads();
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
         const float* lds = lds2 + (it & 1) * WT_LDS;
@@ -896,6 +952,7 @@ __global__ __launch_bounds__(512, 2) void gen_bwd_weight_kernel(WgradArgs a, con
             for (int t = 0; t < NT_B; ++t)
                 accB[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[t], accB[t], 0, 0, 0);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                               // DMA of the next tile has landed
 #pragma unroll
         for (int g = 0; g < 8; ++g) { cur0[g] = nxt0[g]; cur1[g] = nxt1[g]; }
@@ -1013,7 +1070,7 @@ int launch_layer(LayerArgs a, int n0, int N, hipStream_t s) {
     // register-pipelined kernel wins for the Cout 8 / 6 / 4 layers
     constexpr bool DMA_WINS = (MODE != 2 && K >= 4) || (MODE == 2 && K >= 2);
     static const int path = [] { const char* e = getenv("DMC_GEN_LAYER_PATH"); return e ? atoi(e) : 1; }();
-    if (path == 1 && a.W % 4 == 0 && a.W <= LTW) {
+    if (path == 1 && a.W % 4 == 0 && a.W <= P_MAXW) {
         RingArgs ra;
         ra.a = a;
         ra.tiles_y = (a.H + PT_H - 1) / PT_H;

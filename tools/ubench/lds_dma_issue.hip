@@ -1,0 +1,74 @@
+// Micro-benchmark: issue cost of global_load_lds_dwordx4 (LDS-DMA) from ONE wave per CU.
+//   variant 0: s_mov m0 + DMA per row (what the producer wave does)
+//   variant 1: one s_mov m0 per 4 rows, rows 1..3 through the instruction offset (global and LDS
+//              addresses advance together by 1 KB)
+//   variant 2: variant 0 without the s_nop
+//   variant 3: plain global_load_dwordx4 into registers (no LDS), for comparison
+// hipcc --offload-arch=gfx950 -O3 tools/ubench/lds_dma_issue.hip -o lds_dma && ./lds_dma
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+template <int V>
+__global__ __launch_bounds__(64) void k(const float* src, long long* out, int rows_per_iter, int iters, size_t stride) {
+    __shared__ __attribute__((aligned(16))) float lds[32 * 256];
+    const int lane = threadIdx.x;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds;
+    unsigned long long p = (unsigned long long)(src + (size_t)blockIdx.x * stride) + lane * 16;
+    float4 sink = make_float4(0, 0, 0, 0);
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        if (V == 0 || V == 2) {
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) {
+                if (V == 0) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(p), "s"(lds0 + r * 1024) : "memory", "m0");
+                else asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(p), "s"(lds0 + r * 1024) : "memory", "m0");
+                p += 1024;
+            }
+        } else if (V == 1) {
+#pragma unroll 2
+            for (int r = 0; r < 32; r += 4) {
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
+                             "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
+                             :: "v"(p), "s"(lds0 + r * 1024) : "memory", "m0");
+                p += 4096;
+            }
+        } else {
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) {
+                float4 v;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+                sink.x += v.x;   // forces a wait, keeps <= 8 in flight per unroll group
+                p += 1024;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) out[blockIdx.x] = t1 - t0;
+    if (sink.x == 12345.f) out[0] = 0;
+}
+
+template <int V>
+void run(const char* name, const float* src, long long* out, int blocks) {
+    const int iters = 50;
+    k<V><<<blocks, 64>>>(src, out, 32, iters, (size_t)32 * 256 * iters);
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) { printf("%s: %s\n", name, hipGetErrorString(e)); fflush(stdout); }
+    long long h[1024];
+    hipMemcpy(h, out, blocks * 8, hipMemcpyDeviceToHost);
+    double s = 0; for (int i = 0; i < blocks; ++i) s += h[i];
+    fflush(stdout); printf("%-46s blocks %4d: %.1f cycles per 1 KB row (avg over waves; each batch of 32 rows then waits)\n", name, blocks, s / blocks / (32.0 * iters)); fflush(stdout);
+}
+
+int main() {
+    float* src; long long* out;
+    const size_t bytes = (size_t)1024 * 32 * 256 * 50 * 4;
+    hipError_t e1 = hipMalloc(&src, bytes), e2 = hipMemset(src, 0, bytes), e3 = hipMalloc(&out, 8192);
+    printf("alloc %zu bytes: %d %d %d src=%p\n", bytes, (int)e1, (int)e2, (int)e3, (void*)src); fflush(stdout);
+    for (int blocks : {1, 256, 1024}) {
+        run<0>("m0 + nop + DMA per row (warm-up)", src, out, blocks);
+        run<0>("m0 + nop + DMA per row", src, out, blocks);
+        run<2>("m0 + DMA per row (no nop)", src, out, blocks);
+    }
+    return 0;
+}
