@@ -479,19 +479,19 @@ struct MfmaGeom {
 // by hand with s_waitcnt vmcnt(RING_DMA): "everything but the newest chunk has landed".
 __device__ __forceinline__ void dma_row16(unsigned long long src, unsigned lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                 :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)) : "memory", "m0");
+                 :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)) : "memory");
 }
 
 __device__ __forceinline__ void dma_row4(unsigned long long src, unsigned lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
-                 :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)) : "memory", "m0");
+                 :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)) : "memory");
 }
 
 // scalar row base + per-lane byte offset: the producer's address arithmetic is all SALU, it never
 // competes with the consumers' MFMAs for the vector issue port
 __device__ __forceinline__ void dma_row16_s(unsigned long long sbase, unsigned voff, unsigned lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                 :: "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory", "m0");
+                 :: "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
 }
 
 struct RingArgs {
@@ -977,6 +977,185 @@ __global__ __launch_bounds__(512, 2) void gen_bwd_weight_kernel(WgradArgs a, con
     for (int i = threadIdx.x; i < WPART; i += 512) part[i] = lds[i];
 }
 
+// ------------------------------------------------------------------------------------------
+// Producer / consumer version of the weight-gradient kernel (W % 4 == 0).
+//
+// Timeline of the kernel above, per tile and wave (s_memtime): ~15,000 cycles blocked issuing its
+// share of the LDS-DMA and the 16 global gathers of its gradient rows (194 scattered vector-memory
+// instructions per tile and CU), THEN 8,200 cycles of MFMA -- staging and matrix time added up.
+// Here wave 7 is the only wave that touches global memory: it stages, with LDS-DMA and scalar
+// address arithmetic, the 33 input planes (9 rows x 40 columns) AND the 30 gradient planes
+// (7 rows x 32) of the next tile while waves 0..6 run the MFMAs of one tile row each, with both
+// operands coming from LDS.  96 row-contiguous transfers per tile instead of 194 scattered ones.
+// ------------------------------------------------------------------------------------------
+constexpr int PW_H = 7;                                  // tile rows = consumer waves
+constexpr int PW_XROWS = PW_H + 2;
+constexpr int PW_XPLANE = 372;                           // 9 x 40 = 360 floats + pad (372 % 32 == 20: conflict-light gathers)
+constexpr int PW_GPLANE = 228;                           // 7 x 32 = 224 floats + pad (A-fragment reads 2-way)
+constexpr int PW_X = 33 * PW_XPLANE;                     // 12,276
+constexpr int PW_G = 30 * PW_GPLANE;                     // 6,840
+constexpr int PW_BUF = (PW_X + PW_G + 3) / 4 * 4;        // 19,116 floats = 76,464 B; x2 = 152,928 B
+static_assert(2 * PW_BUF * 4 <= 160 * 1024, "LDS");
+static_assert(WPART <= 2 * PW_BUF, "cross-wave reduction reuses the tile buffers");
+
+__device__ __forceinline__ void dma16_s(unsigned long long sbase, unsigned voff, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)) : "memory");
+}
+// producer: stage one tile.  Lane L of instruction h (L = 64 h + lane) moves 16-byte chunk
+// (row L / 10, chunk L % 10) of an input plane; lane (row, chunk) = (lane / 8, lane % 8) of a gradient plane.
+__device__ __forceinline__ void wgrad_stage(const WgradArgs& a, float* buf, unsigned buf_byte, int tile, int per_frame,
+                                            size_t HW, int lane) {
+    const int n = tile / per_frame, r0 = tile - n * per_frame;
+    const int ty0 = (r0 / a.tiles_x) * PW_H, tx0 = (r0 % a.tiles_x) * WT_W;
+    const int W = a.W;
+    // ---- input planes: rows ty0-1 .. ty0+7, columns tx0-4 .. tx0+35 ----
+    const bool x_interior = ty0 >= 1 && ty0 + PW_H < a.H && tx0 >= 4 && tx0 + WT_W + 4 <= W;
+    const int L0 = lane, L1 = 64 + lane;
+    const int row0 = L0 / 10, ch0 = L0 - row0 * 10, row1 = L1 / 10, ch1 = L1 - row1 * 10;
+    const unsigned voff0 = (unsigned)(row0 * W + ch0 * 4) * 4, voff1 = (unsigned)(row1 * W + ch1 * 4) * 4;
+    const long xorg = ((long)(ty0 - 1) * W + (tx0 - 4)) * 4;          // byte offset of (row ty0-1, col tx0-4) in a plane
+    bool ok0 = false, ok1 = false;
+    if (!x_interior) {
+        const int y0 = ty0 - 1 + row0, x0 = tx0 - 4 + ch0 * 4, y1 = ty0 - 1 + row1, x1 = tx0 - 4 + ch1 * 4;
+        ok0 = y0 >= 0 && y0 < a.H && x0 >= 0 && x0 < W;
+        ok1 = y1 >= 0 && y1 < a.H && x1 >= 0 && x1 < W;
+    }
+#pragma unroll
+    for (int plane = 0; plane < 33; ++plane) {
+        const float* pb = plane < 2 ? a.mv + ((size_t)n * 2 + plane) * HW
+                        : plane < NIN ? a.res + ((size_t)n * 3 + (plane - 2)) * HW
+                                      : a.feat + ((size_t)n * NFEAT + (plane - NIN)) * HW;
+        const unsigned long long sbase = (unsigned long long)pb + (unsigned long long)xorg;
+        const unsigned dst = buf_byte + (unsigned)(plane * PW_XPLANE) * 4;
+        if (x_interior) {
+            dma16_s(sbase, voff0, dst);
+            if (lane < PW_XROWS * 10 - 64) dma16_s(sbase, voff1, dst + 1024);
+        } else {
+            // edge tile: lanes whose chunk lies outside the image do not transfer; they zero their chunk
+            float4* l0 = reinterpret_cast<float4*>(buf + plane * PW_XPLANE) + lane;
+            if (ok0) dma16_s(sbase, voff0, dst); else *l0 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lane < PW_XROWS * 10 - 64) {
+                if (ok1) dma16_s(sbase, voff1, dst + 1024); else l0[64] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    // ---- gradient planes: rows ty0 .. ty0+6, columns tx0 .. tx0+31 (zero outside the image) ----
+    const bool g_interior = ty0 + PW_H <= a.H && tx0 + WT_W <= W;
+    const int grow = lane >> 3, gch = lane & 7;
+    const unsigned gvoff = (unsigned)(grow * W + gch * 4) * 4;
+    const bool gok = ty0 + grow < a.H && tx0 + gch * 4 < W;
+    const long gorg = ((long)ty0 * W + tx0) * 4;
+    if (lane < PW_H * 8) {
+#pragma unroll
+        for (int gp = 0; gp < 30; ++gp) {
+            const float* pb = gp < NFEAT ? a.gbuf + ((size_t)n * NFEAT + gp) * HW
+                                         : a.gout + ((size_t)n * 2 + (gp - NFEAT)) * HW;
+            const unsigned long long sbase = (unsigned long long)pb + (unsigned long long)gorg;
+            const unsigned dst = buf_byte + (unsigned)(PW_X + gp * PW_GPLANE) * 4;
+            if (g_interior) dma16_s(sbase, gvoff, dst);
+            else if (gok) dma16_s(sbase, gvoff, dst);
+            else reinterpret_cast<float4*>(buf + PW_X + gp * PW_GPLANE)[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void gen_bwd_weight_pc_kernel(WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds2[2 * PW_BUF];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int j = lane & 15, kq = lane >> 4;          // column / pixel-in-group of this lane
+    const bool ones = (16 * 18 + j) == BIAS_COL;      // bias column lives in N tile 18
+    const size_t HW = (size_t)a.H * a.W;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds2;
+    const int per_frame = a.tiles_x * a.tiles_y;
+    const int ntiles = a.N * per_frame;
+    const bool producer = wave == PW_H;
+
+    f32x4 accA[NT_A], accB[NT_B];
+#pragma unroll
+    for (int t = 0; t < NT_A; ++t) accA[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT_B; ++t) accB[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (producer) {
+        int it = 0;
+        if ((int)blockIdx.x < ntiles) wgrad_stage(a, lds2, lds0, blockIdx.x, per_frame, HW, lane);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+            const int next = tile + (int)gridDim.x;
+            if (next < ntiles)
+                wgrad_stage(a, lds2 + ((it + 1) & 1) * PW_BUF, lds0 + (unsigned)(((it + 1) & 1) * PW_BUF) * 4, next, per_frame, HW, lane);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    } else {
+        // per-lane gather offsets of the B fragments (x[(ci,tap)][pixel kq of the group])
+        int offB[NT_B];
+#pragma unroll
+        for (int t = 0; t < NT_B; ++t) {
+            int nn = 16 * t + j;
+            nn = nn < 297 ? nn : 296;
+            const int ci = nn / 9, tap = nn - ci * 9;
+            offB[t] = ci * PW_XPLANE + (tap / 3) * WX_PITCH + (tap % 3) + kq + WX_COL0;
+        }
+        // A fragments: row j of M tile A = gradient plane j; of M tile B = plane 16 + j (j < 14), else zero
+        const bool rowB = j < 14;
+        const int offA0 = PW_X + j * PW_GPLANE + kq;
+        const int offA1 = PW_X + (rowB ? 16 + j : 0) * PW_GPLANE + kq;
+        // work units = (tile row, group of 4 pixels): 56 per tile.  The SIMD that hosts the producer
+        // runs one consumer wave (wave 3), the others two, so wave 3 takes 14 units and the rest 7:
+        // every SIMD then carries 14 units of MFMA work.
+        const int nrep = 1;
+        int it = 0;
+        asm volatile("s_barrier" ::: "memory");
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+            const float* lds = lds2 + (it & 1) * PW_BUF;
+#pragma unroll 1
+            for (int rep = 0; rep < nrep; ++rep) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = wave;
+                    const int g = i;
+                    const int sA = row * WT_W + g * 4, sB = row * WX_PITCH + g * 4;
+                    const float a0 = lds[offA0 + sA];
+                    const float a1r = lds[offA1 + sA];
+                    const float a1 = rowB ? a1r : 0.f;
+                    float b[NT_B];
+#pragma unroll
+                    for (int t = 0; t < NT_B; ++t) b[t] = lds[offB[t] + sB];
+                    if (ones) b[18] = 1.f;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                        accA[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[t], accA[t], 0, 0, 0);
+                    accA[8] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[18], accA[8], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < NT_B; ++t)
+                        accB[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[t], accB[t], 0, 0, 0);
+                }
+            }
+            asm volatile("s_barrier" ::: "memory");        // next tile staged, this buffer may be refilled
+        }
+    }
+    // cross-wave reduction in LDS, fixed order (wave 0 stores, waves 1..6 add in turn)
+    float* lds = lds2;
+    for (int w = 0; w < PW_H; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < NT_ALL; ++t) {
+                const f32x4 v = t < NT_A ? accA[t < NT_A ? t : 0] : accB[t >= NT_A ? t - NT_A : 0];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int idx = t * 256 + (kq * 4 + q) * 16 + j;   // C row = kq*4+q, col = j
+                    lds[idx] = (w == 0 ? 0.f : lds[idx]) + v[q];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* part = a.partials + (size_t)blockIdx.x * WPART;
+    for (int i = threadIdx.x; i < WPART; i += 512) part[i] = lds[i];
+}
+
 // Stage 1 of the cross-workgroup reduction: partials [groups][WPART] -> [RED_CHUNKS][WPART],
 // coalesced over the WPART axis, fixed summation order.
 constexpr int RED_CHUNKS = 16;
@@ -1166,10 +1345,16 @@ int dmc_gen_tiny_bwd(const float* mv, const float* res, const float* const* w, c
     a.mv = mv; a.res = res; a.feat = saved; a.gout = grad_out; a.gbuf = gbuf; a.partials = partials;
     a.N = N; a.H = H; a.W = W;
     a.tiles_x = (W + WT_W - 1) / WT_W;
-    a.tiles_y = (H + WT_H - 1) / WT_H;
     const int groups = wgrad_groups(N, H, W);
-    if (W % 4 == 0) gen_bwd_weight_kernel<true><<<groups, 512, 0, s>>>(a, workspace + PACKED_TOTAL);
-    else gen_bwd_weight_kernel<false><<<groups, 512, 0, s>>>(a, workspace + PACKED_TOTAL);
+    static const int wpath = [] { const char* e = getenv("DMC_GEN_WGRAD_PATH"); return e ? atoi(e) : 1; }();
+    if (W % 4 == 0 && wpath == 1) {
+        a.tiles_y = (H + PW_H - 1) / PW_H;
+        gen_bwd_weight_pc_kernel<<<groups, 512, 0, s>>>(a);
+    } else {
+        a.tiles_y = (H + WT_H - 1) / WT_H;
+        if (W % 4 == 0) gen_bwd_weight_kernel<true><<<groups, 512, 0, s>>>(a, workspace + PACKED_TOTAL);
+        else gen_bwd_weight_kernel<false><<<groups, 512, 0, s>>>(a, workspace + PACKED_TOTAL);
+    }
     if ((rc = check_launch("gen_bwd_weight"))) return rc;
     gen_bwd_weight_reduce1_kernel<<<dim3(WPART / 256, RED_CHUNKS), 256, 0, s>>>(partials, groups);
     if ((rc = check_launch("gen_bwd_weight_reduce1"))) return rc;
