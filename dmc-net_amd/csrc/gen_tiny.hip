@@ -607,10 +607,16 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_layer_mfma_kernel(RingArgs ra
     const float* zero = a.pk + PACKED_TOTAL;
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds;          // LDS byte address of the ring
 
-    // this workgroup's contiguous run of tiles (vertically adjacent bands follow each other)
-    const int t_begin = (int)((long)blockIdx.x * ra.ntiles / gridDim.x);
-    const int t_end = (int)((long)(blockIdx.x + 1) * ra.ntiles / gridDim.x);
-    const int nitems = (t_end - t_begin) * NCHUNK;
+    // Tile schedule: workgroups are dispatched round-robin over the 8 XCDs (blockIdx % 8), each with
+    // its own L2.  In round k the nwg/8 workgroups of one XCD take nwg/8 CONSECUTIVE tiles (vertically
+    // adjacent bands of the same frames), so the halo rows two neighbouring bands share are fetched
+    // through the same L2 at about the same time and go to HBM once.  (Contiguous per-workgroup runs
+    // re-fetched every halo row from HBM: PMC 767 B/px forward instead of the 618 B/px of the old
+    // one-tile-per-workgroup grid.)
+    const int nwg = gridDim.x;
+    const int t_begin = nwg % 8 == 0 ? (int)(blockIdx.x % 8) * (nwg / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int t_step = nwg;
+    const int nitems = t_begin < ra.ntiles ? (ra.ntiles - t_begin + nwg - 1) / nwg * NCHUNK : 0;
     if (nitems == 0) return;
 
     // weights -> LDS as [ci][dy][i][NTP]: element (ci, dy, rho = 4*t + i), rho = dx*COUT + co
@@ -628,7 +634,7 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_layer_mfma_kernel(RingArgs ra
         const unsigned voff = (unsigned)lane * 16;
 #pragma unroll 1
         for (int pre = 0; pre < 2 && pre < nitems; ++pre) {
-            const int tile = t_begin + pre / NCHUNK, n = tile / ra.tiles_y;
+            const int tile = t_begin + (pre / NCHUNK) * t_step, n = tile / ra.tiles_y;
             ring_stage<MODE, K>(a, lds0 + pre * (P_BUF * 4), n, (tile - n * ra.tiles_y) * PT_H, pre % NCHUNK, HW, voff, zero);
         }
         int tile = t_begin, c = 0, slot = 0;
@@ -638,14 +644,14 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_layer_mfma_kernel(RingArgs ra
             if (q + 1 < nitems) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(RING_DMA) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             if (q + 2 < nitems) {
-                const int c2 = c + 2, tile2 = tile + c2 / NCHUNK, n2 = tile2 / ra.tiles_y;
+                const int c2 = c + 2, tile2 = tile + (c2 / NCHUNK) * t_step, n2 = tile2 / ra.tiles_y;
                 int slot2 = slot + 2; slot2 = slot2 >= RING ? slot2 - RING : slot2;
                 ring_stage<MODE, K>(a, lds0 + (unsigned)slot2 * (P_BUF * 4), n2, (tile2 - n2 * ra.tiles_y) * PT_H,
                                     c2 % NCHUNK, HW, voff, zero);
             }
             slot = slot + 1 == RING ? 0 : slot + 1;
             if (++c == NCHUNK) {
-                c = 0; ++tile;
+                c = 0; tile += t_step;
                 asm volatile("s_barrier" ::: "memory");           // the consumers' edge exchange of this tile
             }
         }
@@ -759,7 +765,7 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_layer_mfma_kernel(RingArgs ra
         for (int s = 0; s < M_SEGS; ++s)
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[s][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        ++tile;
+        tile += t_step;
     }
 }
 

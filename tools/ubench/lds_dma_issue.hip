@@ -49,9 +49,9 @@ __global__ __launch_bounds__(64) void k(const float* src, long long* out, int ro
 }
 
 template <int V>
-void run(const char* name, const float* src, long long* out, int blocks) {
+void run(const char* name, const float* src, long long* out, int blocks, size_t stride = (size_t)32 * 256 * 50) {
     const int iters = 50;
-    k<V><<<blocks, 64>>>(src, out, 32, iters, (size_t)32 * 256 * iters);
+    k<V><<<blocks, 64>>>(src, out, 32, iters, stride);
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) { printf("%s: %s\n", name, hipGetErrorString(e)); fflush(stdout); }
     long long h[1024];
@@ -69,6 +69,8 @@ int main() {
         run<0>("m0 + nop + DMA per row (warm-up)", src, out, blocks);
         run<0>("m0 + nop + DMA per row", src, out, blocks);
         run<2>("m0 + DMA per row (no nop)", src, out, blocks);
+        run<0>("same 1.6 MB for every block (L2-resident)", src, out, blocks, 0);
+        run<0>("same 1.6 MB for every block (L2-resident)", src, out, blocks, 0);
     }
     return 0;
 }
