@@ -90,3 +90,17 @@ struct GradPtrs {
 };
 
 }  // namespace dmc
+
+// ---- LDS-DMA helpers shared by kernels outside gen_tiny.hip -----------------------------------
+// global_load_lds_dwordx4 through inline assembly (the compiler then inserts no vmcnt(0) in front
+// of unrelated ds_reads; completion is tracked by hand with s_waitcnt vmcnt).  Address = 64-bit
+// scalar base + 32-bit per-lane byte offset; the LDS destination is lds_byte_addr + 16 * lane.
+namespace dmc {
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef float mfma_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(size_t)(lds_ptr_t)p; }
+__device__ __forceinline__ void lds_dma16(unsigned long long sbase, unsigned voff, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)) : "memory");
+}
+}  // namespace dmc

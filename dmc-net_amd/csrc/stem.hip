@@ -1,0 +1,228 @@
+// Weight gradient of the classifier's first convolution (2 -> 64 channels, 7x7, stride 2, pad 3)
+// for gfx950.
+//
+// Reference behaviour: the conv1 the reference installs for the 2-channel flow input,
+// code/dmcnet/model.py:285-294 (nn.Conv2d(2, 64, 7, stride 2, padding 3, bias=False)), whose
+// weight gradient PyTorch's autograd computes inside loss.backward() (code/dmcnet/train.py:258).
+// With 2 input channels the library's implicit-GEMM weight-gradient kernel ran at ~24 TFLOP/s
+// (0.80 ms per step at 120 frames); this is the generator's weight-gradient scheme applied to it:
+//
+//   dW[co][(ci,ky,kx)] = sum_{n,oy,ox} dy[n][oy][ox][co] * x[n][ci][2 oy + ky - 3][2 ox + kx - 3]
+//
+// one fp32 MFMA GEMM (v_mfma_f32_16x16x4_f32) with M = 64 output channels (4 tiles; row r of tile
+// mt is channel 4 r + mt, so ONE ds_read_b128 of the NHWC gradient yields all four A fragments),
+// N = 98 (ci, ky, kx) columns in 7 tiles, K = output pixels, 4 per MFMA.  Workgroup = 7 consumer
+// waves (one output row of a 7 x 16 tile each) + 1 producer wave that stages, with LDS-DMA, the
+// next tile's gradient rows (7 x 16 px x 64 ch, 1 KB per instruction) and input patch (2 planes x
+// 19 rows x 40 columns).  Accumulators live in registers for the whole launch and are reduced in
+// a fixed order (waves, then workgroups): deterministic, unlike the library's atomic split-K.
+#include "dmc_common.h"
+
+using namespace dmc;
+
+namespace {
+
+constexpr int S_CO = 64, S_CI = 2, S_K = 7, S_NCOL = S_CI * S_K * S_K;     // 98
+constexpr int S_NT = (S_NCOL + 15) / 16;                                 // 7 column tiles
+constexpr int S_MT = S_CO / 16;                                          // 4 row tiles
+constexpr int S_TH = 7, S_TW = 16;                                       // output tile (rows = consumer waves)
+constexpr int S_XROWS = 2 * S_TH + 5, S_XPITCH = 40;                     // input patch 19 x 40 (cols 2 ox0 - 4 ..)
+constexpr int S_XPLANE = S_XROWS * S_XPITCH;                             // 760
+constexpr int S_X = S_CI * S_XPLANE;                                     // 1520 floats
+constexpr int S_G = S_TH * S_TW * S_CO;                                  // 7168 floats of gradient
+constexpr int S_BUF = S_X + S_G;                                         // 8688 floats = 34,752 B; x2 buffers
+constexpr int S_PART = S_MT * S_NT * 256;                                // 7168 floats per workgroup partial
+constexpr int S_MAX_GROUPS = 256, S_RED = 16;
+static_assert(S_PART <= 2 * S_BUF, "cross-wave reduction reuses the tile buffers");
+
+struct StemArgs {
+    const float* x;        // [N, 2, H, W]
+    const float* dy;       // [N, OH, OW, 64]
+    float* partials;
+    int N, H, W, OH, OW, tiles_x, tiles_y;
+};
+
+// producer: stage one tile (output rows oy0.., columns ox0..)
+__device__ __forceinline__ void stem_stage(const StemArgs& a, float* buf, int tile, int per_frame, int lane) {
+    const int n = tile / per_frame, r0 = tile - n * per_frame;
+    const int oy0 = (r0 / a.tiles_x) * S_TH, ox0 = (r0 % a.tiles_x) * S_TW;
+    const unsigned buf_byte = lds_addr_of(buf);
+    // ---- gradient rows: 16 px x 64 ch = 4 KB contiguous per output row ----
+    const bool g_interior = oy0 + S_TH <= a.OH && ox0 + S_TW <= a.OW;
+#pragma unroll
+    for (int row = 0; row < S_TH; ++row) {
+        const unsigned long long rbase =
+            (unsigned long long)(a.dy + (((size_t)n * a.OH + (oy0 + row)) * a.OW + ox0) * S_CO);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned dst = buf_byte + (unsigned)(S_X + (row * S_TW + q * 4) * S_CO) * 4;
+            if (g_interior) {
+                lds_dma16(rbase + q * 1024, (unsigned)lane * 16, dst);
+            } else {
+                const bool ok = oy0 + row < a.OH && ox0 + q * 4 + (lane >> 4) < a.OW;
+                if (ok) lds_dma16(rbase + q * 1024, (unsigned)lane * 16, dst);
+                else reinterpret_cast<float4*>(buf + S_X + (row * S_TW + q * 4) * S_CO)[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    // ---- input patch: rows 2 oy0 - 3 .. 2 oy0 + 15, columns 2 ox0 - 4 .. 2 ox0 + 35 ----
+    const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 4;
+    const bool x_interior = iy0 >= 0 && iy0 + S_XROWS <= a.H && ix0 >= 0 && ix0 + S_XPITCH <= a.W;
+    const size_t HW = (size_t)a.H * a.W;
+#pragma unroll
+    for (int ci = 0; ci < S_CI; ++ci) {
+        const long org = ((long)iy0 * a.W + ix0) * 4;
+        const unsigned long long pbase = (unsigned long long)(a.x + ((size_t)n * S_CI + ci) * HW) + (unsigned long long)org;
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+            const int L = 64 * h + lane;                              // chunk index: (row, 16-byte chunk)
+            const int row = L / 10, ch = L - row * 10;
+            const unsigned voff = (unsigned)(row * a.W + ch * 4) * 4;
+            const unsigned dst = buf_byte + (unsigned)(ci * S_XPLANE + 256 * h) * 4;
+            if (L < S_XROWS * 10) {
+                const int iy = iy0 + row, ix = ix0 + ch * 4;
+                const bool ok = x_interior || (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W);
+                if (ok) lds_dma16(pbase, voff, dst);
+                else reinterpret_cast<float4*>(buf + ci * S_XPLANE)[L] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void stem_wgrad_kernel(StemArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds2[2 * S_BUF];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int j = lane & 15, kq = lane >> 4;
+    const int per_frame = a.tiles_x * a.tiles_y;
+    const int ntiles = a.N * per_frame;
+
+    mfma_f32x4 acc[S_MT][S_NT];
+#pragma unroll
+    for (int m = 0; m < S_MT; ++m)
+#pragma unroll
+        for (int t = 0; t < S_NT; ++t) acc[m][t] = (mfma_f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (wave == S_TH) {
+        // ------------------------------ producer wave ------------------------------
+        int it = 0;
+        if ((int)blockIdx.x < ntiles) stem_stage(a, lds2, blockIdx.x, per_frame, lane);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+            const int next = tile + (int)gridDim.x;
+            if (next < ntiles) stem_stage(a, lds2 + ((it + 1) & 1) * S_BUF, next, per_frame, lane);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    } else {
+        // ------------------------------ consumer waves ------------------------------
+        // B fragment of column tile t: x[ci][2 oy + ky - 3][2 ox + kx - 3] for (ci, ky, kx) = column 16 t + j
+        int offB[S_NT];
+#pragma unroll
+        for (int t = 0; t < S_NT; ++t) {
+            int nn = 16 * t + j;
+            nn = nn < S_NCOL ? nn : S_NCOL - 1;
+            const int ci = nn / 49, rem = nn - ci * 49, ky = rem / 7, kx = rem - ky * 7;
+            offB[t] = ci * S_XPLANE + (2 * wave + ky) * S_XPITCH + kx + 1 + 2 * kq;
+        }
+        // A fragments: the four channels 4 j .. 4 j + 3 of pixel kq of the group, one 16-byte read
+        const int offA = S_X + (wave * S_TW + kq) * S_CO + 4 * j;
+        int it = 0;
+        asm volatile("s_barrier" ::: "memory");
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+            const float* lds = lds2 + (it & 1) * S_BUF;
+#pragma unroll
+            for (int g = 0; g < S_TW / 4; ++g) {
+                const float4 av = *reinterpret_cast<const float4*>(lds + offA + g * 4 * S_CO);
+                const float am[S_MT] = {av.x, av.y, av.z, av.w};
+                float b[S_NT];
+#pragma unroll
+                for (int t = 0; t < S_NT; ++t) b[t] = lds[offB[t] + g * 8];
+#pragma unroll
+                for (int m = 0; m < S_MT; ++m)
+#pragma unroll
+                    for (int t = 0; t < S_NT; ++t)
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[m], b[t], acc[m][t], 0, 0, 0);
+            }
+            asm volatile("s_barrier" ::: "memory");        // next tile staged, this buffer may be refilled
+        }
+    }
+    // cross-wave reduction in LDS, fixed order (wave 0 stores, waves 1..6 add in turn)
+    float* lds = lds2;
+    for (int w = 0; w < S_TH; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int m = 0; m < S_MT; ++m)
+#pragma unroll
+                for (int t = 0; t < S_NT; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int idx = (m * S_NT + t) * 256 + (kq * 4 + q) * 16 + j;   // C row = kq*4+q, col = j
+                        lds[idx] = (w == 0 ? 0.f : lds[idx]) + acc[m][t][q];
+                    }
+        }
+        __syncthreads();
+    }
+    float* part = a.partials + (size_t)blockIdx.x * S_PART;
+    for (int i = threadIdx.x; i < S_PART; i += 512) part[i] = lds[i];
+}
+
+// partials [groups][S_PART] -> [S_RED][S_PART] (fixed order), written behind the raw partials
+__global__ __launch_bounds__(256) void stem_reduce1_kernel(float* __restrict__ partials, int groups) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int per = (groups + S_RED - 1) / S_RED;
+    const int g0 = blockIdx.y * per, g1 = (g0 + per < groups) ? g0 + per : groups;
+    float s = 0.f;
+    for (int g = g0; g < g1; ++g) s += partials[(size_t)g * S_PART + i];
+    partials[(size_t)(groups + blockIdx.y) * S_PART + i] = s;
+}
+
+// [S_RED][4 x 7 tiles][16][16] -> dW [64][2][7][7]
+__global__ void stem_reduce2_kernel(const float* __restrict__ partials, int groups, float* __restrict__ dw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S_CO * S_NCOL) return;
+    const int co = i / S_NCOL, nn = i - co * S_NCOL;
+    const int m = co & 3, row = co >> 2, t = nn >> 4, col = nn & 15;
+    const size_t off = (size_t)(m * S_NT + t) * 256 + row * 16 + col;
+    float s = 0.f;
+    for (int c = 0; c < S_RED; ++c) s += partials[(size_t)(groups + c) * S_PART + off];
+    dw[i] = s;
+}
+
+int stem_groups(int N, int H, int W) {
+    const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+    const long tiles = (long)N * ((OH + S_TH - 1) / S_TH) * ((OW + S_TW - 1) / S_TW);
+    return (int)(tiles < S_MAX_GROUPS ? tiles : S_MAX_GROUPS);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dmc_stem_wgrad_supported(int H, int W) { return H > 0 && W > 0 && W % 4 == 0 && ((long)H * W) % 4 == 0; }
+
+size_t dmc_stem_wgrad_partials_bytes(int N, int H, int W) {
+    return (size_t)(stem_groups(N, H, W) + S_RED) * S_PART * sizeof(float);
+}
+
+int dmc_stem_wgrad(const float* x, const float* dy, float* dw, float* partials, int N, int H, int W,
+                   dmc_stream_t stream) {
+    if (!x || !dy || !dw || !partials) return fail(DMC_E_INVALID, "dmc_stem_wgrad: null pointer");
+    if (N <= 0 || !dmc_stem_wgrad_supported(H, W))
+        return fail(DMC_E_INVALID, "dmc_stem_wgrad: unsupported shape N=%d H=%d W=%d (W %% 4 == 0 required)", N, H, W);
+    hipStream_t s = (hipStream_t)stream;
+    StemArgs a;
+    a.x = x; a.dy = dy; a.partials = partials;
+    a.N = N; a.H = H; a.W = W; a.OH = (H + 1) / 2; a.OW = (W + 1) / 2;
+    a.tiles_x = (a.OW + S_TW - 1) / S_TW;
+    a.tiles_y = (a.OH + S_TH - 1) / S_TH;
+    const int groups = stem_groups(N, H, W);
+    stem_wgrad_kernel<<<groups, 512, 0, s>>>(a);
+    int rc = check_launch("stem_wgrad");
+    if (rc) return rc;
+    stem_reduce1_kernel<<<dim3(S_PART / 256, S_RED), 256, 0, s>>>(partials, groups);
+    if ((rc = check_launch("stem_reduce1"))) return rc;
+    stem_reduce2_kernel<<<(S_CO * S_NCOL + 255) / 256, 256, 0, s>>>(partials, groups, dw);
+    return check_launch("stem_reduce2");
+}
+
+}  // extern "C"

@@ -321,6 +321,48 @@ def bn_act(x, bn, residual=None, relu=True):
                         training, bn.eps, bn.momentum if bn.momentum is not None else 0.1)
 
 
+class _StemConv(torch.autograd.Function):
+    """conv1 of the classifier for the 2-channel flow input (code/dmcnet/model.py:285-294): the
+    forward convolution is MIOpen's, the weight gradient is dmc_stem_wgrad (MIOpen's implicit-GEMM
+    weight gradient degenerates with 2 input channels: 0.80 ms of a 19.4 ms step).  Only used when
+    the input needs no gradient (the dmcnet variant feeds ``gen_flow.detach()``)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        y = torch.nn.functional.conv2d(x, weight, None, 2, 3)
+        ctx.save_for_backward(x.detach().contiguous(), weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, weight = ctx.saved_tensors
+        n, _, h, w = x.shape
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dw = torch.empty((64, 2, 7, 7), dtype=torch.float32, device=x.device)
+        partials = _floats(lib.dmc_stem_wgrad_partials_bytes(n, h, w), x.device)
+        with _span("stem_wgrad"):
+            _lib.check(lib.dmc_stem_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(partials),
+                                          n, h, w, _stream()), "dmc_stem_wgrad")
+        if weight.is_contiguous(memory_format=torch.channels_last) and not weight.is_contiguous():
+            dw = dw.contiguous(memory_format=torch.channels_last)
+        return None, dw
+
+
+def stem_conv_supported(x, weight):
+    """True when ``conv2d(x, weight, stride 2, padding 3)`` can take the HIP weight gradient."""
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and not x.requires_grad
+            and tuple(weight.shape) == (64, 2, 7, 7) and weight.dtype == torch.float32
+            and x.shape[1] == 2
+            and bool(_lib.load().dmc_stem_wgrad_supported(int(x.shape[2]), int(x.shape[3]))))
+
+
+def stem_conv(x, weight):
+    """conv1(x) for ``x`` [N,2,H,W] (no gradient needed) and ``weight`` [64,2,7,7]."""
+    _need_cuda(x, weight)
+    return _StemConv.apply(x, weight)
+
+
 _STD = (0.229, 0.224, 0.225)
 
 

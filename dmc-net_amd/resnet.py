@@ -85,8 +85,17 @@ class ResNet(nn.Module):
         self.avgpool = nn.AvgPool2d(7, stride=1)
         self.fc = nn.Linear(width, num_classes)
 
+    def _stem(self, x):
+        # 2-channel flow input without a gradient (dmcnet variant): HIP weight gradient for conv1
+        c = self.conv1
+        if (c.in_channels == 2 and c.bias is None and c.stride == (2, 2) and c.padding == (3, 3)
+                and c.dilation == (1, 1) and c.groups == 1 and torch.is_grad_enabled()
+                and c.weight.requires_grad and ops.stem_conv_supported(x, c.weight)):
+            return ops.stem_conv(x, c.weight)
+        return c(x)
+
     def forward(self, x):
-        x = self.maxpool(_bn_act(self.bn1, self.conv1(x)))
+        x = self.maxpool(_bn_act(self.bn1, self._stem(x)))
         for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
             x = stage(x)
         return self.fc(torch.flatten(self.avgpool(x), 1))

@@ -175,6 +175,21 @@ int dmc_prepare_inputs(const unsigned char* frames_u8, const unsigned char* flip
                        float* out_mv, float* out_res, float* workspace, int N, int H, int W,
                        int flow_ds_factor, const float* std4_host, dmc_stream_t stream);
 
+/* ---- classifier stem: weight gradient of conv1 (2 -> 64 channels, 7x7, stride 2, pad 3) ----------
+ * Replaces what autograd computes for the conv1 the reference installs for the 2-channel flow
+ * input, code/dmcnet/model.py:285-294 (nn.Conv2d(2, 64, 7, stride=2, padding=3, bias=False)),
+ * inside loss.backward(), code/dmcnet/train.py:258.  (The forward convolution and, when the input
+ * needs a gradient, the data gradient stay on MIOpen.)
+ * x [N,2,H,W] fp32 NCHW; dy [N,OH,OW,64] fp32 NHWC (channels_last storage of the [N,64,OH,OW]
+ * gradient), OH = (H+1)/2, OW = (W+1)/2; dw [64,2,7,7] fp32 contiguous.  Requires W % 4 == 0
+ * (dmc_stem_wgrad_supported).  partials: dmc_stem_wgrad_partials_bytes(N,H,W) bytes.
+ * Deterministic (fixed summation order).
+ */
+int dmc_stem_wgrad_supported(int H, int W);
+size_t dmc_stem_wgrad_partials_bytes(int N, int H, int W);
+int dmc_stem_wgrad(const float* x, const float* dy, float* dw, float* partials, int N, int H, int W,
+                   dmc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -344,6 +344,37 @@ def test_reducer_single_rank_nccl_is_transparent():
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("n,h,w", [(3, 224, 224), (2, 40, 36), (2, 37, 44), (1, 8, 8), (5, 112, 64)])
+def test_stem_wgrad_unit(n, h, w):
+    """conv1 (2->64, 7x7, stride 2, pad 3) weight gradient through dmc_stem_wgrad against torch's CPU
+    autograd (fp64 accumulate, the oracle's arithmetic); the forward is the same convolution."""
+    x, wt = rnd(71, (n, 2, h, w)), rnd(72, (64, 2, 7, 7)) * 0.1
+    oh, ow = (h + 1) // 2, (w + 1) // 2
+    go = rnd(73, (n, 64, oh, ow))
+    wo = wt.double().requires_grad_(True)
+    yo = F.conv2d(x.double(), wo, None, 2, 3)
+    (yo * go.double()).sum().backward()
+    for cl in (False, True):
+        wg = wt.to(DEV)
+        if cl:
+            wg = wg.contiguous(memory_format=torch.channels_last)
+        wg.requires_grad_(True)
+        xg = x.to(DEV)
+        assert ops.stem_conv_supported(xg, wg)
+        y = ops.stem_conv(xg, wg)
+        (y * go.to(DEV)).sum().backward()
+        assert rel_err(y, yo.float()) < 1e-5
+        assert wg.grad.shape == wg.shape
+        assert rel_err(wg.grad, wo.grad.float()) < 2e-5
+        # deterministic: a second evaluation is bit-identical
+        g1 = wg.grad.clone()
+        wg.grad = None
+        (ops.stem_conv(xg, wg) * go.to(DEV)).sum().backward()
+        assert torch.equal(g1, wg.grad)
+    assert not ops.stem_conv_supported(x.to(DEV).requires_grad_(True), wg)       # input gradient: stock path
+    assert not ops.stem_conv_supported(rnd(74, (1, 2, 10, 10)).to(DEV), wg)                 # W % 4 != 0
+
+
 @pytest.mark.parametrize("shape,res,relu", [((4, 64, 56, 56), False, True), ((4, 64, 56, 56), True, True),
                                              ((3, 128, 7, 9), True, True), ((2, 512, 7, 7), False, False),
                                              ((6, 256, 14, 14), True, False)])
