@@ -310,11 +310,35 @@ def bn_act_supported(x):
     return bool(_lib.load().dmc_bn_act_supported(n * h * w, c))
 
 
+_PENDING_COUNTERS = None
+
+
+class batched_bn_counters:
+    """Context manager: inside it ``bn_act`` defers ``num_batches_tracked += 1`` and one
+    multi-tensor add bumps every counter on exit (20 launches per ResNet-18 forward otherwise)."""
+
+    def __enter__(self):
+        global _PENDING_COUNTERS
+        self._outer = _PENDING_COUNTERS
+        _PENDING_COUNTERS = []
+        return self
+
+    def __exit__(self, *exc):
+        global _PENDING_COUNTERS
+        pending, _PENDING_COUNTERS = _PENDING_COUNTERS, self._outer
+        if pending and exc[0] is None:
+            torch._foreach_add_(pending, 1)
+        return False
+
+
 def bn_act(x, bn, residual=None, relu=True):
     """relu?(bn(x) [+ residual]) for a channels_last ``x`` and an ``nn.BatchNorm2d`` ``bn``."""
     training = bn.training
     if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        if _PENDING_COUNTERS is not None:
+            _PENDING_COUNTERS.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked.add_(1)
     if residual is not None:
         residual = residual.contiguous(memory_format=torch.channels_last)
     return _BnAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, relu,

@@ -95,10 +95,11 @@ class ResNet(nn.Module):
         return c(x)
 
     def forward(self, x):
-        x = self.maxpool(_bn_act(self.bn1, self._stem(x)))
-        for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
-            x = stage(x)
-        return self.fc(torch.flatten(self.avgpool(x), 1))
+        with ops.batched_bn_counters():
+            x = self.maxpool(_bn_act(self.bn1, self._stem(x)))
+            for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
+                x = stage(x)
+            return self.fc(torch.flatten(self.avgpool(x), 1))
 
 
 def build(name, pretrained=False):
