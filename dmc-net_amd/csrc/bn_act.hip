@@ -203,6 +203,189 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(BnArgs a, const float
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Stem: BatchNorm + ReLU + MaxPool2d(3, stride 2, padding 1) in one pass each way.
+//
+// Replaces bn1 -> relu -> maxpool of the ResNet the reference builds (code/dmcnet/model.py:305;
+// torchvision's `self.maxpool(self.relu(self.bn1(x)))`).  The normalised, rectified 112x112x64
+// tensor (385 MB at 120 frames) is never written: the forward emits the pooled map only; the
+// backward recomputes relu(bn(x)) per 3x3 window to find each window's arg-max -- PyTorch's rule:
+// scan the window row-major, take a value only if it is strictly greater, so ties go to the first
+// element -- routes the pooled gradient to it, and feeds the BatchNorm backward sums / dx
+// directly.  Tiles of 8x8 windows: step A computes one arg-max code per (window, channel) into
+// LDS (9x9 windows: the halo row/column of windows that own pixels of this tile), step B gathers
+// per input pixel from the <= 4 windows that contain it, in fixed (py, px) order.
+// ------------------------------------------------------------------------------------------
+struct PoolArgs {
+    const float* x;        // [N,H,W,C]
+    const float* gamma;
+    const float* beta;
+    const float* stats;    // mean[C], invstd[C]
+    const float* dpool;    // [N,PH,PW,C]
+    float* ypool;          // [N,PH,PW,C]
+    float* dx;             // [N,H,W,C]
+    int N, H, W, C, PH, PW;
+};
+
+__device__ __forceinline__ float4 bn_relu4(const float4 x, const float4 mean, const float4 istd,
+                                           const float4 g, const float4 b) {
+    return make_float4(fmaxf(fmaf((x.x - mean.x) * istd.x, g.x, b.x), 0.f), fmaxf(fmaf((x.y - mean.y) * istd.y, g.y, b.y), 0.f),
+                       fmaxf(fmaf((x.z - mean.z) * istd.z, g.z, b.z), 0.f), fmaxf(fmaf((x.w - mean.w) * istd.w, g.w, b.w), 0.f));
+}
+
+__global__ __launch_bounds__(256) void pool_fwd_kernel(PoolArgs a) {
+    const int cq = a.C >> 2;
+    const size_t total = (size_t)a.N * a.PH * a.PW * cq;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+        const int tx = (int)(o & (size_t)(cq - 1));
+        size_t r = o / cq;
+        const int px = (int)(r % a.PW); r /= a.PW;
+        const int py = (int)(r % a.PH);
+        const int n = (int)(r / a.PH);
+        const float4 mean = reinterpret_cast<const float4*>(a.stats)[tx];
+        const float4 istd = reinterpret_cast<const float4*>(a.stats + a.C)[tx];
+        const float4 g = reinterpret_cast<const float4*>(a.gamma)[tx];
+        const float4 b = reinterpret_cast<const float4*>(a.beta)[tx];
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);           // relu(.) >= 0 and the window centre is always inside
+        // clamped coordinates: a clamped position repeats a value of the same window, which cannot
+        // change the maximum -- nine independent loads, no branches
+        float4 xv[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            int iy = 2 * py + k / 3 - 1, ix = 2 * px + k % 3 - 1;
+            iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
+            ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
+            xv[k] = reinterpret_cast<const float4*>(a.x)[((size_t)(n * a.H + iy) * a.W + ix) * cq + tx];
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const float4 v = bn_relu4(xv[k], mean, istd, g, b);
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+        reinterpret_cast<float4*>(a.ypool)[o] = m;
+    }
+}
+
+constexpr int PT = 8;                          // pooled windows per tile side
+// PASS 1: per-channel (sum dz, sum dz * xhat) into scratch[block];  PASS 2: dx
+template <int PASS>
+__global__ __launch_bounds__(256) void pool_bwd_kernel(PoolArgs a, double* __restrict__ scratch,
+                                                       const float* __restrict__ dgamma,
+                                                       const float* __restrict__ dbeta, float inv_count) {
+    __shared__ unsigned codes[(PT + 1) * (PT + 1) * 64];       // arg-max position (0..8) per channel, 4 per word
+    __shared__ double sm[PASS == 1 ? 2 : 1][PASS == 1 ? 256 : 1][4];
+    const int cq = a.C >> 2;
+    const int tx = threadIdx.x % cq, ty = threadIdx.x / cq, rows = 256 / cq;
+    const float4 mean = reinterpret_cast<const float4*>(a.stats)[tx];
+    const float4 istd = reinterpret_cast<const float4*>(a.stats + a.C)[tx];
+    const float4 g = reinterpret_cast<const float4*>(a.gamma)[tx];
+    const float4 b = reinterpret_cast<const float4*>(a.beta)[tx];
+    float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
+    if (PASS == 2) {
+        dg = reinterpret_cast<const float4*>(dgamma)[tx];
+        db = reinterpret_cast<const float4*>(dbeta)[tx];
+    }
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    const int tiles_x = (a.PW + PT - 1) / PT, tiles_y = (a.PH + PT - 1) / PT;
+    const int ntiles = a.N * tiles_y * tiles_x;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n = tile / (tiles_y * tiles_x), tr = tile - n * tiles_y * tiles_x;
+        const int wy0 = (tr / tiles_x) * PT, wx0 = (tr % tiles_x) * PT;
+        __syncthreads();                                        // previous tile's codes are no longer read
+        // ---- step A: arg-max code of windows (wy0 .. wy0+PT, wx0 .. wx0+PT) ----
+        for (int wi = ty; wi < (PT + 1) * (PT + 1); wi += rows) {
+            const int py = wy0 + wi / (PT + 1), px = wx0 + wi % (PT + 1);
+            unsigned code = 0xffffffffu;
+            if (py < a.PH && px < a.PW) {
+                float4 mv = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                unsigned cx = 0, cy = 0, cz = 0, cw = 0;
+                float4 xv[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {                    // nine independent loads (clamped address)
+                    int iy = 2 * py + k / 3 - 1, ix = 2 * px + k % 3 - 1;
+                    iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
+                    ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
+                    xv[k] = reinterpret_cast<const float4*>(a.x)[((size_t)(n * a.H + iy) * a.W + ix) * cq + tx];
+                }
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const int iy = 2 * py + k / 3 - 1, ix = 2 * px + k % 3 - 1;
+                    const bool in = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                    const float4 v = bn_relu4(xv[k], mean, istd, g, b);
+                    if (in && v.x > mv.x) { mv.x = v.x; cx = k; }
+                    if (in && v.y > mv.y) { mv.y = v.y; cy = k; }
+                    if (in && v.z > mv.z) { mv.z = v.z; cz = k; }
+                    if (in && v.w > mv.w) { mv.w = v.w; cw = k; }
+                }
+                code = cx | (cy << 8) | (cz << 16) | (cw << 24);
+            }
+            codes[wi * cq + tx] = code;
+        }
+        __syncthreads();
+        // ---- step B: input pixels (2 wy0 .. 2 wy0 + 15, 2 wx0 .. 2 wx0 + 15) ----
+        for (int pi = ty; pi < 4 * PT * PT; pi += rows) {
+            const int iy = 2 * wy0 + pi / (2 * PT), ix = 2 * wx0 + pi % (2 * PT);
+            if (iy >= a.H || ix >= a.W) continue;
+            const size_t o = ((size_t)(n * a.H + iy) * a.W + ix) * cq + tx;
+            const float4 x = reinterpret_cast<const float4*>(a.x)[o];
+            const float4 xh = make_float4((x.x - mean.x) * istd.x, (x.y - mean.y) * istd.y,
+                                          (x.z - mean.z) * istd.z, (x.w - mean.w) * istd.w);
+            const float4 v = make_float4(fmaf(xh.x, g.x, b.x), fmaf(xh.y, g.y, b.y), fmaf(xh.z, g.z, b.z), fmaf(xh.w, g.w, b.w));
+            float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+            // windows that contain the pixel: py = iy/2 (and iy/2 + 1 when iy is odd), same in x
+            const int py0 = iy >> 1, px0 = ix >> 1, npy = 1 + (iy & 1), npx = 1 + (ix & 1);
+            float4 gp[4];
+            unsigned cd[4];
+            bool okc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                        // four independent loads (clamped), then select
+                const int jy = q >> 1, jx = q & 1;
+                const int py = py0 + jy, px = px0 + jx;
+                okc[q] = jy < npy && jx < npx && py < a.PH && px < a.PW;
+                const int pyc = okc[q] ? py : py0, pxc = okc[q] ? px : px0;
+                cd[q] = codes[((pyc - wy0) * (PT + 1) + (pxc - wx0)) * cq + tx];
+                gp[q] = reinterpret_cast<const float4*>(a.dpool)[((size_t)(n * a.PH + pyc) * a.PW + pxc) * cq + tx];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int py = py0 + (q >> 1), px = px0 + (q & 1);
+                const unsigned k = (unsigned)((iy - 2 * py + 1) * 3 + (ix - 2 * px + 1));
+                if (okc[q] && (cd[q] & 0xff) == k) d.x += gp[q].x;
+                if (okc[q] && ((cd[q] >> 8) & 0xff) == k) d.y += gp[q].y;
+                if (okc[q] && ((cd[q] >> 16) & 0xff) == k) d.z += gp[q].z;
+                if (okc[q] && (cd[q] >> 24) == k) d.w += gp[q].w;
+            }
+            d.x = v.x > 0.f ? d.x : 0.f; d.y = v.y > 0.f ? d.y : 0.f;
+            d.z = v.z > 0.f ? d.z : 0.f; d.w = v.w > 0.f ? d.w : 0.f;
+            if (PASS == 1) {
+                s0.x += d.x; s0.y += d.y; s0.z += d.z; s0.w += d.w;
+                s1.x = fmaf(d.x, xh.x, s1.x); s1.y = fmaf(d.y, xh.y, s1.y);
+                s1.z = fmaf(d.z, xh.z, s1.z); s1.w = fmaf(d.w, xh.w, s1.w);
+            } else {
+                float4 r;
+                r.x = g.x * istd.x * (d.x - db.x * inv_count - xh.x * dg.x * inv_count);
+                r.y = g.y * istd.y * (d.y - db.y * inv_count - xh.y * dg.y * inv_count);
+                r.z = g.z * istd.z * (d.z - db.z * inv_count - xh.z * dg.z * inv_count);
+                r.w = g.w * istd.w * (d.w - db.w * inv_count - xh.w * dg.w * inv_count);
+                reinterpret_cast<float4*>(a.dx)[o] = r;
+            }
+        }
+    }
+    if (PASS == 1) {
+        sm[0][threadIdx.x][0] = s0.x; sm[0][threadIdx.x][1] = s0.y;
+        sm[0][threadIdx.x][2] = s0.z; sm[0][threadIdx.x][3] = s0.w;
+        sm[1][threadIdx.x][0] = s1.x; sm[1][threadIdx.x][1] = s1.y;
+        sm[1][threadIdx.x][2] = s1.z; sm[1][threadIdx.x][3] = s1.w;
+        __syncthreads();
+        for (int i = threadIdx.x; i < cq * 8; i += 256) {
+            const int col = i >> 3, which = (i >> 2) & 1, e = i & 3;
+            double acc = 0.0;
+            for (int t = 0; t < rows; ++t) acc += sm[which][t * cq + col][e];
+            scratch[((size_t)blockIdx.x * a.C + col * 4 + e) * 2 + which] = acc;
+        }
+    }
+}
+
 bool shape_ok(int M, int C) {
     const int cq = C / 4;
     return M > 0 && C > 0 && C % 4 == 0 && cq <= 256 && 256 % cq == 0;
@@ -274,6 +457,57 @@ int dmc_bn_act_bwd(const float* x, const float* residual, const float* gamma, co
     if ((rc = check_launch("bn_bwd_final"))) return rc;
     bn_apply_bwd_kernel<<<stream_blocks((size_t)M * (C / 4)), 256, 0, s>>>(a, dgamma, dbeta, 1.f / (float)M);
     return check_launch("bn_apply_bwd");
+}
+
+int dmc_bn_relu_pool_supported(int N, int H, int W, int C) {
+    return N > 0 && H > 0 && W > 0 && shape_ok(1, C) && C / 4 <= 64 ? 1 : 0;
+}
+
+int dmc_bn_relu_pool_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float* y_pool, float* stats, int N, int H, int W, int C,
+                         int training, float eps, float momentum, dmc_stream_t stream) {
+    if (!x || !gamma || !beta || !running_mean || !running_var || !y_pool || !stats)
+        return fail(DMC_E_INVALID, "dmc_bn_relu_pool_fwd: null pointer");
+    if (!dmc_bn_relu_pool_supported(N, H, W, C))
+        return fail(DMC_E_INVALID, "dmc_bn_relu_pool_fwd: unsupported shape N=%d H=%d W=%d C=%d", N, H, W, C);
+    hipStream_t s = (hipStream_t)stream;
+    const int M = N * H * W;
+    BnArgs a = {x, nullptr, gamma, beta, stats, nullptr, nullptr, nullptr, nullptr, M, C, 1};
+    double* scratch = scratch_of(stats, C);
+    int rc;
+    const int split = split_of(M);
+    if (training) {
+        bn_partial_kernel<0><<<split, 256, 0, s>>>(a, scratch);
+        if ((rc = check_launch("bn_partial"))) return rc;
+    }
+    bn_stats_final_kernel<<<(C + 7) / 8, 256, 0, s>>>(scratch, stats, running_mean, running_var, C,
+                                                       (long)M, training, eps, momentum, split);
+    if ((rc = check_launch("bn_stats_final"))) return rc;
+    PoolArgs p = {x, gamma, beta, stats, nullptr, y_pool, nullptr, N, H, W, C, (H - 1) / 2 + 1, (W - 1) / 2 + 1};
+    pool_fwd_kernel<<<stream_blocks((size_t)N * p.PH * p.PW * (C / 4)), 256, 0, s>>>(p);
+    return check_launch("pool_fwd");
+}
+
+int dmc_bn_relu_pool_bwd(const float* x, const float* gamma, const float* beta, float* stats,
+                         const float* d_pool, float* dx, float* dgamma, float* dbeta, int N, int H,
+                         int W, int C, dmc_stream_t stream) {
+    if (!x || !gamma || !beta || !stats || !d_pool || !dx || !dgamma || !dbeta)
+        return fail(DMC_E_INVALID, "dmc_bn_relu_pool_bwd: null pointer");
+    if (!dmc_bn_relu_pool_supported(N, H, W, C))
+        return fail(DMC_E_INVALID, "dmc_bn_relu_pool_bwd: unsupported shape N=%d H=%d W=%d C=%d", N, H, W, C);
+    hipStream_t s = (hipStream_t)stream;
+    PoolArgs p = {x, gamma, beta, stats, d_pool, nullptr, dx, N, H, W, C, (H - 1) / 2 + 1, (W - 1) / 2 + 1};
+    double* scratch = scratch_of(stats, C);
+    const long tiles = (long)N * ((p.PH + PT - 1) / PT) * ((p.PW + PT - 1) / PT);
+    const int blocks = (int)(tiles < MAX_SPLIT ? tiles : MAX_SPLIT);
+    int rc;
+    pool_bwd_kernel<1><<<blocks, 256, 0, s>>>(p, scratch, nullptr, nullptr, 0.f);
+    if ((rc = check_launch("pool_bwd_partial"))) return rc;
+    bn_bwd_final_kernel<<<(C + 7) / 8, 256, 0, s>>>(scratch, dgamma, dbeta, C, blocks);
+    if ((rc = check_launch("bn_bwd_final"))) return rc;
+    pool_bwd_kernel<2><<<blocks * 4 > 8192 ? 8192 : blocks * 4, 256, 0, s>>>(p, nullptr, dgamma, dbeta,
+                                                                             1.f / (float)((long)N * H * W));
+    return check_launch("pool_bwd_apply");
 }
 
 }  // extern "C"

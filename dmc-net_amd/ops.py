@@ -345,6 +345,69 @@ def bn_act(x, bn, residual=None, relu=True):
                         training, bn.eps, bn.momentum if bn.momentum is not None else 0.1)
 
 
+class _BnReluPool(torch.autograd.Function):
+    """maxpool3x3s2p1(relu(bn(x))) of the ResNet stem (torchvision's bn1 / relu / maxpool behind
+    code/dmcnet/model.py:305,352) on a channels_last ``x``; the rectified tensor is never stored."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, eps, momentum):
+        lib = _lib.load()
+        _need_cuda(x, gamma, beta)
+        n, c, h, w = x.shape
+        ph, pw = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = torch.empty((n, c, ph, pw), dtype=x.dtype, device=x.device,
+                        memory_format=torch.channels_last)
+        stats = _floats(lib.dmc_bn_act_stats_bytes(c), x.device)
+        with _span("bn_relu_pool_fwd"):
+            _lib.check(lib.dmc_bn_relu_pool_fwd(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta),
+                                                _lib.ptr(running_mean), _lib.ptr(running_var),
+                                                _lib.ptr(y), _lib.ptr(stats), n, h, w, c, int(training),
+                                                float(eps), float(momentum), _stream()),
+                       "dmc_bn_relu_pool_fwd")
+        ctx.save_for_backward(x, gamma, beta, stats)
+        ctx.training = bool(training)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, gamma, beta, stats = ctx.saved_tensors
+        if not ctx.training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not implemented")
+        n, c, h, w = x.shape
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(x)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        with _span("bn_relu_pool_bwd"):
+            _lib.check(lib.dmc_bn_relu_pool_bwd(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta),
+                                                _lib.ptr(stats), _lib.ptr(dy), _lib.ptr(dx),
+                                                _lib.ptr(dgamma), _lib.ptr(dbeta), n, h, w, c,
+                                                _stream()), "dmc_bn_relu_pool_bwd")
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def bn_relu_pool_supported(x):
+    """True if the fused stem kernel handles this activation (channels_last fp32 on the GPU)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+        return False
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        return False
+    n, c, h, w = x.shape
+    return bool(_lib.load().dmc_bn_relu_pool_supported(n, h, w, c))
+
+
+def bn_relu_pool(x, bn):
+    """maxpool(3, 2, 1)(relu(bn(x))) for a channels_last ``x`` and an ``nn.BatchNorm2d`` ``bn``."""
+    training = bn.training
+    if training and bn.num_batches_tracked is not None:
+        if _PENDING_COUNTERS is not None:
+            _PENDING_COUNTERS.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked.add_(1)
+    return _BnReluPool.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps,
+                             bn.momentum if bn.momentum is not None else 0.1)
+
+
 class _StemConv(torch.autograd.Function):
     """conv1 of the classifier for the 2-channel flow input (code/dmcnet/model.py:285-294): the
     forward convolution is MIOpen's, the weight gradient is dmc_stem_wgrad (MIOpen's implicit-GEMM

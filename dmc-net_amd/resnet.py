@@ -94,9 +94,18 @@ class ResNet(nn.Module):
             return ops.stem_conv(x, c.weight)
         return c(x)
 
+    def _stem_tail(self, x):
+        # bn1 -> relu -> maxpool(3, 2, 1): one fused HIP pass each way when the activation qualifies
+        bn, mp = self.bn1, self.maxpool
+        if (x.is_cuda and bn.track_running_stats and (bn.training or not torch.is_grad_enabled())
+                and mp.kernel_size == 3 and mp.stride == 2 and mp.padding == 1 and mp.dilation == 1
+                and not mp.ceil_mode and not mp.return_indices and ops.bn_relu_pool_supported(x)):
+            return ops.bn_relu_pool(x, bn)
+        return mp(_bn_act(bn, x))
+
     def forward(self, x):
         with ops.batched_bn_counters():
-            x = self.maxpool(_bn_act(self.bn1, self._stem(x)))
+            x = self._stem_tail(self._stem(x))
             for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
                 x = stage(x)
             return self.fc(torch.flatten(self.avgpool(x), 1))

@@ -175,6 +175,22 @@ int dmc_prepare_inputs(const unsigned char* frames_u8, const unsigned char* flip
                        float* out_mv, float* out_res, float* workspace, int N, int H, int W,
                        int flow_ds_factor, const float* std4_host, dmc_stream_t stream);
 
+/* ---- classifier stem: BatchNorm + ReLU + MaxPool2d(3, stride 2, padding 1) fused -----------------
+ * Replaces `self.maxpool(self.relu(self.bn1(x)))` of the torchvision ResNet the reference builds at
+ * code/dmcnet/model.py:305 (run at :352) and its autograd.  x [N,H,W,C] fp32 NHWC (conv1 output),
+ * y_pool / d_pool [N,PH,PW,C] with PH = (H-1)/2+1, PW = (W-1)/2+1; the rectified full-resolution
+ * tensor is never materialised.  Arg-max ties follow PyTorch (first element in row-major window
+ * order).  stats: dmc_bn_act_stats_bytes(C) bytes, written by fwd (mean, invstd) and read by bwd.
+ * training = 0 normalises with the running statistics (forward only).
+ */
+int dmc_bn_relu_pool_supported(int N, int H, int W, int C);
+int dmc_bn_relu_pool_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float* y_pool, float* stats, int N, int H, int W, int C,
+                         int training, float eps, float momentum, dmc_stream_t stream);
+int dmc_bn_relu_pool_bwd(const float* x, const float* gamma, const float* beta, float* stats,
+                         const float* d_pool, float* dx, float* dgamma, float* dbeta, int N, int H,
+                         int W, int C, dmc_stream_t stream);
+
 /* ---- classifier stem: weight gradient of conv1 (2 -> 64 channels, 7x7, stride 2, pad 3) ----------
  * Replaces what autograd computes for the conv1 the reference installs for the 2-channel flow
  * input, code/dmcnet/model.py:285-294 (nn.Conv2d(2, 64, 7, stride=2, padding=3, bias=False)),

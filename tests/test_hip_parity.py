@@ -344,6 +344,44 @@ def test_reducer_single_rank_nccl_is_transparent():
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("shape", [(3, 64, 112, 112), (2, 64, 17, 23), (2, 128, 8, 8), (1, 64, 1, 5), (2, 64, 30, 31)])
+def test_bn_relu_pool_unit(shape):
+    """Fused BatchNorm + ReLU + MaxPool(3,2,1) of the stem against the stock modules, forward and
+    backward; inputs contain exact ties (zeros after ReLU, duplicated maxima) to pin the arg-max rule."""
+    n, c, h, w = shape
+    x, go = rnd(81, shape), rnd(82, (n, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1))
+    x = torch.round(x * 4) / 4                       # quantised: many equal values inside windows
+    bn_o = torch.nn.BatchNorm2d(c)
+    O.seeded_state_fill(bn_o, 83)
+    bn_m = torch.nn.BatchNorm2d(c)
+    bn_m.load_state_dict(bn_o.state_dict())
+    bn_m.to(DEV)
+    mp = torch.nn.MaxPool2d(3, 2, 1)
+    xo = x.clone().requires_grad_(True)
+    yo = mp(torch.relu(bn_o(xo)))
+    (yo * go).sum().backward()
+    xg = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert ops.bn_relu_pool_supported(xg)
+    y = ops.bn_relu_pool(xg, bn_m)
+    (y * go.to(DEV)).sum().backward()
+    assert y.shape == yo.shape
+    assert rel_err(y, yo) < 1e-5
+    assert rel_err(xg.grad, xo.grad) < 1e-4
+    assert rel_err(bn_m.weight.grad, bn_o.weight.grad) < 1e-4
+    assert rel_err(bn_m.bias.grad, bn_o.bias.grad) < 1e-4
+    assert rel_err(bn_m.running_mean, bn_o.running_mean) < 1e-5
+    assert rel_err(bn_m.running_var, bn_o.running_var) < 1e-5
+    assert int(bn_m.num_batches_tracked) == 1
+    g1 = xg.grad.clone()
+    xg.grad = None
+    (ops.bn_relu_pool(xg, bn_m) * go.to(DEV)).sum().backward()
+    assert torch.equal(g1, xg.grad)                  # deterministic
+    bn_m.load_state_dict(bn_o.state_dict())          # (the second training pass moved the running stats)
+    bn_o.eval(); bn_m.eval()
+    with torch.no_grad():
+        assert rel_err(ops.bn_relu_pool(xg, bn_m), mp(torch.relu(bn_o(x)))) < 1e-5
+
+
 @pytest.mark.parametrize("n,h,w", [(3, 224, 224), (2, 40, 36), (2, 37, 44), (1, 8, 8), (5, 112, 64)])
 def test_stem_wgrad_unit(n, h, w):
     """conv1 (2->64, 7x7, stride 2, pad 3) weight gradient through dmc_stem_wgrad against torch's CPU
