@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(BnArgs a, double* __res
         const int col = i >> 3, which = (i >> 2) & 1, e = i & 3;
         double acc = 0.0;
         for (int t = 0; t < rows; ++t) acc += sm[which][t * cq + col][e];
-        scratch[((size_t)blockIdx.x * a.C + col * 4 + e) * 2 + which] = acc;
+        scratch[((size_t)(col * 4 + e) * MAX_SPLIT + blockIdx.x) * 2 + which] = acc;   // [channel][split][2]
     }
 }
 
@@ -93,11 +93,16 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(BnArgs a, double* __res
 __device__ __forceinline__ void reduce_partials(const double* __restrict__ scratch, int C, int c,
                                                 int split, int sub, double& s, double& ss) {
     s = 0.0; ss = 0.0;
-    if (c < C)
+    // scratch is [channel][split][2]: the 32 lanes of a channel read consecutive 16-byte pairs
+    if (c < C) {
+        const double2* row = reinterpret_cast<const double2*>(scratch) + (size_t)c * MAX_SPLIT;
+#pragma unroll 4
         for (int sp = sub; sp < split; sp += 32) {
-            s += scratch[((size_t)sp * C + c) * 2 + 0];
-            ss += scratch[((size_t)sp * C + c) * 2 + 1];
+            const double2 v = row[sp];
+            s += v.x;
+            ss += v.y;
         }
+    }
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) {
         s += __shfl_down(s, o, 32);
@@ -381,7 +386,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolArgs a, double* __res
             const int col = i >> 3, which = (i >> 2) & 1, e = i & 3;
             double acc = 0.0;
             for (int t = 0; t < rows; ++t) acc += sm[which][t * cq + col][e];
-            scratch[((size_t)blockIdx.x * a.C + col * 4 + e) * 2 + which] = acc;
+            scratch[((size_t)(col * 4 + e) * MAX_SPLIT + blockIdx.x) * 2 + which] = acc;   // [channel][split][2]
         }
     }
 }
