@@ -66,8 +66,12 @@ class GradBucketReducer(object):
         self._seen.add(p)
         b, off, n = self._slot[p]
         flat = self.buckets[b][0]
-        flat[off:off + n].copy_(p.grad.reshape(-1))
-        p.grad = flat[off:off + n].view_as(p)
+        # the bucket slice takes the PARAMETER's memory order (channels_last weights stay
+        # channels_last), so the gradient keeps the strides fused optimizer kernels expect
+        dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+        view = flat[off:off + n].as_strided(p.size(), p.stride()) if dense else flat[off:off + n].view_as(p)
+        view.copy_(p.grad)
+        p.grad = view
         self._ready[b] += 1
         if self._ready[b] == self._pending[b]:
             self._launch(b)
