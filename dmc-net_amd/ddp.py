@@ -57,23 +57,38 @@ class GradBucketReducer(object):
         self._pending = [len(e) for _, e in self.buckets]
         self._ready = [0] * len(self.buckets)
         self._seen = set()
+        self._moved = set()
         self._works = []
         self._active = True
+
+    def _view(self, p):
+        # the bucket slice takes the PARAMETER's memory order (channels_last weights stay
+        # channels_last), so the gradient keeps the strides fused optimizer kernels expect
+        b, off, n = self._slot[p]
+        flat = self.buckets[b][0]
+        dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+        return flat[off:off + n].as_strided(p.size(), p.stride()) if dense else flat[off:off + n].view_as(p)
+
+    def _gather(self, b):
+        """Move the gradients produced so far into bucket ``b`` with ONE multi-tensor copy (a copy
+        per parameter from its hook cost ~75 tiny launches per step) and re-point ``p.grad``."""
+        todo = [p for p, _, _ in self.buckets[b][1] if p in self._seen and p not in self._moved]
+        if not todo:
+            return
+        views = [self._view(p) for p in todo]
+        torch._foreach_copy_(views, [p.grad for p in todo])
+        for p, v in zip(todo, views):
+            p.grad = v
+            self._moved.add(p)
 
     def _on_grad(self, p):
         if not self._active or p in self._seen:
             return
         self._seen.add(p)
-        b, off, n = self._slot[p]
-        flat = self.buckets[b][0]
-        # the bucket slice takes the PARAMETER's memory order (channels_last weights stay
-        # channels_last), so the gradient keeps the strides fused optimizer kernels expect
-        dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
-        view = flat[off:off + n].as_strided(p.size(), p.stride()) if dense else flat[off:off + n].view_as(p)
-        view.copy_(p.grad)
-        p.grad = view
+        b = self._slot[p][0]
         self._ready[b] += 1
         if self._ready[b] == self._pending[b]:
+            self._gather(b)
             self._launch(b)
 
     def _launch(self, b):
@@ -89,6 +104,7 @@ class GradBucketReducer(object):
         self._active = False
         for b, (flat, entries) in enumerate(self.buckets):
             if self._ready[b] > 0:              # some but not all members produced a gradient
+                self._gather(b)
                 for p, off, n in entries:
                     if p not in self._seen:
                         flat[off:off + n].zero_()
