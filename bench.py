@@ -139,8 +139,10 @@ def main():
     ap.add_argument("--config", default="dmcnet", choices=["dmcnet", "gan", "i3d"])
     ap.add_argument("--clip-length", type=int, default=64, help="frames per clip (i3d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--miopen-find", type=int, default=0,
-                    help="1 = torch.backends.cudnn.benchmark (MIOpen exhaustive find during warm-up)")
+    ap.add_argument("--miopen-find", type=int, default=1,
+                    help="1 (default) = cudnn.benchmark as the reference's train.py:118 sets it: MIOpen "
+                         "picks solvers by search, answered from the find-db shipped in "
+                         "dmc-net_amd/miopen_db; 0 = MIOpen's heuristic picks")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -162,7 +164,9 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import dmcnet_amd
-    from dmcnet_amd import dataset, ddp, ops, train
+    from dmcnet_amd import dataset, ddp, miopen, ops, train
+    if args.miopen_find:
+        miopen.enable_find()          # before the first convolution of the process
     if args.config == "i3d":
         return bench_i3d(args, rank, world, dev)
     S = 3
@@ -171,7 +175,7 @@ def main():
     model = dmcnet_amd.Model(args.num_class, S, "mv", base_model="resnet18", use_databn=0,
                              gen_flow_or_delta=1, arch_estimator="DenseNetTiny",
                              arch_d="Discriminator3" if gan else None).to(dev).train()
-    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)   # (enable_find above also set the db path)
     if os.environ.get("DMC_CHANNELS_LAST") == "0":
         model.base_model.to(memory_format=torch.contiguous_format)
     reducer = ddp.GradBucketReducer(list(model.parameters())) if world > 1 else None

@@ -81,8 +81,13 @@ def validate(loader, model, num_segments, lr_cls, lr_mse, device="cuda:0", log=p
 
 def fit(model, stepper, train_loader, val_loader, epochs, lr, weight_decay, lr_steps, lr_decay=0.1,
         epoch_thre=0, eval_freq=5, lr_cls=1.0, lr_mse=10.0, arch="resnet18", model_prefix="model",
-        representation="mv", device="cuda:0", start_epoch=0, best_prec1=0.0, log=print, save=True):
-    """The epoch loop of ``main()`` (code/dmcnet/train.py:175-201)."""
+        representation="mv", device="cuda:0", start_epoch=0, best_prec1=0.0, log=print, save=True,
+        miopen_find=True):
+    """The epoch loop of ``main()`` (code/dmcnet/train.py:175-201).  ``miopen_find`` mirrors the
+    reference's ``cudnn.benchmark = True`` (:118), answered from the shipped MIOpen find-db."""
+    if miopen_find and str(device).startswith("cuda"):
+        from . import miopen
+        miopen.enable_find()
     gan = isinstance(stepper, train.GanTrainStep)
     history = []
     for epoch in range(start_epoch, epochs):

@@ -1,0 +1,33 @@
+"""MIOpen algorithm search for the classifier / discriminator convolutions.
+
+The reference's drivers set ``cudnn.benchmark = True`` (code/dmcnet/train.py:118,
+code/dmcnet_GAN/train.py:119): on ROCm that makes PyTorch ask MIOpen to *find* the fastest solver
+per convolution shape instead of taking its heuristic pick.  On this path that is worth 6 % of the
+dmcnet step (17.9 -> 16.7 ms) -- but the search costs 40 s for the dmcnet shapes and 12 minutes for
+the GAN discriminator's on a fresh machine.  ``miopen_db/`` therefore ships the search results for
+MI355X (gfx950, 256 CUs) as an MIOpen *user find-db*; with it the first step starts at once.
+MIOpen ignores the files if its version differs (their names carry it) and simply searches again.
+"""
+import os
+import shutil
+import tempfile
+
+import torch
+
+_DB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_db")
+
+
+def enable_find(use_shipped_db=True):
+    """``torch.backends.cudnn.benchmark = True`` plus, unless the user already points MIOpen
+    somewhere, ``MIOPEN_USER_DB_PATH`` = a writable copy of the shipped find-db.  Call before the
+    first convolution of the process (MIOpen reads the variable when its handle is created)."""
+    torch.backends.cudnn.benchmark = True
+    if not use_shipped_db or "MIOPEN_USER_DB_PATH" in os.environ or not os.path.isdir(_DB_DIR):
+        return os.environ.get("MIOPEN_USER_DB_PATH")
+    path = _DB_DIR
+    if not os.access(path, os.W_OK):          # MIOpen appends to its user db: it must be writable
+        path = tempfile.mkdtemp(prefix="dmc_miopen_db_")
+        for name in os.listdir(_DB_DIR):
+            shutil.copy(os.path.join(_DB_DIR, name), path)
+    os.environ["MIOPEN_USER_DB_PATH"] = path
+    return path

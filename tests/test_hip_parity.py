@@ -569,7 +569,7 @@ def test_driver_fit_epochs_and_checkpoint(tmp_path):
     try:
         hist, best = driver.fit(m, step, loader, loader, epochs=3, lr=0.01, weight_decay=1e-4,
                                 lr_steps=[20, 35, 45], epoch_thre=1, eval_freq=1, log=None,
-                                model_prefix="t", device=DEV)
+                                model_prefix="t", device=DEV, miopen_find=False)
     finally:
         os.chdir(cwd)
     assert len(hist) == 3 and all("val" in h for h in hist)

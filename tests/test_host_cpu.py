@@ -220,3 +220,22 @@ def test_score_fusion_matches_reference_combine(golden, tmp_path):
     assert s.shape == (3, 51) and s[0, 0] == 1.0
     with pytest.raises(ValueError):
         evaluate.combine((s, l), (s, l[::-1].copy()), (s, l))
+
+
+def test_miopen_find_db_is_shipped_and_selected(monkeypatch, tmp_path):
+    """enable_find() turns on cudnn.benchmark (the reference's train.py:118) and points MIOpen at
+    the shipped find-db unless the user already chose a path."""
+    import os
+    from dmcnet_amd import miopen
+    names = os.listdir(miopen._DB_DIR)
+    assert any(n.endswith(".ufdb.txt") for n in names) and any(n.endswith(".udb.txt") for n in names)
+    prev = torch.backends.cudnn.benchmark
+    try:
+        monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
+        path = miopen.enable_find()
+        assert torch.backends.cudnn.benchmark is True
+        assert os.environ["MIOPEN_USER_DB_PATH"] == path and os.path.isdir(path)
+        monkeypatch.setenv("MIOPEN_USER_DB_PATH", str(tmp_path))
+        assert miopen.enable_find() == str(tmp_path)           # the user's choice wins
+    finally:
+        torch.backends.cudnn.benchmark = prev
