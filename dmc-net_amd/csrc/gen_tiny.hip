@@ -770,6 +770,264 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_layer_mfma_kernel(RingArgs ra
 }
 
 // ------------------------------------------------------------------------------------------
+// Gather variant of the matrix-core layer kernel for layers with 8 output channels.
+//
+// Same 4x4x1 MFMA, same producer / consumer ring, but ALL nine taps are gathered through K:
+//   rows = output channel (NT = COUT/4 row tiles), K = (cin, dy, dx), B = in[ci][y+dy-1][x+dx-1].
+// For COUT 8 that is exactly the MFMA count of the push form (2 tiles x 9 taps = 6 tiles x 3), but
+//   * 32 accumulator registers instead of 96  -> 16 waves per workgroup fit (14 consumers + 2
+//     producers), so a tile is 16 rows: 18 staged rows per 16 instead of 10 per 8 (-10 % traffic),
+//     and chunks are 2 channels, so 13 / 21 / 22 input channels pad to 14 / 22 / 22, not 16 / 24 / 24;
+//   * no push epilogue: no DPP shifts, no cross-wave exchange, no border masks -- the per-tile
+//     timeline of the push kernel showed ~8,000 of 30,000 cycles there for COUT 8.
+// Staged rows sit at float offset 4 of their 256-float LDS row; columns 3 and 4+W.. stay zero (the
+// ring is cleared once, transfers are EXEC-masked to the image width), which is the convolution's
+// zero padding in x.  B operands cost three ds_reads per staged value (one per dx): ~2/3 of the LDS
+// bandwidth with 8 output channels, too much with 2 or 4 -- those layers keep the push kernel.
+// ------------------------------------------------------------------------------------------
+constexpr int GT_H = 16;                            // tile rows
+constexpr int G_CONS = 14, G_PROD = 2, G_WAVES = G_CONS + G_PROD, G_THREADS = G_WAVES * 64;
+constexpr int G_LCH = 2;                            // channels per chunk, one per producer wave
+constexpr int G_ROWS = GT_H + 2;
+constexpr int G_PLANE = G_ROWS * LTW;               // 4608 floats
+constexpr int G_BUF = G_LCH * G_PLANE;              // 9216 floats = 36,864 B per chunk
+constexpr int G_DMA = G_ROWS;                       // 18 row transfers per chunk per producer
+constexpr int G_XOFF = 4;                           // staged column 0 lives at float 4 of the LDS row
+static_assert(G_CONS * M_SEGS * 64 == GT_H * P_MAXW, "14 x 256 pixel slots cover a 16 x 224 tile");
+
+template <int MODE, int K>
+struct GatherGeom {
+    static constexpr int CIN = MODE == 2 ? gin_of(K) : cin_of(K);
+    static constexpr int COUT = cout_of(K);
+    static constexpr int NT = (COUT + 3) / 4;
+    static constexpr int NCHUNK = (CIN + G_LCH - 1) / G_LCH;
+    static constexpr int WL = NCHUNK * G_LCH * 9 * 4 * NT;           // [ci][tap][i][t], zero rows for channels >= CIN
+};
+
+// producer pj stages channel pj of chunk c: 18 rows, one 1 KB row per instruction (scalar addressing)
+template <int MODE, int K>
+__device__ __forceinline__ void gather_stage(const LayerArgs& a, unsigned slot_byte, int n, int ty0, int c,
+                                             size_t HW, unsigned voff, const float* zero, int pj) {
+    constexpr int CIN = GatherGeom<MODE, K>::CIN;
+    const unsigned long long zaddr = (unsigned long long)zero;
+    const bool interior = ty0 >= 1 && ty0 + GT_H < a.H;
+    const int ch = c * G_LCH + pj;
+    unsigned long long base;
+    long pidx;
+    if (MODE == 2) {
+        constexpr int NG = gin_of(K) - 2;
+        const long s1 = ch >= NG;
+        base = (unsigned long long)a.gbuf + s1 * ((unsigned long long)a.gout - (unsigned long long)a.gbuf);
+        pidx = (long)n * (NFEAT - s1 * (NFEAT - 2)) + ch + (1 - s1) * (yoff(K + 1) - NIN) - s1 * NG;
+    } else {
+        const long s1 = ch >= 2, s2 = ch >= NIN;
+        base = (unsigned long long)a.mv + s1 * ((unsigned long long)a.res - (unsigned long long)a.mv) +
+               s2 * ((unsigned long long)a.feat - (unsigned long long)a.res);
+        pidx = (long)n * (2 + s1 + s2 * (NFEAT - 3)) + ch - s1 * 2 - s2 * (NIN - 2);
+    }
+    const bool chok = ch < CIN;
+    const unsigned long long row0 = base + (unsigned long long)((pidx * (long)HW + (long)(ty0 - 1) * a.W) * 4);
+    unsigned long long sptr = chok ? row0 : zaddr;
+    const unsigned long long sstride = chok ? (unsigned long long)a.W * 4 : 0;
+    const unsigned dst = slot_byte + (unsigned)(pj * G_ROWS) * (LTW * 4) + G_XOFF * 4;
+    if (interior) {
+#pragma unroll
+        for (int row = 0; row < G_ROWS; ++row) {
+            dma_row16_s(sptr, voff, dst + row * (LTW * 4));
+            sptr += sstride;
+        }
+    } else {
+#pragma unroll
+        for (int row = 0; row < G_ROWS; ++row) {
+            const int yy = ty0 - 1 + row;
+            dma_row16_s((yy >= 0 && yy < a.H) ? sptr : zaddr, voff, dst + row * (LTW * 4));
+            sptr += sstride;
+        }
+    }
+}
+
+template <int MODE, int K>
+__global__ __launch_bounds__(G_THREADS) void gen_layer_gather_kernel(RingArgs ra) {
+    using G = GatherGeom<MODE, K>;
+    constexpr int CIN = G::CIN, COUT = G::COUT, NT = G::NT, NCHUNK = G::NCHUNK;
+    __shared__ __attribute__((aligned(16))) float lds[RING * G_BUF + G::WL];
+    const LayerArgs& a = ra.a;
+    float* wl = lds + RING * G_BUF;
+    const size_t HW = (size_t)a.H * a.W;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int r = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave: 0..13 consumers, 14..15 producers
+    const float* zero = a.pk + PACKED_TOTAL;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds;
+
+    const int nwg = gridDim.x;
+    const int t_begin = nwg % 8 == 0 ? (int)(blockIdx.x % 8) * (nwg / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int t_step = nwg;
+    const int nitems = t_begin < ra.ntiles ? (ra.ntiles - t_begin + nwg - 1) / nwg * NCHUNK : 0;
+    if (nitems == 0) return;
+
+    // clear the ring once (guard columns and everything right of the image stay zero for good)
+    for (int i = tid; i < RING * G_BUF / 4; i += G_THREADS)
+        reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // weights -> LDS as [ci][tap][i][t]: output channel co = 4 t + i
+    const float* wbase = a.pk + (MODE == 2 ? wb_off(K) : wf_off(K));
+    for (int idx = tid; idx < G::WL; idx += G_THREADS) {
+        const int t = idx % NT, i = (idx / NT) % 4, tap = (idx / (4 * NT)) % 9, ci = idx / (36 * NT);
+        const int co = 4 * t + i;
+        wl[idx] = (co < COUT && ci < CIN) ? wbase[(ci * 9 + tap) * COUT + co] : 0.f;
+    }
+    __syncthreads();
+
+    if (r >= G_CONS) {
+        // ------------------------------ producer waves ------------------------------
+        const int pj = r - G_CONS;
+        if (4 * lane >= a.W) return;                                   // EXEC = lanes that hold image columns
+        const unsigned voff = (unsigned)lane * 16;
+#pragma unroll 1
+        for (int pre = 0; pre < 2 && pre < nitems; ++pre) {
+            const int tile = t_begin + (pre / NCHUNK) * t_step, n = tile / ra.tiles_y;
+            gather_stage<MODE, K>(a, lds0 + pre * (G_BUF * 4), n, (tile - n * ra.tiles_y) * GT_H, pre % NCHUNK, HW, voff, zero, pj);
+        }
+        int tile = t_begin, c = 0, slot = 0;
+#pragma unroll 1
+        for (int q = 0; q < nitems; ++q) {
+            if (q + 1 < nitems) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(G_DMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (q + 2 < nitems) {
+                const int c2 = c + 2, tile2 = tile + (c2 / NCHUNK) * t_step, n2 = tile2 / ra.tiles_y;
+                int slot2 = slot + 2; slot2 = slot2 >= RING ? slot2 - RING : slot2;
+                gather_stage<MODE, K>(a, lds0 + (unsigned)slot2 * (G_BUF * 4), n2, (tile2 - n2 * ra.tiles_y) * GT_H,
+                                      c2 % NCHUNK, HW, voff, zero, pj);
+            }
+            slot = slot + 1 == RING ? 0 : slot + 1;
+            if (++c == NCHUNK) { c = 0; tile += t_step; }
+        }
+        return;
+    }
+
+    // ------------------------------ consumer waves ------------------------------
+    int boff[M_SEGS];                 // LDS offset of the tap (dy = 0, dx = 1) of the lane's pixel
+#pragma unroll
+    for (int s = 0; s < M_SEGS; ++s) {
+        const int p = r * (M_SEGS * 64) + s * 64 + lane;
+        const int yl = p / a.W, x = p - yl * a.W;
+        boff[s] = p < GT_H * a.W ? yl * LTW + x + G_XOFF : G_XOFF;
+    }
+    f32x4 acc[M_SEGS][NT];
+#pragma unroll
+    for (int s = 0; s < M_SEGS; ++s)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[s][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // Results of the previous tile wait in registers and are stored a few per chunk while the next
+    // tile computes: 14 waves storing 32 values each at once is a 115 KB burst that the memory
+    // system absorbs at its ~10 B/clk per-CU share (10,000 of a tile's 56,000 cycles, measured).
+    constexpr int NOUT = M_SEGS * COUT, PER = (NOUT + NCHUNK - 1) / NCHUNK;
+    float pend[M_SEGS][COUT];
+#pragma unroll
+    for (int s = 0; s < M_SEGS; ++s)
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) pend[s][co] = 0.f;
+    long pend_base = -1;                                   // element offset of (frame, channel yoff(K), tile pixel 0); -1: nothing pending
+    int pend_max = 0;
+    float* const outp = MODE == 0 ? a.feat_out : a.gbuf;
+    auto flush_group = [&](int grp) {                      // stores values [grp*PER, grp*PER+PER) of the pending tile
+#pragma unroll
+        for (int gsel = 0; gsel < NCHUNK; ++gsel) {
+            if (grp == gsel) {
+#pragma unroll
+                for (int k = gsel * PER; k < gsel * PER + PER && k < NOUT; ++k) {
+                    const int s = k / COUT, co = k % COUT;
+                    const int p = r * (M_SEGS * 64) + s * 64 + lane;
+                    if (p < pend_max) outp[pend_base + (long)co * (long)HW + p] = pend[s][co];
+                }
+            }
+        }
+    };
+
+    int tile = t_begin, c = 0, slot = 0;
+#pragma unroll 1
+    for (int q = 0; q < nitems; ++q) {
+        asm volatile("s_barrier" ::: "memory");
+        if (pend_base >= 0) flush_group(c);
+        {
+            // one chunk = 2 channels x 3 stages (dy) of 3 K-steps (dx) x 4 segments x NT tiles; the
+            // operands of the next stage are requested before the MFMAs of the current one
+            const float* buf = lds + slot * G_BUF;
+            const float* wp = wl + (c * G_LCH) * 36 * NT + (lane & 3) * NT;
+            float w[2][3][NT], b[2][3][M_SEGS];
+            auto load_stage = [&](int st, int sel) {
+                const int cc = st / 3, dy = st % 3;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float* p = wp + ((cc * 9 + dy * 3 + dx) * 4) * NT;
+                    if (NT == 2) {
+                        const float2 v = *reinterpret_cast<const float2*>(p);
+                        w[sel][dx][0] = v.x; w[sel][dx][NT - 1] = v.y;
+                    } else {
+                        w[sel][dx][0] = p[0];
+                    }
+#pragma unroll
+                    for (int s = 0; s < M_SEGS; ++s) b[sel][dx][s] = buf[cc * G_PLANE + dy * LTW + boff[s] + dx - 1];
+                }
+            };
+            load_stage(0, 0);
+#pragma unroll
+            for (int st = 0; st < G_LCH * 3; ++st) {
+                if (st + 1 < G_LCH * 3) load_stage(st + 1, (st + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int s = 0; s < M_SEGS; ++s)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            acc[s][t] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[st & 1][dx][t], b[st & 1][dx][s], acc[s][t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        slot = slot + 1 == RING ? 0 : slot + 1;
+        if (++c < NCHUNK) continue;
+        c = 0;
+
+        // ---- epilogue: bias / activation into the pending registers (stored during the next tile) ----
+        const int n = tile / ra.tiles_y, ty0 = (tile - n * ra.tiles_y) * GT_H;
+        const int pmax = (a.H - ty0 < GT_H ? a.H - ty0 : GT_H) * a.W;
+        const long base = ((long)n * NFEAT + (yoff(K) - NIN)) * (long)HW + (long)ty0 * a.W;
+        if (MODE == 2) {
+            float fv[M_SEGS][COUT];                       // y_K for LeakyReLU': one batch of loads
+#pragma unroll
+            for (int s = 0; s < M_SEGS; ++s) {
+                const int p = r * (M_SEGS * 64) + s * 64 + lane;
+                const long pp = p < pmax ? p : 0;
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) fv[s][co] = a.feat[base + (long)co * (long)HW + pp];
+            }
+#pragma unroll
+            for (int s = 0; s < M_SEGS; ++s)
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) pend[s][co] = acc[s][co / 4][co % 4] * (fv[s][co] > 0.f ? 1.f : 0.1f);
+        } else {
+#pragma unroll
+            for (int s = 0; s < M_SEGS; ++s)
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) {
+                    const float v = acc[s][co / 4][co % 4] + a.pk[bf_off(K) + co];
+                    pend[s][co] = v > 0.f ? v : 0.1f * v;
+                }
+        }
+        pend_base = base;
+        pend_max = pmax;
+#pragma unroll
+        for (int s = 0; s < M_SEGS; ++s)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[s][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        tile += t_step;
+    }
+    if (pend_base >= 0)
+        for (int grp = 0; grp < NCHUNK; ++grp) flush_group(grp);
+}
+
+// ------------------------------------------------------------------------------------------
 // backward, weight path: one fp32-MFMA GEMM over pixels.
 //
 //   dW[(k,co)][(ci,tap)] = sum_px g_k[co][px] * x[ci][px + tap]
@@ -1255,7 +1513,19 @@ int launch_layer(LayerArgs a, int n0, int N, hipStream_t s) {
     // register-pipelined kernel wins for the Cout 8 / 6 / 4 layers
     constexpr bool DMA_WINS = (MODE != 2 && K >= 4) || (MODE == 2 && K >= 2);
     static const int path = [] { const char* e = getenv("DMC_GEN_LAYER_PATH"); return e ? atoi(e) : 1; }();
-    if (path == 1 && a.W % 4 == 0 && a.W <= P_MAXW) {
+    // measured per layer (N=120, 224x224): the gather form wins where the push kernel pads the
+    // input channels most (5 -> 8, 13 -> 16, 14 -> 16: layers 0, 1 and gradient group 1); the
+    // Cout-6 layers lose (18 instead of 15 MFMAs per channel and pixel), the rest are at the HBM roof
+    constexpr bool GATHER_FORM = (MODE == 0 && K <= 1) || (MODE == 2 && K == 1);
+    static const int gpath = [] { const char* e = getenv("DMC_GEN_GATHER"); return e ? atoi(e) : 1; }();
+    if (GATHER_FORM && gpath == 1 && path == 1 && a.W % 4 == 0 && a.W <= P_MAXW) {
+        RingArgs ra;
+        ra.a = a;
+        ra.tiles_y = (a.H + GT_H - 1) / GT_H;
+        ra.ntiles = ra.tiles_y * N;
+        const int wgs = ra.ntiles < num_cus() ? ra.ntiles : num_cus();
+        if constexpr (GATHER_FORM) gen_layer_gather_kernel<MODE, K><<<wgs, G_THREADS, 0, s>>>(ra);
+    } else if (path == 1 && a.W % 4 == 0 && a.W <= P_MAXW) {
         RingArgs ra;
         ra.a = a;
         ra.tiles_y = (a.H + PT_H - 1) / PT_H;
