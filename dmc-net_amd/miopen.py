@@ -25,7 +25,9 @@ def enable_find(use_shipped_db=True):
     if not use_shipped_db or "MIOPEN_USER_DB_PATH" in os.environ or not os.path.isdir(_DB_DIR):
         return os.environ.get("MIOPEN_USER_DB_PATH")
     path = _DB_DIR
-    if not os.access(path, os.W_OK):          # MIOpen appends to its user db: it must be writable
+    # MIOpen appends to its user db, so it must be writable; with several ranks on one node each
+    # process gets its own copy (no concurrent writers on the shipped files)
+    if not os.access(path, os.W_OK) or int(os.environ.get("WORLD_SIZE", "1")) > 1:
         path = tempfile.mkdtemp(prefix="dmc_miopen_db_")
         for name in os.listdir(_DB_DIR):
             shutil.copy(os.path.join(_DB_DIR, name), path)
