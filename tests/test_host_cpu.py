@@ -196,6 +196,41 @@ def test_grad_bucket_reducer_two_ranks_gloo(tmp_path):
             torch.testing.assert_close(g, p.grad, rtol=1e-5, atol=1e-7)
 
 
+def _ddp_cl_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(5)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(),
+                              torch.nn.Conv2d(8, 4, 3, padding=1)).to(memory_format=torch.channels_last)
+    red = ddp.GradBucketReducer(list(net.parameters()), bucket_bytes=256)
+    torch.manual_seed(9)
+    x = torch.randn(4, 3, 6, 6)
+    shard = slice(rank * 2, rank * 2 + 2)
+    red.begin()
+    net(x[shard]).square().mean().backward()
+    red.finish()
+    ok = all(p.grad.stride() == p.stride() for p in net.parameters())      # bucket views keep the parameter's strides
+    torch.save({"grads": [p.grad.clone() for p in net.parameters()], "x": x, "strides_ok": ok,
+                "state": net.state_dict()}, os.path.join(out_dir, "c%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_grad_bucket_reducer_keeps_channels_last_strides(tmp_path):
+    """channels_last weights: the gradient views into the flat buckets keep the parameters' memory
+    order (what torch's fused Adam kernel requires) and still average to the full-batch gradient."""
+    port = _free_port()
+    mp.spawn(_ddp_cl_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp_path, "c%d.pt" % r)) for r in (0, 1))
+    assert r0["strides_ok"] and r1["strides_ok"]
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(),
+                              torch.nn.Conv2d(8, 4, 3, padding=1)).to(memory_format=torch.channels_last)
+    net.load_state_dict(r0["state"])
+    net(r0["x"]).square().mean().backward()
+    for p, g0, g1 in zip(net.parameters(), r0["grads"], r1["grads"]):
+        assert torch.equal(g0, g1)
+        torch.testing.assert_close(g0, p.grad, rtol=1e-5, atol=1e-7)
+
+
 def test_score_fusion_matches_reference_combine(golden, tmp_path):
     """combine() on the reference's shipped HMDB-51 split-1 score files reproduces the accuracy the
     reference's own combine.py prints for them (fixture g7)."""
