@@ -770,6 +770,311 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_layer_mfma_kernel(RingArgs ra
 }
 
 // ------------------------------------------------------------------------------------------
+// Layers 4 and 5 fused (forward).  Both read the same 31 planes (mv, res, y0..y3) and sit at the
+// HBM roof, so one pass over those planes serves both: while the chunks stream through the ring,
+// layer 4 accumulates for tile rows ty0-1 .. ty0+8 (10 rows: the rows layer 5 needs of y4) and
+// layer 5 accumulates its 31-channel part for rows ty0 .. ty0+7; then y4 = LeakyReLU(.) goes to
+// HBM (the 8 owned rows) and into an LDS tile (all 10 rows, zero outside the image), layer 5 adds
+// its two y4 channels from that tile and finishes (+bias, +mv).  12 staged rows per 8 instead of
+// 2 x 10, and the second read of the 31 planes disappears: -40 % of these two layers' traffic.
+// Same push formulation, flattened pixel slots and producer / consumer ring as above; consumer
+// wave r owns 256 pixels for both layers (shared B operands) plus 64 halo pixels of layer 4.
+// ------------------------------------------------------------------------------------------
+constexpr int F_LCH = 3;                             // channels per chunk
+constexpr int F_ROWS = PT_H + 4;                     // staged rows ty0-2 .. ty0+9
+constexpr int F_PLANE = F_ROWS * LTW;                // 3072 floats
+constexpr int F_BUF = F_LCH * F_PLANE;               // 9216 floats = 36,864 B per chunk
+constexpr int F_DMA = F_LCH * F_ROWS;                // 36 row transfers per chunk
+constexpr int F_CIN = cin_of(4);                     // 31 streamed channels
+constexpr int F_NCHUNK = (F_CIN + F_LCH - 1) / F_LCH;   // 11
+constexpr int F_CH = F_NCHUNK * F_LCH;               // 33 (channels 31, 32: zero rows)
+constexpr int F_S5 = 4;                              // shared segments per wave (the tile's 8 rows); + 1 halo segment for layer 4
+constexpr int F_Y4ROWS = PT_H + 2;
+constexpr int F_Y4 = 2 * F_Y4ROWS * LTW;             // y4 tile: 2 channels x 10 rows x 256
+constexpr int F_WL = F_CH * 3 * 4 * 4;               // combined weight table [ci][dy][i][4]: row tiles 0..2 (rows 0..5 layer 4, 6..11 layer 5)
+static_assert(F_DMA <= 63, "vmcnt is a 6-bit counter");
+static_assert(P_CONS * 64 == 2 * P_MAXW, "7 x 64 halo pixel slots cover the two halo rows of layer 4");
+
+__device__ __forceinline__ void fuse_stage(const LayerArgs& a, unsigned slot_byte, int n, int ty0, int c,
+                                           size_t HW, unsigned voff, const float* zero) {
+    const unsigned long long zaddr = (unsigned long long)zero;
+    const bool interior = ty0 >= 2 && ty0 + PT_H + 2 <= a.H;          // rows ty0-2 .. ty0+9 all inside
+#pragma unroll
+    for (int cc = 0; cc < F_LCH; ++cc) {
+        const int ch = c * F_LCH + cc;
+        const long s1 = ch >= 2, s2 = ch >= NIN;                   // mv | res | feat
+        const unsigned long long base = (unsigned long long)a.mv + s1 * ((unsigned long long)a.res - (unsigned long long)a.mv) +
+                                        s2 * ((unsigned long long)a.feat - (unsigned long long)a.res);
+        const long pidx = (long)n * (2 + s1 + s2 * (NFEAT - 3)) + ch - s1 * 2 - s2 * (NIN - 2);
+        const bool chok = ch < F_CIN;
+        const unsigned long long row0 = base + (unsigned long long)((pidx * (long)HW + (long)(ty0 - 2) * a.W) * 4);
+        unsigned long long sptr = chok ? row0 : zaddr;
+        const unsigned long long sstride = chok ? (unsigned long long)a.W * 4 : 0;
+        const unsigned dst = slot_byte + (unsigned)(cc * F_ROWS) * (LTW * 4);
+        if (interior) {
+#pragma unroll
+            for (int row = 0; row < F_ROWS; ++row) {
+                dma_row16_s(sptr, voff, dst + row * (LTW * 4));
+                sptr += sstride;
+            }
+        } else {
+#pragma unroll
+            for (int row = 0; row < F_ROWS; ++row) {
+                const int yy = ty0 - 2 + row;
+                dma_row16_s((yy >= 0 && yy < a.H) ? sptr : zaddr, voff, dst + row * (LTW * 4));
+                sptr += sstride;
+            }
+        }
+    }
+}
+
+// horizontal-tap combine of one layer's accumulators (rows BASE + dx*2 + co of NTL row tiles) over a run
+// of NS consecutive 64-pixel segments: out[s][co] = P1[p] + P0[p-1] + P2[p+1] with neighbour lanes /
+// segments / waves, zero at the image borders.  push_edges publishes the run's two edge partial
+// sums for the neighbour waves; a barrier must separate it from push_combine2.
+template <int NS, int NTL, int BASE>
+__device__ __forceinline__ void push_edges(const f32x4 (&acc)[NS][NTL], float* xchg, int r, int lane) {
+#pragma unroll
+    for (int co = 0; co < 2; ++co) {
+        const int r0 = BASE + co, r2 = BASE + 4 + co;
+        if (lane == 0) xchg[(r * 2 + 0) * 2 + co] = acc[0][r2 / 4][r2 % 4];
+        if (lane == 63) xchg[(r * 2 + 1) * 2 + co] = acc[NS - 1][r0 / 4][r0 % 4];
+    }
+}
+template <int NS, int NTL, int BASE>
+__device__ __forceinline__ void push_combine2(const f32x4 (&acc)[NS][NTL], float (&out)[NS][2], const float* xchg, int r,
+                                              const bool (&at_left)[NS], const bool (&at_right)[NS]) {
+    float nb_l[2], nb_r[2];
+#pragma unroll
+    for (int co = 0; co < 2; ++co) {
+        nb_l[co] = r > 0 ? xchg[((r - 1) * 2 + 1) * 2 + co] : 0.f;
+        nb_r[co] = r + 1 < P_CONS ? xchg[((r + 1) * 2 + 0) * 2 + co] : 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int co = 0; co < 2; ++co) {
+            const int r0 = BASE + co, r1 = BASE + 2 + co, r2 = BASE + 4 + co;
+            const float p0 = acc[s][r0 / 4][r0 % 4], p1 = acc[s][r1 / 4][r1 % 4], p2 = acc[s][r2 / 4][r2 % 4];
+            const float edge_l = s > 0 ? lane_bcast(acc[s > 0 ? s - 1 : 0][r0 / 4][r0 % 4], 63) : nb_l[co];
+            const float edge_r = s + 1 < NS ? lane_bcast(acc[s + 1 < NS ? s + 1 : s][r2 / 4][r2 % 4], 0) : nb_r[co];
+            const float sh_l = dpp_shr_fill(p0, edge_l), sh_r = dpp_shl_fill(p2, edge_r);
+            out[s][co] = p1 + (at_left[s] ? 0.f : sh_l) + (at_right[s] ? 0.f : sh_r);
+        }
+}
+
+__global__ __launch_bounds__(LTHREADS, 2) void gen_l45_kernel(RingArgs ra) {
+    __shared__ __attribute__((aligned(16))) float lds[RING * F_BUF + F_Y4 + F_WL + 3 * P_CONS * 4];
+    const LayerArgs& a = ra.a;
+    float* y4t = lds + RING * F_BUF;
+    float* wl = y4t + F_Y4;
+    float* xchg4 = wl + F_WL;
+    float* xchg5 = xchg4 + P_CONS * 4;
+    const size_t HW = (size_t)a.H * a.W;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int r = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave: 0..6 = consumers, 7 = producer
+    const float* zero = a.pk + PACKED_TOTAL;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds;
+
+    const int nwg = gridDim.x;
+    const int t_begin = nwg % 8 == 0 ? (int)(blockIdx.x % 8) * (nwg / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int t_step = nwg;
+    const int nitems = t_begin < ra.ntiles ? (ra.ntiles - t_begin + nwg - 1) / nwg * F_NCHUNK : 0;
+    if (nitems == 0) return;
+
+    // weights -> LDS as [ci][dy][i][4]: row rho = 4 t + i; rho 0..5 = layer 4 (dx*2 + co), rho 6..11 =
+    // layer 5: twelve rows fill three row tiles exactly (separately each layer pads 6 rows to 8)
+    for (int e = tid; e < F_WL; e += LTHREADS) {
+        const int t = e % 4, i = (e / 4) % 4, dy = (e / 16) % 3, ci = e / 48;
+        const int rho = 4 * t + i;
+        float v = 0.f;
+        if (rho < 6) {
+            if (ci < cin_of(4)) v = a.pk[wf_off(4) + (ci * 9 + dy * 3 + rho / 2) * 2 + rho % 2];
+        } else if (rho < 12) {
+            if (ci < cin_of(5)) v = a.pk[wf_off(5) + (ci * 9 + dy * 3 + (rho - 6) / 2) * 2 + (rho - 6) % 2];
+        }
+        wl[e] = v;
+    }
+    __syncthreads();
+
+    if (r == P_CONS) {
+        // ------------------------------ producer wave ------------------------------
+        if (4 * lane >= a.W) return;
+        const unsigned voff = (unsigned)lane * 16;
+#pragma unroll 1
+        for (int pre = 0; pre < 2 && pre < nitems; ++pre) {
+            const int tile = t_begin + (pre / F_NCHUNK) * t_step, n = tile / ra.tiles_y;
+            fuse_stage(a, lds0 + pre * (F_BUF * 4), n, (tile - n * ra.tiles_y) * PT_H, pre % F_NCHUNK, HW, voff, zero);
+        }
+        int tile = t_begin, c = 0, slot = 0;
+#pragma unroll 1
+        for (int q = 0; q < nitems; ++q) {
+            if (q + 1 < nitems) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(F_DMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (q + 2 < nitems) {
+                const int c2 = c + 2, tile2 = tile + (c2 / F_NCHUNK) * t_step, n2 = tile2 / ra.tiles_y;
+                int slot2 = slot + 2; slot2 = slot2 >= RING ? slot2 - RING : slot2;
+                fuse_stage(a, lds0 + (unsigned)slot2 * (F_BUF * 4), n2, (tile2 - n2 * ra.tiles_y) * PT_H,
+                           c2 % F_NCHUNK, HW, voff, zero);
+            }
+            slot = slot + 1 == RING ? 0 : slot + 1;
+            if (++c == F_NCHUNK) {
+                c = 0; tile += t_step;
+                asm volatile("s_barrier\n\ts_barrier\n\ts_barrier" ::: "memory");   // edge exchange 4, y4 tile ready, edge exchange 5
+            }
+        }
+        return;
+    }
+
+    // ------------------------------ consumer waves ------------------------------
+    // Wave r owns pixels [256 r, 256 r + 256) of the tile's 8 rows for BOTH layers (4 shared segments:
+    // same pixel, same taps -> the B operands are loaded once and feed both accumulator sets) plus,
+    // for layer 4 only, 64 of the 2 x W halo pixels (row ty0-1 then row ty0+8): 7 x 64 = 2 x 224.
+    int boff[F_S5];                                   // shared segments: staged row above the pixel = yl + 1
+    bool lft[F_S5], rgt[F_S5];
+#pragma unroll
+    for (int s = 0; s < F_S5; ++s) {
+        const int p = r * (F_S5 * 64) + s * 64 + lane;
+        const int yl = p / a.W, x = p - yl * a.W;
+        boff[s] = p < PT_H * a.W ? (yl + 1) * LTW + x : 0;
+        lft[s] = x == 0; rgt[s] = x == a.W - 1;
+    }
+    const int h = r * 64 + lane;                      // halo pixel of layer 4
+    const bool h_ok = h < 2 * a.W, h_top = h < a.W;
+    const int hx = h_top ? h : h - a.W;
+    const int boffe = h_ok ? (h_top ? 0 : (PT_H + 1) * LTW) + hx : 0;     // staged row 0 / 9 is the row above the halo pixel
+    const bool lfte[1] = {hx == 0}, rgte[1] = {hx == a.W - 1};
+    float* xchg4e = xchg5 + P_CONS * 4;
+
+    f32x4 acc[F_S5][3], acc4e[1][2];                 // shared segments: rows of both layers; halo segment: layer 4
+#pragma unroll
+    for (int s = 0; s < F_S5; ++s)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[s][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc4e[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc4e[0][1] = acc4e[0][0];
+    const float bias4[2] = {a.pk[bf_off(4) + 0], a.pk[bf_off(4) + 1]};
+    const float bias5[2] = {a.pk[bf_off(5) + 0], a.pk[bf_off(5) + 1]};
+
+    int tile = t_begin, c = 0, slot = 0;
+#pragma unroll 1
+    for (int q = 0; q < nitems; ++q) {
+        asm volatile("s_barrier" ::: "memory");
+        {
+            const float* buf = lds + slot * F_BUF;
+            float w[2][3][3], b[2][3][F_S5 + 1];
+            auto load_stage = [&](int cc, int sel) {
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const float4 u = *reinterpret_cast<const float4*>(wl + (((c * F_LCH + cc) * 3 + dy) * 4 + (lane & 3)) * 4);
+                    w[sel][dy][0] = u.x; w[sel][dy][1] = u.y; w[sel][dy][2] = u.z;
+#pragma unroll
+                    for (int s = 0; s < F_S5; ++s) b[sel][dy][s] = buf[cc * F_PLANE + dy * LTW + boff[s]];
+                    b[sel][dy][F_S5] = buf[cc * F_PLANE + dy * LTW + boffe];
+                }
+            };
+            load_stage(0, 0);
+#pragma unroll
+            for (int cc = 0; cc < F_LCH; ++cc) {
+                if (cc + 1 < F_LCH) load_stage(cc + 1, (cc + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+                    for (int s = 0; s < F_S5; ++s)
+#pragma unroll
+                        for (int t = 0; t < 3; ++t)
+                            acc[s][t] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[cc & 1][dy][t], b[cc & 1][dy][s], acc[s][t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)      // halo pixels: rows 0..5 (layer 4); rows 6, 7 of tile 1 are ignored
+                        acc4e[0][t] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[cc & 1][dy][t], b[cc & 1][dy][F_S5], acc4e[0][t], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        slot = slot + 1 == RING ? 0 : slot + 1;
+        if (++c < F_NCHUNK) continue;
+        c = 0;
+
+        const int n = tile / ra.tiles_y, ty0 = (tile - n * ra.tiles_y) * PT_H;
+        const int pmax = (a.H - ty0 < PT_H ? a.H - ty0 : PT_H) * a.W;
+        const size_t tile_pix = (size_t)ty0 * a.W;
+        // the delta-mode mv values of the layer-5 epilogue: one batch of loads, issued now so that
+        // their latency hides behind the layer-4 epilogue and the y4 K-steps
+        float mvv[F_S5][2];
+#pragma unroll
+        for (int s = 0; s < F_S5; ++s) {
+            const int p = r * (F_S5 * 64) + s * 64 + lane;
+            const size_t pp = p < pmax ? tile_pix + p : 0;
+#pragma unroll
+            for (int co = 0; co < 2; ++co) mvv[s][co] = a.add_mv ? a.mv[((size_t)n * 2 + co) * HW + pp] : 0.f;
+        }
+        // ---- layer 4: combine, bias, LeakyReLU; y4 -> HBM (owned rows) and LDS tile (10 rows, 0 outside) ----
+        push_edges<F_S5, 3, 0>(acc, xchg4, r, lane);
+        push_edges<1, 2, 0>(acc4e, xchg4e, r, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        float o4[F_S5][2], o4e[1][2];
+        push_combine2<F_S5, 3, 0>(acc, o4, xchg4, r, lft, rgt);
+        push_combine2<1, 2, 0>(acc4e, o4e, xchg4e, r, lfte, rgte);
+#pragma unroll
+        for (int s = 0; s < F_S5; ++s) {
+            const int p = r * (F_S5 * 64) + s * 64 + lane;
+#pragma unroll
+            for (int co = 0; co < 2; ++co) {
+                float v = o4[s][co] + bias4[co];
+                v = v > 0.f ? v : 0.1f * v;
+                v = p < pmax ? v : 0.f;                                    // rows below the image: zero padding for layer 5
+                if (p < PT_H * a.W) y4t[co * (F_Y4ROWS * LTW) + boff[s]] = v;    // tile row yl + 1
+                if (p < pmax) a.feat_out[((size_t)n * NFEAT + (yoff(4) - NIN) + co) * HW + tile_pix + p] = v;
+            }
+        }
+        {
+            const bool inimg = h_top ? ty0 >= 1 : ty0 + PT_H < a.H;
+#pragma unroll
+            for (int co = 0; co < 2; ++co) {
+                float v = o4e[0][co] + bias4[co];
+                v = v > 0.f ? v : 0.1f * v;
+                if (h_ok) y4t[co * (F_Y4ROWS * LTW) + boffe] = inimg ? v : 0.f;  // tile row 0 / 9
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // y4 tile complete
+        // ---- layer 5: the two y4 channels (K = 2 x 3 dy) from the LDS tile ----
+#pragma unroll
+        for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                // rows 6..11 only (tiles 1, 2): layer 4 does not read y4, its rows of this table are zero
+                const float4 v = *reinterpret_cast<const float4*>(wl + (((F_CIN + cy) * 3 + dy) * 4 + (lane & 3)) * 4);
+#pragma unroll
+                for (int s = 0; s < F_S5; ++s) {
+                    // pixel row ty0+yl <-> y4-tile row yl+1 (= boff's row); tap dy reads tile row yl + dy
+                    const float bb = y4t[cy * (F_Y4ROWS * LTW) + boff[s] - LTW + dy * LTW];
+                    acc[s][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(v.y, bb, acc[s][1], 0, 0, 0);
+                    acc[s][2] = __builtin_amdgcn_mfma_f32_4x4x1f32(v.z, bb, acc[s][2], 0, 0, 0);
+                }
+            }
+        push_edges<F_S5, 3, 6>(acc, xchg5, r, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        float o5[F_S5][2];
+        push_combine2<F_S5, 3, 6>(acc, o5, xchg5, r, lft, rgt);
+#pragma unroll
+        for (int s = 0; s < F_S5; ++s) {
+            const int p = r * (F_S5 * 64) + s * 64 + lane;
+            if (p < pmax) {
+#pragma unroll
+                for (int co = 0; co < 2; ++co)
+                    a.out[((size_t)n * 2 + co) * HW + tile_pix + p] = o5[s][co] + bias5[co] + mvv[s][co];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < F_S5; ++s)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc[s][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc4e[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc4e[0][1] = acc4e[0][0];
+        tile += t_step;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Gather variant of the matrix-core layer kernel for layers with 8 output channels.
 //
 // Same 4x4x1 MFMA, same producer / consumer ring, but ALL nine taps are gathered through K:
@@ -1583,8 +1888,24 @@ int dmc_gen_tiny_fwd(const float* mv, const float* res, const float* const* w,
         if ((rc = launch_layer<0, 1>(a, n0, nn, s))) return rc;
         if ((rc = launch_layer<0, 2>(a, n0, nn, s))) return rc;
         if ((rc = launch_layer<0, 3>(a, n0, nn, s))) return rc;
-        if ((rc = launch_layer<0, 4>(a, n0, nn, s))) return rc;
-        if ((rc = launch_layer<1, 5>(a, n0, nn, s))) return rc;
+        static const int fuse45 = [] { const char* e = getenv("DMC_GEN_FUSE45"); return e ? atoi(e) : 1; }();
+        static const int lpath = [] { const char* e = getenv("DMC_GEN_LAYER_PATH"); return e ? atoi(e) : 1; }();
+        if (fuse45 && lpath == 1 && W % 4 == 0 && W <= P_MAXW) {
+            RingArgs ra;
+            ra.a = a;
+            const size_t HWf = (size_t)H * W;
+            ra.a.mv = mv + (size_t)n0 * 2 * HWf; ra.a.res = res + (size_t)n0 * 3 * HWf;
+            ra.a.feat = saved + (size_t)n0 * NFEAT * HWf; ra.a.feat_out = saved + (size_t)n0 * NFEAT * HWf;
+            ra.a.out = out + (size_t)n0 * 2 * HWf;
+            ra.tiles_y = (H + PT_H - 1) / PT_H;
+            ra.ntiles = ra.tiles_y * nn;
+            const int wgs = ra.ntiles < num_cus() ? ra.ntiles : num_cus();
+            gen_l45_kernel<<<wgs, LTHREADS, 0, s>>>(ra);
+            if ((rc = check_launch("gen_l45"))) return rc;
+        } else {
+            if ((rc = launch_layer<0, 4>(a, n0, nn, s))) return rc;
+            if ((rc = launch_layer<1, 5>(a, n0, nn, s))) return rc;
+        }
     }
     return DMC_OK;
 }
