@@ -246,7 +246,7 @@ def main():
                 "launch_ms": round(fwd_ms, 4),
                 "hbm": {"achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 5),
-                        "note": "algorithmic 28 B/px; 'traffic' = measured HBM bytes of the 6 layer launches",
+                        "note": "algorithmic 28 B/px; 'traffic' = measured HBM bytes of the layer launches (layers 4+5 are one fused launch)",
                         "traffic_gbs": None if traffic is None else round(traffic / (fwd_ms * 1e-3) / 1e9, 1)}},
             "kernels_ms": {k: round(v[0], 4) for k, v in spans.items()},
         }
