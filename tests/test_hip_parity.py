@@ -54,7 +54,13 @@ def test_generator_forward_backward_vs_oracle_and_golden(golden, tag, shape, sd)
         assert rel_err(pm.grad, g["%s_grad_%s" % (tag, k)]) < 1e-4, k
 
 
-@pytest.mark.parametrize("shape", [(1, 5, 1, 1), (1, 5, 3, 5), (2, 5, 8, 32), (1, 5, 9, 33), (2, 5, 64, 260)])
+# W % 4 == 0 and W <= 224 take the matrix-core kernels (push, gather, fused layers 4+5, producer /
+# consumer weight gradient): tiles that end inside the image, images shorter than one tile, a
+# single 4-pixel column, widths where the 64-pixel segments straddle rows differently; the other
+# shapes take the VALU fallback kernels
+@pytest.mark.parametrize("shape", [(1, 5, 1, 1), (1, 5, 3, 5), (2, 5, 8, 32), (1, 5, 9, 33), (2, 5, 64, 260),
+                                   (1, 5, 8, 4), (2, 5, 9, 8), (3, 5, 17, 220), (1, 5, 33, 224), (2, 5, 16, 64),
+                                   (1, 5, 7, 12), (2, 5, 23, 100), (1, 5, 2, 224), (1, 5, 40, 228)])
 @pytest.mark.parametrize("delta", [False, True])
 def test_generator_edge_shapes(shape, delta):
     o, m = tiny_pair(12)
