@@ -276,7 +276,8 @@ constexpr int PT = 8;                          // pooled windows per tile side
 template <int PASS>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolArgs a, double* __restrict__ scratch,
                                                        const float* __restrict__ dgamma,
-                                                       const float* __restrict__ dbeta, float inv_count) {
+                                                       const float* __restrict__ dbeta, float inv_count,
+                                                       unsigned* __restrict__ gcodes) {
     __shared__ unsigned codes[(PT + 1) * (PT + 1) * 64];       // arg-max position (0..8) per channel, 4 per word
     __shared__ double sm[PASS == 1 ? 2 : 1][PASS == 1 ? 256 : 1][4];
     const int cq = a.C >> 2;
@@ -301,7 +302,10 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolArgs a, double* __res
         for (int wi = ty; wi < (PT + 1) * (PT + 1); wi += rows) {
             const int py = wy0 + wi / (PT + 1), px = wx0 + wi % (PT + 1);
             unsigned code = 0xffffffffu;
-            if (py < a.PH && px < a.PW) {
+            if (PASS == 2 && gcodes) {
+                // the arg-max codes were computed (and stored by each window's owner tile) in pass 1
+                if (py < a.PH && px < a.PW) code = gcodes[((size_t)(n * a.PH + py) * a.PW + px) * cq + tx];
+            } else if (py < a.PH && px < a.PW) {
                 float4 mv = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
                 unsigned cx = 0, cy = 0, cz = 0, cw = 0;
                 float4 xv[9];
@@ -323,6 +327,8 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolArgs a, double* __res
                     if (in && v.w > mv.w) { mv.w = v.w; cw = k; }
                 }
                 code = cx | (cy << 8) | (cz << 16) | (cw << 24);
+                if (PASS == 1 && gcodes && wi / (PT + 1) < PT && wi % (PT + 1) < PT)      // owned window
+                    gcodes[((size_t)(n * a.PH + py) * a.PW + px) * cq + tx] = code;
             }
             codes[wi * cq + tx] = code;
         }
@@ -493,9 +499,13 @@ int dmc_bn_relu_pool_fwd(const float* x, const float* gamma, const float* beta, 
     return check_launch("pool_fwd");
 }
 
+size_t dmc_bn_relu_pool_codes_bytes(int N, int H, int W, int C) {
+    return (size_t)N * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * (C / 4) * sizeof(unsigned);
+}
+
 int dmc_bn_relu_pool_bwd(const float* x, const float* gamma, const float* beta, float* stats,
-                         const float* d_pool, float* dx, float* dgamma, float* dbeta, int N, int H,
-                         int W, int C, dmc_stream_t stream) {
+                         const float* d_pool, float* dx, float* dgamma, float* dbeta, void* codes,
+                         int N, int H, int W, int C, dmc_stream_t stream) {
     if (!x || !gamma || !beta || !stats || !d_pool || !dx || !dgamma || !dbeta)
         return fail(DMC_E_INVALID, "dmc_bn_relu_pool_bwd: null pointer");
     if (!dmc_bn_relu_pool_supported(N, H, W, C))
@@ -506,12 +516,12 @@ int dmc_bn_relu_pool_bwd(const float* x, const float* gamma, const float* beta, 
     const long tiles = (long)N * ((p.PH + PT - 1) / PT) * ((p.PW + PT - 1) / PT);
     const int blocks = (int)(tiles < MAX_SPLIT ? tiles : MAX_SPLIT);
     int rc;
-    pool_bwd_kernel<1><<<blocks, 256, 0, s>>>(p, scratch, nullptr, nullptr, 0.f);
+    pool_bwd_kernel<1><<<blocks, 256, 0, s>>>(p, scratch, nullptr, nullptr, 0.f, (unsigned*)codes);
     if ((rc = check_launch("pool_bwd_partial"))) return rc;
     bn_bwd_final_kernel<<<(C + 7) / 8, 256, 0, s>>>(scratch, dgamma, dbeta, C, blocks);
     if ((rc = check_launch("bn_bwd_final"))) return rc;
     pool_bwd_kernel<2><<<blocks * 4 > 8192 ? 8192 : blocks * 4, 256, 0, s>>>(p, nullptr, dgamma, dbeta,
-                                                                             1.f / (float)((long)N * H * W));
+                                                                             1.f / (float)((long)N * H * W), (unsigned*)codes);
     return check_launch("pool_bwd_apply");
 }
 

@@ -378,11 +378,12 @@ class _BnReluPool(torch.autograd.Function):
         dy = dy.contiguous(memory_format=torch.channels_last)
         dx = torch.empty_like(x)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        codes = _floats(lib.dmc_bn_relu_pool_codes_bytes(n, h, w, c), x.device)
         with _span("bn_relu_pool_bwd"):
             _lib.check(lib.dmc_bn_relu_pool_bwd(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta),
                                                 _lib.ptr(stats), _lib.ptr(dy), _lib.ptr(dx),
-                                                _lib.ptr(dgamma), _lib.ptr(dbeta), n, h, w, c,
-                                                _stream()), "dmc_bn_relu_pool_bwd")
+                                                _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(codes),
+                                                n, h, w, c, _stream()), "dmc_bn_relu_pool_bwd")
         return dx, dgamma, dbeta, None, None, None, None, None
 
 

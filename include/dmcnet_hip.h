@@ -182,14 +182,17 @@ int dmc_prepare_inputs(const unsigned char* frames_u8, const unsigned char* flip
  * tensor is never materialised.  Arg-max ties follow PyTorch (first element in row-major window
  * order).  stats: dmc_bn_act_stats_bytes(C) bytes, written by fwd (mean, invstd) and read by bwd.
  * training = 0 normalises with the running statistics (forward only).
+ * codes: dmc_bn_relu_pool_codes_bytes() bytes of scratch (the windows' arg-max positions, written by the
+ * backward's first pass and read by its second), or NULL to recompute them in the second pass.
  */
 int dmc_bn_relu_pool_supported(int N, int H, int W, int C);
 int dmc_bn_relu_pool_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
                          float* running_var, float* y_pool, float* stats, int N, int H, int W, int C,
                          int training, float eps, float momentum, dmc_stream_t stream);
+size_t dmc_bn_relu_pool_codes_bytes(int N, int H, int W, int C);
 int dmc_bn_relu_pool_bwd(const float* x, const float* gamma, const float* beta, float* stats,
-                         const float* d_pool, float* dx, float* dgamma, float* dbeta, int N, int H,
-                         int W, int C, dmc_stream_t stream);
+                         const float* d_pool, float* dx, float* dgamma, float* dbeta, void* codes,
+                         int N, int H, int W, int C, dmc_stream_t stream);
 
 /* ---- classifier stem: weight gradient of conv1 (2 -> 64 channels, 7x7, stride 2, pad 3) ----------
  * Replaces what autograd computes for the conv1 the reference installs for the 2-channel flow
