@@ -1671,38 +1671,43 @@ __global__ __launch_bounds__(512, 2) void gen_bwd_weight_pc_kernel(WgradArgs a) 
         const bool rowB = j < 14;
         const int offA0 = PW_X + j * PW_GPLANE + kq;
         const int offA1 = PW_X + (rowB ? 16 + j : 0) * PW_GPLANE + kq;
-        // work units = (tile row, group of 4 pixels): 56 per tile.  The SIMD that hosts the producer
-        // runs one consumer wave (wave 3), the others two, so wave 3 takes 14 units and the rest 7:
-        // every SIMD then carries 14 units of MFMA work.
-        const int nrep = 1;
+        // The bias gradient of layers 0 and 1 (M tile A) is a plain row sum of the A operand: it is
+        // accumulated on the vector ALU (one add per group) instead of spending a 9th MFMA per group
+        // on a column of ones; tile B's bias column shares N tile 18 with real columns and stays.
+        float bias_a = 0.f;
         int it = 0;
         asm volatile("s_barrier" ::: "memory");
         for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
             const float* lds = lds2 + (it & 1) * PW_BUF;
-#pragma unroll 1
-            for (int rep = 0; rep < nrep; ++rep) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int row = wave;
-                    const int g = i;
-                    const int sA = row * WT_W + g * 4, sB = row * WX_PITCH + g * 4;
-                    const float a0 = lds[offA0 + sA];
-                    const float a1r = lds[offA1 + sA];
-                    const float a1 = rowB ? a1r : 0.f;
-                    float b[NT_B];
+            for (int g = 0; g < 8; ++g) {
+                const int sA = wave * WT_W + g * 4, sB = wave * WX_PITCH + g * 4;
+                const float a0 = lds[offA0 + sA];
+                const float a1r = lds[offA1 + sA];
+                const float a1 = rowB ? a1r : 0.f;
+                float b[NT_B];
 #pragma unroll
-                    for (int t = 0; t < NT_B; ++t) b[t] = lds[offB[t] + sB];
-                    if (ones) b[18] = 1.f;
+                for (int t = 0; t < NT_B; ++t) b[t] = lds[offB[t] + sB];
+                if (ones) b[18] = 1.f;
+                bias_a += a0;
 #pragma unroll
-                    for (int t = 0; t < 8; ++t)
-                        accA[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[t], accA[t], 0, 0, 0);
-                    accA[8] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[18], accA[8], 0, 0, 0);
+                for (int t = 0; t < 8; ++t)
+                    accA[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[t], accA[t], 0, 0, 0);
 #pragma unroll
-                    for (int t = 0; t < NT_B; ++t)
-                        accB[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[t], accB[t], 0, 0, 0);
-                }
+                for (int t = 0; t < NT_B; ++t)
+                    accB[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[t], accB[t], 0, 0, 0);
             }
             asm volatile("s_barrier" ::: "memory");        // next tile staged, this buffer may be refilled
+        }
+        // fold the row sums into accumulator slot 8 (N tile 18), column BIAS_COL - 288 = 9, in the MFMA
+        // C layout: lane (j, kq) holds rows kq*4 + q of column j
+        float tot = bias_a;
+        tot += __shfl_xor(tot, 16);
+        tot += __shfl_xor(tot, 32);                                    // every lane of row j: the row's total
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float rv = __shfl(tot, kq * 4 + q);                  // lanes 0..15 hold rows 0..15
+            accA[8][q] = ones ? rv : 0.f;
         }
     }
     // cross-wave reduction in LDS, fixed order (wave 0 stores, waves 1..6 add in turn)
