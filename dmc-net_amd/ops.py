@@ -411,9 +411,11 @@ def bn_relu_pool(x, bn):
 
 class _StemConv(torch.autograd.Function):
     """conv1 of the classifier for the 2-channel flow input (code/dmcnet/model.py:285-294): the
-    forward convolution is MIOpen's, the weight gradient is dmc_stem_wgrad (MIOpen's implicit-GEMM
-    weight gradient degenerates with 2 input channels: 0.80 ms of a 19.4 ms step).  Only used when
-    the input needs no gradient (the dmcnet variant feeds ``gen_flow.detach()``)."""
+    forward convolution is MIOpen's; with 2 input channels MIOpen's implicit-GEMM *gradients*
+    degenerate (weight gradient 0.80 ms, data gradient 2.1 ms at 120 frames), so
+      * the weight gradient is dmc_stem_wgrad (0.24 ms, deterministic);
+      * the data gradient (needed only by the GAN variant, whose classifier loss reaches the
+        generator) is a batched GEMM  W^T[98,64] x dy[64, OH*OW]  followed by ``fold`` (col2im)."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -427,19 +429,26 @@ class _StemConv(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         n, _, h, w = x.shape
         dy = dy.contiguous(memory_format=torch.channels_last)
-        dw = torch.empty((64, 2, 7, 7), dtype=torch.float32, device=x.device)
-        partials = _floats(lib.dmc_stem_wgrad_partials_bytes(n, h, w), x.device)
-        with _span("stem_wgrad"):
-            _lib.check(lib.dmc_stem_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(partials),
-                                          n, h, w, _stream()), "dmc_stem_wgrad")
-        if weight.is_contiguous(memory_format=torch.channels_last) and not weight.is_contiguous():
-            dw = dw.contiguous(memory_format=torch.channels_last)
-        return None, dw
+        dw = dx = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((64, 2, 7, 7), dtype=torch.float32, device=x.device)
+            partials = _floats(lib.dmc_stem_wgrad_partials_bytes(n, h, w), x.device)
+            with _span("stem_wgrad"):
+                _lib.check(lib.dmc_stem_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(partials),
+                                              n, h, w, _stream()), "dmc_stem_wgrad")
+            if weight.is_contiguous(memory_format=torch.channels_last) and not weight.is_contiguous():
+                dw = dw.contiguous(memory_format=torch.channels_last)
+        if ctx.needs_input_grad[0]:
+            oh, ow = dy.shape[2], dy.shape[3]
+            g = dy.permute(0, 2, 3, 1).reshape(n, oh * ow, 64)            # a view of the NHWC storage
+            cols = torch.matmul(weight.reshape(64, 98).t(), g.transpose(1, 2))   # [N, 98, OH*OW]
+            dx = torch.nn.functional.fold(cols, (h, w), kernel_size=7, padding=3, stride=2)
+        return dx, dw
 
 
 def stem_conv_supported(x, weight):
     """True when ``conv2d(x, weight, stride 2, padding 3)`` can take the HIP weight gradient."""
-    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and not x.requires_grad
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32
             and tuple(weight.shape) == (64, 2, 7, 7) and weight.dtype == torch.float32
             and x.shape[1] == 2
             and bool(_lib.load().dmc_stem_wgrad_supported(int(x.shape[2]), int(x.shape[3]))))

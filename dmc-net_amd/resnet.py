@@ -86,11 +86,11 @@ class ResNet(nn.Module):
         self.fc = nn.Linear(width, num_classes)
 
     def _stem(self, x):
-        # 2-channel flow input without a gradient (dmcnet variant): HIP weight gradient for conv1
+        # 2-channel flow input: own gradients for conv1 (MIOpen's degenerate with 2 input channels)
         c = self.conv1
         if (c.in_channels == 2 and c.bias is None and c.stride == (2, 2) and c.padding == (3, 3)
                 and c.dilation == (1, 1) and c.groups == 1 and torch.is_grad_enabled()
-                and c.weight.requires_grad and ops.stem_conv_supported(x, c.weight)):
+                and (c.weight.requires_grad or x.requires_grad) and ops.stem_conv_supported(x, c.weight)):
             return ops.stem_conv(x, c.weight)
         return c(x)
 

@@ -415,7 +415,14 @@ def test_stem_wgrad_unit(n, h, w):
         wg.grad = None
         (ops.stem_conv(xg, wg) * go.to(DEV)).sum().backward()
         assert torch.equal(g1, wg.grad)
-    assert not ops.stem_conv_supported(x.to(DEV).requires_grad_(True), wg)       # input gradient: stock path
+    # data gradient (GAN variant): GEMM + fold against autograd
+    xo = x.double().requires_grad_(True)
+    (F.conv2d(xo, wt.double(), None, 2, 3) * go.double()).sum().backward()
+    xg = x.to(DEV).requires_grad_(True)
+    wg2 = wt.to(DEV)                                   # no weight gradient wanted: only dx is computed
+    assert ops.stem_conv_supported(xg, wg2)
+    (ops.stem_conv(xg, wg2) * go.to(DEV)).sum().backward()
+    assert rel_err(xg.grad, xo.grad.float()) < 2e-5
     assert not ops.stem_conv_supported(rnd(74, (1, 2, 10, 10)).to(DEV), wg)                 # W % 4 != 0
 
 
