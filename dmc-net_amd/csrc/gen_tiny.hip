@@ -469,14 +469,19 @@ struct MfmaGeom {
     static constexpr int NROW = 3 * COUT;
     static constexpr int NT = (NROW + 3) / 4;
     static constexpr int NTP = NT <= 2 ? 2 : NT <= 4 ? 4 : 8;     // padded tile count (vector loads)
-    static constexpr int NCHUNK = (CIN + LCH - 1) / LCH;
-    static constexpr int WL = NCHUNK * LCH * 3 * 4 * NTP;          // LDS weight copy, zero rows for channels >= CIN
+    // channels per staged chunk: 4, except 3 for the compute-bound layer 2 (21 input channels pad
+    // to nothing instead of 24: -12 % MFMAs; measured 242 -> 229 us).  Layer 3 (27 = 9 x 3) is at
+    // the HBM roof and got slower with the smaller chunks (more barriers, less data in flight)
+    static constexpr int CH = (MODE != 2 && CIN == 21) ? 3 : LCH;
+    static constexpr int NCHUNK = (CIN + CH - 1) / CH;
+    static constexpr int DMA = CH * P_ROWS;                        // row transfers per chunk
+    static constexpr int WL = NCHUNK * CH * 3 * 4 * NTP;           // LDS weight copy, zero rows for channels >= CIN
 };
 
 // LDS-DMA issued through inline assembly: the compiler does not see an LDS write, so it inserts
 // no s_waitcnt vmcnt(0) in front of the consumers' ds_reads (with the builtin it does, which
 // serialises every prefetch with the compute it was meant to overlap).  Completion is tracked
-// by hand with s_waitcnt vmcnt(RING_DMA): "everything but the newest chunk has landed".
+// by hand with s_waitcnt vmcnt(<row transfers per chunk>): "everything but the newest chunk has landed".
 __device__ __forceinline__ void dma_row16(unsigned long long src, unsigned lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                  :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)) : "memory");
@@ -509,9 +514,10 @@ __device__ __forceinline__ void ring_stage(const LayerArgs& a, unsigned slot_byt
     constexpr int CIN = MfmaGeom<MODE, K>::CIN;
     const unsigned long long zaddr = (unsigned long long)zero;
     const bool interior = ty0 >= 1 && ty0 + PT_H < a.H;                            // rows ty0-1 .. ty0+PT_H all inside
+    constexpr int CH = MfmaGeom<MODE, K>::CH;
 #pragma unroll
-    for (int cc = 0; cc < LCH; ++cc) {
-        const int ch = c * LCH + cc;
+    for (int cc = 0; cc < CH; ++cc) {
+        const int ch = c * CH + cc;
         unsigned long long base;
         long pidx;
         if (MODE == 2) {
@@ -548,7 +554,7 @@ __device__ __forceinline__ void ring_stage(const LayerArgs& a, unsigned slot_byt
     }
 }
 
-// consumer: one staged chunk = LCH stages of 3 K-steps (dy) x 4 segments x NT row tiles.  The LDS
+// consumer: one staged chunk = CH stages of 3 K-steps (dy) x 4 segments x NT row tiles.  The LDS
 // operands of stage cc+1 are requested before the MFMAs of stage cc (register double buffer);
 // sched_barriers keep the compiler from hoisting every load of the chunk to the top.
 template <int MODE, int K, int NT_>
@@ -579,8 +585,8 @@ __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[M_SEGS][NT_], const floa
     };
     load_stage(0, 0);
 #pragma unroll
-    for (int cc = 0; cc < LCH; ++cc) {
-        if (cc + 1 < LCH) load_stage(cc + 1, (cc + 1) & 1);
+    for (int cc = 0; cc < G::CH; ++cc) {
+        if (cc + 1 < G::CH) load_stage(cc + 1, (cc + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
@@ -641,7 +647,7 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_layer_mfma_kernel(RingArgs ra
 #pragma unroll 1
         for (int q = 0; q < nitems; ++q) {
             // chunk q has landed (only chunk q+1 may still be in flight); consumers are done with q-1
-            if (q + 1 < nitems) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(RING_DMA) : "memory");
+            if (q + 1 < nitems) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(G::DMA) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             if (q + 2 < nitems) {
                 const int c2 = c + 2, tile2 = tile + (c2 / NCHUNK) * t_step, n2 = tile2 / ra.tiles_y;
@@ -683,7 +689,7 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_layer_mfma_kernel(RingArgs ra
 #pragma unroll 1
     for (int q = 0; q < nitems; ++q) {
         asm volatile("s_barrier" ::: "memory");
-        mfma_chunk<MODE, K, NT>(acc, lds + slot * P_BUF, wl, c * LCH, boff, lane);
+        mfma_chunk<MODE, K, NT>(acc, lds + slot * P_BUF, wl, c * G::CH, boff, lane);
         slot = slot + 1 == RING ? 0 : slot + 1;
         if (++c < NCHUNK) continue;
         c = 0;
