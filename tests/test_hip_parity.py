@@ -426,6 +426,46 @@ def test_stem_wgrad_unit(n, h, w):
     assert not ops.stem_conv_supported(rnd(74, (1, 2, 10, 10)).to(DEV), wg)                 # W % 4 != 0
 
 
+def test_stem_kernels_full_size_properties():
+    """BASELINE size (120 frames): size-independent properties of the stem kernels.
+    conv1 weight gradient: linear in dy and additive over a split of the batch; fused
+    bn1+ReLU+maxpool: agrees with the stock modules run on the same device, and its input gradient
+    sums to ~0 per channel (a BatchNorm backward property: sum_x dx = 0)."""
+    n, h, w = 120, 224, 224
+    g = torch.Generator(device=DEV).manual_seed(91)
+    x = torch.randn((n, 2, h, w), device=DEV, generator=g)
+    wt = (torch.randn((64, 2, 7, 7), device=DEV, generator=g) * 0.1).contiguous(memory_format=torch.channels_last)
+    go = torch.randn((n, 64, 112, 112), device=DEV, generator=g).contiguous(memory_format=torch.channels_last)
+
+    def wgrad(xs, gs, scale=1.0):
+        wp = wt.clone().requires_grad_(True)
+        (ops.stem_conv(xs, wp) * (gs * scale)).sum().backward()
+        return wp.grad
+    full = wgrad(x, go)
+    assert rel_err(wgrad(x, go, 2.0), 2.0 * full) < 1e-6
+    halves = wgrad(x[:60], go[:60]) + wgrad(x[60:], go[60:])
+    assert rel_err(halves, full) < 2e-5
+    assert torch.equal(full, wgrad(x, go))                                    # deterministic
+
+    act = torch.randn((n, 64, 112, 112), device=DEV, generator=g).contiguous(memory_format=torch.channels_last)
+    gp = torch.randn((n, 64, 56, 56), device=DEV, generator=g).contiguous(memory_format=torch.channels_last)
+    bn_a, bn_b = torch.nn.BatchNorm2d(64).to(DEV), torch.nn.BatchNorm2d(64).to(DEV)
+    with torch.no_grad():
+        bn_a.weight.uniform_(0.5, 1.5, generator=g); bn_a.bias.uniform_(-0.5, 0.5, generator=g)
+    bn_b.load_state_dict(bn_a.state_dict())
+    xa = act.clone().requires_grad_(True)
+    ya = ops.bn_relu_pool(xa, bn_a)
+    (ya * gp).sum().backward()
+    xb = act.clone().requires_grad_(True)
+    yb = torch.nn.functional.max_pool2d(torch.relu(bn_b(xb)), 3, 2, 1)
+    (yb * gp).sum().backward()
+    assert rel_err(ya, yb) < 1e-5
+    assert rel_err(xa.grad, xb.grad) < 1e-4
+    assert rel_err(bn_a.weight.grad, bn_b.weight.grad) < 1e-4 and rel_err(bn_a.bias.grad, bn_b.bias.grad) < 1e-4
+    per_channel = xa.grad.sum(dim=(0, 2, 3)).abs().max() / xa.grad.abs().sum(dim=(0, 2, 3)).max()
+    assert float(per_channel) < 1e-5
+
+
 @pytest.mark.parametrize("shape,res,relu", [((4, 64, 56, 56), False, True), ((4, 64, 56, 56), True, True),
                                              ((3, 128, 7, 9), True, True), ((2, 512, 7, 7), False, False),
                                              ((6, 256, 14, 14), True, False)])
