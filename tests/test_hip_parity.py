@@ -75,6 +75,46 @@ def test_generator_edge_shapes(shape, delta):
         assert rel_err(pm.grad, po.grad) < 1e-4, k
 
 
+@pytest.mark.parametrize("sign", [1.0, -1.0])
+def test_generator_full_batch_vs_oracle(sign):
+    """BASELINE size, 120 frames of 224x224 (3,360 tiles: every persistent workgroup walks ~13
+    tiles through its LDS ring, which the smaller cases never do): forward and all twelve parameter
+    gradients against the CPU oracle.
+    With generic weights this comparison is ill-conditioned at this size: among 170 million hidden
+    pre-activations some lie within rounding of zero, a different fp32 summation order flips their
+    LeakyReLU branch, and each flip moves a gradient entry by ~1e-3 of its size (measured: every
+    implementation, including the independent VALU kernels, sits 2e-4 .. 1.5e-3 from an fp64
+    evaluation).  The test therefore pins the branches: small hidden weights and biases of +1 (all
+    slopes 1) or -1 (all slopes 0.1) -- every tile, halo row, channel mapping and reduction is
+    still exercised, and the result must match an fp64 evaluation as well as the fp32 oracle does."""
+    import copy
+    o, m = tiny_pair(14)
+    with torch.no_grad():
+        for name, p in o.named_parameters():
+            if name.startswith("conv_"):
+                if name.endswith("weight"):
+                    p.mul_(0.02)
+                else:
+                    p.fill_(sign)
+    m.load_state_dict(o.state_dict())
+    x = rnd(21, (120, 5, 224, 224))
+    r = rnd(22, (120, 2, 224, 224))
+    yo = o(x) + x[:, :2]
+    (yo * r).sum().backward()
+    o64 = copy.deepcopy(o).double()
+    for p in o64.parameters():
+        p.grad = None
+    ((o64(x.double()) + x[:, :2].double()) * r.double()).sum().backward()
+    y = m.forward_mv_res(x[:, :2].contiguous().to(DEV), x[:, 2:].contiguous().to(DEV), add_mv=True)
+    (y * r.to(DEV)).sum().backward()
+    assert rel_err(y, yo) < 1e-5
+    for (k, po), (_, pm), (_, p64) in zip(o.named_parameters(), m.named_parameters(), o64.named_parameters()):
+        scale = float(p64.grad.abs().max())
+        e_hip = float((pm.grad.double().cpu() - p64.grad).abs().max()) / scale
+        e_ref = float((po.grad.double() - p64.grad).abs().max()) / scale
+        assert e_hip <= max(4 * e_ref, 2e-5), (k, e_hip, e_ref)
+
+
 def test_generator_linearity_in_last_layer_and_determinism():
     """Size-independent properties at the full 224x224 size: the output is affine in
     predict_flow's parameters, and two runs are bit-identical (fixed-order reductions)."""
