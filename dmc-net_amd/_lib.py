@@ -36,8 +36,8 @@ SIGNATURES = {
     "dmc_prepare_inputs": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "dmc_bn_act_supported": (_I, [_I, _I]),
     "dmc_bn_act_stats_bytes": (_Z, [_I]),
-    "dmc_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
-    "dmc_bn_act_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "dmc_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
+    "dmc_bn_act_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "dmc_bn_relu_pool_supported": (_I, [_I, _I, _I, _I]),
     "dmc_bn_relu_pool_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P]),
     "dmc_bn_relu_pool_codes_bytes": (_Z, [_I, _I, _I, _I]),

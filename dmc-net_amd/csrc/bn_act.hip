@@ -30,6 +30,7 @@ struct BnArgs {
     float* dx;
     float* dres;           // nullable
     int M, C, relu;
+    unsigned char* mask;   // nullable: 4 ReLU sign bits per float4 (written by the forward, read by the backward)
 };
 
 // MODE 0: per-channel (sum x, sum x^2).   MODE 1: (sum dz, sum dz * xhat), dz = dy * relu'(.)
@@ -60,7 +61,11 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(BnArgs a, double* __res
             float4 d = reinterpret_cast<const float4*>(a.dy)[o];
             const float4 xh = make_float4((x.x - mean.x) * istd.x, (x.y - mean.y) * istd.y,
                                           (x.z - mean.z) * istd.z, (x.w - mean.w) * istd.w);
-            if (a.relu) {
+            if (a.relu && a.mask) {                 // sign bits saved by the forward: no residual re-read
+                const unsigned mb = a.mask[o];
+                d.x = (mb & 1) ? d.x : 0.f; d.y = (mb & 2) ? d.y : 0.f;
+                d.z = (mb & 4) ? d.z : 0.f; d.w = (mb & 8) ? d.w : 0.f;
+            } else if (a.relu) {
                 float4 v = make_float4(fmaf(xh.x, g.x, b.x), fmaf(xh.y, g.y, b.y),
                                        fmaf(xh.z, g.z, b.z), fmaf(xh.w, g.w, b.w));
                 if (a.res) {
@@ -165,6 +170,8 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(BnArgs a) {
             v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
         }
         if (a.relu) {
+            if (a.mask)
+                a.mask[o] = (unsigned char)((v.x > 0.f ? 1 : 0) | (v.y > 0.f ? 2 : 0) | (v.z > 0.f ? 4 : 0) | (v.w > 0.f ? 8 : 0));
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
         reinterpret_cast<float4*>(a.y)[o] = v;
@@ -188,7 +195,11 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(BnArgs a, const float
         float4 d = reinterpret_cast<const float4*>(a.dy)[o];
         const float4 xh = make_float4((x.x - mean.x) * istd.x, (x.y - mean.y) * istd.y,
                                       (x.z - mean.z) * istd.z, (x.w - mean.w) * istd.w);
-        if (a.relu) {
+        if (a.relu && a.mask) {
+            const unsigned mb = a.mask[o];
+            d.x = (mb & 1) ? d.x : 0.f; d.y = (mb & 2) ? d.y : 0.f;
+            d.z = (mb & 4) ? d.z : 0.f; d.w = (mb & 8) ? d.w : 0.f;
+        } else if (a.relu) {
             float4 v = make_float4(fmaf(xh.x, g.x, b.x), fmaf(xh.y, g.y, b.y), fmaf(xh.z, g.z, b.z),
                                    fmaf(xh.w, g.w, b.w));
             if (a.res) {
@@ -430,13 +441,14 @@ size_t dmc_bn_act_stats_bytes(int C) {
 }
 
 int dmc_bn_act_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
-                   float* running_mean, float* running_var, float* y, float* stats, int M, int C,
-                   int relu, int training, float eps, float momentum, dmc_stream_t stream) {
+                   float* running_mean, float* running_var, float* y, float* stats,
+                   unsigned char* relu_mask, int M, int C, int relu, int training, float eps,
+                   float momentum, dmc_stream_t stream) {
     if (!x || !gamma || !beta || !running_mean || !running_var || !y || !stats)
         return fail(DMC_E_INVALID, "dmc_bn_act_fwd: null pointer");
     if (!shape_ok(M, C)) return fail(DMC_E_INVALID, "dmc_bn_act_fwd: unsupported shape M=%d C=%d", M, C);
     hipStream_t s = (hipStream_t)stream;
-    BnArgs a = {x, residual, gamma, beta, stats, nullptr, y, nullptr, nullptr, M, C, relu};
+    BnArgs a = {x, residual, gamma, beta, stats, nullptr, y, nullptr, nullptr, M, C, relu, relu_mask};
     double* scratch = scratch_of(stats, C);
     int rc;
     const int split = split_of(M);
@@ -453,12 +465,14 @@ int dmc_bn_act_fwd(const float* x, const float* residual, const float* gamma, co
 
 int dmc_bn_act_bwd(const float* x, const float* residual, const float* gamma, const float* beta,
                    float* stats, const float* dy, float* dx, float* dresidual, float* dgamma,
-                   float* dbeta, int M, int C, int relu, dmc_stream_t stream) {
+                   float* dbeta, const unsigned char* relu_mask, int M, int C, int relu,
+                   dmc_stream_t stream) {
     if (!x || !gamma || !beta || !stats || !dy || !dx || !dgamma || !dbeta)
         return fail(DMC_E_INVALID, "dmc_bn_act_bwd: null pointer");
     if (!shape_ok(M, C)) return fail(DMC_E_INVALID, "dmc_bn_act_bwd: unsupported shape M=%d C=%d", M, C);
     hipStream_t s = (hipStream_t)stream;
-    BnArgs a = {x, residual, gamma, beta, stats, dy, nullptr, dx, dresidual, M, C, relu};
+    BnArgs a = {x, residual, gamma, beta, stats, dy, nullptr, dx, dresidual, M, C, relu,
+                const_cast<unsigned char*>(relu_mask)};
     double* scratch = scratch_of(stats, C);
     int rc;
     const int split = split_of(M);
@@ -483,7 +497,7 @@ int dmc_bn_relu_pool_fwd(const float* x, const float* gamma, const float* beta, 
         return fail(DMC_E_INVALID, "dmc_bn_relu_pool_fwd: unsupported shape N=%d H=%d W=%d C=%d", N, H, W, C);
     hipStream_t s = (hipStream_t)stream;
     const int M = N * H * W;
-    BnArgs a = {x, nullptr, gamma, beta, stats, nullptr, nullptr, nullptr, nullptr, M, C, 1};
+    BnArgs a = {x, nullptr, gamma, beta, stats, nullptr, nullptr, nullptr, nullptr, M, C, 1, nullptr};
     double* scratch = scratch_of(stats, C);
     int rc;
     const int split = split_of(M);

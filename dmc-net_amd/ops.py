@@ -267,20 +267,25 @@ class _BnAct(torch.autograd.Function):
         m = n * h * w
         y = torch.empty_like(x)           # keeps the channels_last strides
         stats = _floats(lib.dmc_bn_act_stats_bytes(c), x.device)
+        # with a residual the ReLU sign depends on it: keep 4 sign bits per float4 (1/16 of the
+        # residual's size) so that the backward neither re-reads nor even keeps the residual
+        mask = None
+        if relu and training and residual is not None:
+            mask = torch.empty(m * (c // 4), dtype=torch.uint8, device=x.device)
         with _span("bn_act_fwd"):
             _lib.check(lib.dmc_bn_act_fwd(_lib.ptr(x), _lib.ptr(residual), _lib.ptr(gamma),
                                           _lib.ptr(beta), _lib.ptr(running_mean),
-                                          _lib.ptr(running_var), _lib.ptr(y), _lib.ptr(stats), m, c,
-                                          int(relu), int(training), float(eps), float(momentum),
-                                          _stream()), "dmc_bn_act_fwd")
-        ctx.save_for_backward(x, residual if relu else None, gamma, beta, stats)
+                                          _lib.ptr(running_var), _lib.ptr(y), _lib.ptr(stats),
+                                          _lib.ptr(mask), m, c, int(relu), int(training), float(eps),
+                                          float(momentum), _stream()), "dmc_bn_act_fwd")
+        ctx.save_for_backward(x, residual if (relu and mask is None) else None, gamma, beta, stats, mask)
         ctx.relu, ctx.training, ctx.has_res = bool(relu), bool(training), residual is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x, residual, gamma, beta, stats = ctx.saved_tensors
+        x, residual, gamma, beta, stats, mask = ctx.saved_tensors
         if not ctx.training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not implemented")
         n, c, h, w = x.shape
@@ -293,7 +298,7 @@ class _BnAct(torch.autograd.Function):
         with _span("bn_act_bwd"):
             _lib.check(lib.dmc_bn_act_bwd(_lib.ptr(x), _lib.ptr(residual), _lib.ptr(gamma),
                                           _lib.ptr(beta), _lib.ptr(stats), _lib.ptr(dy), _lib.ptr(dx),
-                                          _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta),
+                                          _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(mask),
                                           n * h * w, c, int(ctx.relu), _stream()), "dmc_bn_act_bwd")
         if want_dres and not ctx.relu:
             dres = dy

@@ -149,16 +149,21 @@ int dmc_disc_tail_bwd(const float* x, const float* keep, const float* gamma, flo
  * as nn.BatchNorm2d does.  dmc_bn_act_supported() tells whether (M, C) is handled
  * (C % 4 == 0, C/4 <= 256, 256 % (C/4) == 0); callers use the stock op otherwise.
  * stats: workspace of dmc_bn_act_stats_bytes(C); the forward leaves (mean, invstd) in its first
- * 2*C floats for the backward.  The backward recomputes the ReLU mask from x (and residual).
+ * 2*C floats for the backward.  relu_mask (nullable, M*C/4 bytes): the forward stores the four ReLU
+ * sign bits of every float4; a backward given the same buffer reads them instead of re-reading the
+ * residual (`residual` may then be NULL).  Without it the backward recomputes the signs from x
+ * (and residual).
  */
 int dmc_bn_act_supported(int M, int C);
 size_t dmc_bn_act_stats_bytes(int C);
 int dmc_bn_act_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
-                   float* running_mean, float* running_var, float* y, float* stats, int M, int C,
-                   int relu, int training, float eps, float momentum, dmc_stream_t stream);
+                   float* running_mean, float* running_var, float* y, float* stats,
+                   unsigned char* relu_mask, int M, int C, int relu, int training, float eps,
+                   float momentum, dmc_stream_t stream);
 int dmc_bn_act_bwd(const float* x, const float* residual, const float* gamma, const float* beta,
                    float* stats, const float* dy, float* dx, float* dresidual, float* dgamma,
-                   float* dbeta, int M, int C, int relu, dmc_stream_t stream);
+                   float* dbeta, const unsigned char* relu_mask, int M, int C, int relu,
+                   dmc_stream_t stream);
 
 /* ---- GPU-side input preparation -----------------------------------------------------------------
  * Replaces the tensor side of CoviarDataSet.__getitem__, code/dmcnet/dataset.py:215-263 (channel
