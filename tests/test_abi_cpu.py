@@ -50,6 +50,16 @@ def test_hot_path_fails_loudly_on_cpu_tensors():
         m(mv, res)
     with pytest.raises(_lib.DmcHipError):
         dmcnet_amd.ops.flow_mse(torch.zeros(4), torch.zeros(4))
+    # the classifier-side HIP ops refuse CPU tensors too (their callers fall back to stock modules
+    # only through the *_supported() predicates, which are False on the CPU)
+    bn = torch.nn.BatchNorm2d(64)
+    xcl = torch.zeros(2, 64, 8, 8).contiguous(memory_format=torch.channels_last)
+    assert not dmcnet_amd.ops.bn_act_supported(xcl) and not dmcnet_amd.ops.bn_relu_pool_supported(xcl)
+    assert not dmcnet_amd.ops.stem_conv_supported(torch.zeros(1, 2, 8, 8), torch.zeros(64, 2, 7, 7))
+    for call in (lambda: dmcnet_amd.ops.bn_act(xcl, bn), lambda: dmcnet_amd.ops.bn_relu_pool(xcl, bn),
+                 lambda: dmcnet_amd.ops.stem_conv(torch.zeros(1, 2, 8, 8), torch.zeros(64, 2, 7, 7))):
+        with pytest.raises(_lib.DmcHipError):
+            call()
 
 
 @pytest.mark.parametrize("arch_d", [None, "Discriminator", "Discriminator3", "Discriminator4"])
