@@ -462,6 +462,11 @@ constexpr int RING = 3;                             // chunk buffers: one comput
 constexpr int RING_DMA = LCH * P_ROWS;              // 40 row transfers per chunk, all by the producer
 static_assert(RING_DMA <= 63, "vmcnt is a 6-bit counter");
 
+// Scheduling fences around each stage's MFMA group: needed while the kernels were register-starved
+// (without them the compiler hoisted every LDS load of a chunk and spilled); since the producer /
+// consumer split its own schedule is as good or better (layers 4+5: 286 -> 265 us), except for the
+// 6-tile (Cout 8) push kernels, which keep them.
+constexpr int FENCE_MIN_NT = 6;
 template <int MODE, int K>
 struct MfmaGeom {
     static constexpr int CIN = MODE == 2 ? gin_of(K) : cin_of(K);
@@ -475,6 +480,7 @@ struct MfmaGeom {
     static constexpr int CH = (MODE != 2 && CIN == 21) ? 3 : LCH;
     static constexpr int NCHUNK = (CIN + CH - 1) / CH;
     static constexpr int DMA = CH * P_ROWS;                        // row transfers per chunk
+    static constexpr bool FENCE = FENCE_MIN_NT <= NT;             // scheduling fences around the MFMA groups
     static constexpr int WL = NCHUNK * CH * 3 * 4 * NTP;           // LDS weight copy, zero rows for channels >= CIN
 };
 
@@ -587,7 +593,7 @@ __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[M_SEGS][NT_], const floa
 #pragma unroll
     for (int cc = 0; cc < G::CH; ++cc) {
         if (cc + 1 < G::CH) load_stage(cc + 1, (cc + 1) & 1);
-        __builtin_amdgcn_sched_barrier(0);
+        if (G::FENCE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -595,7 +601,7 @@ __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[M_SEGS][NT_], const floa
 #pragma unroll
                 for (int t = 0; t < G::NT; ++t)
                     acc[s][t] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[cc & 1][dy][t], b[cc & 1][dy][s], acc[s][t], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        if (G::FENCE) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -982,7 +988,6 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_l45_kernel(RingArgs ra) {
 #pragma unroll
             for (int cc = 0; cc < F_LCH; ++cc) {
                 if (cc + 1 < F_LCH) load_stage(cc + 1, (cc + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
@@ -994,7 +999,6 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_l45_kernel(RingArgs ra) {
                     for (int t = 0; t < 2; ++t)      // halo pixels: rows 0..5 (layer 4); rows 6, 7 of tile 1 are ignored
                         acc4e[0][t] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[cc & 1][dy][t], b[cc & 1][dy][F_S5], acc4e[0][t], 0, 0, 0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
         slot = slot + 1 == RING ? 0 : slot + 1;
@@ -1285,7 +1289,6 @@ __global__ __launch_bounds__(G_THREADS) void gen_layer_gather_kernel(RingArgs ra
 #pragma unroll
             for (int st = 0; st < G_LCH * 3; ++st) {
                 if (st + 1 < G_LCH * 3) load_stage(st + 1, (st + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
@@ -1293,7 +1296,6 @@ __global__ __launch_bounds__(G_THREADS) void gen_layer_gather_kernel(RingArgs ra
 #pragma unroll
                         for (int t = 0; t < NT; ++t)
                             acc[s][t] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[st & 1][dx][t], b[st & 1][dx][s], acc[s][t], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
         slot = slot + 1 == RING ? 0 : slot + 1;
