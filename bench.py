@@ -30,6 +30,24 @@ GEN_FLOP_PER_PX = 9108         # 4,554 MAC, SURVEY.md 8(d)
 GEN_BYTES_PER_PX = 28          # read 5 ch + write 2 ch fp32 (fused, inference-style)
 
 HP = dict(lr=0.01, weight_decay=1e-4, lr_cls_mult=0.01, lr_mse_mult=1.0)
+TRAFFIC_JSON = os.path.join("profiles", "r2_gen_traffic.json")
+
+
+def measured_traffic(px):
+    """HBM bytes per generator-forward call from the PMC counters: collected with rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE (separate passes, calibrated; tools/pmc_traffic.py) on the SAME kernel
+    source -- the JSON records the sha256 of gen_tiny.hip it was measured on and the figure is
+    reported only while that still matches the source in the tree (else null: stale)."""
+    import hashlib
+    path = os.path.join(ROOT, TRAFFIC_JSON)
+    if not os.path.exists(path):
+        return None, "no PMC measurement in the tree (%s)" % TRAFFIC_JSON
+    rec = json.load(open(path))
+    src = os.path.join(ROOT, "dmc-net_amd", "csrc", "gen_tiny.hip")
+    sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+    if rec.get("kernel_source_sha16") != sha:
+        return None, "%s was measured on another version of gen_tiny.hip (stale, not reported)" % TRAFFIC_JSON
+    return int(rec["gen_fwd_bytes_per_px"] * px), "%s: %s; kernel source sha16 %s" % (TRAFFIC_JSON, rec["method"], sha)
 
 
 def usable_cores():
@@ -44,7 +62,10 @@ def usable_cores():
     return max(1, min(n, 64))     # beyond ~64 threads torch's CPU convs stop scaling
 
 
-def cpu_baseline(batch, num_segments, num_class, budget_s=20.0):
+CPU_TIMED_STEPS = 5
+
+
+def cpu_baseline(batch, num_segments, num_class, budget_s=30.0):
     """The oracle's dmcnet train step on the host cores (kind 'port')."""
     from oracle import dmc_oracle as O
     cores = usable_cores()
@@ -59,18 +80,21 @@ def cpu_baseline(batch, num_segments, num_class, budget_s=20.0):
     t0 = time.time()
     O.dmcnet_train_step(m, oc, og, probe, num_segments, 1.0, 10.0)
     per_clip = (time.time() - t0) / 2
-    b = int(max(2, min(batch, budget_s / 2 / max(per_clip, 1e-6))))
+    b = int(max(2, min(batch, budget_s / (CPU_TIMED_STEPS + 1) / max(per_clip, 1e-6))))
     data = O.synthetic_batch(1234, b, num_segments, num_class, flow_ds_factor=16)
+    O.dmcnet_train_step(m, oc, og, data, num_segments, 1.0, 10.0)      # warm-up at the timed size
     times = []
-    for _ in range(2):
+    for _ in range(CPU_TIMED_STEPS):
         t0 = time.time()
         O.dmcnet_train_step(m, oc, og, data, num_segments, 1.0, 10.0)
         times.append(time.time() - t0)
-    dt = min(times)
+    dt = sorted(times)[len(times) // 2]
     return {"value": round(b / dt, 3), "unit": "clips/sec", "cores": cores, "kind": "port",
             "sample": "oracle dmcnet train step (torch CPU fp32, %d threads), %d clips x %d segments x "
-                      "224x224 per step (the B=%d workload cut to fit ~%ds), best of 2 timed steps after "
-                      "warm-up" % (cores, b, num_segments, batch, int(budget_s))}
+                      "224x224 per step (the B=%d workload cut to fit ~%ds of CPU work), median of %d timed "
+                      "steps after 2 warm-ups (SURVEY 8d)" % (cores, b, num_segments, batch, int(budget_s),
+                                                               CPU_TIMED_STEPS),
+            "step_s": [round(t, 3) for t in times]}
 
 
 def bench_i3d(args, rank, world, dev):
@@ -132,8 +156,8 @@ def bench_i3d(args, rank, world, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)      # >= 50 timed steps after 10 warm-ups
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=40, help="clips per GPU")
     ap.add_argument("--num-class", type=int, default=51)
     ap.add_argument("--config", default="dmcnet", choices=["dmcnet", "gan", "i3d"])
@@ -178,7 +202,7 @@ def main():
     torch.backends.cudnn.benchmark = bool(args.miopen_find)   # (enable_find above also set the db path)
     if os.environ.get("DMC_CHANNELS_LAST") == "0":
         model.base_model.to(memory_format=torch.contiguous_format)
-    reducer = ddp.GradBucketReducer(list(model.parameters())) if world > 1 else None
+    reducer = ddp.for_model(model) if world > 1 else None
     if gan:
         stepper = train.GanTrainStep(model, S, 1.0, 1.0, 0.01, 10.0, lr_d_mult=1.0, reducer=reducer, **HP)
     else:
@@ -197,9 +221,14 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     ops.profile_mark()
+    # one event per step boundary (recorded on the launch stream, read after the region): per-step
+    # device times for the median; the headline stays the wall time of the whole region
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         out = one(i)
+        marks[i + 1].record()
     ops.profile_mark()
     torch.cuda.synchronize()
     if world > 1:
@@ -212,6 +241,11 @@ def main():
         elapsed = float(t)
     loss = float(out["loss"])
     spans = probe.summary()
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    if gan and args.steps > 1:      # D and G steps alternate: a "step" is their pair average
+        pair = [marks[i].elapsed_time(marks[i + 2]) / 2 for i in range(0, args.steps - 1, 2)]
+        step_ms = sorted(pair)
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
 
     if rank == 0:
         n_frames = args.batch * S
@@ -219,17 +253,13 @@ def main():
         fwd_ms, _ = spans["gen_tiny_fwd"]
         tf = px * GEN_FLOP_PER_PX / (fwd_ms * 1e-3) / 1e12
         gbs = px * GEN_BYTES_PER_PX / (fwd_ms * 1e-3) / 1e9
-        # HBM bytes per forward call from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, calibrated;
-        # collected offline with tools/pmc_traffic.py, see profiles/r1_gen_traffic.csv)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1_gen_traffic.json")
-        if os.path.exists(tpath):
-            traffic = int(json.load(open(tpath))["gen_fwd_bytes_per_px"] * px)
+        traffic, traffic_src = measured_traffic(px)
         line = {
             "metric": "clips/sec (3-seg 224x224) DMC-gen+ResNet-18 train step",
             "value": round(world * args.batch * args.steps / elapsed, 3), "unit": "clips/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "ms_per_step_median": round(median_ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("dmcnet_GAN HMDB-51 split1 (Discriminator3, alternating D/G)" if gan else
                                     "HMDB-51 split1 dmcnet (no GAN), 3 segments, ResNet-18, DenseNetTiny "
@@ -246,7 +276,8 @@ def main():
                 "launch_ms": round(fwd_ms, 4),
                 "hbm": {"achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 5),
-                        "note": "algorithmic 28 B/px; 'traffic' = measured HBM bytes of the layer launches (layers 4+5 are one fused launch)",
+                        "note": "algorithmic 28 B/px; 'traffic' = measured HBM bytes of the forward's launches",
+                        "traffic_source": traffic_src,
                         "traffic_gbs": None if traffic is None else round(traffic / (fwd_ms * 1e-3) / 1e9, 1)}},
             "kernels_ms": {k: round(v[0], 4) for k, v in spans.items()},
         }

@@ -19,6 +19,8 @@ SIGNATURES = {
     "dmc_version": (_I, []),
     "dmc_last_error": (ctypes.c_char_p, []),
     "dmc_profile_mark": (_I, [_P]),
+    "dmc_set_option": (_I, [ctypes.c_char_p, _I]),
+    "dmc_get_option": (_I, [ctypes.c_char_p]),
     "dmc_gen_tiny_workspace_bytes": (_Z, []),
     "dmc_gen_tiny_saved_bytes": (_Z, [_I, _I, _I]),
     "dmc_gen_tiny_gbuf_bytes": (_Z, [_I, _I, _I]),
@@ -36,12 +38,13 @@ SIGNATURES = {
     "dmc_prepare_inputs": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "dmc_bn_act_supported": (_I, [_I, _I]),
     "dmc_bn_act_stats_bytes": (_Z, [_I]),
-    "dmc_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
-    "dmc_bn_act_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "dmc_bn_act_scratch_bytes": (_Z, [_I]),
+    "dmc_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
+    "dmc_bn_act_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "dmc_bn_relu_pool_supported": (_I, [_I, _I, _I, _I]),
-    "dmc_bn_relu_pool_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P]),
+    "dmc_bn_relu_pool_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P]),
     "dmc_bn_relu_pool_codes_bytes": (_Z, [_I, _I, _I, _I]),
-    "dmc_bn_relu_pool_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dmc_bn_relu_pool_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dmc_stem_wgrad_supported": (_I, [_I, _I]),
     "dmc_stem_wgrad_partials_bytes": (_Z, [_I, _I, _I]),
     "dmc_stem_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),

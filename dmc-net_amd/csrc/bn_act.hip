@@ -413,11 +413,6 @@ bool shape_ok(int M, int C) {
     return M > 0 && C > 0 && C % 4 == 0 && cq <= 256 && 256 % cq == 0;
 }
 
-double* scratch_of(float* stats, int C) {
-    const size_t head = (((size_t)2 * C * sizeof(float)) + 15) / 16 * 16;
-    return reinterpret_cast<double*>(reinterpret_cast<char*>(stats) + head);
-}
-
 // enough row-splits to fill the chip (>= 64 rows each), at most MAX_SPLIT
 int split_of(int M) {
     int sp = M / 64;
@@ -435,21 +430,19 @@ extern "C" {
 
 int dmc_bn_act_supported(int M, int C) { return shape_ok(M, C) ? 1 : 0; }
 
-size_t dmc_bn_act_stats_bytes(int C) {
-    const size_t head = (((size_t)2 * C * sizeof(float)) + 15) / 16 * 16;
-    return head + (size_t)MAX_SPLIT * C * 2 * sizeof(double);
-}
+size_t dmc_bn_act_stats_bytes(int C) { return (((size_t)2 * C * sizeof(float)) + 15) / 16 * 16; }
+size_t dmc_bn_act_scratch_bytes(int C) { return (size_t)MAX_SPLIT * C * 2 * sizeof(double); }
 
 int dmc_bn_act_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
-                   float* running_mean, float* running_var, float* y, float* stats,
+                   float* running_mean, float* running_var, float* y, float* stats, void* scratch_,
                    unsigned char* relu_mask, int M, int C, int relu, int training, float eps,
                    float momentum, dmc_stream_t stream) {
-    if (!x || !gamma || !beta || !running_mean || !running_var || !y || !stats)
+    if (!x || !gamma || !beta || !running_mean || !running_var || !y || !stats || (training && !scratch_))
         return fail(DMC_E_INVALID, "dmc_bn_act_fwd: null pointer");
     if (!shape_ok(M, C)) return fail(DMC_E_INVALID, "dmc_bn_act_fwd: unsupported shape M=%d C=%d", M, C);
     hipStream_t s = (hipStream_t)stream;
     BnArgs a = {x, residual, gamma, beta, stats, nullptr, y, nullptr, nullptr, M, C, relu, relu_mask};
-    double* scratch = scratch_of(stats, C);
+    double* scratch = static_cast<double*>(scratch_);
     int rc;
     const int split = split_of(M);
     if (training) {
@@ -464,16 +457,16 @@ int dmc_bn_act_fwd(const float* x, const float* residual, const float* gamma, co
 }
 
 int dmc_bn_act_bwd(const float* x, const float* residual, const float* gamma, const float* beta,
-                   float* stats, const float* dy, float* dx, float* dresidual, float* dgamma,
-                   float* dbeta, const unsigned char* relu_mask, int M, int C, int relu,
+                   const float* stats, void* scratch_, const float* dy, float* dx, float* dresidual,
+                   float* dgamma, float* dbeta, const unsigned char* relu_mask, int M, int C, int relu,
                    dmc_stream_t stream) {
-    if (!x || !gamma || !beta || !stats || !dy || !dx || !dgamma || !dbeta)
+    if (!x || !gamma || !beta || !stats || !scratch_ || !dy || !dx || !dgamma || !dbeta)
         return fail(DMC_E_INVALID, "dmc_bn_act_bwd: null pointer");
     if (!shape_ok(M, C)) return fail(DMC_E_INVALID, "dmc_bn_act_bwd: unsupported shape M=%d C=%d", M, C);
     hipStream_t s = (hipStream_t)stream;
     BnArgs a = {x, residual, gamma, beta, stats, dy, nullptr, dx, dresidual, M, C, relu,
                 const_cast<unsigned char*>(relu_mask)};
-    double* scratch = scratch_of(stats, C);
+    double* scratch = static_cast<double*>(scratch_);
     int rc;
     const int split = split_of(M);
     bn_partial_kernel<1><<<split, 256, 0, s>>>(a, scratch);
@@ -489,16 +482,16 @@ int dmc_bn_relu_pool_supported(int N, int H, int W, int C) {
 }
 
 int dmc_bn_relu_pool_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
-                         float* running_var, float* y_pool, float* stats, int N, int H, int W, int C,
-                         int training, float eps, float momentum, dmc_stream_t stream) {
-    if (!x || !gamma || !beta || !running_mean || !running_var || !y_pool || !stats)
+                         float* running_var, float* y_pool, float* stats, void* scratch_, int N, int H,
+                         int W, int C, int training, float eps, float momentum, dmc_stream_t stream) {
+    if (!x || !gamma || !beta || !running_mean || !running_var || !y_pool || !stats || (training && !scratch_))
         return fail(DMC_E_INVALID, "dmc_bn_relu_pool_fwd: null pointer");
     if (!dmc_bn_relu_pool_supported(N, H, W, C))
         return fail(DMC_E_INVALID, "dmc_bn_relu_pool_fwd: unsupported shape N=%d H=%d W=%d C=%d", N, H, W, C);
     hipStream_t s = (hipStream_t)stream;
     const int M = N * H * W;
     BnArgs a = {x, nullptr, gamma, beta, stats, nullptr, nullptr, nullptr, nullptr, M, C, 1, nullptr};
-    double* scratch = scratch_of(stats, C);
+    double* scratch = static_cast<double*>(scratch_);
     int rc;
     const int split = split_of(M);
     if (training) {
@@ -517,16 +510,16 @@ size_t dmc_bn_relu_pool_codes_bytes(int N, int H, int W, int C) {
     return (size_t)N * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * (C / 4) * sizeof(unsigned);
 }
 
-int dmc_bn_relu_pool_bwd(const float* x, const float* gamma, const float* beta, float* stats,
-                         const float* d_pool, float* dx, float* dgamma, float* dbeta, void* codes,
-                         int N, int H, int W, int C, dmc_stream_t stream) {
-    if (!x || !gamma || !beta || !stats || !d_pool || !dx || !dgamma || !dbeta)
+int dmc_bn_relu_pool_bwd(const float* x, const float* gamma, const float* beta, const float* stats,
+                         void* scratch_, const float* d_pool, float* dx, float* dgamma, float* dbeta,
+                         void* codes, int N, int H, int W, int C, dmc_stream_t stream) {
+    if (!x || !gamma || !beta || !stats || !scratch_ || !d_pool || !dx || !dgamma || !dbeta)
         return fail(DMC_E_INVALID, "dmc_bn_relu_pool_bwd: null pointer");
     if (!dmc_bn_relu_pool_supported(N, H, W, C))
         return fail(DMC_E_INVALID, "dmc_bn_relu_pool_bwd: unsupported shape N=%d H=%d W=%d C=%d", N, H, W, C);
     hipStream_t s = (hipStream_t)stream;
     PoolArgs p = {x, gamma, beta, stats, d_pool, nullptr, dx, N, H, W, C, (H - 1) / 2 + 1, (W - 1) / 2 + 1};
-    double* scratch = scratch_of(stats, C);
+    double* scratch = static_cast<double*>(scratch_);
     const long tiles = (long)N * ((p.PH + PT - 1) / PT) * ((p.PW + PT - 1) / PT);
     const int blocks = (int)(tiles < MAX_SPLIT ? tiles : MAX_SPLIT);
     int rc;

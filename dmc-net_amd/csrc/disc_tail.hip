@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void tail_apply_kernel(const float* __restrict
                                                          const float* __restrict__ stats,
                                                          float* __restrict__ y, int C, int HW,
                                                          int use_bn) {
-    const int nc = blockIdx.y;            // n * C + c
+    const int nc = blockIdx.x;            // n * C + c (grid.x: no 65,535 limit on frames x channels)
     const int c = nc % C;
     const float k = keep ? keep[nc] : 1.f;
     float scale = 1.f, shift = 0.f;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void tail_apply_kernel(const float* __restrict
     }
     const float* xp = x + (size_t)nc * HW;
     float* yp = y + (size_t)nc * HW;
-    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int i0 = (blockIdx.y * 256 + threadIdx.x) * 4;
     if ((HW & 3) == 0) {
         if (i0 < HW) {
             const float4 v = *reinterpret_cast<const float4*>(xp + i0);
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void tail_bwd_apply_kernel(
     const float* __restrict__ stats, const float* __restrict__ dgamma,
     const float* __restrict__ dbeta, const float* __restrict__ dy, float* __restrict__ dx, int C,
     int HW, float inv_count, int use_bn) {
-    const int nc = blockIdx.y;
+    const int nc = blockIdx.x;
     const int c = nc % C;
     const float k = keep ? keep[nc] : 1.f;
     float mean = 0.f, invstd = 1.f, gs = 1.f, mb = 0.f, mg = 0.f;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void tail_bwd_apply_kernel(
     const float* xp = x + (size_t)nc * HW;
     const float* gp = dy + (size_t)nc * HW;
     float* dp = dx + (size_t)nc * HW;
-    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int i0 = (blockIdx.y * 256 + threadIdx.x) * 4;
     for (int j = 0; j < 4; ++j) {
         if (i0 + j < HW) {
             const float xv = xp[i0 + j];
@@ -203,7 +203,7 @@ int dmc_disc_tail_fwd(const float* x, const float* keep, const float* gamma, con
                                                              (long)N * HW, training, eps, momentum);
         if ((rc = check_launch("disc_tail_stats_final"))) return rc;
     }
-    tail_apply_kernel<<<dim3((HW + 1023) / 1024, N * C), 256, 0, s>>>(x, keep, gamma, beta, stats, y, C, HW, use_bn);
+    tail_apply_kernel<<<dim3(N * C, (HW + 1023) / 1024), 256, 0, s>>>(x, keep, gamma, beta, stats, y, C, HW, use_bn);
     return check_launch("disc_tail_apply");
 }
 
@@ -224,7 +224,7 @@ int dmc_disc_tail_bwd(const float* x, const float* keep, const float* gamma, flo
         tail_bwd_final_kernel<<<(C + 63) / 64, 64, 0, s>>>(scratch, dgamma, dbeta, C);
         if ((rc = check_launch("disc_tail_bwd_final"))) return rc;
     }
-    tail_bwd_apply_kernel<<<dim3((HW + 1023) / 1024, N * C), 256, 0, s>>>(
+    tail_bwd_apply_kernel<<<dim3(N * C, (HW + 1023) / 1024), 256, 0, s>>>(
         x, keep, gamma, stats, dgamma, dbeta, dy, dx, C, HW, 1.f / ((float)N * (float)HW), use_bn);
     return check_launch("disc_tail_bwd_apply");
 }

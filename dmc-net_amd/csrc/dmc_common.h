@@ -26,6 +26,14 @@ inline int check_launch(const char* what) {
     return DMC_OK;
 }
 
+// ---- kernel-selection options (dmc_set_option / dmc_get_option, storage in losses.hip) ----------
+// The library never reads the environment.  These few integers select between kernel variants for
+// A/B measurements; the defaults are the fastest measured path.  They are relaxed atomics read
+// once per entry-point call -- the only process-wide state of the library.
+enum Option { OPT_GEN_LAYER_PATH = 0, OPT_GEN_GATHER, OPT_GEN_FUSE45, OPT_GEN_WGRAD_PATH, OPT_GEN_FUSE_FWD,
+              OPT_GEN_FUSE_BWD, OPT_COUNT };
+int option(Option o);
+
 // ---- EstimatorDenseNetTiny geometry (code/dmcnet/model.py:172-194) --------------------------
 // Physical channel order used by every kernel: [mv0 mv1 r0 r1 r2 | y0(8) | y1(8) | y2(6) | y3(4)
 // | y4(2)] -- features are APPENDED, so layer k reads physical channels [0, CIN[k]).  The

@@ -1792,17 +1792,9 @@ int wgrad_groups(int N, int H, int W) {
     return (int)(tiles < WGRAD_MAX_GROUPS ? tiles : WGRAD_MAX_GROUPS);
 }
 
-// Frames are processed in chunks small enough for a chunk's planes (inputs + 28 features, or
-// 28 features + 28 gradients) to stay resident in the 256 MiB Infinity Cache between layers.
-int frames_per_pass(int N, int H, int W) {
-    static const long budget = [] {
-        const char* e = getenv("DMC_GEN_CACHE_MB");
-        return (e ? atol(e) : (1L << 20)) << 20;   // default: one pass (chunking measured slower)
-    }();
-    const long per_frame = (long)(NIN + 2 * NFEAT) * H * W * sizeof(float);
-    long f = budget / (per_frame > 0 ? per_frame : 1);
-    return (int)(f < 1 ? 1 : (f > N ? N : f));
-}
+// All frames in one pass per layer (processing the frames in Infinity-Cache-sized chunks was
+// measured slower: under-filled grids).
+int frames_per_pass(int N, int, int) { return N; }
 
 int num_cus() {
     static const int n = [] {
@@ -1830,12 +1822,12 @@ int launch_layer(LayerArgs a, int n0, int N, hipStream_t s) {
     // rides on each staged channel (Cout 2: layers 4, 5; gradient groups 2, 3, 4), the
     // register-pipelined kernel wins for the Cout 8 / 6 / 4 layers
     constexpr bool DMA_WINS = (MODE != 2 && K >= 4) || (MODE == 2 && K >= 2);
-    static const int path = [] { const char* e = getenv("DMC_GEN_LAYER_PATH"); return e ? atoi(e) : 1; }();
+    const int path = option(OPT_GEN_LAYER_PATH);
     // measured per layer (N=120, 224x224): the gather form wins where the push kernel pads the
     // input channels most (5 -> 8, 13 -> 16, 14 -> 16: layers 0, 1 and gradient group 1); the
     // Cout-6 layers lose (18 instead of 15 MFMAs per channel and pixel), the rest are at the HBM roof
     constexpr bool GATHER_FORM = (MODE == 0 && K <= 1) || (MODE == 2 && K == 1);
-    static const int gpath = [] { const char* e = getenv("DMC_GEN_GATHER"); return e ? atoi(e) : 1; }();
+    const int gpath = option(OPT_GEN_GATHER);
     if (GATHER_FORM && gpath == 1 && path == 1 && a.W % 4 == 0 && a.W <= P_MAXW) {
         RingArgs ra;
         ra.a = a;
@@ -1901,8 +1893,7 @@ int dmc_gen_tiny_fwd(const float* mv, const float* res, const float* const* w,
         if ((rc = launch_layer<0, 1>(a, n0, nn, s))) return rc;
         if ((rc = launch_layer<0, 2>(a, n0, nn, s))) return rc;
         if ((rc = launch_layer<0, 3>(a, n0, nn, s))) return rc;
-        static const int fuse45 = [] { const char* e = getenv("DMC_GEN_FUSE45"); return e ? atoi(e) : 1; }();
-        static const int lpath = [] { const char* e = getenv("DMC_GEN_LAYER_PATH"); return e ? atoi(e) : 1; }();
+        const int fuse45 = option(OPT_GEN_FUSE45), lpath = option(OPT_GEN_LAYER_PATH);
         if (fuse45 && lpath == 1 && W % 4 == 0 && W <= P_MAXW) {
             RingArgs ra;
             ra.a = a;
@@ -1956,7 +1947,7 @@ int dmc_gen_tiny_bwd(const float* mv, const float* res, const float* const* w, c
     a.N = N; a.H = H; a.W = W;
     a.tiles_x = (W + WT_W - 1) / WT_W;
     const int groups = wgrad_groups(N, H, W);
-    static const int wpath = [] { const char* e = getenv("DMC_GEN_WGRAD_PATH"); return e ? atoi(e) : 1; }();
+    const int wpath = option(OPT_GEN_WGRAD_PATH);
     if (W % 4 == 0 && wpath == 1) {
         a.tiles_y = (H + PW_H - 1) / PW_H;
         gen_bwd_weight_pc_kernel<<<groups, 512, 0, s>>>(a);

@@ -2,6 +2,9 @@
 //
 // Reference behaviour: nn.MSELoss()(gen_flow, input_flow)  code/dmcnet/train.py:167,245;
 // output.view(-1,S,C).mean(1) + CrossEntropyLoss           code/dmcnet/train.py:239-241.
+#include <atomic>
+#include <string.h>
+
 #include "dmc_common.h"
 
 using namespace dmc;
@@ -110,18 +113,22 @@ __global__ __launch_bounds__(1024) void consensus_ce_kernel(const float* __restr
         }
         se = __shfl(wave_sum(se), 0, 64);
         const float lse = __logf(se) + mx;
-        const int t = (int)target[b];
+        // a label outside [0, C) never indexes memory: the clip's loss and gradient become NaN (torch's
+        // CrossEntropyLoss device-asserts instead; an asynchronous C ABI cannot raise)
+        const int64_t t64 = target[b];
+        const bool t_ok = t64 >= 0 && t64 < (int64_t)C;
+        const int t = t_ok ? (int)t64 : 0;
         if (lane == 0) {
             float a = 0.f;
             for (int s = 0; s < S; ++s) a += lb[(size_t)s * C + t];
-            loss += lse - a * inv_s;
+            loss += t_ok ? lse - a * inv_s : NAN;
         }
         if (grad != nullptr) {
             for (int c = lane; c < C; c += 64) {
                 float a = 0.f;
                 for (int s = 0; s < S; ++s) a += lb[(size_t)s * C + c];
                 const float p = __expf(a * inv_s - lse);
-                const float g = (p - (c == t ? 1.f : 0.f)) * inv_n;
+                const float g = t_ok ? (p - (c == t ? 1.f : 0.f)) * inv_n : NAN;
                 for (int s = 0; s < S; ++s) grad[((size_t)b * S + s) * C + c] = g;
             }
         }
@@ -135,7 +142,21 @@ __global__ __launch_bounds__(1024) void consensus_ce_kernel(const float* __restr
     }
 }
 
+const char* const OPTION_NAMES[OPT_COUNT] = {"gen_layer_path", "gen_gather", "gen_fuse45", "gen_wgrad_path",
+                                             "gen_fuse_fwd", "gen_fuse_bwd"};
+std::atomic<int> g_options[OPT_COUNT] = {{1}, {1}, {1}, {1}, {1}, {1}};
+int option_index(const char* name) {
+    if (!name) return -1;
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (strcmp(name, OPTION_NAMES[i]) == 0) return i;
+    return -1;
+}
+
 }  // namespace
+
+namespace dmc {
+int option(Option o) { return g_options[o].load(std::memory_order_relaxed); }
+}  // namespace dmc
 
 // Empty kernel with a recognisable name: bench.py brackets its timed region with it so that a
 // rocprofv3 kernel trace can be cut to that region (tools/rocprof_region.py).
@@ -185,7 +206,18 @@ int dmc_profile_mark(dmc_stream_t stream) {
     return check_launch("dmc_profile_mark");
 }
 
-int dmc_version(void) { return 100; }   // 0.1.0
+int dmc_version(void) { return 200; }   // 0.2.0
+
+int dmc_set_option(const char* name, int value) {
+    const int i = option_index(name);
+    if (i < 0) return fail(DMC_E_INVALID, "dmc_set_option: unknown option '%s'", name ? name : "(null)");
+    g_options[i].store(value, std::memory_order_relaxed);
+    return DMC_OK;
+}
+int dmc_get_option(const char* name) {
+    const int i = option_index(name);
+    return i < 0 ? -1 : g_options[i].load(std::memory_order_relaxed);
+}
 const char* dmc_last_error(void) { return err_buf(); }
 
 }  // extern "C"

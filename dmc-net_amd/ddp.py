@@ -7,42 +7,88 @@ rank computes its own mean loss over its shard of the batch and the averaged gra
 gathered-batch gradients when shards are equal.  BatchNorm statistics stay per rank, as they are
 per replica under DataParallel.
 
+Bucket plan: the reference steps up to three optimizers whose parameters are
+selected by key substring (``base_model`` / ``gen_flow_model`` / ``discriminator``,
+code/dmcnet/train.py:125-129, code/dmcnet_GAN/train.py:135), and each training phase produces
+gradients for a subset of them only:
+
+  dmcnet step      classifier graph -> base_model (44.8 MB);  independent MSE graph -> gen_flow_model (18 KB)
+  GAN D step       base_model + discriminator (2.16 MB); the generator's gradients are discarded
+                   (code/dmcnet_GAN/train.py:301-302)
+  GAN G step       gen_flow_model only (code/dmcnet_GAN/train.py:371)
+
+so buckets are cut PER PARAMETER SET and never span two sets: the generator's 18 KB travel alone
+(they are ready as soon as the short MSE graph is done and, in the G step, nothing else is
+reduced), a set that produced no gradient costs nothing, and ``finish()`` only waits.
+
 xGMI is point to point, so a ring all-reduce is bound by one link (~153 GB/s): the 44.8 MB of
 ResNet-18 gradients cost ~0.5 ms; a few large buckets in reverse execution order are enough.
 """
 import torch
 import torch.distributed as dist
 
+SET_TAGS = ("base_model", "gen_flow_model", "discriminator")
+
+
+def param_sets_of(model, tags=SET_TAGS):
+    """[(tag, [parameters])] by key substring, the reference's optimizer routing; parameters that
+    match no tag form a trailing ``"other"`` set."""
+    sets = [(t, []) for t in tags]
+    other = []
+    for k, p in model.named_parameters():
+        for t, lst in sets:
+            if t in k:
+                lst.append(p)
+                break
+        else:
+            other.append(p)
+    sets = [(t, lst) for t, lst in sets if lst]
+    if other:
+        sets.append(("other", other))
+    return sets
+
 
 class GradBucketReducer(object):
     def __init__(self, params, bucket_bytes=16 << 20, group=None, broadcast_from=0):
-        """``params``: parameters in forward order (``model.parameters()``); buckets are filled in
-        reverse, the order in which backward produces gradients."""
+        """``params``: either parameters in forward order (one set), or a list of
+        ``(name, [parameters])`` sets (see :func:`param_sets_of`).  Within a set buckets are filled
+        in reverse, the order in which backward produces gradients; no bucket spans two sets."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.params = [p for p in params if p.requires_grad]
+        params = list(params)
+        if params and isinstance(params[0], (tuple, list)):
+            sets = [(name, [p for p in ps if p.requires_grad]) for name, ps in params]
+        else:
+            sets = [("all", [p for p in params if p.requires_grad])]
+        self.sets = [(name, ps) for name, ps in sets if ps]
+        self.params = [p for _, ps in self.sets for p in ps]
         self._use_avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
         self.buckets = []          # (flat buffer, [(param, offset, numel)])
-        cur, cur_bytes = [], 0
-        for p in reversed(self.params):
-            cur.append(p)
-            cur_bytes += p.numel() * p.element_size()
-            if cur_bytes >= bucket_bytes:
-                self._close(cur)
-                cur, cur_bytes = [], 0
-        if cur:
-            self._close(cur)
+        self.bucket_set = []       # set name of each bucket
+        for name, ps in self.sets:
+            cur, cur_bytes = [], 0
+            for p in reversed(ps):
+                cur.append(p)
+                cur_bytes += p.numel() * p.element_size()
+                if cur_bytes >= bucket_bytes:
+                    self._close(cur, name)
+                    cur, cur_bytes = [], 0
+            if cur:
+                self._close(cur, name)
         self._slot = {}
         for b, (_, entries) in enumerate(self.buckets):
             for p, off, n in entries:
                 self._slot[p] = (b, off, n)
         self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self._active = False
+        #: what the last begin()..finish() reduced: [(set name, bucket index, bytes, where)] with
+        #: where = "hook" (launched from backward) or "finish" (a partially filled bucket)
+        self.last_reduced = []
         if self.world > 1 and broadcast_from is not None:
             for p in self.params:
                 dist.broadcast(p.data, src=broadcast_from, group=group)
 
-    def _close(self, plist):
+    def _close(self, plist, name):
         total = sum(p.numel() for p in plist)
         flat = torch.zeros(total, dtype=plist[0].dtype, device=plist[0].device)
         entries, off = [], 0
@@ -50,6 +96,7 @@ class GradBucketReducer(object):
             entries.append((p, off, p.numel()))
             off += p.numel()
         self.buckets.append((flat, entries))
+        self.bucket_set.append(name)
 
     # -- per step ------------------------------------------------------------------------
     def begin(self):
@@ -59,6 +106,7 @@ class GradBucketReducer(object):
         self._seen = set()
         self._moved = set()
         self._works = []
+        self.last_reduced = []
         self._active = True
 
     def _view(self, p):
@@ -66,7 +114,8 @@ class GradBucketReducer(object):
         # channels_last), so the gradient keeps the strides fused optimizer kernels expect
         b, off, n = self._slot[p]
         flat = self.buckets[b][0]
-        dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+        dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last)) \
+            or (p.dim() == 5 and p.is_contiguous(memory_format=torch.channels_last_3d))
         return flat[off:off + n].as_strided(p.size(), p.stride()) if dense else flat[off:off + n].view_as(p)
 
     def _gather(self, b):
@@ -89,18 +138,23 @@ class GradBucketReducer(object):
         self._ready[b] += 1
         if self._ready[b] == self._pending[b]:
             self._gather(b)
-            self._launch(b)
+            self._launch(b, "hook")
 
-    def _launch(self, b):
+    def _launch(self, b, where):
+        flat = self.buckets[b][0]
+        self.last_reduced.append((self.bucket_set[b], b, flat.numel() * flat.element_size(), where))
+        self._ready[b] = -1        # launched
         if self.world == 1:
             return
-        flat = self.buckets[b][0]
         op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
         self._works.append((b, dist.all_reduce(flat, op=op, group=self.group, async_op=True)))
-        self._ready[b] = -1        # launched
 
     def finish(self):
-        """Call after backward: reduces partially filled buckets, waits, rescales."""
+        """Call after backward, before the optimizers step: waits for the exchanges launched from
+        the hooks.  Buckets none of whose members produced a gradient are not touched (their
+        parameters keep ``grad=None`` and Adam skips them, as in the reference); a bucket only
+        SOME of whose members produced one -- not the case in any shipped recipe -- is completed
+        with zeros and reduced here."""
         self._active = False
         for b, (flat, entries) in enumerate(self.buckets):
             if self._ready[b] > 0:              # some but not all members produced a gradient
@@ -108,13 +162,28 @@ class GradBucketReducer(object):
                 for p, off, n in entries:
                     if p not in self._seen:
                         flat[off:off + n].zero_()
-                self._launch(b)
+                self._launch(b, "finish")
         for b, work in self._works:
             work.wait()
             if not self._use_avg:
                 self.buckets[b][0].div_(self.world)
         self._works = []
 
+    def reduced_bytes(self, by_set=False):
+        """Bytes all-reduced by the last step (optionally per parameter set)."""
+        if not by_set:
+            return sum(n for _, _, n, _ in self.last_reduced)
+        out = {}
+        for name, _, n, _ in self.last_reduced:
+            out[name] = out.get(name, 0) + n
+        return out
+
     def remove(self):
         for h in self._handles:
             h.remove()
+
+
+def for_model(model, bucket_bytes=16 << 20, group=None, broadcast_from=0):
+    """The reducer every driver uses: one bucket set per optimizer of the reference."""
+    return GradBucketReducer(param_sets_of(model), bucket_bytes=bucket_bytes, group=group,
+                             broadcast_from=broadcast_from)

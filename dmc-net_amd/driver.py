@@ -54,7 +54,7 @@ def train_epoch(loader, stepper, epoch, device="cuda:0", freeze=False, print_fre
 
 
 @torch.no_grad()
-def validate(loader, model, num_segments, lr_cls, lr_mse, device="cuda:0", log=print):
+def validate(loader, model, num_segments, lr_cls, lr_mse, device="cuda:0", log=print, loss_mse="MSELoss"):
     """``validate()``: eval mode, CE on the segment consensus + flow MSE, Prec@1/5; returns the
     dict of averages (``top1`` is what the reference returns)."""
     meters = {k: train.AverageMeter() for k in ("loss", "loss_cls", "loss_mse", "top1", "top5")}
@@ -63,14 +63,16 @@ def validate(loader, model, num_segments, lr_cls, lr_mse, device="cuda:0", log=p
         input_flow, input_mv, input_residual, target = _to(batch, device)
         flow = input_flow.reshape((-1,) + tuple(input_mv.shape[-3:]))
         out = model(input_mv, input_residual)
-        output, gen_flow = out[0], out[-2] if getattr(model, "att", 0) == 1 else out[-1]
+        att = getattr(model, "att", 0) == 1
+        output, gen_flow = out[0], (out[-2] if att else out[-1])
         loss_cls, consensus = ops.consensus_ce(output, target, num_segments)
-        loss_mse = ops.flow_mse(gen_flow, flow)
+        # att == 1: criterion_mse(att_flow * gen_flow, att_flow * input_flow), code/dmcnet/train.py:332-335
+        loss_mse_v = train.flow_loss(loss_mse, gen_flow, flow, out[-1] if att else None)
         n = flow.shape[0]
         prec1, prec5 = train.accuracy(consensus, target, topk=(1, 5))
-        meters["loss"].update(loss_cls * lr_cls + loss_mse * lr_mse, n)
+        meters["loss"].update(loss_cls * lr_cls + loss_mse_v * lr_mse, n)
         meters["loss_cls"].update(loss_cls, n)
-        meters["loss_mse"].update(loss_mse, n)
+        meters["loss_mse"].update(loss_mse_v, n)
         meters["top1"].update(prec1, n)
         meters["top5"].update(prec5, n)
     res = {k: float(m.avg) for k, m in meters.items()}
@@ -100,7 +102,8 @@ def fit(model, stepper, train_loader, val_loader, epochs, lr, weight_decay, lr_s
                          log=log)
         entry = {"epoch": epoch, "train": tr}
         if epoch % eval_freq == 0 or epoch == epochs - 1:
-            va = validate(val_loader, model, stepper.num_segments, lr_cls, lr_mse, device, log=log)
+            va = validate(val_loader, model, stepper.num_segments, lr_cls, lr_mse, device, log=log,
+                          loss_mse=getattr(stepper, "loss_mse", "MSELoss"))
             entry["val"] = va
             is_best = va["top1"] > best_prec1
             best_prec1 = max(va["top1"], best_prec1)

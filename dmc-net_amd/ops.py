@@ -174,6 +174,9 @@ class _ConsensusCE(torch.autograd.Function):
     def forward(ctx, logits, target, num_segments):
         lib = _lib.load()
         _need_cuda(logits, target)
+        if logits.dtype != torch.float32 or target.dtype != torch.int64:
+            raise _lib.DmcHipError("consensus_ce expects fp32 logits and int64 class labels, got %s / %s"
+                                   % (logits.dtype, target.dtype))
         logits, target = logits.contiguous(), target.contiguous()
         n, c = logits.shape
         if n % num_segments != 0 or target.numel() * num_segments != n:
@@ -266,7 +269,9 @@ class _BnAct(torch.autograd.Function):
         n, c, h, w = x.shape
         m = n * h * w
         y = torch.empty_like(x)           # keeps the channels_last strides
-        stats = _floats(lib.dmc_bn_act_stats_bytes(c), x.device)
+        stats = _floats(lib.dmc_bn_act_stats_bytes(c), x.device)      # (mean, invstd): kept for backward
+        # reduction workspace (16 KB x C): transient -- training forwards only, never saved
+        scratch = _floats(lib.dmc_bn_act_scratch_bytes(c), x.device) if training else None
         # with a residual the ReLU sign depends on it: keep 4 sign bits per float4 (1/16 of the
         # residual's size) so that the backward neither re-reads nor even keeps the residual
         mask = None
@@ -276,7 +281,7 @@ class _BnAct(torch.autograd.Function):
             _lib.check(lib.dmc_bn_act_fwd(_lib.ptr(x), _lib.ptr(residual), _lib.ptr(gamma),
                                           _lib.ptr(beta), _lib.ptr(running_mean),
                                           _lib.ptr(running_var), _lib.ptr(y), _lib.ptr(stats),
-                                          _lib.ptr(mask), m, c, int(relu), int(training), float(eps),
+                                          _lib.ptr(scratch), _lib.ptr(mask), m, c, int(relu), int(training), float(eps),
                                           float(momentum), _stream()), "dmc_bn_act_fwd")
         ctx.save_for_backward(x, residual if (relu and mask is None) else None, gamma, beta, stats, mask)
         ctx.relu, ctx.training, ctx.has_res = bool(relu), bool(training), residual is not None
@@ -295,9 +300,10 @@ class _BnAct(torch.autograd.Function):
         # without ReLU the residual's gradient is dy itself
         dres = torch.empty_like(x) if (want_dres and ctx.relu) else None
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        scratch = _floats(lib.dmc_bn_act_scratch_bytes(c), x.device)
         with _span("bn_act_bwd"):
             _lib.check(lib.dmc_bn_act_bwd(_lib.ptr(x), _lib.ptr(residual), _lib.ptr(gamma),
-                                          _lib.ptr(beta), _lib.ptr(stats), _lib.ptr(dy), _lib.ptr(dx),
+                                          _lib.ptr(beta), _lib.ptr(stats), _lib.ptr(scratch), _lib.ptr(dy), _lib.ptr(dx),
                                           _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(mask),
                                           n * h * w, c, int(ctx.relu), _stream()), "dmc_bn_act_bwd")
         if want_dres and not ctx.relu:
@@ -363,10 +369,11 @@ class _BnReluPool(torch.autograd.Function):
         y = torch.empty((n, c, ph, pw), dtype=x.dtype, device=x.device,
                         memory_format=torch.channels_last)
         stats = _floats(lib.dmc_bn_act_stats_bytes(c), x.device)
+        scratch = _floats(lib.dmc_bn_act_scratch_bytes(c), x.device) if training else None
         with _span("bn_relu_pool_fwd"):
             _lib.check(lib.dmc_bn_relu_pool_fwd(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta),
                                                 _lib.ptr(running_mean), _lib.ptr(running_var),
-                                                _lib.ptr(y), _lib.ptr(stats), n, h, w, c, int(training),
+                                                _lib.ptr(y), _lib.ptr(stats), _lib.ptr(scratch), n, h, w, c, int(training),
                                                 float(eps), float(momentum), _stream()),
                        "dmc_bn_relu_pool_fwd")
         ctx.save_for_backward(x, gamma, beta, stats)
@@ -384,9 +391,10 @@ class _BnReluPool(torch.autograd.Function):
         dx = torch.empty_like(x)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         codes = _floats(lib.dmc_bn_relu_pool_codes_bytes(n, h, w, c), x.device)
+        scratch = _floats(lib.dmc_bn_act_scratch_bytes(c), x.device)
         with _span("bn_relu_pool_bwd"):
             _lib.check(lib.dmc_bn_relu_pool_bwd(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta),
-                                                _lib.ptr(stats), _lib.ptr(dy), _lib.ptr(dx),
+                                                _lib.ptr(stats), _lib.ptr(scratch), _lib.ptr(dy), _lib.ptr(dx),
                                                 _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(codes),
                                                 n, h, w, c, _stream()), "dmc_bn_relu_pool_bwd")
         return dx, dgamma, dbeta, None, None, None, None, None

@@ -111,10 +111,41 @@ class ResNet(nn.Module):
             return self.fc(torch.flatten(self.avgpool(x), 1))
 
 
-def build(name, pretrained=False):
-    """``pretrained`` mirrors the reference's call; ImageNet weights are not obtainable offline,
-    so it only emits a note -- load a checkpoint with ``--weights`` semantics instead."""
+def _torchvision_init(net):
+    """torchvision's ResNet initialisation: kaiming_normal_(fan_out, relu) for every convolution,
+    BatchNorm weight 1 / bias 0 (the Linear keeps nn.Linear's default), so that a from-scratch run
+    starts from the same distribution as the upstream architecture."""
+    for m in net.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        elif isinstance(m, nn.BatchNorm2d):
+            nn.init.constant_(m.weight, 1.0)
+            nn.init.constant_(m.bias, 0.0)
+
+
+def build(name, pretrained=False, weights=None):
+    """``pretrained`` mirrors the reference's call (code/dmcnet/model.py:305 always passes True):
+    torchvision's ImageNet weights cannot be downloaded here, so ``pretrained=True`` without
+    ``weights`` WARNS that the classifier starts from torchvision's random initialisation -- a
+    different recipe from the reference's.  ``weights`` (a path to, or a dict of, a torchvision
+    ``resnetNN`` state dict; also taken from $DMC_RESNET_WEIGHTS) loads them as
+    ``pretrained=True`` would; ``fc`` / ``conv1`` mismatches are left to ``Model._prepare_tsn``,
+    which replaces those layers anyway."""
+    import os
+    import warnings
     if name not in _CFG:
         raise ValueError("Unknown base model: {}".format(name))
     kind, depths = _CFG[name]
-    return ResNet(kind, depths)
+    net = ResNet(kind, depths)
+    _torchvision_init(net)
+    if weights is None:
+        weights = os.environ.get("DMC_RESNET_WEIGHTS")
+    if weights is not None:
+        sd = torch.load(weights, map_location="cpu") if isinstance(weights, (str, bytes, os.PathLike)) else weights
+        net.load_state_dict(sd, strict=True)
+    elif pretrained:
+        warnings.warn("%s: pretrained=True was requested (as the reference does) but no ImageNet weights "
+                      "are available offline; the classifier starts from torchvision's random "
+                      "initialisation. Pass weights=<torchvision state dict>, set DMC_RESNET_WEIGHTS, or "
+                      "load a checkpoint with train.load_reference_weights." % name, stacklevel=2)
+    return net

@@ -44,8 +44,7 @@ class GroupedAdam(torch.optim.Adam):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 elif p.is_cuda and st["step"].device != p.device:      # e.g. a loaded state dict
                     st["step"] = st["step"].to(p.device)
-                key = key + (p.is_cuda,)
-                b = buckets.setdefault(key, ([], [], [], [], []))
+                b = buckets.setdefault(key + (p.is_cuda,), ([], [], [], [], []))
                 b[0].append(p); b[1].append(p.grad); b[2].append(st["exp_avg"])
                 b[3].append(st["exp_avg_sq"]); b[4].append(st["step"])
         for (lr, wd, (b1, b2), eps, on_gpu), (ps, gs, ms, vs, steps) in buckets.items():
@@ -150,13 +149,38 @@ def _without_param_grads(*modules):
             p.requires_grad_(True)
 
 
+FLOW_LOSSES = ("MSELoss", "SmoothL1Loss", "L1")
+
+
+def flow_loss(kind, gen_flow, flow, att_flow=None):
+    """``criterion_mse`` of the reference (``--loss_mse``, code/dmcnet/train.py:166-172): MSELoss is
+    the HIP kernel (every shipped recipe); SmoothL1Loss / L1 and the attention-weighted form
+    ``criterion(att * gen, att * flow)`` (code/dmcnet/train.py:335, code/dmcnet_GAN/train.py:352),
+    whose gradient also reaches ``att`` through the target, run on the stock PyTorch-ROCm ops."""
+    if kind not in FLOW_LOSSES:
+        raise ValueError("loss_mse must be one of %s, got %r" % (FLOW_LOSSES, kind))
+    if att_flow is not None:
+        gen_flow, flow = att_flow * gen_flow, att_flow * flow
+    elif kind == "MSELoss":
+        return ops.flow_mse(gen_flow, flow)
+    fn = {"MSELoss": F.mse_loss, "SmoothL1Loss": F.smooth_l1_loss, "L1": F.l1_loss}[kind]
+    return fn(gen_flow, flow)
+
+
 class DmcnetTrainStep(object):
-    """One iteration of code/dmcnet/train.py:221-266."""
+    """One iteration of code/dmcnet/train.py:221-266.  ``att=1`` (a model built with att=1 returns
+    (base_out, gen_flow, att_flow)) uses the attention-weighted reconstruction loss the reference's
+    validate() computes (:320-335; its train() cannot unpack that model's 3-tuple at all)."""
 
     def __init__(self, model, num_segments, lr_cls, lr_mse, lr, weight_decay, lr_cls_mult,
-                 lr_mse_mult, reducer=None):
+                 lr_mse_mult, reducer=None, loss_mse="MSELoss", att=0):
+        if loss_mse not in FLOW_LOSSES:
+            raise ValueError("loss_mse must be one of %s, got %r" % (FLOW_LOSSES, loss_mse))
+        if bool(att) != bool(getattr(model, "att", 0)):
+            raise ValueError("att=%r but the model was built with att=%r" % (att, getattr(model, "att", 0)))
         self.model, self.num_segments = model, num_segments
         self.lr_cls, self.lr_mse = lr_cls, lr_mse
+        self.loss_mse, self.att = loss_mse, int(att)
         self.optimizer_cls, self.optimizer_gf = make_optimizers(model, lr, weight_decay,
                                                                 lr_cls_mult, lr_mse_mult)
         self.reducer = reducer
@@ -166,9 +190,11 @@ class DmcnetTrainStep(object):
         flow = input_flow.reshape((-1,) + tuple(input_mv.shape[-3:]))
         self.optimizer_cls.zero_grad(set_to_none=True)
         self.optimizer_gf.zero_grad(set_to_none=True)
-        output, gen_flow = self.model(input_mv, input_residual)
+        outs = self.model(input_mv, input_residual)
+        output, gen_flow = outs[0], outs[1]
+        att_flow = outs[2] if self.att == 1 else None
         loss_cls, consensus = ops.consensus_ce(output, target, self.num_segments)
-        loss_mse = ops.flow_mse(gen_flow, flow)
+        loss_mse = flow_loss(self.loss_mse, gen_flow, flow, att_flow)
         loss = loss_cls * self.lr_cls + loss_mse * self.lr_mse
         if self.reducer is not None:
             self.reducer.begin()
@@ -190,8 +216,13 @@ class GanTrainStep(object):
     the classifier, odd ``i`` trains the generator."""
 
     def __init__(self, model, num_segments, lr_cls, lr_adv_g, lr_adv_d, lr_mse, lr, weight_decay,
-                 lr_cls_mult, lr_mse_mult, lr_d_mult, reducer=None):
+                 lr_cls_mult, lr_mse_mult, lr_d_mult, reducer=None, loss_mse="MSELoss", att=0):
+        if loss_mse not in FLOW_LOSSES:
+            raise ValueError("loss_mse must be one of %s, got %r" % (FLOW_LOSSES, loss_mse))
+        if bool(att) != bool(getattr(model, "att", 0)):
+            raise ValueError("att=%r but the model was built with att=%r" % (att, getattr(model, "att", 0)))
         self.model, self.num_segments = model, num_segments
+        self.loss_mse, self.att = loss_mse, int(att)
         self.lr_cls, self.lr_adv_g, self.lr_adv_d, self.lr_mse = lr_cls, lr_adv_g, lr_adv_d, lr_mse
         self.optimizer_cls, self.optimizer_gf, self.optimizer_d = make_optimizers(
             model, lr, weight_decay, lr_cls_mult, lr_mse_mult, lr_d_mult)
@@ -210,7 +241,7 @@ class GanTrainStep(object):
             # only optimizer_cls and optimizer_d step (GAN train.py:301-302): the generator's
             # gradients would be thrown away
             with _without_param_grads(self.model.gen_flow_model):
-                output, validity, gen_flow = self.model(input_mv, input_residual, flow)
+                output, validity, gen_flow = self.model(input_mv, input_residual, flow)[:3]   # att=1: att_flow unused (GAN train.py:266-267)
             loss_cls, consensus = ops.consensus_ce(output, target, self.num_segments)
             loss_adv, _ = ops.consensus_ce(validity, torch.cat((fake, valid), 0), 1)
             loss = loss_cls * self.lr_cls + loss_adv * self.lr_adv_d
@@ -221,10 +252,11 @@ class GanTrainStep(object):
             # only optimizer_gf steps (GAN train.py:371): classifier / discriminator weight
             # gradients would be thrown away; their BatchNorm running statistics still update
             with _without_param_grads(self.model.base_model, self.model.discriminator):
-                output, validity, gen_flow = self.model(input_mv, input_residual)
+                outs = self.model(input_mv, input_residual)
+            output, validity, gen_flow = outs[:3]
             loss_cls, consensus = ops.consensus_ce(output, target, self.num_segments)
             loss_adv, _ = ops.consensus_ce(validity, valid, 1)
-            loss_mse = ops.flow_mse(gen_flow, flow)
+            loss_mse = flow_loss(self.loss_mse, gen_flow, flow, outs[3] if self.att == 1 else None)   # GAN train.py:349-352
             loss = loss_cls * self.lr_cls + loss_adv * self.lr_adv_g + loss_mse * self.lr_mse
             self._backward(loss)
             self.optimizer_gf.step()

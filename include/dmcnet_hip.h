@@ -18,7 +18,9 @@
  *     (code/dmcnet/model.py:187-194: layer k sees [y_{k-1}, ..., y_0, mv(2), residual(3)]);
  *   - return value: DMC_OK (0) or a negative DMC_E_* code; dmc_last_error() gives the text
  *     (thread-local);
- *   - no global mutable state: safe from several host threads on distinct streams.
+ *   - no global mutable state apart from the kernel-selection options of dmc_set_option() (A/B
+ *     measurement knobs, relaxed atomics, defaults = fastest path); the library never reads the
+ *     environment: safe from several host threads on distinct streams.
  */
 #ifndef DMCNET_HIP_H
 #define DMCNET_HIP_H
@@ -40,6 +42,14 @@ typedef void* dmc_stream_t; /* hipStream_t */
 int dmc_version(void);
 /* Text of the last error on this host thread ("" if none). */
 const char* dmc_last_error(void);
+/* Kernel-selection options for A/B measurements (tools/, bench.py); every default is 1 = the
+ * fastest measured path.  Names: "gen_layer_path" (0: VALU layer kernels instead of the matrix-core
+ * ones), "gen_gather" (0: push form for the Cout-8 layers), "gen_fuse45" (0: layers 4 and 5 as two
+ * launches), "gen_wgrad_path" (0: all-waves-stage weight gradient), "gen_fuse_fwd" / "gen_fuse_bwd"
+ * (0: the layer-by-layer forward / data-gradient launches instead of the fused groups).
+ * dmc_set_option returns DMC_E_INVALID for an unknown name; dmc_get_option returns -1 for one. */
+int dmc_set_option(const char* name, int value);
+int dmc_get_option(const char* name);
 /* Launches an empty kernel named dmc_profile_mark_kernel on `stream`: a marker that brackets
  * a region of interest in a rocprofv3 kernel trace (no reference counterpart; tooling only). */
 int dmc_profile_mark(dmc_stream_t stream);
@@ -111,6 +121,8 @@ int dmc_flow_mse_bwd(const float* gen_flow, const float* flow, const float* grad
  *   loss_out  one float: mean over B of -log softmax(consensus)[target],
  *   grad_logits [B*S, C] = (softmax - onehot) / (B*S), i.e. dloss/dlogits for upstream grad 1
  *   (may be NULL to skip).
+ * A label outside [0, C) is never used as an index: the loss and that clip's gradient rows become
+ * NaN (torch's CrossEntropyLoss asserts on the device instead).
  */
 int dmc_consensus_ce_fwd_bwd(const float* logits, const int64_t* target, float* consensus,
                              float* loss_out, float* grad_logits, int B, int S, int C,
@@ -148,21 +160,24 @@ int dmc_disc_tail_bwd(const float* x, const float* keep, const float* gamma, flo
  * tensor).  Training mode uses batch statistics and updates running_mean / running_var exactly
  * as nn.BatchNorm2d does.  dmc_bn_act_supported() tells whether (M, C) is handled
  * (C % 4 == 0, C/4 <= 256, 256 % (C/4) == 0); callers use the stock op otherwise.
- * stats: workspace of dmc_bn_act_stats_bytes(C); the forward leaves (mean, invstd) in its first
- * 2*C floats for the backward.  relu_mask (nullable, M*C/4 bytes): the forward stores the four ReLU
+ * stats: dmc_bn_act_stats_bytes(C) bytes (2*C floats): the forward leaves (mean, invstd) there for
+ * the backward -- the only thing a caller keeps between the two.  scratch: dmc_bn_act_scratch_bytes(C)
+ * bytes of reduction workspace, transient (dead when the call's kernels have run; NULL allowed for
+ * an eval-mode forward, which reduces nothing).  relu_mask (nullable, M*C/4 bytes): the forward stores the four ReLU
  * sign bits of every float4; a backward given the same buffer reads them instead of re-reading the
  * residual (`residual` may then be NULL).  Without it the backward recomputes the signs from x
  * (and residual).
  */
 int dmc_bn_act_supported(int M, int C);
 size_t dmc_bn_act_stats_bytes(int C);
+size_t dmc_bn_act_scratch_bytes(int C);
 int dmc_bn_act_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
-                   float* running_mean, float* running_var, float* y, float* stats,
+                   float* running_mean, float* running_var, float* y, float* stats, void* scratch,
                    unsigned char* relu_mask, int M, int C, int relu, int training, float eps,
                    float momentum, dmc_stream_t stream);
 int dmc_bn_act_bwd(const float* x, const float* residual, const float* gamma, const float* beta,
-                   float* stats, const float* dy, float* dx, float* dresidual, float* dgamma,
-                   float* dbeta, const unsigned char* relu_mask, int M, int C, int relu,
+                   const float* stats, void* scratch, const float* dy, float* dx, float* dresidual,
+                   float* dgamma, float* dbeta, const unsigned char* relu_mask, int M, int C, int relu,
                    dmc_stream_t stream);
 
 /* ---- GPU-side input preparation -----------------------------------------------------------------
@@ -185,19 +200,20 @@ int dmc_prepare_inputs(const unsigned char* frames_u8, const unsigned char* flip
  * code/dmcnet/model.py:305 (run at :352) and its autograd.  x [N,H,W,C] fp32 NHWC (conv1 output),
  * y_pool / d_pool [N,PH,PW,C] with PH = (H-1)/2+1, PW = (W-1)/2+1; the rectified full-resolution
  * tensor is never materialised.  Arg-max ties follow PyTorch (first element in row-major window
- * order).  stats: dmc_bn_act_stats_bytes(C) bytes, written by fwd (mean, invstd) and read by bwd.
+ * order).  stats: dmc_bn_act_stats_bytes(C) bytes, written by fwd (mean, invstd) and read by bwd;
+ * scratch: dmc_bn_act_scratch_bytes(C) bytes, transient (NULL allowed when training == 0).
  * training = 0 normalises with the running statistics (forward only).
  * codes: dmc_bn_relu_pool_codes_bytes() bytes of scratch (the windows' arg-max positions, written by the
  * backward's first pass and read by its second), or NULL to recompute them in the second pass.
  */
 int dmc_bn_relu_pool_supported(int N, int H, int W, int C);
 int dmc_bn_relu_pool_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
-                         float* running_var, float* y_pool, float* stats, int N, int H, int W, int C,
-                         int training, float eps, float momentum, dmc_stream_t stream);
+                         float* running_var, float* y_pool, float* stats, void* scratch, int N, int H,
+                         int W, int C, int training, float eps, float momentum, dmc_stream_t stream);
 size_t dmc_bn_relu_pool_codes_bytes(int N, int H, int W, int C);
-int dmc_bn_relu_pool_bwd(const float* x, const float* gamma, const float* beta, float* stats,
-                         const float* d_pool, float* dx, float* dgamma, float* dbeta, void* codes,
-                         int N, int H, int W, int C, dmc_stream_t stream);
+int dmc_bn_relu_pool_bwd(const float* x, const float* gamma, const float* beta, const float* stats,
+                         void* scratch, const float* d_pool, float* dx, float* dgamma, float* dbeta,
+                         void* codes, int N, int H, int W, int C, dmc_stream_t stream);
 
 /* ---- classifier stem: weight gradient of conv1 (2 -> 64 channels, 7x7, stride 2, pad 3) ----------
  * Replaces what autograd computes for the conv1 the reference installs for the 2-channel flow

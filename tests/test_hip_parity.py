@@ -374,7 +374,7 @@ def test_reducer_single_rank_nccl_is_transparent():
         ra = a.step(batch)
         _, m2 = _product(False, 41)
         m2.train()
-        b = T.DmcnetTrainStep(m2, 3, 1.0, 10.0, reducer=ddp.GradBucketReducer(list(m2.parameters())), **kw)
+        b = T.DmcnetTrainStep(m2, 3, 1.0, 10.0, reducer=ddp.for_model(m2), **kw)
         rb = b.step(batch)
         assert rel_err(ra["loss"], rb["loss"]) < 1e-5
         # MIOpen's NHWC weight-gradient kernels split K with atomics, so two runs of the same

@@ -10,6 +10,7 @@ import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+import torch.nn.functional as F
 
 import dmcnet_amd
 from dmcnet_amd import dataset, ddp, train, transforms
@@ -196,6 +197,94 @@ def test_grad_bucket_reducer_two_ranks_gloo(tmp_path):
             torch.testing.assert_close(g, p.grad, rtol=1e-5, atol=1e-7)
 
 
+class _ToyGan(torch.nn.Module):
+    """Three sub-modules with the reference's attribute names (what the optimizer routing and the
+    bucket plan key on); the generator is a conv so that the phases of the real steps can be
+    emulated on the CPU (the real generator has no CPU path)."""
+
+    def __init__(self):
+        super().__init__()
+        self.gen_flow_model = torch.nn.Conv2d(5, 2, 3, padding=1)
+        self.base_model = torch.nn.Sequential(torch.nn.Conv2d(2, 8, 3, padding=1), torch.nn.ReLU(),
+                                              torch.nn.AdaptiveAvgPool2d(1), torch.nn.Flatten(),
+                                              torch.nn.Linear(8, 4))
+        self.discriminator = torch.nn.Sequential(torch.nn.Conv2d(2, 4, 3, stride=2, padding=1),
+                                                 torch.nn.Flatten(), torch.nn.Linear(4 * 4 * 4, 2))
+
+
+def _phase_losses(net, x, flow, t, phase):
+    g = net.gen_flow_model(x)
+    if phase == "dmcnet":          # classifier sees a detached cue; MSE graph independent
+        return F.cross_entropy(net.base_model(g.detach()), t) + 10.0 * F.mse_loss(g, flow)
+    if phase == "D":               # generator weights are constants in the D step
+        with train._without_param_grads(net.gen_flow_model):
+            g = net.gen_flow_model(x)
+            v = net.discriminator(torch.cat((g, flow), 0))
+            tv = torch.cat((torch.zeros(len(x)), torch.ones(len(x)))).long()
+            return F.cross_entropy(net.base_model(g), t) + 0.01 * F.cross_entropy(v, tv)
+    with train._without_param_grads(net.base_model, net.discriminator):      # G step
+        g = net.gen_flow_model(x)
+        return (F.cross_entropy(net.base_model(g), t) + 10.0 * F.mse_loss(g, flow)
+                + F.cross_entropy(net.discriminator(g), torch.ones(len(x)).long()))
+
+
+def _ddp_plan_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(200 + rank)
+    net = _ToyGan()
+    red = ddp.for_model(net, bucket_bytes=256)       # base_model / discriminator split in several buckets
+    torch.manual_seed(11)
+    x, flow, t = torch.randn(4, 5, 8, 8), torch.randn(4, 2, 8, 8), torch.randint(0, 4, (4,))
+    sh = slice(rank * 2, rank * 2 + 2)
+    rec = {"sets": [n for n, _ in red.sets], "bucket_set": list(red.bucket_set), "x": x, "flow": flow, "t": t,
+           "state": {k: v.clone() for k, v in net.state_dict().items()}}
+    for phase in ("dmcnet", "D", "G"):
+        for p in net.parameters():
+            p.grad = None
+        red.begin()
+        _phase_losses(net, x[sh], flow[sh], t[sh], phase).backward()
+        red.finish()
+        rec[phase] = {"reduced": list(red.last_reduced), "bytes": red.reduced_bytes(by_set=True),
+                      "grads": {k: (None if p.grad is None else p.grad.clone()) for k, p in net.named_parameters()}}
+    torch.save(rec, os.path.join(out_dir, "p%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_bucket_plan_per_optimizer_two_ranks_gloo(tmp_path):
+    """one bucket set per optimizer; the dmcnet step reduces classifier + generator,
+    the GAN D step classifier + discriminator only, the G step the generator's few bytes only --
+    and never anything from finish()."""
+    port = _free_port()
+    mp.spawn(_ddp_plan_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp_path, "p%d.pt" % r)) for r in (0, 1))
+    assert r0["sets"] == ["base_model", "gen_flow_model", "discriminator"]
+    assert r0["bucket_set"].count("gen_flow_model") == 1 and r0["bucket_set"].count("discriminator") > 1
+    net = _ToyGan()
+    net.load_state_dict(r0["state"])
+    nbytes = {tag: sum(p.numel() * 4 for k, p in net.named_parameters() if tag in k) for tag in r0["sets"]}
+    expect = {"dmcnet": {"base_model", "gen_flow_model"}, "D": {"base_model", "discriminator"},
+              "G": {"gen_flow_model"}}
+    for phase, sets in expect.items():
+        rec = r0[phase]
+        assert set(rec["bytes"]) == sets, (phase, rec["bytes"])
+        assert all(where == "hook" for _, _, _, where in rec["reduced"])         # nothing left to finish()
+        for tag in sets:
+            assert rec["bytes"][tag] == nbytes[tag]
+        if phase == "G":
+            assert sum(rec["bytes"].values()) == nbytes["gen_flow_model"]         # 372 B here, 18 KB in the real model
+        # equal on both ranks, and equal to the single-process gradient over the whole batch
+        for p in net.parameters():
+            p.grad = None
+        _phase_losses(net, r0["x"], r0["flow"], r0["t"], phase).backward()
+        for k, p in net.named_parameters():
+            g0, g1 = rec["grads"][k], r1[phase]["grads"][k]
+            assert (g0 is None) == (p.grad is None), (phase, k)
+            if g0 is not None:
+                assert torch.equal(g0, g1)
+                torch.testing.assert_close(g0, p.grad, rtol=1e-5, atol=1e-7)
+
+
 def _ddp_cl_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -274,3 +363,62 @@ def test_miopen_find_db_is_shipped_and_selected(monkeypatch, tmp_path):
         assert miopen.enable_find() == str(tmp_path)           # the user's choice wins
     finally:
         torch.backends.cudnn.benchmark = prev
+
+
+def test_grouped_adam_multi_tensor_group_matches_torch_adam():
+    """A param group holding several tensors (the bucket key grew per parameter and the
+    unpack raised): GroupedAdam must equal torch.optim.Adam step for step."""
+    torch.manual_seed(3)
+    a = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Linear(4, 3))
+    b = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Linear(4, 3))
+    b.load_state_dict(a.state_dict())
+    oa = train.GroupedAdam(a.parameters(), lr=0.01, weight_decay=1e-4, eps=1e-3)     # ONE group, four tensors
+    ob = torch.optim.Adam(b.parameters(), lr=0.01, weight_decay=1e-4, eps=1e-3)
+    x = torch.randn(6, 5)
+    for _ in range(3):
+        for net, opt in ((a, oa), (b, ob)):
+            opt.zero_grad()
+            net(x).square().mean().backward()
+            opt.step()
+    for p, q in zip(a.parameters(), b.parameters()):
+        torch.testing.assert_close(p, q, rtol=1e-6, atol=1e-7)
+
+
+def test_flow_loss_variants_and_attention_weighting():
+    """--loss_mse choices (code/dmcnet/train.py:166-172) and the att-weighted form (:335); the MSE
+    kernel itself has no CPU path, so the plain MSELoss case raises loudly here."""
+    g = torch.randn(2, 2, 8, 8, requires_grad=True)
+    f, att = torch.randn(2, 2, 8, 8), torch.rand(2, 2, 8, 8, requires_grad=True)
+    assert torch.equal(train.flow_loss("L1", g, f), F.l1_loss(g, f))
+    assert torch.equal(train.flow_loss("SmoothL1Loss", g, f), F.smooth_l1_loss(g, f))
+    l = train.flow_loss("MSELoss", g, f, att)
+    assert torch.equal(l, F.mse_loss(att * g, att * f))
+    l.backward()
+    assert att.grad is not None and g.grad is not None       # the gradient reaches att through both arguments
+    with pytest.raises(ValueError):
+        train.flow_loss("Huber", g, f)
+    with pytest.raises(Exception):
+        train.flow_loss("MSELoss", g, f)                      # HIP only
+    m = dmcnet_amd.Model(51, 3, "mv", base_model="resnet18", use_databn=0, arch_estimator="DenseNetTiny")
+    with pytest.raises(ValueError):
+        train.DmcnetTrainStep(m, 3, 1.0, 10.0, 0.01, 1e-4, 0.01, 1.0, att=1)      # model built with att=0
+    with pytest.raises(ValueError):
+        train.DmcnetTrainStep(m, 3, 1.0, 10.0, 0.01, 1e-4, 0.01, 1.0, loss_mse="Huber")
+
+
+def test_resnet_build_warns_without_weights_and_uses_torchvision_init(tmp_path):
+    from dmcnet_amd import resnet
+    with pytest.warns(UserWarning, match="pretrained=True"):
+        net = resnet.build("resnet18", pretrained=True)
+    bn = net.layer1[0].bn1
+    assert float(bn.weight.min()) == 1.0 and float(bn.bias.abs().max()) == 0.0
+    w = net.layer2[0].conv1.weight                       # kaiming_normal_(fan_out): std = sqrt(2 / (128*9))
+    assert abs(float(w.std()) - (2.0 / (128 * 9)) ** 0.5) < 0.1 * (2.0 / (128 * 9)) ** 0.5
+    sd = {k: torch.full_like(v, 0.5) if v.is_floating_point() else v for k, v in net.state_dict().items()}
+    path = str(tmp_path / "rn18.pt")
+    torch.save(sd, path)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                   # with weights there is nothing to warn about
+        net2 = resnet.build("resnet18", pretrained=True, weights=path)
+    assert float(net2.conv1.weight.mean()) == 0.5

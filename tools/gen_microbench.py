@@ -5,6 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dmcnet_amd
 from dmcnet_amd import ops
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+# kernel-selection options for A/B runs: name=value arguments, e.g. gen_fuse_fwd=0 gen_gather=0
+for arg in sys.argv[2:]:
+    k, v = arg.split("=")
+    dmcnet_amd._lib.check(dmcnet_amd._lib.load().dmc_set_option(k.encode(), int(v)), "dmc_set_option")
 dev = "cuda:0"
 torch.manual_seed(0)
 m = dmcnet_amd.model.EstimatorDenseNetTiny(5).to(dev)
