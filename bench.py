@@ -65,7 +65,7 @@ def usable_cores():
 CPU_TIMED_STEPS = 5
 
 
-def cpu_baseline(batch, num_segments, num_class, budget_s=30.0):
+def cpu_baseline(batch, num_segments, num_class, budget_s=25.0):
     """The oracle's dmcnet train step on the host cores (kind 'port')."""
     from oracle import dmc_oracle as O
     cores = usable_cores()
@@ -80,7 +80,7 @@ def cpu_baseline(batch, num_segments, num_class, budget_s=30.0):
     t0 = time.time()
     O.dmcnet_train_step(m, oc, og, probe, num_segments, 1.0, 10.0)
     per_clip = (time.time() - t0) / 2
-    b = int(max(2, min(batch, budget_s / (CPU_TIMED_STEPS + 1) / max(per_clip, 1e-6))))
+    b = int(max(2, min(batch, budget_s / CPU_TIMED_STEPS / max(1.4 * per_clip, 1e-6))))   # 1.4: large batches run ~40 % slower per clip
     data = O.synthetic_batch(1234, b, num_segments, num_class, flow_ds_factor=16)
     O.dmcnet_train_step(m, oc, og, data, num_segments, 1.0, 10.0)      # warm-up at the timed size
     times = []
