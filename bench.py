@@ -97,6 +97,46 @@ def cpu_baseline(batch, num_segments, num_class, budget_s=25.0):
             "step_s": [round(t, 3) for t in times]}
 
 
+def bench_prepare(dev, n_frames, flow_ds_factor, iters=20):
+    """Sub-line for the HBM-bound input-preparation kernel: uint8 frames as decoded
+    (256x340x7) -> crop + flip + blockify + normalised fp32 planes at 224x224.  Algorithmic bytes per
+    output pixel: 7 read + 28 written = 35.  Two workloads: the validation-style copy crop (no
+    resampling) and the training-style random-scale crop (bilinear resize of the box)."""
+    import random
+    from dmcnet_amd import ops, transforms
+    g = torch.Generator(device=dev).manual_seed(7)
+    frames = ops.u8_frames_buffer((n_frames, 256, 340, 7), dev)
+    frames.copy_(torch.randint(0, 256, frames.shape, generator=g, device=dev, dtype=torch.uint8))
+    out = {}
+    pipes = {"copy_crop": transforms.Compose([transforms.GroupCenterCrop(224), transforms.GroupRandomHorizontalFlip()]),
+             "multiscale_crop_resize": transforms.Compose([transforms.GroupMultiScaleCrop(224, [1, .875, .75]),
+                                                           transforms.GroupRandomHorizontalFlip()])}
+    random.seed(11)
+    for name, pipe in pipes.items():
+        plans, flips = [], []
+        for _ in range(n_frames):
+            plan, size, flip = transforms.geometry_plan(pipe, (256, 340))
+            plans.append(plan); flips.append(int(flip))
+        boxes = torch.tensor(plans, dtype=torch.int32, device=dev)
+        fl = torch.tensor(flips, dtype=torch.uint8, device=dev)
+        for _ in range(3):
+            ops.prepare_inputs(frames, fl, flow_ds_factor, boxes=boxes, out_size=(224, 224))
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            ops.prepare_inputs(frames, fl, flow_ds_factor, boxes=boxes, out_size=(224, 224))
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / iters
+        px = n_frames * 224 * 224
+        src = sum(p[2] * p[3] for p in plans) * 7            # bytes of the boxes actually sampled
+        gbs = (src + px * 28) / (ms * 1e-3) / 1e9
+        out[name] = {"ms": round(ms, 4), "GB/s": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+    out["note"] = ("dmc_prepare_inputs_crop, %d frames 256x340x7 uint8 -> 224x224 fp32 planes, flow_ds_factor %d; "
+                   "bytes = 7 B per sampled source pixel + 28 B per output pixel; bound: hbm" % (n_frames, flow_ds_factor))
+    return out
+
+
 def bench_i3d(args, rank, world, dev):
     """BASELINE config 5: I3D over the per-frame DMC generator; micro-batch of 3 clips x T frames,
     trunk under bf16 autocast, generator fp32; D and G phases alternate (iter_size 1)."""
@@ -281,6 +321,8 @@ def main():
                         "traffic_gbs": None if traffic is None else round(traffic / (fwd_ms * 1e-3) / 1e9, 1)}},
             "kernels_ms": {k: round(v[0], 4) for k, v in spans.items()},
         }
+        if world == 1:
+            line["prepare_inputs"] = bench_prepare(dev, n_frames, 0 if gan else 16)
         if world == 1 and not args.no_cpu_baseline and not gan:
             line["cpu_baseline"] = cpu_baseline(args.batch, S, args.num_class)
         print(json.dumps(line))

@@ -36,6 +36,8 @@ SIGNATURES = {
     "dmc_disc_tail_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dmc_prepare_inputs_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "dmc_prepare_inputs": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "dmc_prepare_crop_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "dmc_prepare_inputs_crop": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "dmc_bn_act_supported": (_I, [_I, _I]),
     "dmc_bn_act_stats_bytes": (_Z, [_I]),
     "dmc_bn_act_scratch_bytes": (_Z, [_I]),

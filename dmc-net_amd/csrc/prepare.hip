@@ -82,6 +82,177 @@ __global__ __launch_bounds__(256) void prepare_kernel(PrepArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Crop + bilinear resize + flip + blockify + normalise in one go (reference:
+// GroupMultiScaleCrop / GroupCenterCrop / GroupScale, code/dmcnet/transforms.py:36-46,62-78,117-139,
+// then GroupRandomHorizontalFlip :47-58, then dataset.py:215-263).  The host only draws the random
+// crop box and the flip bit; the uint8 frames travel as decoded (7 B/px instead of 28).
+//
+// Resize arithmetic = this package's transforms.resize_bilinear (cv2.INTER_LINEAR's half-pixel-centre
+// convention), operation for operation in fp32 with contraction off, so results are bit-identical:
+//   pos = (i + 0.5) * float(n_in / n_out) - 0.5 in fp32;  lo = floor(pos);  f = double(pos) - lo
+//   (numpy promotes float32 - int64 to float64, and everything downstream with it);  indices clamped;
+//   top = a*(1-fx) + b*fx;  bot = c*(1-fx) + d*fx;  v = rint(top*(1-fy) + bot*fy) clipped to [0,255], in fp64.
+// A box of the output size is copied (no arithmetic), as resize_bilinear does.  A crop AFTER the resize
+// (GroupScale + GroupCenterCrop, the validation pipeline) is a window (cy, cx) of the resized image.
+// ------------------------------------------------------------------------------------------
+struct CropArgs {
+    const unsigned char* frames;   // [N][H0][W0][7]
+    const int* boxes;              // [N][8] = y0, x0, h, w, rh, rw, cy, cx (device), or null = whole frame
+    const unsigned char* flip;     // [N] or null
+    float* flow; float* mv; float* res;
+    float* block_mean;             // [N][2][bh][bw] (factor > 0)
+    int N, H0, W0, OH, OW, factor, bh, bw;
+    float std_mean, std_r, std_g, std_b;
+};
+
+// box (y0, x0, h, w) of the frame is resized to rh x rw, of which the window at (cy, cx) of the output
+// size is kept (GroupScale + GroupCenterCrop); rh x rw == h x w means "no resampling"
+struct Box { int y0, x0, h, w, rh, rw, cy, cx; };
+__device__ __forceinline__ Box box_of(const CropArgs& a, int n) {
+    Box b = {0, 0, a.H0, a.W0, a.OH, a.OW, 0, 0};
+    if (a.boxes) {
+        const int* p = a.boxes + (size_t)n * 8;
+        b.y0 = p[0]; b.x0 = p[1]; b.h = p[2]; b.w = p[3]; b.rh = p[4]; b.rw = p[5]; b.cy = p[6]; b.cx = p[7];
+    }
+    return b;
+}
+
+struct Tap { int lo, hi; double f; };
+__device__ __forceinline__ Tap tap_of(int i, int n_out, int n_in) {
+    const float scale = (float)((double)n_in / (double)n_out);
+    const float pos = ((float)i + 0.5f) * scale - 0.5f;
+    const float fl = floorf(pos);
+    const int lo = (int)fl;
+    Tap t;
+    t.f = (double)pos - (double)lo;
+    t.lo = lo < 0 ? 0 : (lo > n_in - 1 ? n_in - 1 : lo);
+    t.hi = lo + 1 < 0 ? 0 : (lo + 1 > n_in - 1 ? n_in - 1 : lo + 1);
+    return t;
+}
+
+// value of channel c at output pixel (y, x) BEFORE the flip's sign change (x already un-mirrored by the caller)
+__device__ __forceinline__ int resized_u8(const CropArgs& a, const unsigned char* fr, const Box& b, int y, int x, int c) {
+    if (b.h == b.rh && b.w == b.rw)
+        return fr[((size_t)(b.y0 + b.cy + y) * a.W0 + (b.x0 + b.cx + x)) * 7 + c];
+    const Tap ty = tap_of(y + b.cy, b.rh, b.h), tx = tap_of(x + b.cx, b.rw, b.w);
+    const unsigned char* r0 = fr + ((size_t)(b.y0 + ty.lo) * a.W0 + b.x0) * 7 + c;
+    const unsigned char* r1 = fr + ((size_t)(b.y0 + ty.hi) * a.W0 + b.x0) * 7 + c;
+    const double p00 = (double)r0[(size_t)tx.lo * 7], p01 = (double)r0[(size_t)tx.hi * 7];
+    const double p10 = (double)r1[(size_t)tx.lo * 7], p11 = (double)r1[(size_t)tx.hi * 7];
+    const double top = p00 * (1.0 - tx.f) + p01 * tx.f;
+    const double bot = p10 * (1.0 - tx.f) + p11 * tx.f;
+    double v = rint(top * (1.0 - ty.f) + bot * ty.f);
+    v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+    return (int)v;
+}
+
+// one wave per (frame, flow channel, block): integer sum of the block's resized + flipped pixels
+__global__ __launch_bounds__(256) void crop_block_mean_kernel(CropArgs a) {
+    const long total = (long)a.N * 2 * a.bh * a.bw;
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= total) return;
+    const int lane = threadIdx.x & 63;
+    const int bx = (int)(i % a.bw), by = (int)((i / a.bw) % a.bh);
+    const int c = (int)((i / ((long)a.bw * a.bh)) % 2), n = (int)(i / ((long)a.bw * a.bh * 2));
+    const bool flipped = a.flip && a.flip[n];
+    const Box b = box_of(a, n);
+    const unsigned char* fr = a.frames + (size_t)n * a.H0 * a.W0 * 7;
+    int sum = 0;
+    for (int k = lane; k < a.factor * a.factor; k += 64) {
+        const int y = by * a.factor + k / a.factor, x = bx * a.factor + k % a.factor;
+        if (y < a.OH && x < a.OW) {
+            const int xs = flipped ? a.OW - 1 - x : x;
+            sum += flip_value(resized_u8(a, fr, b, y, xs, c), c, flipped);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
+    if (lane == 0) a.block_mean[i] = (float)((double)sum / (double)(a.factor * a.factor));
+}
+
+// 4 consecutive output pixels per thread, float4 stores into the seven planes.  Identity-size
+// boxes read their 28 source bytes as aligned dwords + byte alignment (no byte loads).
+__global__ __launch_bounds__(256) void prepare_crop_kernel(CropArgs a) {
+    const int qw = (a.OW + 3) / 4;                                  // 4-pixel groups per row
+    const size_t OHW = (size_t)a.OH * a.OW;
+    const size_t total = (size_t)a.N * a.OH * qw;
+    const bool vec_ok = (a.OW & 3) == 0;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
+        const int n = (int)(g / ((size_t)a.OH * qw));
+        const int rem = (int)(g - (size_t)n * a.OH * qw);
+        const int y = rem / qw, x0 = (rem - y * qw) * 4;
+        const bool flipped = a.flip && a.flip[n];
+        const Box b = box_of(a, n);
+        const unsigned char* fr = a.frames + (size_t)n * a.H0 * a.W0 * 7;
+        int v[4][7];
+        const bool identity = b.h == b.rh && b.w == b.rw;
+        if (identity && x0 + 3 < a.OW) {
+            // source pixels xs .. xs+3 (ascending in memory): 28 contiguous bytes
+            const int xs = flipped ? a.OW - 4 - x0 : x0;
+            const size_t off = ((size_t)(b.y0 + b.cy + y) * a.W0 + (b.x0 + b.cx + xs)) * 7;
+            const size_t base = (size_t)(fr - a.frames) + off;
+            const unsigned* w32 = reinterpret_cast<const unsigned*>(a.frames + (base & ~(size_t)3));
+            const unsigned sh = (unsigned)(base & 3);
+            unsigned d[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d[k] = w32[k];              // (the 8th dword is inside the buffer's 16-byte tail pad)
+            unsigned char bytes[28];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                const unsigned u = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sh);
+                bytes[4 * k + 0] = u & 255; bytes[4 * k + 1] = (u >> 8) & 255;
+                bytes[4 * k + 2] = (u >> 16) & 255; bytes[4 * k + 3] = u >> 24;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int js = flipped ? 3 - j : j;
+#pragma unroll
+                for (int c = 0; c < 7; ++c) v[j][c] = flip_value(bytes[js * 7 + c], c, flipped);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int x = x0 + j < a.OW ? x0 + j : a.OW - 1;
+                const int xs = flipped ? a.OW - 1 - x : x;
+#pragma unroll
+                for (int c = 0; c < 7; ++c) v[j][c] = flip_value(resized_u8(a, fr, b, y, xs, c), c, flipped);
+            }
+        }
+        float o[7][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = x0 + j < a.OW ? x0 + j : a.OW - 1;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float f = a.factor > 0
+                    ? a.block_mean[(((size_t)n * 2 + c) * a.bh + y / a.factor) * a.bw + x / a.factor]
+                    : (float)v[j][c];
+                o[c][j] = (f / 255.0f - 0.5f) / a.std_mean;
+                o[2 + c][j] = ((float)v[j][2 + c] / 255.0f - 0.5f) / a.std_mean;
+            }
+            o[4][j] = ((float)v[j][4] / 255.0f - 0.5f) / a.std_r;
+            o[5][j] = ((float)v[j][5] / 255.0f - 0.5f) / a.std_g;
+            o[6][j] = ((float)v[j][6] / 255.0f - 0.5f) / a.std_b;
+        }
+        const size_t pix = (size_t)y * a.OW + x0;
+#pragma unroll
+        for (int c = 0; c < 7; ++c) {
+            float* dst = c < 2 ? a.flow + ((size_t)n * 2 + c) * OHW
+                       : c < 4 ? a.mv + ((size_t)n * 2 + (c - 2)) * OHW
+                               : a.res + ((size_t)n * 3 + (c - 4)) * OHW;
+            if (vec_ok) {
+                *reinterpret_cast<float4*>(dst + pix) = make_float4(o[c][0], o[c][1], o[c][2], o[c][3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (x0 + j < a.OW) dst[pix + j] = o[c][j];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -116,6 +287,38 @@ int dmc_prepare_inputs(const unsigned char* frames_u8, const unsigned char* flip
     size_t want = ((size_t)N * H * W + 255) / 256;
     prepare_kernel<<<(int)(want > 8192 ? 8192 : want), 256, 0, s>>>(a);
     return check_launch("prepare_inputs");
+}
+
+size_t dmc_prepare_crop_workspace_bytes(int N, int OH, int OW, int flow_ds_factor) {
+    return dmc_prepare_inputs_workspace_bytes(N, OH, OW, flow_ds_factor);
+}
+
+int dmc_prepare_inputs_crop(const unsigned char* frames_u8, const int* boxes, const unsigned char* flip,
+                            float* out_flow, float* out_mv, float* out_res, float* workspace, int N,
+                            int H0, int W0, int OH, int OW, int flow_ds_factor, const float* std4_host,
+                            dmc_stream_t stream) {
+    if (!frames_u8 || !out_flow || !out_mv || !out_res || !workspace || !std4_host)
+        return fail(DMC_E_INVALID, "dmc_prepare_inputs_crop: null pointer");
+    if (N <= 0 || H0 <= 0 || W0 <= 0 || OH <= 0 || OW <= 0 || flow_ds_factor < 0)
+        return fail(DMC_E_INVALID, "dmc_prepare_inputs_crop: bad shape");
+    if (!boxes && (H0 != OH || W0 != OW))
+        return fail(DMC_E_INVALID, "dmc_prepare_inputs_crop: without boxes the frames must measure OH x OW");
+    hipStream_t s = (hipStream_t)stream;
+    CropArgs a;
+    a.frames = frames_u8; a.boxes = boxes; a.flip = flip; a.flow = out_flow; a.mv = out_mv; a.res = out_res;
+    a.block_mean = workspace; a.N = N; a.H0 = H0; a.W0 = W0; a.OH = OH; a.OW = OW; a.factor = flow_ds_factor;
+    a.bh = flow_ds_factor ? (OH + flow_ds_factor - 1) / flow_ds_factor : 0;
+    a.bw = flow_ds_factor ? (OW + flow_ds_factor - 1) / flow_ds_factor : 0;
+    a.std_mean = std4_host[0]; a.std_r = std4_host[1]; a.std_g = std4_host[2]; a.std_b = std4_host[3];
+    int rc;
+    if (flow_ds_factor > 0) {
+        const long total = (long)N * 2 * a.bh * a.bw;
+        crop_block_mean_kernel<<<(int)((total + 3) / 4), 256, 0, s>>>(a);
+        if ((rc = check_launch("prepare_crop_block_mean"))) return rc;
+    }
+    const size_t want = ((size_t)N * OH * ((OW + 3) / 4) + 255) / 256;
+    prepare_crop_kernel<<<(int)(want > 16384 ? 16384 : want), 256, 0, s>>>(a);
+    return check_launch("prepare_inputs_crop");
 }
 
 }  // extern "C"

@@ -116,6 +116,15 @@ class SyntheticCoviarDataSet(data.Dataset):
         flow, mv, res = to_tensors(frames, self.flow_ds_factor)
         return flow, mv, res, int(rs.randint(0, self.num_class))
 
+    def raw_item(self, index):
+        """uint8 frames for the GPU-side preparation (same contract as ``CoviarDataSet.raw_item``)."""
+        rs = np.random.RandomState(self.seed + index)
+        frames = synthetic_clip_u8(rs, self.num_segments, self.size)           # [S,7,H,W]
+        label = int(rs.randint(0, self.num_class))
+        hwc = np.ascontiguousarray(frames.transpose(0, 2, 3, 1))
+        sz = self.size
+        return hwc, np.asarray([0, 0, sz, sz, sz, sz, 0, 0], np.int32), (sz, sz), False, label
+
 
 def synthetic_batch_on_device(seed, batch, num_segments, num_class, device, size=224,
                               flow_ds_factor=0):
@@ -186,7 +195,9 @@ class CoviarDataSet(data.Dataset):
     def __len__(self):
         return len(self._video_list)
 
-    def __getitem__(self, index):
+    def _load_frames(self, index):
+        """The decoded side of ``__getitem__`` (code/dmcnet/dataset.py:151-213): S uint8 HWC frames
+        [flow_x flow_y mv_x mv_y r g b] of the sampled positions and the label."""
         from coviar import load
         from PIL import Image
         if self._representation != "mv":
@@ -211,6 +222,68 @@ class CoviarDataSet(data.Dataset):
                 mv = np.clip(mv + 128, 0, 255).astype(np.uint8)
             res = np.clip(load(path, gop_index, gop_pos, 2, self._accumulate) + 128, 0, 255)
             frames.append(np.concatenate((flow, mv, res.astype(np.uint8)), axis=2))
+        return frames, label
+
+    def __getitem__(self, index):
+        frames, label = self._load_frames(index)
         frames = np.transpose(np.array(self._transform(frames)), (0, 3, 1, 2))
         flow, mv, res = to_tensors(frames, self._flow_ds_factor)
         return flow, mv, res, label
+
+    def raw_item(self, index):
+        """The same sample for the GPU-side preparation (``ops.prepare_inputs`` / ``DevicePrep``):
+        ``(frames uint8 [S,H0,W0,7] as decoded, plan int32 [8], out_size (h, w), flip bool, label)``
+        (plan: transforms.geometry_plan).
+        Consumes the RNG exactly as ``__getitem__`` does; 7 B/px cross PCIe instead of 28."""
+        from . import transforms as T
+        frames, label = self._load_frames(index)
+        box, out, flip = T.geometry_plan(self._transform, frames[0].shape)
+        return np.ascontiguousarray(np.stack(frames)).astype(np.uint8), np.asarray(box, np.int32), out, flip, label
+
+
+class RawView(data.Dataset):
+    """``ds.raw_item`` as a Dataset (for a DataLoader whose batches go to :class:`DevicePrep`)."""
+
+    def __init__(self, ds):
+        self.ds = ds
+
+    def __len__(self):
+        return len(self.ds)
+
+    def __getitem__(self, index):
+        return self.ds.raw_item(index)
+
+
+def collate_raw(items):
+    """Batch of raw items -> (frames uint8 [B,S,H0,W0,7], plans int32 [B,8], out_size, flips uint8 [B],
+    labels int64 [B]); frames of one batch must share (H0, W0) and out_size."""
+    frames = torch.from_numpy(np.stack([it[0] for it in items]))
+    boxes = torch.from_numpy(np.stack([it[1] for it in items]))
+    outs = {tuple(it[2]) for it in items}
+    if len(outs) != 1:
+        raise ValueError("collate_raw: mixed output sizes %s" % sorted(outs))
+    flips = torch.tensor([1 if it[3] else 0 for it in items], dtype=torch.uint8)
+    labels = torch.tensor([int(it[4]) for it in items], dtype=torch.int64)
+    return frames, boxes, outs.pop(), flips, labels
+
+
+class DevicePrep(object):
+    """Raw batch (``collate_raw``) -> the (input_flow, input_mv, input_residual, target) batch of the
+    reference's loader, computed on the GPU by ``dmc_prepare_inputs_crop``: crop, bilinear resize,
+    flip with x negation, 16x16 flow blockify, /255 and normalisation
+    (code/dmcnet/transforms.py:36-139, code/dmcnet/dataset.py:215-263)."""
+
+    def __init__(self, device, flow_ds_factor=0):
+        self.device, self.flow_ds_factor = torch.device(device), flow_ds_factor
+
+    def __call__(self, raw):
+        from . import ops
+        frames, boxes, out, flips, labels = raw
+        b, s = frames.shape[:2]
+        fr = ops.u8_frames_buffer((b * s,) + tuple(frames.shape[2:]), self.device)
+        fr.copy_(frames.flatten(0, 1), non_blocking=True)
+        bx = boxes.to(self.device, non_blocking=True).repeat_interleave(s, 0)
+        fl = flips.to(self.device, non_blocking=True).repeat_interleave(s, 0)
+        flow, mv, res = ops.prepare_inputs(fr, fl, self.flow_ds_factor, boxes=bx, out_size=out)
+        shp = lambda t: t.reshape((b, s) + tuple(t.shape[1:]))
+        return shp(flow), shp(mv), shp(res), labels.to(self.device, non_blocking=True)

@@ -26,14 +26,16 @@ def _to(batch, device):
 
 
 def train_epoch(loader, stepper, epoch, device="cuda:0", freeze=False, print_freq=PRINT_FREQ,
-                log=print):
-    """One epoch of ``train()``.  ``stepper`` is a DmcnetTrainStep or a GanTrainStep."""
+                log=print, prep=None):
+    """One epoch of ``train()``.  ``stepper`` is a DmcnetTrainStep or a GanTrainStep.  ``prep`` (a
+    ``dataset.DevicePrep``) turns the loader's raw uint8 batches (``dataset.RawView`` +
+    ``dataset.collate_raw``) into the float batch on the GPU instead of in the loader workers."""
     meters = {k: train.AverageMeter() for k in ("loss", "loss_cls", "loss_mse", "top1", "top5")}
     gan = isinstance(stepper, train.GanTrainStep)
     stepper.model.train()
     t0 = time.time()
     for i, batch in enumerate(loader):
-        batch = _to(batch, device)
+        batch = prep(batch) if prep is not None else _to(batch, device)
         out = stepper.step(batch, i) if gan else stepper.step(batch, freeze=freeze)
         n = batch[0].shape[0] * stepper.num_segments
         prec1, prec5 = train.accuracy(out["output"], batch[3], topk=(1, 5))
@@ -54,13 +56,14 @@ def train_epoch(loader, stepper, epoch, device="cuda:0", freeze=False, print_fre
 
 
 @torch.no_grad()
-def validate(loader, model, num_segments, lr_cls, lr_mse, device="cuda:0", log=print, loss_mse="MSELoss"):
+def validate(loader, model, num_segments, lr_cls, lr_mse, device="cuda:0", log=print, loss_mse="MSELoss",
+             prep=None):
     """``validate()``: eval mode, CE on the segment consensus + flow MSE, Prec@1/5; returns the
     dict of averages (``top1`` is what the reference returns)."""
     meters = {k: train.AverageMeter() for k in ("loss", "loss_cls", "loss_mse", "top1", "top5")}
     model.eval()
     for batch in loader:
-        input_flow, input_mv, input_residual, target = _to(batch, device)
+        input_flow, input_mv, input_residual, target = prep(batch) if prep is not None else _to(batch, device)
         flow = input_flow.reshape((-1,) + tuple(input_mv.shape[-3:]))
         out = model(input_mv, input_residual)
         att = getattr(model, "att", 0) == 1
@@ -84,7 +87,7 @@ def validate(loader, model, num_segments, lr_cls, lr_mse, device="cuda:0", log=p
 def fit(model, stepper, train_loader, val_loader, epochs, lr, weight_decay, lr_steps, lr_decay=0.1,
         epoch_thre=0, eval_freq=5, lr_cls=1.0, lr_mse=10.0, arch="resnet18", model_prefix="model",
         representation="mv", device="cuda:0", start_epoch=0, best_prec1=0.0, log=print, save=True,
-        miopen_find=True):
+        miopen_find=True, prep=None):
     """The epoch loop of ``main()`` (code/dmcnet/train.py:175-201).  ``miopen_find`` mirrors the
     reference's ``cudnn.benchmark = True`` (:118), answered from the shipped MIOpen find-db."""
     if miopen_find and str(device).startswith("cuda"):
@@ -99,11 +102,11 @@ def fit(model, stepper, train_loader, val_loader, epochs, lr, weight_decay, lr_s
         if gan:
             train.adjust_learning_rate(stepper.optimizer_d, epoch, lr_steps, lr_decay, lr, weight_decay)
         tr = train_epoch(train_loader, stepper, epoch, device, freeze=(epoch < epoch_thre and not gan),
-                         log=log)
+                         log=log, prep=prep)
         entry = {"epoch": epoch, "train": tr}
         if epoch % eval_freq == 0 or epoch == epochs - 1:
             va = validate(val_loader, model, stepper.num_segments, lr_cls, lr_mse, device, log=log,
-                          loss_mse=getattr(stepper, "loss_mse", "MSELoss"))
+                          loss_mse=getattr(stepper, "loss_mse", "MSELoss"), prep=prep)
             entry["val"] = va
             is_best = va["top1"] > best_prec1
             best_prec1 = max(va["top1"], best_prec1)

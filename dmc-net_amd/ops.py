@@ -5,7 +5,8 @@ import torch
 
 from . import _lib
 
-__all__ = ["gen_tiny", "flow_mse", "consensus_ce", "disc_tail", "bn_act", "bn_act_supported", "prepare_inputs"]
+__all__ = ["gen_tiny", "flow_mse", "consensus_ce", "disc_tail", "bn_act", "bn_act_supported", "prepare_inputs",
+           "u8_frames_buffer"]
 
 
 class EventProbe(object):
@@ -476,29 +477,55 @@ def stem_conv(x, weight):
 _STD = (0.229, 0.224, 0.225)
 
 
-def prepare_inputs(frames_u8, flip=None, flow_ds_factor=0):
-    """uint8 [N,H,W,7] HWC frames (+ optional [N] flip flags) on the GPU -> (input_flow [N,2,H,W],
-    input_mv [N,2,H,W], input_residual [N,3,H,W]) exactly as the reference's dataset produces them
-    (code/dmcnet/dataset.py:215-263, transforms.py:47-58)."""
+def u8_frames_buffer(shape, device):
+    """A contiguous uint8 tensor of ``shape`` whose storage has 16 spare bytes behind it (what
+    ``prepare_inputs`` wants for its aligned 4-pixel reads): the H2D copy target of a loader."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    return torch.empty(n + 16, dtype=torch.uint8, device=device)[:n].view(tuple(shape))
+
+
+def prepare_inputs(frames_u8, flip=None, flow_ds_factor=0, boxes=None, out_size=None):
+    """uint8 [N,H0,W0,7] HWC frames (+ optional [N] flip flags, [N,8] int32 geometry plans
+    (y0,x0,h,w,rh,rw,cy,cx -- see transforms.geometry_plan) and an output size) on the GPU ->
+    (input_flow [N,2,H,W], input_mv [N,2,H,W], input_residual
+    [N,3,H,W]) exactly as the reference's loader produces them: crop + bilinear resize
+    (code/dmcnet/transforms.py:36-139), flip (:47-58), blockify / normalise
+    (code/dmcnet/dataset.py:215-263).  Without ``boxes`` / ``out_size`` the frames are taken whole."""
     import ctypes
     lib = _lib.load()
     if not frames_u8.is_cuda or frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 \
             or frames_u8.shape[-1] != 7:
         raise _lib.DmcHipError("prepare_inputs expects a CUDA uint8 tensor [N,H,W,7]")
-    frames_u8 = frames_u8.contiguous()
-    n, h, w, _ = frames_u8.shape
+    n, h0, w0, _ = frames_u8.shape
     dev = frames_u8.device
+    oh, ow = (h0, w0) if out_size is None else (int(out_size[0]), int(out_size[1]))
+    # the 4-pixel path reads whole aligned dwords: it needs 16 spare bytes behind the last frame.
+    # ``u8_frames_buffer`` allocates such tensors; anything else is copied once into one.
+    spare = frames_u8.untyped_storage().nbytes() - frames_u8.storage_offset() - frames_u8.numel()
+    if frames_u8.is_contiguous() and spare >= 16:
+        padded = frames_u8
+    else:
+        padded = u8_frames_buffer(frames_u8.shape, dev)
+        padded.copy_(frames_u8)
     if flip is not None:
         flip = flip.to(dev, torch.uint8).contiguous()
-    flow = torch.empty((n, 2, h, w), dtype=torch.float32, device=dev)
-    mv = torch.empty((n, 2, h, w), dtype=torch.float32, device=dev)
-    res = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev)
-    work = _floats(lib.dmc_prepare_inputs_workspace_bytes(n, h, w, int(flow_ds_factor)), dev)
+    if boxes is not None:
+        boxes = boxes.to(dev, torch.int32).contiguous()
+        if tuple(boxes.shape) != (n, 8):
+            raise ValueError("boxes must be [N,8] (y0, x0, h, w, rh, rw, cy, cx)")
+    elif (oh, ow) != (h0, w0):
+        boxes = torch.tensor([[0, 0, h0, w0, oh, ow, 0, 0]] * n, dtype=torch.int32, device=dev)
+    flow = torch.empty((n, 2, oh, ow), dtype=torch.float32, device=dev)
+    mv = torch.empty((n, 2, oh, ow), dtype=torch.float32, device=dev)
+    res = torch.empty((n, 3, oh, ow), dtype=torch.float32, device=dev)
+    work = _floats(lib.dmc_prepare_crop_workspace_bytes(n, oh, ow, int(flow_ds_factor)), dev)
     std = torch.tensor(_STD, dtype=torch.float64).float()
     std4 = (ctypes.c_float * 4)(float(torch.mean(std)), float(std[0]), float(std[1]), float(std[2]))
     with _span("prepare_inputs"):
-        _lib.check(lib.dmc_prepare_inputs(_lib.ptr(frames_u8), _lib.ptr(flip), _lib.ptr(flow),
-                                          _lib.ptr(mv), _lib.ptr(res), _lib.ptr(work), n, h, w,
-                                          int(flow_ds_factor), ctypes.cast(std4, ctypes.c_void_p),
-                                          _stream()), "dmc_prepare_inputs")
+        _lib.check(lib.dmc_prepare_inputs_crop(_lib.ptr(padded), _lib.ptr(boxes), _lib.ptr(flip), _lib.ptr(flow),
+                                               _lib.ptr(mv), _lib.ptr(res), _lib.ptr(work), n, h0, w0, oh, ow,
+                                               int(flow_ds_factor), ctypes.cast(std4, ctypes.c_void_p),
+                                               _stream()), "dmc_prepare_inputs_crop")
     return flow, mv, res

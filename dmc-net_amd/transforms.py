@@ -113,3 +113,58 @@ class GroupMultiScaleCrop(object):
         if more_fix_crop:
             grid += [(0, 2), (4, 2), (2, 4), (2, 0), (1, 1), (3, 1), (1, 3), (3, 3)]
         return [(i * sw, j * sh) for i, j in grid]
+
+
+def geometry_plan(transform, im_shape):
+    """What ``transform`` (a Compose of the classes above) WOULD do to frames of ``im_shape`` (H, W[, C]),
+    without touching pixels: ``(plan, (out_h, out_w), flip)`` with
+    ``plan = (y0, x0, h, w, rh, rw, cy, cx)`` -- the box (y0, x0, h, w) of the frame is resized to
+    rh x rw and the out_h x out_w window at (cy, cx) of that image is the result -- and the
+    horizontal-flip decision.  Covers the reference's pipelines: crop -> resize -> flip (training)
+    and scale -> centre crop (validation / test).  The random draws are made in the order applying the
+    transforms makes them (choice(pairs), randint, randint, random()), so a loader that ships the
+    plan to the GPU (``ops.prepare_inputs``) consumes the RNG exactly like one that applies the
+    transforms on the CPU."""
+    h, w = int(im_shape[0]), int(im_shape[1])
+    box, rs, win, flip = [0, 0, h, w], None, None, False      # rs: resized size; win: (cy, cx, oh, ow) after it
+    ts = transform.transforms if isinstance(transform, Compose) else [transform]
+
+    def crop(top, left, ch, cw):
+        nonlocal box, win
+        if rs is None:                                           # still in source pixels
+            box = [box[0] + top, box[1] + left, ch, cw]
+        else:                                                    # a window of the resized image
+            cy, cx = (win[0], win[1]) if win else (0, 0)
+            win = (cy + top, cx + left, ch, cw)
+
+    for t in ts:
+        if flip:
+            raise ValueError("geometry_plan: a geometric transform after the flip is not supported")
+        cur_h, cur_w = (win[2], win[3]) if win else (rs if rs else (box[2], box[3]))
+        if isinstance(t, GroupCenterCrop):
+            crop((cur_h - t.size) // 2, (cur_w - t.size) // 2, t.size, t.size)
+        elif isinstance(t, (GroupScale, GroupMultiScaleCrop)):
+            if rs is not None:
+                raise ValueError("geometry_plan: two resampling passes; apply the transforms on the CPU")
+            if isinstance(t, GroupMultiScaleCrop):
+                cw, ch, ow, oh = t._sample_crop_size((cur_h, cur_w))
+                crop(ow, oh, cw, ch)
+                rs = (t.input_size[0], t.input_size[1])
+            else:
+                rs = (t.size, t.size)
+        elif isinstance(t, GroupRandomHorizontalFlip):
+            flip = random.random() < 0.5
+        else:
+            raise ValueError("geometry_plan: unsupported transform %r" % (t,))
+    if rs is None:
+        rs = (box[2], box[3])
+    if win is None:
+        win = (0, 0, rs[0], rs[1])
+    return (box[0], box[1], box[2], box[3], rs[0], rs[1], win[0], win[1]), (win[2], win[3]), flip
+
+
+def apply_plan(img, plan, out, flip):
+    """The CPU evaluation of a plan (what the GPU kernel computes in uint8)."""
+    y0, x0, h, w, rh, rw, cy, cx = plan
+    r = resize_bilinear(img[y0:y0 + h, x0:x0 + w], rh, rw)[cy:cy + out[0], cx:cx + out[1]]
+    return flip_with_x_negation(r) if flip else r

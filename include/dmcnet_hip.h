@@ -195,6 +195,25 @@ int dmc_prepare_inputs(const unsigned char* frames_u8, const unsigned char* flip
                        float* out_mv, float* out_res, float* workspace, int N, int H, int W,
                        int flow_ds_factor, const float* std4_host, dmc_stream_t stream);
 
+/* Crop + bilinear resize + flip + blockify + normalise on the device: the whole of
+ * GroupMultiScaleCrop / GroupCenterCrop / GroupScale (code/dmcnet/transforms.py:36-46,62-78,
+ * 117-139), GroupRandomHorizontalFlip (:47-58) and dataset.py:215-263 except the random draws,
+ * which stay on the host (crop box, flip bit).
+ * frames_u8 [N,H0,W0,7] uint8 as decoded, allocated with >= 16 spare bytes behind the last frame
+ * (the 4-pixel path reads whole aligned dwords); boxes [N,8] int32 DEVICE array
+ * (y0, x0, h, w, rh, rw, cy, cx): the box (y0, x0, h, w) of each frame is resized to rh x rw with the
+ * half-pixel-centre bilinear rule (bit-identical to this package's transforms.resize_bilinear;
+ * rh x rw == h x w copies) and the OH x OW window at (cy, cx) of that image is produced
+ * (crop -> resize: cy = cx = 0, rh x rw = OH x OW; scale -> centre crop: the window); NULL = the
+ * whole frame, which must then measure OH x OW; flip as above (applied last); outputs
+ * [N,2,OH,OW], [N,2,OH,OW], [N,3,OH,OW] fp32.  workspace: dmc_prepare_crop_workspace_bytes().
+ */
+size_t dmc_prepare_crop_workspace_bytes(int N, int OH, int OW, int flow_ds_factor);
+int dmc_prepare_inputs_crop(const unsigned char* frames_u8, const int* boxes, const unsigned char* flip,
+                            float* out_flow, float* out_mv, float* out_res, float* workspace, int N,
+                            int H0, int W0, int OH, int OW, int flow_ds_factor, const float* std4_host,
+                            dmc_stream_t stream);
+
 /* ---- classifier stem: BatchNorm + ReLU + MaxPool2d(3, stride 2, padding 1) fused -----------------
  * Replaces `self.maxpool(self.relu(self.bn1(x)))` of the torchvision ResNet the reference builds at
  * code/dmcnet/model.py:305 (run at :352) and its autograd.  x [N,H,W,C] fp32 NHWC (conv1 output),

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""G9: the tensor contract of the dataset, produced by the REFERENCE's own
+``CoviarDataSet.__getitem__`` (code/dmcnet/dataset.py:151-281) run in this container:
+
+    python tests/golden/make_golden_dataset.py
+
+The reference's dataset.py / transforms.py are imported as they are (stub ``cv2`` / ``skimage`` /
+``torchvision`` modules for what this image lacks; ``np.float = float`` because dataset.py:41 uses
+the removed alias), ``coviar.load`` is the seeded stand-in of tests/golden/coviar_fixture.py and the
+flow frames are the files that module writes.  Transforms: the reference's own ``GroupCenterCrop``
+and ``GroupRandomHorizontalFlip`` (pure numpy; ``GroupScale`` / ``GroupMultiScaleCrop`` call
+cv2.resize, which is absent).  Stored: the reference's 4-tuple per case, ``flow_ds_factor = 0``.
+NOT pinned: ``flow_ds_factor = 16`` -- skimage's ``block_reduce`` is absent; that one function stays
+restated from its documentation.
+"""
+import os
+import random
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from tests.golden import coviar_fixture as CF            # noqa: E402
+from tests.golden.make_golden import import_ref, install_stubs   # noqa: E402
+
+
+def main():
+    install_stubs()
+    sys.modules["coviar"] = CF.coviar_module()
+    if not hasattr(np, "float"):
+        np.float = float                                   # dataset.py:41 (removed numpy alias)
+    ref_ds = import_ref("dmcnet", "dataset")
+    ref_tf = import_ref("dmcnet", "transforms")
+    Compose = sys.modules["torchvision"].transforms.Compose
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        data_root, flow_root, lst = CF.write_dataset(tmp)
+        for tag, is_train, minmax, seed, index, with_flip in CF.CASES:
+            ts = [ref_tf.GroupCenterCrop(CF.CROP)] + ([ref_tf.GroupRandomHorizontalFlip()] if with_flip else [])
+            ds = ref_ds.CoviarDataSet(data_root, flow_root, "hmdb51", lst, "mv", 1, 0, False, Compose(ts), 3,
+                                      is_train, True, 12, mv_minmaxnorm=minmax)
+            assert len(ds) == len(CF.VIDEOS)
+            random.seed(seed)
+            flow, mv, res, label = ds[index]
+            out[tag + "_flow"], out[tag + "_mv"], out[tag + "_res"] = flow.numpy(), mv.numpy(), res.numpy()
+            out[tag + "_label"] = np.int64(label)
+            print(tag, tuple(flow.shape), tuple(mv.shape), tuple(res.shape), label, float(mv.mean()))
+    np.savez_compressed(os.path.join(HERE, "g9_dataset_item.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()

@@ -578,6 +578,58 @@ def test_prepare_inputs_bit_exact(size, factor):
     assert torch.equal(f.cpu(), f0)
 
 
+@pytest.mark.parametrize("factor", [0, 16])
+def test_prepare_inputs_crop_resize_flip_bit_exact(factor):
+    """Crop + bilinear resize + flip + blockify + normalise on the GPU == the CPU transforms followed by
+    the dataset's tensor conversion, bit for bit, for the reference's training pipeline
+    (GroupMultiScaleCrop + GroupRandomHorizontalFlip: every scale pair, both flip outcomes) and its
+    validation pipeline (GroupScale + GroupCenterCrop); code/dmcnet/transforms.py:36-139,
+    dataset.py:215-263."""
+    import random
+    from dmcnet_amd import dataset, transforms
+    rs = np.random.RandomState(31)
+    pipes = [transforms.Compose([transforms.GroupMultiScaleCrop(224, [1, .875, .75]),
+                                 transforms.GroupRandomHorizontalFlip()]),
+             transforms.Compose([transforms.GroupScale(256), transforms.GroupCenterCrop(224)]),
+             transforms.Compose([transforms.GroupCenterCrop(224), transforms.GroupRandomHorizontalFlip()])]
+    frames, plans, flips, want = [], [], [], []
+    for k in range(9):
+        f = rs.randint(0, 256, (256, 340, 7)).astype(np.uint8)
+        random.seed(100 + k)
+        plan, out, flip = transforms.geometry_plan(pipes[k % 3], f.shape)
+        assert out == (224, 224)
+        frames.append(f); plans.append(plan); flips.append(int(flip))
+        want.append(np.transpose(np.asarray(transforms.apply_plan(f, plan, out, flip)), (2, 0, 1)))
+    assert 0 < sum(flips) < len(flips) and any(p[2] != 224 for p in plans)
+    ref = dataset.to_tensors(np.stack(want), factor)
+    got = ops.prepare_inputs(torch.from_numpy(np.stack(frames)).to(DEV), torch.tensor(flips, dtype=torch.uint8),
+                             factor, boxes=torch.tensor(plans, dtype=torch.int32), out_size=(224, 224))
+    for g, r, name in zip(got, ref, ("flow", "mv", "res")):
+        assert torch.equal(g.cpu(), r), name
+
+
+def test_device_prep_matches_reference_getitem(golden, tmp_path, monkeypatch):
+    """a19 end to end on the GPU: raw uint8 item -> DevicePrep (dmc_prepare_inputs_crop) == the 4-tuple
+    the REFERENCE's CoviarDataSet.__getitem__ returned for the same files (golden G9)."""
+    import random
+    import sys
+    from dmcnet_amd import dataset, transforms
+    from tests.golden import coviar_fixture as CF
+    monkeypatch.setitem(sys.modules, "coviar", CF.coviar_module())
+    data_root, flow_root, lst = CF.write_dataset(str(tmp_path))
+    g = golden("g9_dataset_item")
+    prep = dataset.DevicePrep(DEV, flow_ds_factor=0)
+    for tag, is_train, minmax, seed, index, with_flip in CF.CASES:
+        ts = [transforms.GroupCenterCrop(CF.CROP)] + ([transforms.GroupRandomHorizontalFlip()] if with_flip else [])
+        ds = dataset.CoviarDataSet(data_root, flow_root, "hmdb51", lst, "mv", 1, 0, False, transforms.Compose(ts),
+                                   3, is_train, True, 12, mv_minmaxnorm=minmax)
+        random.seed(seed)
+        flow, mv, res, label = prep(dataset.collate_raw([ds.raw_item(index)]))
+        assert int(label[0]) == int(g[tag + "_label"])
+        for got, key in ((flow, "_flow"), (mv, "_mv"), (res, "_res")):
+            assert torch.equal(got[0].cpu(), torch.from_numpy(g[tag + key])), (tag, key)
+
+
 def test_i3d_forward_vs_reference_golden(golden):
     """BASELINE config 5: I3D trunk over the per-frame HIP generator, eval mode, against the
     reference's own i3d.py (golden G8); bf16-autocast trunk sanity."""
@@ -672,3 +724,27 @@ def test_driver_fit_epochs_and_checkpoint(tmp_path):
     assert set(ck) >= {"epoch", "arch", "state_dict", "best_prec1", "optimizer_cls", "optimizer_gf"}
     assert all(k.startswith("module.") for k in ck["state_dict"])
     assert not torch.equal(m.base_model.fc.weight.detach(), w_cls)   # unfrozen after epoch_thre
+
+
+def test_driver_epoch_from_raw_uint8_batches_matches_float_loader():
+    """The wired GPU-side input path: RawView + collate_raw + DevicePrep feed the same epoch as the
+    float loader (dataset tensors made on the CPU): identical inputs, so the deterministic generator /
+    MSE side is bit-identical and the classifier side agrees to MIOpen's run-to-run level."""
+    from dmcnet_amd import dataset, driver
+    ds = dataset.SyntheticCoviarDataSet(4, 51, num_segments=3, flow_ds_factor=16, size=224)
+    float_loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False)
+    raw_loader = torch.utils.data.DataLoader(dataset.RawView(ds), batch_size=2, shuffle=False,
+                                             collate_fn=dataset.collate_raw)
+    prep = dataset.DevicePrep(DEV, flow_ds_factor=16)
+    a = next(iter(float_loader))
+    b = prep(next(iter(raw_loader)))
+    for x, y in zip(a, b):
+        assert torch.equal(x.to(DEV), y)
+    res = []
+    for loader, p in ((float_loader, None), (raw_loader, prep)):
+        _, m = _product(False, 41)
+        m.train()
+        step = T.DmcnetTrainStep(m, 3, 1.0, 10.0, lr=0.01, weight_decay=1e-4, lr_cls_mult=0.01, lr_mse_mult=1.0)
+        res.append(driver.train_epoch(loader, step, 0, DEV, log=None, prep=p))
+    assert res[0]["loss_mse"] == res[1]["loss_mse"]
+    assert abs(res[0]["loss"] - res[1]["loss"]) <= 1e-5 * abs(res[0]["loss"])

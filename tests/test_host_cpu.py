@@ -422,3 +422,71 @@ def test_resnet_build_warns_without_weights_and_uses_torchvision_init(tmp_path):
         warnings.simplefilter("error")                   # with weights there is nothing to warn about
         net2 = resnet.build("resnet18", pretrained=True, weights=path)
     assert float(net2.conv1.weight.mean()) == 0.5
+
+
+# ------------------------------------------------------------- a19: tensor contract vs the reference
+def _coviar_dataset(tmp_path, is_train, minmax, with_flip, monkeypatch):
+    import sys
+    from tests.golden import coviar_fixture as CF
+    monkeypatch.setitem(sys.modules, "coviar", CF.coviar_module())
+    data_root, flow_root, lst = CF.write_dataset(str(tmp_path))
+    ts = [transforms.GroupCenterCrop(CF.CROP)] + ([transforms.GroupRandomHorizontalFlip()] if with_flip else [])
+    return dataset.CoviarDataSet(data_root, flow_root, "hmdb51", lst, "mv", 1, 0, False, transforms.Compose(ts),
+                                 3, is_train, True, 12, mv_minmaxnorm=minmax)
+
+
+def test_dataset_item_bit_exact_vs_reference_getitem(golden, tmp_path, monkeypatch):
+    """SURVEY 8 a19, pinned: the reference's own CoviarDataSet.__getitem__ (code/dmcnet/dataset.py:151-281)
+    was run on the seeded stand-in of tests/golden/coviar_fixture.py (golden G9,
+    tests/golden/make_golden_dataset.py); this dataset must return the same 4-tuple bit for bit --
+    sampling, RNG call order, the MV scaling, clipping, crop, flip with x negation, /255 and
+    normalisation.  (flow_ds_factor = 16 stays unpinned: skimage is absent, blockify is restated.)"""
+    from tests.golden import coviar_fixture as CF
+    g = golden("g9_dataset_item")
+    flips = 0
+    for tag, is_train, minmax, seed, index, with_flip in CF.CASES:
+        ds = _coviar_dataset(tmp_path, is_train, minmax, with_flip, monkeypatch)
+        assert len(ds) == len(CF.VIDEOS)
+        random.seed(seed)
+        flow, mv, res, label = ds[index]
+        assert label == int(g[tag + "_label"])
+        assert torch.equal(flow, torch.from_numpy(g[tag + "_flow"])), tag
+        assert torch.equal(mv, torch.from_numpy(g[tag + "_mv"])), tag
+        assert torch.equal(res, torch.from_numpy(g[tag + "_res"])), tag
+        # the GPU-side plan draws the same random numbers and describes the same geometry
+        random.seed(seed)
+        frames, box, out, flip, label2 = ds.raw_item(index)
+        assert label2 == label and out == (CF.CROP, CF.CROP) and frames.shape == (3, CF.H0, CF.W0, 7)
+        assert box.tolist() == [(CF.H0 - CF.CROP) // 2, (CF.W0 - CF.CROP) // 2, CF.CROP, CF.CROP,
+                                CF.CROP, CF.CROP, 0, 0]
+        flips += int(flip)
+        crop = [transforms.apply_plan(f, box, out, flip) for f in frames]
+        back = dataset.to_tensors(np.transpose(np.array(crop), (0, 3, 1, 2)), 0)
+        assert torch.equal(back[1], mv) and torch.equal(back[0], flow) and torch.equal(back[2], res)
+    assert 0 < flips < sum(1 for c in CF.CASES if c[5])      # both flip outcomes are covered
+
+
+def test_geometry_plan_matches_applied_transforms():
+    """plan + (crop, resize, flip) == applying the Compose, for the reference's train and val pipelines."""
+    rs = np.random.RandomState(5)
+    frames = [rs.randint(0, 256, (256, 340, 7)).astype(np.uint8) for _ in range(2)]
+    pipes = [transforms.Compose([transforms.GroupMultiScaleCrop(224, [1, .875, .75]),
+                                 transforms.GroupRandomHorizontalFlip()]),
+             transforms.Compose([transforms.GroupCenterCrop(224)]),
+             transforms.Compose([transforms.GroupScale(256), transforms.GroupCenterCrop(224)])]
+    for pipe in pipes:
+        for seed in range(6):
+            random.seed(seed)
+            want = pipe(frames)
+            random.seed(seed)
+            plan, out, flip = transforms.geometry_plan(pipe, frames[0].shape)
+            state = random.getstate()
+            got = [transforms.apply_plan(f, plan, out, flip) for f in frames]
+            for a, b in zip(got, want):
+                assert np.array_equal(np.asarray(a), np.asarray(b))
+            random.seed(seed)
+            pipe(frames)
+            assert random.getstate() == state                  # same RNG consumption
+    with pytest.raises(ValueError):
+        transforms.geometry_plan(transforms.Compose([transforms.GroupScale(256), transforms.GroupScale(224)]),
+                                 (240, 320, 7))
