@@ -31,6 +31,11 @@ struct BnArgs {
     float* dres;           // nullable
     int M, C, relu;
     unsigned char* mask;   // nullable: 4 ReLU sign bits per float4 (written by the forward, read by the backward)
+    // discriminator blocks (activation BEFORE the BatchNorm: x = keep * LeakyReLU(conv)): the backward
+    // continues through the mask and the LeakyReLU, dx *= keep[n][c] * (x > 0 ? 1 : slope)
+    const float* keep;     // nullable [N][C]
+    int hw;                // pixels per frame (row -> n)
+    float slope;           // 0: no activation derivative
 };
 
 // MODE 0: per-channel (sum x, sum x^2).   MODE 1: (sum dz, sum dz * xhat), dz = dy * relu'(.)
@@ -215,6 +220,12 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(BnArgs a, const float
         r.y = g.y * istd.y * (d.y - db.y * inv_count - xh.y * dg.y * inv_count);
         r.z = g.z * istd.z * (d.z - db.z * inv_count - xh.z * dg.z * inv_count);
         r.w = g.w * istd.w * (d.w - db.w * inv_count - xh.w * dg.w * inv_count);
+        if (a.slope != 0.f) {
+            float4 k = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (a.keep) k = reinterpret_cast<const float4*>(a.keep)[(size_t)((o / cq) / a.hw) * cq + tx];
+            r.x *= k.x * (x.x > 0.f ? 1.f : a.slope); r.y *= k.y * (x.y > 0.f ? 1.f : a.slope);
+            r.z *= k.z * (x.z > 0.f ? 1.f : a.slope); r.w *= k.w * (x.w > 0.f ? 1.f : a.slope);
+        }
         reinterpret_cast<float4*>(a.dx)[o] = r;
     }
 }
@@ -408,6 +419,34 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolArgs a, double* __res
     }
 }
 
+// dx = dz * keep[n][c] * (z > 0 ? 1 : slope): the mask + LeakyReLU derivative alone (first
+// discriminator block, which has no BatchNorm)
+__global__ __launch_bounds__(256) void act_mask_bwd_kernel(const float* __restrict__ z, const float* __restrict__ keep,
+                                                           const float* __restrict__ dz, float* __restrict__ dx,
+                                                           int M, int C, int hw, float slope) {
+    const int cq = C >> 2;
+    const size_t total = (size_t)M * cq;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+        const int tx = (int)(o % cq);
+        const float4 x = reinterpret_cast<const float4*>(z)[o];
+        float4 d = reinterpret_cast<const float4*>(dz)[o];
+        float4 k = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (keep) k = reinterpret_cast<const float4*>(keep)[(size_t)((o / cq) / hw) * cq + tx];
+        d.x *= k.x * (x.x > 0.f ? 1.f : slope); d.y *= k.y * (x.y > 0.f ? 1.f : slope);
+        d.z *= k.z * (x.z > 0.f ? 1.f : slope); d.w *= k.w * (x.w > 0.f ? 1.f : slope);
+        reinterpret_cast<float4*>(dx)[o] = d;
+    }
+}
+
+// per-channel sums from bn_partial_kernel<0>'s partials (the bias gradient of a convolution)
+__global__ __launch_bounds__(256) void channel_sum_final_kernel(const double* __restrict__ scratch,
+                                                                float* __restrict__ out, int C, int split) {
+    const int c = blockIdx.x * 8 + (threadIdx.x >> 5), sub = threadIdx.x & 31;
+    double s, ss;
+    reduce_partials(scratch, C, c, split, sub, s, ss);
+    if (c < C && sub == 0) out[c] = (float)s;
+}
+
 bool shape_ok(int M, int C) {
     const int cq = C / 4;
     return M > 0 && C > 0 && C % 4 == 0 && cq <= 256 && 256 % cq == 0;
@@ -530,6 +569,60 @@ int dmc_bn_relu_pool_bwd(const float* x, const float* gamma, const float* beta, 
     pool_bwd_kernel<2><<<blocks * 4 > 8192 ? 8192 : blocks * 4, 256, 0, s>>>(p, nullptr, dgamma, dbeta,
                                                                              1.f / (float)((long)N * H * W), (unsigned*)codes);
     return check_launch("pool_bwd_apply");
+}
+
+// y = (x - mean) * invstd * gamma + beta with GIVEN statistics (stats = mean[C], invstd[C]): the
+// apply pass alone, for callers whose producer already reduced the statistics
+// (dmc_conv_nhwc_fwd + dmc_conv_nhwc_stats_final).
+int dmc_bn_apply_nhwc(const float* x, const float* gamma, const float* beta, const float* stats, float* y,
+                      int M, int C, dmc_stream_t stream) {
+    if (!x || !gamma || !beta || !stats || !y) return fail(DMC_E_INVALID, "dmc_bn_apply_nhwc: null pointer");
+    if (!shape_ok(M, C)) return fail(DMC_E_INVALID, "dmc_bn_apply_nhwc: unsupported shape M=%d C=%d", M, C);
+    BnArgs a = {x, nullptr, gamma, beta, stats, nullptr, y, nullptr, nullptr, M, C, 0, nullptr};
+    bn_apply_fwd_kernel<<<stream_blocks((size_t)M * (C / 4)), 256, 0, (hipStream_t)stream>>>(a);
+    return check_launch("bn_apply_nhwc");
+}
+
+// Backward of  y = BN(z),  z = keep[n][c] * LeakyReLU_slope(pre)  down to d(pre): the BatchNorm
+// backward (batch statistics; dgamma, dbeta as usual) followed by the mask and the LeakyReLU
+// derivative (sign(z) == sign(pre) wherever keep != 0).  gamma == NULL: no BatchNorm (dz = dy).
+// hw = pixels per frame (maps a row of the [M][C] matrix to its frame for `keep`).
+int dmc_bn_bwd_act_nhwc(const float* z, const float* gamma, const float* beta, const float* stats, void* scratch_,
+                        const float* dy, float* dpre, float* dgamma, float* dbeta, const float* keep, int hw,
+                        float slope, int M, int C, dmc_stream_t stream) {
+    if (!z || !dy || !dpre || hw <= 0) return fail(DMC_E_INVALID, "dmc_bn_bwd_act_nhwc: bad argument");
+    if (!shape_ok(M, C)) return fail(DMC_E_INVALID, "dmc_bn_bwd_act_nhwc: unsupported shape M=%d C=%d", M, C);
+    hipStream_t s = (hipStream_t)stream;
+    if (!gamma) {
+        act_mask_bwd_kernel<<<stream_blocks((size_t)M * (C / 4)), 256, 0, s>>>(z, keep, dy, dpre, M, C, hw, slope);
+        return check_launch("act_mask_bwd");
+    }
+    if (!beta || !stats || !scratch_ || !dgamma || !dbeta)
+        return fail(DMC_E_INVALID, "dmc_bn_bwd_act_nhwc: null BatchNorm pointer");
+    BnArgs a = {z, nullptr, gamma, beta, stats, dy, nullptr, dpre, nullptr, M, C, 0, nullptr, keep, hw, slope};
+    double* scratch = static_cast<double*>(scratch_);
+    int rc;
+    const int split = split_of(M);
+    bn_partial_kernel<1><<<split, 256, 0, s>>>(a, scratch);
+    if ((rc = check_launch("bn_bwd_partial"))) return rc;
+    bn_bwd_final_kernel<<<(C + 7) / 8, 256, 0, s>>>(scratch, dgamma, dbeta, C, split);
+    if ((rc = check_launch("bn_bwd_final"))) return rc;
+    bn_apply_bwd_kernel<<<stream_blocks((size_t)M * (C / 4)), 256, 0, s>>>(a, dgamma, dbeta, 1.f / (float)M);
+    return check_launch("bn_apply_bwd_act");
+}
+
+// out[c] = sum over the M rows of g[.][c] (the bias gradient of a convolution), deterministic.
+int dmc_channel_sum_nhwc(const float* g, void* scratch_, float* out, int M, int C, dmc_stream_t stream) {
+    if (!g || !scratch_ || !out) return fail(DMC_E_INVALID, "dmc_channel_sum_nhwc: null pointer");
+    if (!shape_ok(M, C)) return fail(DMC_E_INVALID, "dmc_channel_sum_nhwc: unsupported shape M=%d C=%d", M, C);
+    hipStream_t s = (hipStream_t)stream;
+    BnArgs a = {g, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, M, C, 0, nullptr};
+    const int split = split_of(M);
+    bn_partial_kernel<0><<<split, 256, 0, s>>>(a, static_cast<double*>(scratch_));
+    int rc = check_launch("channel_sum_partial");
+    if (rc) return rc;
+    channel_sum_final_kernel<<<(C + 7) / 8, 256, 0, s>>>(static_cast<const double*>(scratch_), out, C, split);
+    return check_launch("channel_sum_final");
 }
 
 }  // extern "C"

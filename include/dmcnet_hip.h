@@ -180,6 +180,20 @@ int dmc_bn_act_bwd(const float* x, const float* residual, const float* gamma, co
                    float* dgamma, float* dbeta, const unsigned char* relu_mask, int M, int C, int relu,
                    dmc_stream_t stream);
 
+/* Pieces of the same kernels for a producer that has already reduced the statistics (the
+ * discriminator blocks, whose convolution epilogue does it): the apply pass alone; the backward
+ * of  y = BN(z), z = keep[n][c] * LeakyReLU_slope(pre)  (code/dmcnet_GAN/model.py:254-279: Conv ->
+ * LeakyReLU(0.2) -> Dropout2d -> BatchNorm2d) down to d(pre) = the gradient of the convolution's
+ * output, gamma == NULL meaning "no BatchNorm" (first block); and a per-channel row sum (the
+ * convolution's bias gradient).  scratch: dmc_bn_act_scratch_bytes(C).
+ */
+int dmc_bn_apply_nhwc(const float* x, const float* gamma, const float* beta, const float* stats, float* y,
+                      int M, int C, dmc_stream_t stream);
+int dmc_bn_bwd_act_nhwc(const float* z, const float* gamma, const float* beta, const float* stats, void* scratch,
+                        const float* dy, float* dpre, float* dgamma, float* dbeta, const float* keep, int hw,
+                        float slope, int M, int C, dmc_stream_t stream);
+int dmc_channel_sum_nhwc(const float* g, void* scratch, float* out, int M, int C, dmc_stream_t stream);
+
 /* ---- GPU-side input preparation -----------------------------------------------------------------
  * Replaces the tensor side of CoviarDataSet.__getitem__, code/dmcnet/dataset.py:215-263 (channel
  * split, flow block_reduce(mean)+repeat when flow_ds_factor != 0, /255, (x-0.5)/std) and the
@@ -233,6 +247,42 @@ size_t dmc_bn_relu_pool_codes_bytes(int N, int H, int W, int C);
 int dmc_bn_relu_pool_bwd(const float* x, const float* gamma, const float* beta, const float* stats,
                          void* scratch, const float* d_pool, float* dx, float* dgamma, float* dbeta,
                          void* codes, int N, int H, int W, int C, dmc_stream_t stream);
+
+/* ---- NHWC convolutions on the fp32 matrix cores ---------------------------------------------------
+ * Replace nn.Conv2d (3x3 padding 1, or 1x1 padding 0; stride 1 or 2; Cin, Cout multiples of 16) and
+ * its autograd wherever the hot path runs them:
+ *   - the PatchGAN discriminator blocks, code/dmcnet_GAN/model.py:254-279 (Conv2d(in, out, 3, stride,
+ *     1) with bias, followed by LeakyReLU(0.2), Dropout2d(0.25), BatchNorm2d(out, eps=0.8)) as chained
+ *     in Discriminator..Discriminator5, :282-438;
+ *   - the torchvision ResNet the reference builds at code/dmcnet/model.py:305 and runs at :352
+ *     (BasicBlock 3x3 convolutions and the 1x1 stride-2 shortcut convolutions, bias-free).
+ * Layouts: activations NHWC fp32 ([N][H][W][C], the memory of a channels_last tensor), weights
+ * OHWI ([Cout][KH][KW][Cin], the memory of a channels_last weight); OH = (H + 2 pad - KH) / stride + 1.
+ * dmc_conv_nhwc_supported() says whether a shape is handled (callers use the stock op otherwise).
+ *
+ * fwd: y = conv(x, w) [+ bias] [LeakyReLU(0.2) if act == 1] [* keep[n][co]] -- the Dropout2d keep mask
+ * [N][Cout], already divided by 1 - p -- and, if stat_partials != NULL, per-channel (sum, sum of squares)
+ * of y per workgroup row, [dmc_conv_nhwc_stat_blocks()][Cout][2] doubles, which
+ * dmc_conv_nhwc_stats_final() turns into the (mean, invstd) pair [2*C] and the running-statistics
+ * update of the nn.BatchNorm2d that follows (count = N*OH*OW).
+ * dgrad: dx = conv_transpose(dy, w); wt = workspace of dmc_conv_nhwc_wt_bytes().
+ * wgrad: dw (OHWI) = sum over pixels, deterministic (fixed-order split-K reduction, no atomics);
+ * workspace of dmc_conv_nhwc_wgrad_bytes().
+ */
+int dmc_conv_nhwc_supported(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int dmc_conv_nhwc_stat_blocks(int N, int H, int W, int Cout, int KH, int stride, int pad);
+int dmc_conv_nhwc_fwd(const float* x, const float* w, const float* bias, const float* keep, float* y,
+                      double* stat_partials, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                      int pad, int act, dmc_stream_t stream);
+int dmc_conv_nhwc_stats_final(const double* partials, int nblk, int C, long count, float* stats,
+                              float* running_mean, float* running_var, float eps, float momentum,
+                              dmc_stream_t stream);
+size_t dmc_conv_nhwc_wt_bytes(int Cin, int Cout, int KH, int KW);
+int dmc_conv_nhwc_dgrad(const float* dy, const float* w, float* wt, float* dx, int N, int H, int W, int Cin,
+                        int Cout, int KH, int KW, int stride, int pad, dmc_stream_t stream);
+size_t dmc_conv_nhwc_wgrad_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int dmc_conv_nhwc_wgrad(const float* x, const float* dy, float* dw, float* workspace, int N, int H, int W,
+                        int Cin, int Cout, int KH, int KW, int stride, int pad, dmc_stream_t stream);
 
 /* ---- classifier stem: weight gradient of conv1 (2 -> 64 channels, 7x7, stride 2, pad 3) ----------
  * Replaces what autograd computes for the conv1 the reference installs for the 2-channel flow

@@ -45,10 +45,11 @@ def _grads(model):
     return {k: p.grad.detach().clone().cpu() for k, p in model.named_parameters() if p.grad is not None}
 
 
-def run_phases(model, batches, gan, reducer, do_step, shard, state_after_first=None):
+def run_phases(model, batches, gan, reducer, do_step, shard, state_after_first=None, local=None):
     """dmcnet: one step ('step').  gan: a D step then a G step ('D', 'G').  ``do_step=False`` leaves
-    the weights alone (gradients only); ``state_after_first`` is then loaded before the second phase."""
-    res = {"grads": {}, "bytes": {}, "where": {}}
+    the weights alone (gradients only); ``state_after_first`` is then loaded before the second phase.
+    ``local``: dict filled by hooks with this rank's gradients BEFORE the exchange."""
+    res = {"grads": {}, "bytes": {}, "where": {}, "local": {}}
     if gan:
         step = T.GanTrainStep(model, 3, 1.0, 1.0, 0.01, 10.0, lr_d_mult=1.0, reducer=reducer, **HP)
         opts = (step.optimizer_cls, step.optimizer_gf, step.optimizer_d)
@@ -72,6 +73,9 @@ def run_phases(model, batches, gan, reducer, do_step, shard, state_after_first=N
         else:
             step.step(batch)
         res["grads"][tag] = _grads(model)
+        if local is not None:
+            res["local"][tag] = dict(local)
+            local.clear()
         if reducer is not None:
             res["bytes"][tag] = reducer.reduced_bytes(by_set=True)
             res["where"][tag] = [w for _, _, _, w in reducer.last_reduced]
@@ -88,8 +92,12 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=int(os.environ["WORLD_SIZE"]))
     gan = phase == "gan"
     model = build(gan).to(DEV).train()
+    # hooks registered BEFORE the reducer's run first: they keep this rank's own gradients
+    local = {}
+    for k, p in model.named_parameters():
+        p.register_post_accumulate_grad_hook(lambda q, k=k: local.__setitem__(k, q.grad.detach().clone().cpu()))
     reducer = ddp.for_model(model)
-    res = run_phases(model, shard_batches(rank), gan, reducer, do_step=True, shard=rank)
+    res = run_phases(model, shard_batches(rank), gan, reducer, do_step=True, shard=rank, local=local)
     res["params"] = {k: p.detach().clone().cpu() for k, p in model.named_parameters()}
     torch.save(res, os.path.join(out_dir, "%s_r%d.pt" % (phase, rank)))
     dist.barrier()
