@@ -58,6 +58,11 @@ SIGNATURES = {
     "dmc_conv_nhwc_dgrad": (_I, [_P] * 4 + [_I] * 9 + [_P]),
     "dmc_conv_nhwc_wgrad_bytes": (_Z, [_I] * 9),
     "dmc_conv_nhwc_wgrad": (_I, [_P] * 4 + [_I] * 9 + [_P]),
+    "dmc_disc_first_supported": (_I, [_I]),
+    "dmc_disc_first_fwd": (_I, [_P] * 5 + [_I] * 5 + [_P]),
+    "dmc_disc_first_dgrad": (_I, [_P] * 3 + [_I] * 4 + [_P]),
+    "dmc_disc_first_wgrad_bytes": (_Z, [_I]),
+    "dmc_disc_first_wgrad": (_I, [_P] * 5 + [_I] * 4 + [_P]),
     "dmc_stem_wgrad_supported": (_I, [_I, _I]),
     "dmc_stem_wgrad_partials_bytes": (_Z, [_I, _I, _I]),
     "dmc_stem_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),

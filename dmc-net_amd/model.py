@@ -181,25 +181,44 @@ class _DiscriminatorBase(nn.Module):
             c = w
         self.adv_layer = nn.Linear(self.FLAT, 2)
         self.forced_masks = None
+        # OHWI weights (channels_last memory) are what the NHWC matrix-core kernels read; values and
+        # state-dict keys are unchanged
+        self.to(memory_format=torch.channels_last)
 
     def _add(self, name, block):
         self.add_module(name, block)
         self.block_names.append(name)
 
+    def _keep(self, name, x, drop):
+        if not self.training:
+            return None
+        if self.forced_masks is not None:
+            return self.forced_masks[name].to(x.device, torch.float32)
+        return (torch.rand((x.shape[0], getattr(self, name)[0].out_channels), device=x.device) >= drop.p).float() \
+            / (1.0 - drop.p)
+
     def forward(self, x):
-        for name in self.block_names:
+        """Blocks run on the fused HIP path (``ops.disc_block``: NHWC activations, convolution on the
+        fp32 matrix cores with bias / LeakyReLU / mask / BatchNorm statistics in its epilogue) whenever
+        the shape qualifies -- every block of Discriminator..Discriminator3 and Discriminator5 does;
+        otherwise (Discriminator4's 8-channel blocks, CPU tensors) the convolution goes to
+        PyTorch-ROCm and the tail to ``ops.disc_tail``."""
+        nhwc = False
+        for i, name in enumerate(self.block_names):
             blk = getattr(self, name)
             conv, drop = blk[0], blk[2]
             bn = blk[3] if len(blk) == 4 else None
+            keep = self._keep(name, x, drop)
+            first = i == 0 and not nhwc
+            if ops.disc_block_supported(x, conv, first) and (bn is None or not first):
+                x = ops.disc_block(x, conv, keep, bn, self.training, first=first)
+                nhwc = True
+                continue
             x = F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding)
-            keep = None
-            if self.training:
-                if self.forced_masks is not None:
-                    keep = self.forced_masks[name].to(x.device, torch.float32)
-                else:
-                    keep = (torch.rand(x.shape[:2], device=x.device) >= drop.p).float() / (1.0 - drop.p)
-            x = ops.disc_tail(x, keep, bn, self.training)
-        return self.adv_layer(x.reshape(x.shape[0], -1))
+            x = ops.disc_tail(x.contiguous(), keep, bn, self.training)
+            nhwc = False
+        # flatten in the reference's NCHW order (the Linear's weight is laid out for it)
+        return self.adv_layer(x.contiguous().reshape(x.shape[0], -1))
 
 
 class Discriminator(_DiscriminatorBase):

@@ -6,7 +6,7 @@ import torch
 from . import _lib
 
 __all__ = ["gen_tiny", "flow_mse", "consensus_ce", "disc_tail", "bn_act", "bn_act_supported", "prepare_inputs",
-           "u8_frames_buffer"]
+           "u8_frames_buffer", "conv_nhwc", "conv_nhwc_supported", "disc_block", "disc_block_supported"]
 
 
 class EventProbe(object):
@@ -472,6 +472,250 @@ def stem_conv(x, weight):
     """conv1(x) for ``x`` [N,2,H,W] (no gradient needed) and ``weight`` [64,2,7,7]."""
     _need_cuda(x, weight)
     return _StemConv.apply(x, weight)
+
+
+# ------------------------------------------------------------------ NHWC convolutions (conv_nhwc.hip)
+_CL = torch.channels_last
+
+
+def _is_cl(t):
+    return t.dim() == 4 and t.is_contiguous(memory_format=_CL)
+
+
+def conv_nhwc_supported(x, weight, stride, padding):
+    """True if ``conv2d(x, weight, stride=stride, padding=padding)`` can run on the HIP implicit-GEMM
+    kernels (fp32, channels_last x, 3x3/pad 1 or 1x1/pad 0, stride 1 or 2, channels multiples of 16)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and weight.dtype == torch.float32):
+        return False
+    n, cin, h, w = x.shape
+    cout, cin2, kh, kw = weight.shape
+    if cin2 != cin:
+        return False
+    return bool(_lib.load().dmc_conv_nhwc_supported(n, h, w, cin, cout, kh, kw, int(stride), int(padding)))
+
+
+def _conv_geom(x, weight, stride, padding):
+    n, cin, h, w = x.shape
+    cout, _, kh, kw = weight.shape
+    oh, ow = (h + 2 * padding - kh) // stride + 1, (w + 2 * padding - kw) // stride + 1
+    return n, h, w, cin, cout, kh, kw, oh, ow
+
+
+def _conv_fwd(x, weight, bias, keep, stride, padding, act, want_stats):
+    lib = _lib.load()
+    n, h, w, cin, cout, kh, kw, oh, ow = _conv_geom(x, weight, stride, padding)
+    y = torch.empty((n, cout, oh, ow), dtype=torch.float32, device=x.device, memory_format=_CL)
+    part, nblk = None, 0
+    if want_stats:
+        nblk = lib.dmc_conv_nhwc_stat_blocks(n, h, w, cout, kh, stride, padding)
+        part = torch.empty((nblk, cout, 2), dtype=torch.float64, device=x.device)
+    _lib.check(lib.dmc_conv_nhwc_fwd(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(keep), _lib.ptr(y),
+                                     _lib.ptr(part), n, h, w, cin, cout, kh, kw, stride, padding, int(act),
+                                     _stream()), "dmc_conv_nhwc_fwd")
+    return y, part, nblk
+
+
+def _conv_dgrad(dy, weight, x_shape, stride, padding):
+    lib = _lib.load()
+    n, cin, h, w = x_shape
+    cout, _, kh, kw = weight.shape
+    dx = torch.empty((n, cin, h, w), dtype=torch.float32, device=dy.device, memory_format=_CL)
+    wt = _floats(lib.dmc_conv_nhwc_wt_bytes(cin, cout, kh, kw), dy.device)
+    _lib.check(lib.dmc_conv_nhwc_dgrad(_lib.ptr(dy), _lib.ptr(weight), _lib.ptr(wt), _lib.ptr(dx), n, h, w, cin,
+                                       cout, kh, kw, stride, padding, _stream()), "dmc_conv_nhwc_dgrad")
+    return dx
+
+
+def _conv_wgrad(x, dy, weight, stride, padding):
+    lib = _lib.load()
+    n, cin, h, w = x.shape
+    cout, _, kh, kw = weight.shape
+    dw = torch.empty((cout, cin, kh, kw), dtype=torch.float32, device=x.device, memory_format=_CL)
+    work = _floats(lib.dmc_conv_nhwc_wgrad_bytes(n, h, w, cin, cout, kh, kw, stride, padding), x.device)
+    _lib.check(lib.dmc_conv_nhwc_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(work), n, h, w, cin, cout,
+                                       kh, kw, stride, padding, _stream()), "dmc_conv_nhwc_wgrad")
+    return dw
+
+
+def _as_cl(t):
+    return t if _is_cl(t) else t.contiguous(memory_format=_CL)
+
+
+def _grad_like(dw, weight):
+    """dw (channels_last memory) in the strides of ``weight`` (no copy when weight is channels_last)."""
+    return dw if _is_cl(weight) and weight.stride() == dw.stride() else dw.contiguous().view_as(weight).contiguous()
+
+
+class _ConvNHWC(torch.autograd.Function):
+    """nn.Conv2d(bias=False) on the fp32 matrix cores: the ResNet's 3x3 / 1x1 convolutions
+    (torchvision BasicBlock behind code/dmcnet/model.py:305,352)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, padding):
+        _need_cuda(x, weight)
+        x, wcl = _as_cl(x), _as_cl(weight)
+        with _span("conv_nhwc_fwd"):
+            y, _, _ = _conv_fwd(x, wcl, None, None, stride, padding, 0, False)
+        ctx.save_for_backward(x, weight)
+        ctx.geom = (stride, padding)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, padding = ctx.geom
+        dy, wcl = _as_cl(dy), _as_cl(weight)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            with _span("conv_nhwc_dgrad"):
+                dx = _conv_dgrad(dy, wcl, x.shape, stride, padding)
+        if ctx.needs_input_grad[1]:
+            with _span("conv_nhwc_wgrad"):
+                dw = _grad_like(_conv_wgrad(x, dy, wcl, stride, padding), weight)
+        return dx, dw, None, None
+
+
+def conv_nhwc(x, weight, stride=1, padding=1):
+    """conv2d(x, weight, None, stride, padding) for a channels_last ``x`` (see conv_nhwc_supported)."""
+    return _ConvNHWC.apply(x, weight, int(stride), int(padding))
+
+
+class _DiscBlock(torch.autograd.Function):
+    """One discriminator block, Conv2d(3x3, stride s, padding 1, bias) -> LeakyReLU(0.2) ->
+    Dropout2d keep mask -> [BatchNorm2d(eps 0.8)], code/dmcnet_GAN/model.py:254-279, on NHWC tensors:
+    the convolution epilogue applies bias / LeakyReLU / mask and reduces the BatchNorm statistics, one
+    streaming pass normalises; the backward folds the BatchNorm backward, the mask and the LeakyReLU
+    derivative into one pass and feeds the matrix-core data / weight gradients.
+    ``first`` = the 2-channel NCHW input block (direct kernels, disc_first.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, keep, gamma, beta, running_mean, running_var, stride, training, eps,
+                momentum, first):
+        lib = _lib.load()
+        _need_cuda(x, weight, bias, keep, gamma, beta)
+        use_bn = gamma is not None
+        cout = weight.shape[0]
+        if first:
+            x = x.contiguous()
+            m, _, h, w = x.shape
+            oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+            wq = weight.contiguous()
+            z = torch.empty((m, cout, oh, ow), dtype=torch.float32, device=x.device, memory_format=_CL)
+            with _span("disc_first_fwd"):
+                _lib.check(lib.dmc_disc_first_fwd(_lib.ptr(x), _lib.ptr(wq), _lib.ptr(bias), _lib.ptr(keep), _lib.ptr(z),
+                                                  m, h, w, cout, 1, _stream()), "dmc_disc_first_fwd")
+            part, nblk = None, 0
+            if use_bn:
+                raise NotImplementedError("the 2-channel first block has no BatchNorm in any discriminator")
+        else:
+            x, wq = _as_cl(x), _as_cl(weight)
+            with _span("disc_conv_fwd"):
+                z, part, nblk = _conv_fwd(x, wq, bias, keep, stride, 1, 1, use_bn and training)
+        y, stats = z, None
+        if use_bn:
+            m_rows = z.shape[0] * z.shape[2] * z.shape[3]
+            stats = _floats(lib.dmc_bn_act_stats_bytes(cout), x.device)
+            y = torch.empty_like(z)
+            with _span("disc_bn_fwd"):
+                if training:
+                    _lib.check(lib.dmc_conv_nhwc_stats_final(_lib.ptr(part), nblk, cout, m_rows, _lib.ptr(stats),
+                                                             _lib.ptr(running_mean), _lib.ptr(running_var),
+                                                             float(eps), float(momentum), _stream()),
+                               "dmc_conv_nhwc_stats_final")
+                    _lib.check(lib.dmc_bn_apply_nhwc(_lib.ptr(z), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(stats),
+                                                     _lib.ptr(y), m_rows, cout, _stream()), "dmc_bn_apply_nhwc")
+                else:
+                    _lib.check(lib.dmc_bn_act_fwd(_lib.ptr(z), None, _lib.ptr(gamma), _lib.ptr(beta),
+                                                  _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(y),
+                                                  _lib.ptr(stats), None, None, m_rows, cout, 0, 0, float(eps),
+                                                  float(momentum), _stream()), "dmc_bn_act_fwd")
+        ctx.save_for_backward(x, weight, z, keep, gamma, beta, stats)
+        ctx.cfg = (int(stride), bool(training), bool(first), use_bn, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, weight, z, keep, gamma, beta, stats = ctx.saved_tensors
+        stride, training, first, use_bn, has_bias = ctx.cfg
+        if use_bn and not training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not implemented")
+        dy = _as_cl(dy)
+        m, cout, oh, ow = z.shape
+        rows = m * oh * ow
+        g = torch.empty_like(z)
+        dgamma = dbeta = None
+        scratch = _floats(lib.dmc_bn_act_scratch_bytes(cout), z.device)
+        if use_bn:
+            dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        with _span("disc_bn_bwd"):
+            _lib.check(lib.dmc_bn_bwd_act_nhwc(_lib.ptr(z), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(stats),
+                                               _lib.ptr(scratch), _lib.ptr(dy), _lib.ptr(g), _lib.ptr(dgamma),
+                                               _lib.ptr(dbeta), _lib.ptr(keep), oh * ow, 0.2, rows, cout, _stream()),
+                       "dmc_bn_bwd_act_nhwc")
+        dx = dw = db = None
+        want_w = ctx.needs_input_grad[1]
+        if first:
+            wq = weight.contiguous()
+            mm, _, h, w = x.shape
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                with _span("disc_first_dgrad"):
+                    _lib.check(lib.dmc_disc_first_dgrad(_lib.ptr(g), _lib.ptr(wq), _lib.ptr(dx), mm, h, w, cout,
+                                                        _stream()), "dmc_disc_first_dgrad")
+            if want_w:
+                dw = torch.empty_like(wq)
+                db = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
+                work = _floats(lib.dmc_disc_first_wgrad_bytes(cout), x.device)
+                with _span("disc_first_wgrad"):
+                    _lib.check(lib.dmc_disc_first_wgrad(_lib.ptr(x), _lib.ptr(g), _lib.ptr(dw), _lib.ptr(db),
+                                                        _lib.ptr(work), mm, h, w, cout, _stream()),
+                               "dmc_disc_first_wgrad")
+                dw = dw.view_as(weight)
+        else:
+            wq = _as_cl(weight)
+            if ctx.needs_input_grad[0]:
+                with _span("disc_conv_dgrad"):
+                    dx = _conv_dgrad(g, wq, x.shape, stride, 1)
+            if want_w:
+                with _span("disc_conv_wgrad"):
+                    dw = _grad_like(_conv_wgrad(x, g, wq, stride, 1), weight)
+                if has_bias:
+                    db = torch.empty(cout, dtype=torch.float32, device=x.device)
+                    _lib.check(lib.dmc_channel_sum_nhwc(_lib.ptr(g), _lib.ptr(scratch), _lib.ptr(db), rows, cout,
+                                                        _stream()), "dmc_channel_sum_nhwc")
+        if not want_w:
+            db = None
+        return dx, dw, db, None, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+def disc_block_supported(x, conv, first):
+    """True if the HIP discriminator-block path handles this convolution (else the stock ops run)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+        return False
+    if conv.kernel_size != (3, 3) or conv.padding != (1, 1) or conv.dilation != (1, 1) or conv.groups != 1:
+        return False
+    if first:
+        return conv.in_channels == 2 and conv.stride == (2, 2) and \
+            bool(_lib.load().dmc_disc_first_supported(conv.out_channels))
+    if conv.stride not in ((1, 1), (2, 2)):
+        return False
+    return conv_nhwc_supported(x, conv.weight, conv.stride[0], 1) and \
+        bool(_lib.load().dmc_bn_act_supported(1, conv.out_channels))
+
+
+def disc_block(x, conv, keep, bn, training, first=False):
+    """x -> BN(keep * LeakyReLU_0.2(conv(x))) (BN optional) through the fused NHWC path.  ``x`` is the
+    NCHW 2-channel cue for ``first`` blocks, a channels_last activation otherwise."""
+    if bn is not None and training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    if keep is not None:
+        keep = keep.contiguous()
+    if bn is None:
+        return _DiscBlock.apply(x, conv.weight, conv.bias, keep, None, None, None, None, conv.stride[0], training,
+                                0.0, 0.0, first)
+    return _DiscBlock.apply(x, conv.weight, conv.bias, keep, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                            conv.stride[0], training, bn.eps, bn.momentum if bn.momentum is not None else 0.1, first)
 
 
 _STD = (0.229, 0.224, 0.225)

@@ -284,6 +284,23 @@ size_t dmc_conv_nhwc_wgrad_bytes(int N, int H, int W, int Cin, int Cout, int KH,
 int dmc_conv_nhwc_wgrad(const float* x, const float* dy, float* dw, float* workspace, int N, int H, int W,
                         int Cin, int Cout, int KH, int KW, int stride, int pad, dmc_stream_t stream);
 
+/* ---- first discriminator block: Conv2d(2, Cout, 3, stride 2, padding 1) on the NCHW cue ------------
+ * Replaces the convolution (+ LeakyReLU(0.2) + Dropout2d keep mask) of `discriminator_block(ch_in, 16,
+ * bn=False)`, code/dmcnet_GAN/model.py:254-265 as used at :287,:308,:334,:371,:400, and its autograd.
+ * x [M,2,H,W] NCHW fp32 (the generated / TV-L1 flow), w [Cout,2,3,3] (PyTorch's layout), Cout 16 (8 for
+ * Discriminator4); z, g: [M,OH,OW,Cout] NHWC, OH = (H-1)/2+1.  keep: [M,Cout] or NULL; act != 0
+ * applies LeakyReLU(0.2).  wgrad writes dw [Cout,2,3,3] and db [Cout] (NULL to skip) deterministically;
+ * workspace: dmc_disc_first_wgrad_bytes(Cout).
+ */
+int dmc_disc_first_supported(int Cout);
+int dmc_disc_first_fwd(const float* x, const float* w, const float* bias, const float* keep, float* z, int M,
+                       int H, int W, int Cout, int act, dmc_stream_t stream);
+int dmc_disc_first_dgrad(const float* g, const float* w, float* dx, int M, int H, int W, int Cout,
+                         dmc_stream_t stream);
+size_t dmc_disc_first_wgrad_bytes(int Cout);
+int dmc_disc_first_wgrad(const float* x, const float* g, float* dw, float* db, void* workspace, int M, int H,
+                         int W, int Cout, dmc_stream_t stream);
+
 /* ---- classifier stem: weight gradient of conv1 (2 -> 64 channels, 7x7, stride 2, pad 3) ----------
  * Replaces what autograd computes for the conv1 the reference installs for the 2-channel flow
  * input, code/dmcnet/model.py:285-294 (nn.Conv2d(2, 64, 7, stride=2, padding=3, bias=False)),

@@ -748,3 +748,97 @@ def test_driver_epoch_from_raw_uint8_batches_matches_float_loader():
         res.append(driver.train_epoch(loader, step, 0, DEV, log=None, prep=p))
     assert res[0]["loss_mse"] == res[1]["loss_mse"]
     assert abs(res[0]["loss"] - res[1]["loss"]) <= 1e-5 * abs(res[0]["loss"])
+
+
+CONV_CASES = [  # (N, Cin, H, W, Cout, k, stride)
+    (2, 64, 56, 56, 64, 3, 1),       # ResNet layer1
+    (2, 64, 56, 56, 128, 3, 2),      # layer2.0.conv1
+    (2, 64, 56, 56, 128, 1, 2),      # layer2.0.downsample
+    (3, 128, 28, 28, 128, 3, 1),
+    (2, 256, 14, 14, 256, 3, 1),
+    (5, 512, 7, 7, 512, 3, 1),       # layer4: the 64-pixel tile configuration
+    (2, 256, 14, 14, 512, 3, 2),
+    (2, 16, 112, 112, 16, 3, 1),     # discriminator blocks
+    (2, 16, 112, 112, 32, 3, 2),
+    (3, 32, 56, 56, 32, 3, 1),
+    (1, 32, 13, 11, 64, 3, 2),       # ragged: odd sizes, tiles ending inside the image
+    (3, 48, 9, 7, 80, 3, 1),         # channel counts that are multiples of 16 only
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_nhwc_fwd_dgrad_wgrad_vs_fp64(case):
+    """The matrix-core NHWC convolution and both gradients against an fp64 evaluation of
+    F.conv2d (the arithmetic the reference's nn.Conv2d performs), for the ResNet-18 and discriminator
+    shapes; results are deterministic (two runs bit-identical)."""
+    n, cin, h, w, cout, k, stride = case
+    pad = k // 2
+    x, wt = rnd(201, (n, cin, h, w)), rnd(202, (cout, cin, k, k)) * 0.1
+    xo, wo = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    yo = F.conv2d(xo, wo, None, stride, pad)
+    go = rnd(203, tuple(yo.shape))
+    (yo * go.double()).sum().backward()
+    xg = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wg = wt.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert ops.conv_nhwc_supported(xg, wg, stride, pad)
+    y = ops.conv_nhwc(xg, wg, stride, pad)
+    (y * go.to(DEV)).sum().backward()
+    assert y.shape == yo.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert rel_err(y, yo) < 2e-6
+    assert rel_err(xg.grad, xo.grad) < 2e-6
+    assert rel_err(wg.grad, wo.grad) < 5e-6
+    assert wg.grad.stride() == wg.stride()
+    g1, d1 = wg.grad.clone(), xg.grad.clone()
+    xg.grad = wg.grad = None
+    (ops.conv_nhwc(xg, wg, stride, pad) * go.to(DEV)).sum().backward()
+    assert torch.equal(g1, wg.grad) and torch.equal(d1, xg.grad)
+
+
+@pytest.mark.parametrize("first,cin,cout,stride,use_bn,hw", [(True, 2, 16, 2, False, 40), (False, 16, 16, 1, True, 20),
+                                                             (False, 16, 32, 2, True, 21), (False, 64, 128, 2, True, 9)])
+def test_disc_block_unit(first, cin, cout, stride, use_bn, hw):
+    """One fused discriminator block (conv + bias + LeakyReLU(0.2) + keep mask [+ BatchNorm eps 0.8])
+    against the stock modules in fp64: output, every gradient, running statistics; eval mode."""
+    n = 5
+    x = rnd(211, (n, cin, hw, hw + 3))
+    conv_o = torch.nn.Conv2d(cin, cout, 3, stride, 1)
+    bn_o = torch.nn.BatchNorm2d(cout, 0.8) if use_bn else None
+    O.seeded_state_fill(conv_o, 212)
+    if use_bn:
+        O.seeded_state_fill(bn_o, 213)
+    keep = (torch.from_numpy(np.random.RandomState(214).rand(n, cout)) < 0.75).float() / 0.75
+    conv_m = torch.nn.Conv2d(cin, cout, 3, stride, 1)
+    conv_m.load_state_dict(conv_o.state_dict())
+    conv_m = conv_m.to(DEV).to(memory_format=torch.channels_last)
+    bn_m = None
+    if use_bn:
+        bn_m = torch.nn.BatchNorm2d(cout, 0.8)
+        bn_m.load_state_dict(bn_o.state_dict())
+        bn_m.to(DEV)
+    conv_d = conv_o.double()
+    bn_d = bn_o.double() if use_bn else None
+    xo = x.double().requires_grad_(True)
+    zo = F.leaky_relu(conv_d(xo), 0.2) * keep.double()[:, :, None, None]
+    yo = bn_d(zo) if use_bn else zo
+    r = rnd(215, tuple(yo.shape))
+    (yo * r.double()).sum().backward()
+    xg = x.to(DEV)
+    if not first:
+        xg = xg.contiguous(memory_format=torch.channels_last)
+    xg.requires_grad_(True)
+    assert ops.disc_block_supported(xg, conv_m, first)
+    y = ops.disc_block(xg, conv_m, keep.to(DEV), bn_m, True, first=first)
+    (y * r.to(DEV)).sum().backward()
+    assert rel_err(y, yo) < 1e-5
+    assert rel_err(xg.grad, xo.grad) < 2e-5
+    assert rel_err(conv_m.weight.grad, conv_d.weight.grad) < 2e-5
+    assert rel_err(conv_m.bias.grad, conv_d.bias.grad) < 2e-5
+    if use_bn:
+        assert rel_err(bn_m.weight.grad, bn_d.weight.grad) < 2e-5 and rel_err(bn_m.bias.grad, bn_d.bias.grad) < 2e-5
+        assert rel_err(bn_m.running_mean, bn_d.running_mean) < 1e-5 and rel_err(bn_m.running_var, bn_d.running_var) < 1e-5
+        assert int(bn_m.num_batches_tracked) == 1
+        bn_d.eval(); bn_m.eval()
+    with torch.no_grad():
+        ye = ops.disc_block(xg.detach(), conv_m, None, bn_m, False, first=first)
+        ze = F.leaky_relu(conv_d(x.double()), 0.2)
+        assert rel_err(ye, bn_d(ze) if use_bn else ze) < 1e-5
