@@ -49,8 +49,18 @@ struct ConvArgs {
     int oy0, ox0, ostep;   // written pixel = (oy0 + yy * ostep, ox0 + xx * ostep); forward: 0, 0, 1
     int OHs, OWs;          // extent of the (yy, xx) sub-grid
     int act;               // 0: none, 1: LeakyReLU(0.2)
-    signed char tap_dy[9], tap_dx[9], tap_w[9];   // input offset of each tap and its index in the weight array
+    // per tap: input offset (dy, dx) and index in the weight array, 4 bits each (offsets biased by 8),
+    // packed in 64-bit words so that the (wave-uniform) lookup is two scalar shifts -- a byte table in
+    // the kernel argument is read with vector loads, and waiting for one drains every prefetch in flight
+    unsigned long long tap_dy, tap_dx, tap_w;
     int M;                 // N * OHs * OWs
+
+    __host__ void set_tap(int t, int dy, int dx, int wi) {
+        const unsigned long long m = ~(15ull << (4 * t));
+        tap_dy = (tap_dy & m) | ((unsigned long long)(dy + 8) << (4 * t));
+        tap_dx = (tap_dx & m) | ((unsigned long long)(dx + 8) << (4 * t));
+        tap_w = (tap_w & m) | ((unsigned long long)wi << (4 * t));
+    }
 };
 
 // One index map serves every use.  The launch enumerates a sub-grid (yy, xx) of output pixels and a
@@ -111,7 +121,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
     float4 ra[NA], rb[NB];
     auto load_step = [&](int t) {
         const int tap = t / nci, ci0 = (t - tap * nci) * BK;
-        const int dy = a.tap_dy[tap], dx = a.tap_dx[tap];
+        const int dy = (int)((a.tap_dy >> (4 * tap)) & 15) - 8, dx = (int)((a.tap_dx >> (4 * tap)) & 15) - 8;
         const long toff = ((long)dy * a.W + dx) * cinq + ci0;
 #pragma unroll
         for (int r = 0; r < NA; ++r) {
@@ -119,7 +129,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
             const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
             ra[r] = ok ? *reinterpret_cast<const float4*>(a.x + a_base[r] + toff) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        const int tw = a.tap_w[tap];
+        const int tw = (int)((a.tap_w >> (4 * tap)) & 15);
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
             const int c = tid / QK + r * (256 / QK);
@@ -502,10 +512,11 @@ int dmc_conv_nhwc_fwd(const float* x, const float* w, const float* bias, const f
     a.OH = (H + 2 * pad - KH) / stride + 1; a.OW = (W + 2 * pad - KW) / stride + 1;
     a.KK = KH * KW; a.ntaps = KH * KW; a.stride = stride;
     a.oy0 = 0; a.ox0 = 0; a.ostep = 1; a.OHs = a.OH; a.OWs = a.OW; a.act = act;
+    a.tap_dy = a.tap_dx = a.tap_w = 0;
     for (int ky = 0; ky < KH; ++ky)
         for (int kx = 0; kx < KW; ++kx) {
             const int t = ky * KW + kx;
-            a.tap_dy[t] = (signed char)(ky - pad); a.tap_dx[t] = (signed char)(kx - pad); a.tap_w[t] = (signed char)t;
+            a.set_tap(t, ky - pad, kx - pad, t);
         }
     a.M = N * a.OH * a.OW;
     return launch_conv(a, (hipStream_t)stream);
@@ -531,6 +542,7 @@ int dmc_conv_nhwc_dgrad(const float* dy, const float* w, float* wt, float* dx, i
     a.N = N; a.H = OH; a.W = OW; a.Cin = Cout;           // the "input" of this GEMM is dy
     a.OH = H; a.OW = W; a.Cout = Cin;                    // its "output" is dx
     a.KK = KK; a.stride = 1; a.act = 0;
+    a.tap_dy = a.tap_dx = a.tap_w = 0;
     for (int py = 0; py < stride; ++py)
         for (int px = 0; px < stride; ++px) {
             a.oy0 = py; a.ox0 = px; a.ostep = stride;
@@ -539,9 +551,7 @@ int dmc_conv_nhwc_dgrad(const float* dy, const float* w, float* wt, float* dx, i
             for (int ky = 0; ky < KH; ++ky)
                 for (int kx = 0; kx < KW; ++kx) {
                     if ((py + pad - ky) % stride != 0 || (px + pad - kx) % stride != 0) continue;
-                    a.tap_dy[nt] = (signed char)((py + pad - ky) / stride);
-                    a.tap_dx[nt] = (signed char)((px + pad - kx) / stride);
-                    a.tap_w[nt] = (signed char)(ky * KW + kx);
+                    a.set_tap(nt, (py + pad - ky) / stride, (px + pad - kx) / stride, ky * KW + kx);
                     ++nt;
                 }
             a.ntaps = nt;

@@ -49,6 +49,9 @@ class _NoSpan(object):
 
 
 PROBE = None          # set to an EventProbe to time the calls below
+#: test hook: a list that receives every discriminator block's z = keep * LeakyReLU(conv + bias) (the
+#: tensor whose sign pattern decides the LeakyReLU branches), in call order; None = off
+DEBUG_DISC_Z = None
 
 
 def _span(name):
@@ -611,6 +614,8 @@ class _DiscBlock(torch.autograd.Function):
             x, wq = _as_cl(x), _as_cl(weight)
             with _span("disc_conv_fwd"):
                 z, part, nblk = _conv_fwd(x, wq, bias, keep, stride, 1, 1, use_bn and training)
+        if DEBUG_DISC_Z is not None:
+            DEBUG_DISC_Z.append(z)
         y, stats = z, None
         if use_bn:
             m_rows = z.shape[0] * z.shape[2] * z.shape[3]
