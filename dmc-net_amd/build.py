@@ -32,11 +32,14 @@ def build_library(force=False, verbose=False):
         if not os.path.exists(path):
             continue
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(obj)
+        hdrs = [os.path.join(CSRC, "dmc_common.h"), os.path.join(ROOT, "include", "dmcnet_hip.h"), os.path.abspath(__file__)]
+        if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in [path] + hdrs):
+            continue                              # object newer than its source and the shared headers
         cmd = [HIPCC] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", path, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-        objs.append(obj)
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))

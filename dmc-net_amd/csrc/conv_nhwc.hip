@@ -437,6 +437,137 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient for few channels (Cin <= 32): all nine taps in one pass.
+//
+// With 16 or 32 input channels a [Cout x Cin] tile per tap leaves the 64 x 64 kernel above 75-94 %
+// idle and re-reads the activations nine times.  Here a workgroup walks 8 x 8 blocks of output
+// pixels; per block it stages the dy tile [64 px][CO_T] and the input patch ((8 s + 2)^2 pixels, all
+// Cin channels) once, and each of its 4 waves takes 4 of the 16 pixel groups (K = 4 pixels per MFMA)
+// against ALL columns (tap, ci): CO_T/16 x 9 Cin/16 accumulator tiles per wave, kept in registers over
+// the workgroup's whole run of blocks, then summed across waves (LDS, fixed order) and written as one
+// partial [Cout][9][Cin] per workgroup for conv_wgrad_reduce_kernel.
+// ------------------------------------------------------------------------------------------
+template <int CIN, int CO_T, int STRIDE>
+struct SmallWg {
+    static constexpr int PW = 8 * STRIDE + 2;              // patch edge (pixels)
+    // pitches (floats): consecutive k-lanes (pixels) of a ds_read_b32 must land 16 banks apart
+    static constexpr int XP = STRIDE == 1 ? 48 : 40;       // patch pixel pitch (>= CIN; pixel step = STRIDE * XP)
+    static constexpr int DP = 48;                          // dy row pitch (>= CO_T)
+    static constexpr int X_FLOATS = PW * PW * XP;
+    static constexpr int D_FLOATS = 64 * DP;
+    static constexpr int NT = 9 * CIN / 16, MT = CO_T / 16;
+    static constexpr int OUT = CO_T * 9 * CIN;             // floats of one partial tile
+};
+
+template <int CIN, int CO_T, int STRIDE>
+__global__ __launch_bounds__(256) void conv_wgrad_small_kernel(WgradConvArgs a, int blocks_y, int blocks_x,
+                                                               int nblocks) {
+    using G = SmallWg<CIN, CO_T, STRIDE>;
+    constexpr int PW = G::PW, XP = G::XP, DP = G::DP, NT = G::NT, MT = G::MT;
+    __shared__ __attribute__((aligned(16))) float lds[G::X_FLOATS + G::D_FLOATS > G::OUT ? G::X_FLOATS + G::D_FLOATS : G::OUT];
+    float* xs = lds;
+    float* ds = lds + G::X_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int co0 = blockIdx.y * CO_T;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // this wave's pixel groups g = 4 wave .. 4 wave + 3: group g covers row g / 2, columns 4 (g % 2) .. +3
+    for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        const int n = b / (blocks_y * blocks_x), r = b - n * (blocks_y * blocks_x);
+        const int oy0 = (r / blocks_x) * 8, ox0 = (r % blocks_x) * 8;
+        const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
+        __syncthreads();                                    // previous block's tiles are no longer read
+        // ---- stage the input patch: PW*PW pixels x CIN/4 quads ----
+        constexpr int XQ = CIN / 4;
+        for (int e = tid; e < PW * PW * XQ; e += 256) {
+            const int q = e % XQ, pp = e / XQ, py = pp / PW, px = pp - py * PW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                v = *reinterpret_cast<const float4*>(a.x + (((long)n * a.H + iy) * a.W + ix) * CIN + 4 * q);
+            *reinterpret_cast<float4*>(xs + pp * XP + 4 * q) = v;
+        }
+        // ---- stage dy: 64 pixels x CO_T/4 quads (zero outside the image) ----
+        constexpr int DQ = CO_T / 4;
+        for (int e = tid; e < 64 * DQ; e += 256) {
+            const int q = e % DQ, p = e / DQ, oy = oy0 + (p >> 3), ox = ox0 + (p & 7);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (oy < a.OH && ox < a.OW && co0 + 4 * q < a.Cout)
+                v = *reinterpret_cast<const float4*>(a.dy + (((long)n * a.OH + oy) * a.OW + ox) * a.Cout + co0 + 4 * q);
+            *reinterpret_cast<float4*>(ds + p * DP + 4 * q) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            const int g = wave * 4 + gg;
+            const int prow = g >> 1, pcol = (g & 1) * 4 + kq;                 // this lane's pixel of the group
+            float av[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) av[i] = ds[(prow * 8 + pcol) * DP + 16 * i + i16];
+            const float* xrow = xs + ((prow * STRIDE) * PW + pcol * STRIDE) * XP + i16;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float* xt = xrow + ((t / 3) * PW + (t % 3)) * XP;
+#pragma unroll
+                for (int c = 0; c < CIN / 16; ++c) {
+                    const float bv = xt[16 * c];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+                        acc[i][t * (CIN / 16) + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc[i][t * (CIN / 16) + c], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- cross-wave sum (fixed order) and store: lane holds column ci = i16 of tile (t, c), rows co = 4 kq + e ----
+    __syncthreads();
+    float* out = a.part + ((size_t)blockIdx.x * a.Cout + co0) * 9 * CIN;     // partial [wg][Cout][9][CIN]
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int t = j / (CIN / 16), c = j % (CIN / 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int idx = ((16 * i + 4 * kq + e) * 9 + t) * CIN + 16 * c + i16;
+                        lds[idx] = (w == 0 ? 0.f : lds[idx]) + acc[i][j][e];
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < G::OUT; e += 256)
+        if (co0 + e / (9 * CIN) < a.Cout) out[e] = lds[e];
+}
+
+template <int CIN, int CO_T, int STRIDE>
+int launch_wgrad_small(WgradConvArgs a, float* dw, float* workspace, hipStream_t s) {
+    const int by = (a.OH + 7) / 8, bx = (a.OW + 7) / 8, nblocks = a.N * by * bx;
+    const int co_tiles = (a.Cout + CO_T - 1) / CO_T;
+    int wgs = 512 / co_tiles;                                   // ~2 workgroups per CU in total
+    if (wgs > nblocks) wgs = nblocks;
+    a.part = wgs > 1 ? workspace : dw;
+    conv_wgrad_small_kernel<CIN, CO_T, STRIDE><<<dim3(wgs, co_tiles), 256, 0, s>>>(a, by, bx, nblocks);
+    int rc = check_launch("conv_wgrad_small");
+    if (rc || wgs == 1) return rc;
+    const long numel = (long)a.Cout * 9 * CIN;
+    const long blocks = (numel / 4 + 255) / 256;
+    conv_wgrad_reduce_kernel<<<(int)(blocks > 1024 ? 1024 : blocks), 256, 0, s>>>(workspace, dw, wgs, numel);
+    return check_launch("conv_wgrad_reduce");
+}
+
+bool wgrad_small_ok(int Cin, int KH, int KW, int pad) { return (Cin == 16 || Cin == 32) && KH == 3 && KW == 3 && pad == 1; }
+
 int wgrad_slices(long M, int tiles) {
     // enough workgroups to fill 256 CUs about three times over, slices of at least 1024 pixels
     long want = (768 + tiles - 1) / tiles;
@@ -577,6 +708,7 @@ int dmc_conv_nhwc_stats_final(const double* partials, int nblk, int C, long coun
 // dmc_conv_nhwc_wgrad_bytes() bytes (the split-K partials; unused when one slice suffices).
 size_t dmc_conv_nhwc_wgrad_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    if (wgrad_small_ok(Cin, KH, KW, pad)) return (size_t)512 * Cout * 9 * Cin * sizeof(float) + 16;
     const int tiles = ((Cout + WG_T - 1) / WG_T) * ((Cin + WG_T - 1) / WG_T) * KH * KW;
     const int ns = wgrad_slices((long)N * OH * OW, tiles);
     return (size_t)(ns > 1 ? ns : 0) * Cout * KH * KW * Cin * sizeof(float) + 16;
@@ -593,6 +725,13 @@ int dmc_conv_nhwc_wgrad(const float* x, const float* dy, float* dw, float* works
     a.stride = stride; a.pad = pad;
     a.OH = (H + 2 * pad - KH) / stride + 1; a.OW = (W + 2 * pad - KW) / stride + 1;
     a.M = N * a.OH * a.OW;
+    if (wgrad_small_ok(Cin, KH, KW, pad)) {
+        a.part = nullptr; a.per_slice = 0; a.tiles_ci = a.tiles_co = 0;
+        if (Cin == 16 && stride == 1) return Cout % 32 == 0 ? launch_wgrad_small<16, 32, 1>(a, dw, workspace, s) : launch_wgrad_small<16, 16, 1>(a, dw, workspace, s);
+        if (Cin == 16) return Cout % 32 == 0 ? launch_wgrad_small<16, 32, 2>(a, dw, workspace, s) : launch_wgrad_small<16, 16, 2>(a, dw, workspace, s);
+        if (stride == 1) return Cout % 32 == 0 ? launch_wgrad_small<32, 32, 1>(a, dw, workspace, s) : launch_wgrad_small<32, 16, 1>(a, dw, workspace, s);
+        return Cout % 32 == 0 ? launch_wgrad_small<32, 32, 2>(a, dw, workspace, s) : launch_wgrad_small<32, 16, 2>(a, dw, workspace, s);
+    }
     a.tiles_ci = (Cin + WG_T - 1) / WG_T; a.tiles_co = (Cout + WG_T - 1) / WG_T;
     const int tiles = a.tiles_ci * a.tiles_co * KH * KW;
     const int ns = wgrad_slices(a.M, tiles);

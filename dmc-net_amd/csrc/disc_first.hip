@@ -97,50 +97,96 @@ __global__ __launch_bounds__(256) void disc_first_dgrad_kernel(const float* __re
     }
 }
 
-// thread t < COUT * 19 owns output (co, j): j < 18 = (ci, tap) of dw, j == 18 = db; it walks the
-// workgroup's pixel range (g values and input taps come from L1 / the scalar-friendly broadcast reads).
-constexpr int FW_MAX_BLOCKS = 1024;
+// Weight / bias gradient on the matrix cores: one GEMM over output pixels,
+//   rows = co (16; A operand = g, lane (co = l & 15, k = l >> 4) reads g[pixel 4 q + k][co]: the wave's
+//          64 lanes read 256 contiguous bytes),
+//   cols = j: 18 (ci, tap) columns of dw + a ones column for db, in two 16-column tiles (B operand =
+//          the tap-shifted input, gathered from the NCHW planes: L1 / L2 hits, each value serves 2.25 taps),
+//   K    = pixels, 4 per v_mfma_f32_16x16x4_f32.
+// A wave owns a contiguous run of pixel quads and keeps its two accumulator tiles in registers; pixel
+// coordinates advance incrementally (no divisions in the loop).  Partials [wave][2][16 x 16] are summed
+// in fixed order in fp64 by the final kernel: deterministic.
+constexpr int FW_WAVES = 2048;                 // 256 CUs x 8 waves
+typedef float fw_f32x4 __attribute__((ext_vector_type(4)));
+
 template <int COUT>
-__global__ __launch_bounds__(320) void disc_first_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                               double* __restrict__ part, int M, int H, int W, int OH,
-                                                               int OW) {
-    const int t = threadIdx.x;
-    if (t >= COUT * 19) return;
-    const int co = t % COUT, j = t / COUT;
-    const int ci = j / 9, tap = j % 9, ky = tap / 3, kx = tap % 3;
+__global__ __launch_bounds__(256) void disc_first_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                               float* __restrict__ part, int M, int H, int W, int OH,
+                                                               int OW, long quads_per_wave) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
     const long total = (long)M * OH * OW;
-    const long per = (total + gridDim.x - 1) / gridDim.x;
-    const long p0 = (long)blockIdx.x * per, p1 = p0 + per < total ? p0 + per : total;
-    double acc = 0.0;
-    for (long q0 = p0; q0 < p1; q0 += 256) {                 // short fp32 runs, fp64 across them
-        const long q1 = q0 + 256 < p1 ? q0 + 256 : p1;
-        float run = 0.f;
-#pragma unroll 8
-        for (long p = q0; p < q1; ++p) {
-            const float gv = g[p * COUT + co];
-            float xv = 1.f;
-            if (j < 18) {
-                const int n = (int)(p / ((long)OH * OW));
-                const int rem = (int)(p - (long)n * OH * OW);
-                const int oy = rem / OW, ox = rem - oy * OW;
-                const int iy = 2 * oy + ky - 1, ix = 2 * ox + kx - 1;
-                xv = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((long)n * 2 + ci) * H + iy) * W + ix] : 0.f;
-            }
-            run = fmaf(gv, xv, run);
-        }
-        acc += (double)run;
+    const long q0 = (long)gw * quads_per_wave;
+    long q1 = q0 + quads_per_wave;
+    const long nquads = (total + 3) / 4;
+    if (q1 > nquads) q1 = nquads;
+    // column roles of this lane: tile 0 column j0 = i16 (ci = j0 / 9, tap = j0 % 9); tile 1 column
+    // 16 + i16: j = 16, 17 -> (ci 1, taps 7, 8), j = 18 -> ones (db), the rest zero
+    const int ci0 = i16 / 9, t0 = i16 % 9, ky0 = t0 / 3 - 1, kx0 = t0 % 3 - 1;
+    const int ky1 = 1, kx1 = (i16 == 0) ? 0 : 1;            // taps 7 = (2, 1), 8 = (2, 2) -> offsets (+1, 0), (+1, +1)
+    const bool t1_tap = i16 < 2, t1_one = i16 == 2;
+    const bool co_ok = i16 < COUT;
+    fw_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    // this lane's pixel of the current quad
+    long p = 4 * q0 + kq;
+    int n = 0, oy = 0, ox = 0;
+    if (q0 < q1) {
+        n = (int)(p / ((long)OH * OW));
+        const int rem = (int)(p - (long)n * OH * OW);
+        oy = rem / OW; ox = rem - oy * OW;
     }
-    part[(size_t)blockIdx.x * (COUT * 19) + t] = acc;
+    const long plane = (long)H * W;
+    constexpr int U = 8;                                     // quads in flight per lane
+    for (long q = q0; q < q1; q += U) {
+        float av[U], b0[U], b1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool pok = p < total && q + u < q1;
+            av[u] = 0.f; b0[u] = 0.f; b1[u] = (t1_one && pok) ? 1.f : 0.f;
+            if (pok) {
+                if (co_ok) av[u] = g[p * COUT + i16];
+                const int iy = 2 * oy + ky0, ix = 2 * ox + kx0;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) b0[u] = x[((long)n * 2 + ci0) * plane + (long)iy * W + ix];
+                if (t1_tap) {
+                    const int jy = 2 * oy + ky1, jx = 2 * ox + kx1;
+                    if (jy < H && jx < W) b1[u] = x[((long)n * 2 + 1) * plane + (long)jy * W + jx];
+                }
+            }
+            p += 4; ox += 4;
+            if (ox >= OW) {                                  // next row / frame: once per OW / 4 quads
+                n = (int)(p / ((long)OH * OW));
+                const int rem = (int)(p - (long)n * OH * OW);
+                oy = rem / OW; ox = rem - oy * OW;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], b0[u], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], b1[u], acc1, 0, 0, 0);
+        }
+    }
+    // D layout: lane holds column j = i16 (+16), rows co = 4 kq + e
+    float* out = part + (size_t)gw * 512;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        out[(4 * kq + e) * 16 + i16] = acc0[e];
+        out[256 + (4 * kq + e) * 16 + i16] = acc1[e];
+    }
 }
 
 template <int COUT>
-__global__ void disc_first_wgrad_final_kernel(const double* __restrict__ part, int nblk, float* __restrict__ dw,
-                                              float* __restrict__ db) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= COUT * 19) return;
+__global__ __launch_bounds__(64) void disc_first_wgrad_final_kernel(const float* __restrict__ part, int nwaves,
+                                                                    float* __restrict__ dw, float* __restrict__ db) {
+    // one wave per output (co, j): 64 lanes stride over the partials, fp64, fixed order
+    const int t = blockIdx.x;                       // < COUT * 19
+    const int co = t % COUT, j = t / COUT, lane = threadIdx.x;
+    const int idx = (j >> 4) * 256 + co * 16 + (j & 15);
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * (COUT * 19) + t];
-    const int co = t % COUT, j = t / COUT;
+    for (int b = lane; b < nwaves; b += 64) s += (double)part[(size_t)b * 512 + idx];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane != 0) return;
     if (j < 18) dw[(co * 2 + j / 9) * 9 + j % 9] = (float)s;
     else if (db) db[co] = (float)s;
 }
@@ -148,11 +194,6 @@ __global__ void disc_first_wgrad_final_kernel(const double* __restrict__ part, i
 int blocks_for(long n) {
     long b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
-}
-
-int wgrad_blocks(long pixels) {
-    long b = pixels / 2048;
-    return (int)(b < 1 ? 1 : (b > FW_MAX_BLOCKS ? FW_MAX_BLOCKS : b));
 }
 
 }  // namespace
@@ -187,7 +228,7 @@ int dmc_disc_first_dgrad(const float* g, const float* w, float* dx, int M, int H
     return check_launch("disc_first_dgrad");
 }
 
-size_t dmc_disc_first_wgrad_bytes(int Cout) { return (size_t)FW_MAX_BLOCKS * Cout * 19 * sizeof(double); }
+size_t dmc_disc_first_wgrad_bytes(int Cout) { (void)Cout; return (size_t)FW_WAVES * 512 * sizeof(float); }
 
 int dmc_disc_first_wgrad(const float* x, const float* g, float* dw, float* db, void* workspace, int M, int H,
                          int W, int Cout, dmc_stream_t stream) {
@@ -196,14 +237,18 @@ int dmc_disc_first_wgrad(const float* x, const float* g, float* dw, float* db, v
         return fail(DMC_E_INVALID, "dmc_disc_first_wgrad: unsupported shape");
     const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
     hipStream_t s = (hipStream_t)stream;
-    const int nb = wgrad_blocks((long)M * OH * OW);
-    double* part = static_cast<double*>(workspace);
-    if (Cout == 16) disc_first_wgrad_kernel<16><<<nb, 320, 0, s>>>(x, g, part, M, H, W, OH, OW);
-    else disc_first_wgrad_kernel<8><<<nb, 320, 0, s>>>(x, g, part, M, H, W, OH, OW);
+    const long nquads = ((long)M * OH * OW + 3) / 4;
+    long per = (nquads + FW_WAVES - 1) / FW_WAVES;
+    if (per < 16) per = 16;
+    const int nwaves = (int)((nquads + per - 1) / per);
+    const int nb = (nwaves + 3) / 4;
+    float* part = static_cast<float*>(workspace);
+    if (Cout == 16) disc_first_wgrad_kernel<16><<<nb, 256, 0, s>>>(x, g, part, M, H, W, OH, OW, per);
+    else disc_first_wgrad_kernel<8><<<nb, 256, 0, s>>>(x, g, part, M, H, W, OH, OW, per);
     int rc = check_launch("disc_first_wgrad");
     if (rc) return rc;
-    if (Cout == 16) disc_first_wgrad_final_kernel<16><<<(16 * 19 + 63) / 64, 64, 0, s>>>(part, nb, dw, db);
-    else disc_first_wgrad_final_kernel<8><<<(8 * 19 + 63) / 64, 64, 0, s>>>(part, nb, dw, db);
+    if (Cout == 16) disc_first_wgrad_final_kernel<16><<<16 * 19, 64, 0, s>>>(part, nb * 4, dw, db);
+    else disc_first_wgrad_final_kernel<8><<<8 * 19, 64, 0, s>>>(part, nb * 4, dw, db);
     return check_launch("disc_first_wgrad_final");
 }
 
