@@ -565,7 +565,7 @@ __device__ __forceinline__ void ring_stage(const LayerArgs& a, unsigned slot_byt
 // sched_barriers keep the compiler from hoisting every load of the chunk to the top.
 template <int MODE, int K, int NT_>
 __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[M_SEGS][NT_], const float* buf, const float* wl,
-                                           int c0, const int (&boff)[M_SEGS], int lane) {
+                                           int c0, int boffq, int lane) {
     using G = MfmaGeom<MODE, K>;
     float w[2][3][G::NTP], b[2][3][M_SEGS];
     auto load_stage = [&](int cc, int sel) {
@@ -585,8 +585,9 @@ __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[M_SEGS][NT_], const floa
                     }
                 }
             }
-#pragma unroll
-            for (int s = 0; s < M_SEGS; ++s) b[sel][dy][s] = buf[cc * P_PLANE + dy * LTW + boff[s]];
+            // the lane's four consecutive pixels: one 16-byte read feeds the four "segments"
+            const float4 bq = *reinterpret_cast<const float4*>(buf + cc * P_PLANE + dy * LTW + boffq);
+            b[sel][dy][0] = bq.x; b[sel][dy][1] = bq.y; b[sel][dy][2] = bq.z; b[sel][dy][3] = bq.w;
         }
     };
     load_stage(0, 0);
@@ -672,19 +673,15 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_layer_mfma_kernel(RingArgs ra
 
     // ------------------------------ consumer waves ------------------------------
     // The tile's PT_H x W pixels are numbered row-major, p = y*W + x; consumer wave r owns pixels
-    // [256 r, 256 r + 256) as 4 segments of 64, one pixel per lane.  A 224-wide row is 3.5 segments,
-    // so segments straddle rows: nothing is wasted on columns >= W, and output addresses are simply
-    // ty0*W + p (every store instruction writes 256 contiguous bytes).
-    int boff[M_SEGS];                 // LDS offset of the lane's pixel in staged row 0 (the row above it)
-    bool at_left[M_SEGS], at_right[M_SEGS];
-#pragma unroll
-    for (int s = 0; s < M_SEGS; ++s) {
-        const int p = r * (M_SEGS * 64) + s * 64 + lane;
-        const int yl = p / a.W, x = p - yl * a.W;
-        boff[s] = p < PT_H * a.W ? yl * LTW + x : 0;
-        at_left[s] = x == 0;
-        at_right[s] = x == a.W - 1;
-    }
+    // [256 r, 256 r + 256) and lane l of it the FOUR CONSECUTIVE pixels 256 r + 4 l + e, e = 0..3 (W % 4 ==
+    // 0: a quad never straddles rows; a 224-wide row is 56 lanes, so waves straddle rows and nothing is
+    // wasted on columns >= W).  MFMA "segment" e = element e of every lane's quad: its B operands come
+    // from one 16-byte LDS read, the horizontal neighbours of pixels e = 1, 2 are the lane's own
+    // accumulators (only e = 0 / e = 3 need a lane shift), and every global access is 16 bytes per lane.
+    const int p0 = r * (M_SEGS * 64) + 4 * lane;
+    const int yl0 = p0 / a.W, x0 = p0 - yl0 * a.W;
+    const int boffq = p0 < PT_H * a.W ? yl0 * LTW + x0 : 0;   // LDS offset of the quad in staged row 0 (the row above it)
+    const bool at_left = x0 == 0, at_right = x0 + 4 == a.W;
     f32x4 acc[M_SEGS][NT];
 #pragma unroll
     for (int s = 0; s < M_SEGS; ++s)
@@ -695,82 +692,73 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_layer_mfma_kernel(RingArgs ra
 #pragma unroll 1
     for (int q = 0; q < nitems; ++q) {
         asm volatile("s_barrier" ::: "memory");
-        mfma_chunk<MODE, K, NT>(acc, lds + slot * P_BUF, wl, c * G::CH, boff, lane);
+        mfma_chunk<MODE, K, NT>(acc, lds + slot * P_BUF, wl, c * G::CH, boffq, lane);
         slot = slot + 1 == RING ? 0 : slot + 1;
         if (++c < NCHUNK) continue;
         c = 0;
 
-        // ---- epilogue: horizontal taps by lane shifts, then bias / activation / store ----
+        // ---- epilogue: horizontal taps (own registers / lane shifts), then bias / activation / store ----
         const int n = tile / ra.tiles_y, ty0 = (tile - n * ra.tiles_y) * PT_H;
         const int pmax = (a.H - ty0 < PT_H ? a.H - ty0 : PT_H) * a.W;      // pixels of this tile inside the image
         const size_t tile_pix = (size_t)ty0 * a.W;
+        const bool inside = p0 < pmax;
+        const size_t pix = tile_pix + (inside ? p0 : 0);
+        float4 extra[COUT];              // MODE 1: mv (delta add), MODE 2: y_K (LeakyReLU'): one batch of loads
+        if (MODE != 0) {
+#pragma unroll
+            for (int co = 0; co < COUT; ++co)
+                extra[co] = MODE == 1 ? (a.add_mv ? *reinterpret_cast<const float4*>(a.mv + ((size_t)n * 2 + co) * HW + pix)
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f))
+                                      : *reinterpret_cast<const float4*>(a.feat + ((size_t)n * NFEAT + (yoff(K) - NIN) + co) * HW + pix);
+        }
         // the pixel left of this wave's first one / right of its last one belongs to the neighbour
         // wave: exchange those two partial sums per channel through LDS
         float nb_l[COUT], nb_r[COUT];
-        {
 #pragma unroll
-            for (int co = 0; co < COUT; ++co) {
-                const int r0 = co, r2 = 2 * COUT + co;
-                if (lane == 0) xchg[(r * 2 + 0) * 8 + co] = acc[0][r2 / 4][r2 % 4];
-                if (lane == 63) xchg[(r * 2 + 1) * 8 + co] = acc[M_SEGS - 1][r0 / 4][r0 % 4];
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll
-            for (int co = 0; co < COUT; ++co) {
-                nb_l[co] = r > 0 ? xchg[((r - 1) * 2 + 1) * 8 + co] : 0.f;
-                nb_r[co] = r + 1 < P_CONS ? xchg[((r + 1) * 2 + 0) * 8 + co] : 0.f;
-            }
+        for (int co = 0; co < COUT; ++co) {
+            const int r0 = co, r2 = 2 * COUT + co;
+            if (lane == 0) xchg[(r * 2 + 0) * 8 + co] = acc[0][r2 / 4][r2 % 4];
+            if (lane == 63) xchg[(r * 2 + 1) * 8 + co] = acc[M_SEGS - 1][r0 / 4][r0 % 4];
         }
-        float extra[M_SEGS][COUT];       // MODE 1: mv (delta add), MODE 2: y_K (LeakyReLU'): one batch of loads
-        if (MODE != 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
-            for (int s = 0; s < M_SEGS; ++s) {
-                const int p = r * (M_SEGS * 64) + s * 64 + lane;
-                const size_t pix = p < pmax ? tile_pix + p : 0;
-#pragma unroll
-                for (int co = 0; co < COUT; ++co)
-                    extra[s][co] = MODE == 1 ? (a.add_mv ? a.mv[((size_t)n * 2 + co) * HW + pix] : 0.f)
-                                             : a.feat[((size_t)n * NFEAT + (yoff(K) - NIN) + co) * HW + pix];
-            }
+        for (int co = 0; co < COUT; ++co) {
+            nb_l[co] = r > 0 ? xchg[((r - 1) * 2 + 1) * 8 + co] : 0.f;
+            nb_r[co] = r + 1 < P_CONS ? xchg[((r + 1) * 2 + 0) * 8 + co] : 0.f;
         }
 #pragma unroll
-        for (int s = 0; s < M_SEGS; ++s) {
-            const int p = r * (M_SEGS * 64) + s * 64 + lane;
-            const size_t pix = tile_pix + p;
-            float v[COUT];
+        for (int co = 0; co < COUT; ++co) {
+            const int r0 = co, r1 = COUT + co, r2 = 2 * COUT + co;
+            // (the shifts run with all lanes active -- a DPP read from an inactive lane is invalid -- and
+            // only then are the image-border lanes masked: the zero padding of the convolution)
+            const float sh_l = dpp_shr_fill(acc[M_SEGS - 1][r0 / 4][r0 % 4], nb_l[co]);
+            const float sh_r = dpp_shl_fill(acc[0][r2 / 4][r2 % 4], nb_r[co]);
+            float v[M_SEGS];
 #pragma unroll
-            for (int co = 0; co < COUT; ++co) {
-                const int r0 = co, r1 = COUT + co, r2 = 2 * COUT + co;
-                const float p0 = acc[s][r0 / 4][r0 % 4];
-                const float p1 = acc[s][r1 / 4][r1 % 4];
-                const float p2 = acc[s][r2 / 4][r2 % 4];
-                // neighbour pixels are neighbour lanes (the previous / next segment's edge lane at the
-                // segment ends); at the image's left / right border the neighbour is zero padding
-                const float edge_l = s > 0 ? lane_bcast(acc[s > 0 ? s - 1 : 0][r0 / 4][r0 % 4], 63) : nb_l[co];
-                const float edge_r = s + 1 < M_SEGS ? lane_bcast(acc[s + 1 < M_SEGS ? s + 1 : s][r2 / 4][r2 % 4], 0) : nb_r[co];
-                // (the shifts run with all lanes active -- a DPP read from an inactive lane is invalid --
-                // and only then are the border lanes masked)
-                const float sh_l = dpp_shr_fill(p0, edge_l), sh_r = dpp_shl_fill(p2, edge_r);
-                const float from_l = at_left[s] ? 0.f : sh_l;
-                const float from_r = at_right[s] ? 0.f : sh_r;
-                v[co] = p1 + from_l + from_r;
+            for (int e = 0; e < M_SEGS; ++e) {
+                const float from_l = e > 0 ? acc[e > 0 ? e - 1 : 0][r0 / 4][r0 % 4] : (at_left ? 0.f : sh_l);
+                const float from_r = e + 1 < M_SEGS ? acc[e + 1 < M_SEGS ? e + 1 : e][r2 / 4][r2 % 4] : (at_right ? 0.f : sh_r);
+                v[e] = acc[e][r1 / 4][r1 % 4] + from_l + from_r;
+            }
+            const float ex[4] = {MODE != 0 ? extra[co].x : 0.f, MODE != 0 ? extra[co].y : 0.f,
+                                 MODE != 0 ? extra[co].z : 0.f, MODE != 0 ? extra[co].w : 0.f};
+#pragma unroll
+            for (int e = 0; e < M_SEGS; ++e) {
                 if (MODE == 0) {
-                    v[co] += a.pk[bf_off(K) + co];
-                    v[co] = v[co] > 0.f ? v[co] : 0.1f * v[co];
+                    v[e] += a.pk[bf_off(K) + co];
+                    v[e] = v[e] > 0.f ? v[e] : 0.1f * v[e];
                 } else if (MODE == 1) {
-                    v[co] += a.pk[bf_off(K) + co];
-                    v[co] += extra[s][co];
+                    v[e] += a.pk[bf_off(K) + co];
+                    v[e] += ex[e];
                 } else {
-                    v[co] *= extra[s][co] > 0.f ? 1.f : 0.1f;
+                    v[e] *= ex[e] > 0.f ? 1.f : 0.1f;
                 }
             }
-            if (p < pmax) {
-#pragma unroll
-                for (int co = 0; co < COUT; ++co) {
-                    if (MODE == 0) a.feat_out[((size_t)n * NFEAT + (yoff(K) - NIN) + co) * HW + pix] = v[co];
-                    else if (MODE == 1) a.out[((size_t)n * 2 + co) * HW + pix] = v[co];
-                    else a.gbuf[((size_t)n * NFEAT + (yoff(K) - NIN) + co) * HW + pix] = v[co];
-                }
+            if (inside) {
+                const float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                if (MODE == 0) *reinterpret_cast<float4*>(a.feat_out + ((size_t)n * NFEAT + (yoff(K) - NIN) + co) * HW + pix) = o;
+                else if (MODE == 1) *reinterpret_cast<float4*>(a.out + ((size_t)n * 2 + co) * HW + pix) = o;
+                else *reinterpret_cast<float4*>(a.gbuf + ((size_t)n * NFEAT + (yoff(K) - NIN) + co) * HW + pix) = o;
             }
         }
 #pragma unroll
@@ -1794,7 +1782,7 @@ int wgrad_groups(int N, int H, int W) {
 
 // All frames in one pass per layer (processing the frames in Infinity-Cache-sized chunks was
 // measured slower: under-filled grids).
-int frames_per_pass(int N, int, int) { return N; }
+int frames_per_pass(int N, int, int) { const int f = option(OPT_GEN_FRAMES); return f > 0 && f < N ? f : N; }
 
 int num_cus() {
     static const int n = [] {
