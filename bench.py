@@ -207,6 +207,10 @@ def main():
                     help="1 (default) = cudnn.benchmark as the reference's train.py:118 sets it: MIOpen "
                          "picks solvers by search, answered from the find-db shipped in "
                          "dmc-net_amd/miopen_db; 0 = MIOpen's heuristic picks")
+    ap.add_argument("--own-conv", type=int, default=0,
+                    help="1 = the classifier's 3x3 / 1x1 convolutions on this package's matrix-core NHWC kernels "
+                         "(fused conv -> bn op); 0 (default) = PyTorch-ROCm (MIOpen) convolutions, the faster of "
+                         "the two so far")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -228,7 +232,8 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import dmcnet_amd
-    from dmcnet_amd import dataset, ddp, miopen, ops, train
+    from dmcnet_amd import dataset, ddp, miopen, ops, resnet, train
+    resnet.OWN_CONV = bool(args.own_conv)
     if args.miopen_find:
         miopen.enable_find()          # before the first convolution of the process
     if args.config == "i3d":

@@ -44,6 +44,7 @@ SIGNATURES = {
     "dmc_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
     "dmc_bn_act_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "dmc_bn_apply_nhwc": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
+    "dmc_bn_apply_act_nhwc": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "dmc_bn_bwd_act_nhwc": (_I, [_P] * 10 + [_I, _F, _I, _I, _P]),
     "dmc_channel_sum_nhwc": (_I, [_P, _P, _P, _I, _I, _P]),
     "dmc_bn_relu_pool_supported": (_I, [_I, _I, _I, _I]),
@@ -51,7 +52,7 @@ SIGNATURES = {
     "dmc_bn_relu_pool_codes_bytes": (_Z, [_I, _I, _I, _I]),
     "dmc_bn_relu_pool_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dmc_conv_nhwc_supported": (_I, [_I] * 9),
-    "dmc_conv_nhwc_stat_blocks": (_I, [_I] * 7),
+    "dmc_conv_nhwc_stat_blocks": (_I, [_I] * 8),
     "dmc_conv_nhwc_fwd": (_I, [_P] * 6 + [_I] * 10 + [_P]),
     "dmc_conv_nhwc_stats_final": (_I, [_P, _I, _I, ctypes.c_long, _P, _P, _P, _F, _F, _P]),
     "dmc_conv_nhwc_wt_bytes": (_Z, [_I] * 4),

@@ -571,16 +571,22 @@ int dmc_bn_relu_pool_bwd(const float* x, const float* gamma, const float* beta, 
     return check_launch("pool_bwd_apply");
 }
 
-// y = (x - mean) * invstd * gamma + beta with GIVEN statistics (stats = mean[C], invstd[C]): the
-// apply pass alone, for callers whose producer already reduced the statistics
-// (dmc_conv_nhwc_fwd + dmc_conv_nhwc_stats_final).
+// y = relu?((x - mean) * invstd * gamma + beta [+ residual]) with GIVEN statistics (stats = mean[C],
+// invstd[C]): the apply pass alone, for callers whose producer already reduced the statistics
+// (dmc_conv_nhwc_fwd + dmc_conv_nhwc_stats_final).  relu_mask as in dmc_bn_act_fwd (nullable).
+int dmc_bn_apply_act_nhwc(const float* x, const float* residual, const float* gamma, const float* beta,
+                          const float* stats, float* y, unsigned char* relu_mask, int M, int C, int relu,
+                          dmc_stream_t stream) {
+    if (!x || !gamma || !beta || !stats || !y) return fail(DMC_E_INVALID, "dmc_bn_apply_act_nhwc: null pointer");
+    if (!shape_ok(M, C)) return fail(DMC_E_INVALID, "dmc_bn_apply_act_nhwc: unsupported shape M=%d C=%d", M, C);
+    BnArgs a = {x, residual, gamma, beta, stats, nullptr, y, nullptr, nullptr, M, C, relu, relu_mask};
+    bn_apply_fwd_kernel<<<stream_blocks((size_t)M * (C / 4)), 256, 0, (hipStream_t)stream>>>(a);
+    return check_launch("bn_apply_act_nhwc");
+}
+
 int dmc_bn_apply_nhwc(const float* x, const float* gamma, const float* beta, const float* stats, float* y,
                       int M, int C, dmc_stream_t stream) {
-    if (!x || !gamma || !beta || !stats || !y) return fail(DMC_E_INVALID, "dmc_bn_apply_nhwc: null pointer");
-    if (!shape_ok(M, C)) return fail(DMC_E_INVALID, "dmc_bn_apply_nhwc: unsupported shape M=%d C=%d", M, C);
-    BnArgs a = {x, nullptr, gamma, beta, stats, nullptr, y, nullptr, nullptr, M, C, 0, nullptr};
-    bn_apply_fwd_kernel<<<stream_blocks((size_t)M * (C / 4)), 256, 0, (hipStream_t)stream>>>(a);
-    return check_launch("bn_apply_nhwc");
+    return dmc_bn_apply_act_nhwc(x, nullptr, gamma, beta, stats, y, nullptr, M, C, 0, stream);
 }
 
 // Backward of  y = BN(z),  z = keep[n][c] * LeakyReLU_slope(pre)  down to d(pre): the BatchNorm

@@ -54,6 +54,7 @@ struct ConvArgs {
     // the kernel argument is read with vector loads, and waiting for one drains every prefetch in flight
     unsigned long long tap_dy, tap_dx, tap_w;
     int M;                 // N * OHs * OWs
+    int ablate;            // measurement only (option conv_ablate): 1 = no transfers, 2 = no barriers
 
     __host__ void set_tap(int t, int dy, int dx, int wi) {
         const unsigned long long m = ~(15ull << (4 * t));
@@ -267,6 +268,250 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Second generation of the same implicit GEMM for Cin % 32 == 0 (the ResNet's 3x3 / 1x1 convolutions, the
+// discriminator blocks from 32 channels on, and every data gradient whose dy has >= 32 channels):
+//   * v_mfma_f32_32x32x2_f32: 64 cycles per instruction and per dependent accumulator, so one wave per SIMD
+//     already keeps the matrix pipe full, and half the LDS operand traffic of the 16x16x4 form;
+//     rows = output channels (A = weights), columns = pixels (B = input), 32 x 32 tiles;
+//   * operand tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes = eight
+//     128-byte rows of 32 k-values per instruction), no staging registers, double-buffered: the
+//     transfers of K-step t+1 are in flight during the MFMAs of step t, one barrier per step; each wave
+//     issues its share in four pieces behind the MFMAs of the step's four k-groups;
+//   * LDS-DMA writes lane-linear, so rows cannot be padded; the 16-byte quad q of tile row r is stored
+//     in slot q ^ ((r >> 1) & 7) instead -- applied to the SOURCE address of each lane and again by the
+//     fragment reads -- which makes every ds_read_b128 of 16 consecutive rows conflict-free;
+//   * out-of-image taps and rows beyond M / Cout read 16 zero bytes (g_zeros).
+// ------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __attribute__((aligned(16))) float g_zeros[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ void dma16_v(const void* src, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"((unsigned long long)src), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)) : "memory");
+}
+
+constexpr int C2_THREADS = 256;
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(C2_THREADS) void conv2_kernel(ConvArgs a) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;   // 32 x 32 tiles per wave: pixels x channels
+    static_assert(WM * WN == 4 && BM % (32 * WM) == 0 && BN % (32 * WN) == 0, "wave layout");
+    constexpr int NDP = BM / 32, NDW = BN / 32;            // DMA instructions per wave and step: pixel rows, weight rows
+    constexpr int ND = NDP + NDW;
+    constexpr int BUF = (BM + BN) * 128;                   // bytes per buffer: tile rows of 32 floats
+    __shared__ __attribute__((aligned(1024))) float lds[2 * (BM + BN) * 32];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int m0 = blockIdx.x * BM, co0 = blockIdx.y * BN;
+    const unsigned lds0 = lds_addr_of(lds);
+    const unsigned long long zeros = (unsigned long long)g_zeros;
+
+    // ---- this lane's share of the transfers: instruction d = wave + 4 j moves tile rows 8 d .. 8 d + 7,
+    // lane -> (row 8 d + lane / 8, slot lane % 8), source quad = slot ^ ((row >> 1) & 7).  Per pixel row the
+    // lane keeps the address of its quad at tap offset (0, 0) and a bit mask of the taps that fall inside
+    // the image, so a step costs one add and one select per transfer ----
+    const int rr = lane >> 3, sl = lane & 7;
+    unsigned long long p_addr[NDP];
+    unsigned p_mask[NDP];
+#pragma unroll
+    for (int j = 0; j < NDP; ++j) {
+        const int row = 8 * (wave + 4 * j) + rr;
+        const int q = sl ^ ((row >> 1) & 7);
+        const int m = m0 + row;
+        p_mask[j] = 0; p_addr[j] = zeros;
+        if (m < a.M) {
+            const int n = m / (a.OHs * a.OWs), rem = m - n * (a.OHs * a.OWs);
+            const int yy = rem / a.OWs, xx = rem - yy * a.OWs;
+            const int iy0 = yy * a.stride, ix0 = xx * a.stride;
+            p_addr[j] = (unsigned long long)a.x + ((((long)n * a.H + iy0) * a.W + ix0) * a.Cin + 4 * q) * 4;
+            for (int t = 0; t < a.ntaps; ++t) {
+                const int iy = iy0 + (int)((a.tap_dy >> (4 * t)) & 15) - 8, ix = ix0 + (int)((a.tap_dx >> (4 * t)) & 15) - 8;
+                if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) p_mask[j] |= 1u << t;
+            }
+        }
+    }
+    unsigned long long w_addr[NDW];   // (co, tap 0, ci 0) + the lane's quad; Cout % BN == 0: every row exists
+#pragma unroll
+    for (int j = 0; j < NDW; ++j) {
+        const int row = 8 * (wave + 4 * j) + rr;            // row within the weight tile
+        const int q = sl ^ ((row >> 1) & 7);
+        w_addr[j] = (unsigned long long)a.w + ((long)(co0 + row) * a.KK * a.Cin + 4 * q) * 4;
+    }
+
+    // step state of the transfers being issued (the NEXT K-step): all scalar
+    int tap_n = 0, ci_n = 0;
+    long toff = 0, woff = 0;
+    auto set_step = [&]() {
+        const int dy = (int)((a.tap_dy >> (4 * tap_n)) & 15) - 8, dx = (int)((a.tap_dx >> (4 * tap_n)) & 15) - 8;
+        const int tw = (int)((a.tap_w >> (4 * tap_n)) & 15);
+        toff = (((long)dy * a.W + dx) * a.Cin + ci_n) * 4;
+        woff = ((long)tw * a.Cin + ci_n) * 4;
+    };
+    auto issue_one = [&](int j, int buf) {                          // j is a compile-time constant at every call
+        const unsigned base = lds0 + buf * BUF;
+        if (j < NDP) {
+            const bool ok = (p_mask[j < NDP ? j : 0] >> tap_n) & 1;
+            const unsigned long long src = ok ? p_addr[j < NDP ? j : 0] + (unsigned long long)toff : zeros;
+            dma16_v(reinterpret_cast<const void*>(src), base + (wave + 4 * j) * 1024);
+        } else {
+            const int jw = j - NDP;
+            dma16_v(reinterpret_cast<const void*>(w_addr[jw >= 0 && jw < NDW ? jw : 0] + (unsigned long long)woff),
+                    base + BM * 128 + (wave + 4 * jw) * 1024);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragment reads: lane -> tile row (lane & 31), k-quad 2 g + (lane >> 5), stored in slot quad ^ ((row >> 1) & 7);
+    // tile bases are multiples of 32 rows, so the swizzle term depends on the lane only
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int swz = (l31 >> 1) & 7;
+    int foff[4];                                                  // byte offset within a 32-row tile, per k-group g
+#pragma unroll
+    for (int g = 0; g < 4; ++g) foff[g] = l31 * 128 + (((2 * g + khalf) ^ swz) << 4);
+    const int prow0 = wm * (BM / WM), crow0 = BM + wn * (BN / WN);
+
+    const int T_steps = a.ntaps * (a.Cin >> 5);
+    if (T_steps > 0) {
+        set_step();
+#pragma unroll
+        for (int j = 0; j < ND; ++j) issue_one(j, 0);
+        ci_n = 32;
+        if (ci_n == a.Cin) { ci_n = 0; tap_n = 1; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+    for (int t = 0; t < T_steps; ++t) {
+        const int buf = t & 1;
+        const bool more = t + 1 < T_steps;
+        if (more) set_step();
+        const char* base = reinterpret_cast<const char*>(lds) + buf * BUF;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 xa[TM], wa[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                xa[i] = *reinterpret_cast<const float4*>(base + (prow0 + 32 * i) * 128 + foff[g]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                wa[j] = *reinterpret_cast<const float4*>(base + (crow0 + 32 * j) * 128 + foff[g]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j].x, xa[i].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j].y, xa[i].y, acc[i][j], 0, 0, 0);
+            // the next step's transfers, a quarter of them behind each k-group's MFMAs (they land during the
+            // remaining groups; nothing is issued, or waited for, in front of the step's first MFMA).  A
+            // dedicated producer wave was measured too: its ~40 transfers per step serialise on one wave's
+            // issue (60-100 cycles each) and the consumers wait at the barrier (0.29 -> 0.46 ms for layer1)
+            if (more && !(a.ablate & 1)) {
+#pragma unroll
+                for (int j = g * ND / 4; j < (g + 1) * ND / 4; ++j) issue_one(j, buf ^ 1);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j].z, xa[i].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j].w, xa[i].w, acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            ci_n += 32;
+            if (ci_n == a.Cin) { ci_n = 0; ++tap_n; }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // step t+1 has landed (this wave's share), own reads of buf done
+        __builtin_amdgcn_s_barrier();                              // ... everyone's; and nobody reads buf any more
+    }
+
+    // ---- epilogue: lane holds pixel column l31 of tile i; channels 8 gq + 4 khalf + e of tile j in acc[4 gq + e] ----
+    float s1[TN][16], s2[TN][16];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s1[j][e] = 0.f; s2[j][e] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + prow0 + 32 * i + l31;
+        const bool mok = m < a.M;
+        int n = 0;
+        long opix = 0;
+        if (mok) {
+            n = m / (a.OHs * a.OWs);
+            const int rem = m - n * (a.OHs * a.OWs);
+            const int yy = rem / a.OWs, xx = rem - yy * a.OWs;
+            opix = ((long)n * a.OH + (a.oy0 + yy * a.ostep)) * a.OW + (a.ox0 + xx * a.ostep);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int co = co0 + wn * (BN / WN) + 32 * j + 8 * gq + 4 * khalf;
+                if (co >= a.Cout) continue;
+                float v[4] = {acc[i][j][4 * gq], acc[i][j][4 * gq + 1], acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]};
+                if (a.bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(a.bias + co);
+                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                }
+                if (a.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+                }
+                if (a.keep && mok) {
+                    const float4 kv = *reinterpret_cast<const float4*>(a.keep + (long)n * a.Cout + co);
+                    v[0] *= kv.x; v[1] *= kv.y; v[2] *= kv.z; v[3] *= kv.w;
+                }
+                if (mok) {
+                    *reinterpret_cast<float4*>(a.y + opix * a.Cout + co) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { s1[j][4 * gq + e] += v[e]; s2[j][4 * gq + e] += v[e] * v[e]; }
+                }
+            }
+    }
+    if (a.stat_part) {
+        // per-channel sums of this workgroup's tile: 32 pixel lanes -> waves (WM) -> one store per channel
+        double* red = reinterpret_cast<double*>(lds);         // [WM][BN][2]; the operand tiles are dead (last barrier)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                double d1 = (double)s1[j][e], d2 = (double)s2[j][e];
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) {
+                    d1 += __shfl_xor(d1, o, 64);
+                    d2 += __shfl_xor(d2, o, 64);
+                }
+                if (l31 == 0) {
+                    const int c = wn * (BN / WN) + 32 * j + 8 * (e >> 2) + 4 * khalf + (e & 3);
+                    red[(wm * BN + c) * 2 + 0] = d1;
+                    red[(wm * BN + c) * 2 + 1] = d2;
+                }
+            }
+        __syncthreads();
+        if (tid < BN && co0 + tid < a.Cout) {
+            double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { d1 += red[(w * BN + tid) * 2 + 0]; d2 += red[(w * BN + tid) * 2 + 1]; }
+            double* dst = a.stat_part + ((size_t)blockIdx.x * a.Cout + co0 + tid) * 2;
+            dst[0] = d1; dst[1] = d2;
+        }
+    }
+}
+
 // ---- data-gradient weights: wt[ci][tap][co] = w[co][tap][ci] ------------------------------------
 __global__ __launch_bounds__(256) void conv_pack_wt_kernel(const float* __restrict__ w, float* __restrict__ wt,
                                                            int Cout, int KK, int Cin) {
@@ -425,15 +670,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradConvArgs a) {
         }
 }
 
+// sum of the nslice partials: 16 float4 outputs x 16 slice lanes per workgroup (each lane sums every 16th slice in
+// order, then the 16 lanes are combined in order through LDS): fixed summation order, numel / 64 workgroups
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                                 int nslice, long numel) {
-    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < numel; i += (long)gridDim.x * 1024) {
+    __shared__ float4 red[16][17];
+    const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    for (long i0 = (long)blockIdx.x * 64; i0 < numel; i0 += (long)gridDim.x * 64) {
+        const long i = i0 + 4 * o;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = 0; k < nslice; ++k) {
-            const float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * numel + i);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        if (i < numel)
+            for (int k = sl; k < nslice; k += 16) {
+                const float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * numel + i);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        red[sl][o] = s;
+        __syncthreads();
+        if (sl == 0 && i < numel) {
+            float4 t = red[0][o];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) { const float4 v = red[k][o]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+            *reinterpret_cast<float4*>(dw + i) = t;
         }
-        *reinterpret_cast<float4*>(dw + i) = s;
+        __syncthreads();
     }
 }
 
@@ -561,12 +820,256 @@ int launch_wgrad_small(WgradConvArgs a, float* dw, float* workspace, hipStream_t
     int rc = check_launch("conv_wgrad_small");
     if (rc || wgs == 1) return rc;
     const long numel = (long)a.Cout * 9 * CIN;
-    const long blocks = (numel / 4 + 255) / 256;
-    conv_wgrad_reduce_kernel<<<(int)(blocks > 1024 ? 1024 : blocks), 256, 0, s>>>(workspace, dw, wgs, numel);
+    const long blocks = (numel + 63) / 64;
+    conv_wgrad_reduce_kernel<<<(int)(blocks > 4096 ? 4096 : blocks), 256, 0, s>>>(workspace, dw, wgs, numel);
     return check_launch("conv_wgrad_reduce");
 }
 
 bool wgrad_small_ok(int Cin, int KH, int KW, int pad) { return (Cin == 16 || Cin == 32) && KH == 3 && KW == 3 && pad == 1; }
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient, second generation (Cin % 64 == 0, Cout % 64 == 0; 3x3 pad 1 or 1x1 pad 0; stride 1 / 2).
+//
+// A workgroup owns a 64 (co) x 64 (ci) block of dw for ALL taps and a run of "steps"; a step is R full
+// output rows of one image.  Per step it stages, by LDS-DMA and double-buffered, the dy tile
+// [R*OW pixels][64 co] and the input patch [(R-1)s+KS rows][(OW-1)s+KS columns][64 ci] (zeros outside the
+// image) ONCE, and each of the 4 waves accumulates its 32 x 32 quarter of the block for every tap from
+// that patch: per pair of pixels one A read (dy), NT B reads (x at the tap offsets), NT
+// v_mfma_f32_32x32x2_f32 on NT independent accumulators (9 x 16 registers, resident over the whole run).
+// The activations are read from L2 about once (rows shared by consecutive steps) instead of once per
+// tap.  Unpadded 256-byte pixel rows: the operand reads are 32 consecutive floats per half-wave
+// (conflict-free), so nothing needs a swizzle.  Partials [group][Cout][KK][Cin] are summed in group order
+// by conv_wgrad_reduce_kernel: deterministic, no atomics, nothing to zero.
+// ------------------------------------------------------------------------------------------
+struct Wgrad2Args {
+    const float* x;        // [N][H][W][Cin]
+    const float* dy;       // [N][OH][OW][Cout]
+    float* part;           // [groups][Cout][KK][Cin]
+    int N, H, W, Cin, OH, OW, Cout;
+    int R, P, Ppad;        // output rows per step, pixels per step (R * OW), rounded up to a multiple of 4
+    int XR, XC;            // patch rows / columns
+    int groups_per_img;    // ceil(OH / R)
+    int steps, per_group;  // total steps, steps per workgroup
+    int tiles_ci;
+    int dma_per_it;        // transfers a wave issues per pixel-pair iteration
+    unsigned inv_xc, inv_ow;   // ceil(2^32 / XC), ceil(2^32 / OW): exact quotients for the small indices used here
+};
+
+// 3x3: 8 waves = 4 quarters of the 64 x 64 block x 2 tap groups (taps 0-4 / 5-8), two waves per SIMD: while one
+// waits for its LDS operands or issues transfers, the other's MFMAs keep the pipe busy (with 4 waves of 9
+// accumulators each, one per SIMD, the pipe idled 40 % of the time).  1x1: 4 waves.
+template <int KS>
+struct Wg2 {
+    static constexpr int NT = KS * KS;
+    static constexpr int WAVES = KS == 3 ? 8 : 4;
+    static constexpr int NTL = KS == 3 ? 5 : 1;             // accumulators per wave
+};
+
+template <int KS, int STRIDE>
+__global__ __launch_bounds__(Wg2<KS>::WAVES * 64) void conv_wgrad2_kernel(Wgrad2Args a) {
+    constexpr int NT = Wg2<KS>::NT, PAD = KS / 2, WAVES = Wg2<KS>::WAVES, NTL = Wg2<KS>::NTL;
+    extern __shared__ __attribute__((aligned(1024))) float lds2[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int quarter = wave & 3, tg = wave >> 2;                  // tap group: taps tap0 .. tap0 + ntl - 1
+    const int wi = quarter & 1, wj = quarter >> 1;                 // this wave's co half / ci half of the block
+    const int tap0 = tg * NTL, ntl = NT - tap0 < NTL ? NT - tap0 : NTL;
+    const int tci = blockIdx.x % a.tiles_ci, tco = blockIdx.x / a.tiles_ci;
+    const int co0 = tco * 64, ci0 = tci * 64;
+    const int dy_rows = a.Ppad;                                    // pixel rows of the dy tile
+    const int x_rows = a.XR * a.XC;                                // pixel rows of the patch
+    const int dy_dma = (dy_rows + 3) >> 2, x_dma = (x_rows + 3) >> 2;   // 1 KB transfers (4 pixel rows each)
+    const int buf_floats = (dy_dma + x_dma) * 256;                  // every float of a buffer is written by each step's transfers
+    const unsigned lds0 = lds_addr_of(lds2);
+    const char* zeros = reinterpret_cast<const char*>(g_zeros);
+
+    const int s_begin = blockIdx.y * a.per_group;
+    const int s_end = s_begin + a.per_group < a.steps ? s_begin + a.per_group : a.steps;
+    const int sub = lane >> 4, q16 = lane & 15;                    // DMA: lane -> (pixel row 4 d + sub, 16-byte quad q16)
+
+    // transfers of one step, as slots d = 0 .. dy_dma + x_dma - 1 (1 KB each); wave w issues slots w, w + WAVES, ...
+    // The step's scalars are set by set_step(); issue_slot(d) is then one transfer.  The next step's slots are
+    // issued a few per pixel-pair iteration of the current step, behind its MFMAs.
+    const int n_slots = dy_dma + x_dma;
+    const char* dyb = nullptr;
+    const char* xb = nullptr;
+    int prem = 0, iy0 = 0;
+    unsigned ibase = 0;
+    auto set_step = [&](int step, int buf) {
+        const int n = step / a.groups_per_img, oy0 = (step - n * a.groups_per_img) * a.R;
+        ibase = lds0 + (unsigned)buf * buf_floats * 4;
+        dyb = reinterpret_cast<const char*>(a.dy + (((long)n * a.OH + oy0) * a.OW) * a.Cout + co0 + 4 * q16);
+        prem = (a.OH - oy0) * a.OW;                                // pixels of this image at or below row oy0
+        iy0 = oy0 * STRIDE - PAD;
+        xb = reinterpret_cast<const char*>(a.x + ((long)n * a.H * a.W) * a.Cin + ci0 + 4 * q16);
+    };
+    auto issue_slot = [&](int d) {
+        if (d < dy_dma) {                                           // wave-uniform
+            const int p = 4 * d + sub;
+            const bool ok = p < a.P && p < prem;
+            dma16_v(ok ? dyb + (long)p * a.Cout * 4 : zeros, ibase + d * 1024);
+        } else {
+            const int pp = 4 * (d - dy_dma) + sub;
+            const int pr = (int)(((unsigned long long)pp * a.inv_xc) >> 32), pc = pp - pr * a.XC;
+            const int iy = iy0 + pr, ix = pc - PAD;
+            const bool ok = pp < x_rows && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            dma16_v(ok ? xb + ((long)iy * a.W + ix) * a.Cin * 4 : zeros, ibase + d * 1024);
+        }
+    };
+
+    f32x16 acc[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    int tapoff[NTL];                                                // float offset of this wave's taps in the patch
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        const int tap = tap0 + (t < ntl ? t : ntl - 1);             // (an unused slot repeats the last tap: valid address)
+        tapoff[t] = ((tap / KS) * a.XC + (tap % KS)) * 64;
+    }
+
+    if (s_begin < s_end) {
+        set_step(s_begin, 0);
+#pragma unroll 1
+        for (int d = wave; d < n_slots; d += WAVES) issue_slot(d);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int wrap = (STRIDE * a.XC - a.OW * STRIDE) * 64;
+    const int n_it = a.Ppad >> 2;                                   // iterations of two pixel pairs
+#pragma unroll 1
+    for (int step = s_begin; step < s_end; ++step) {
+        const int buf = (step - s_begin) & 1;
+        const bool more = step + 1 < s_end;
+        if (more) set_step(step + 1, buf ^ 1);
+        int d_n = more ? wave : n_slots;
+        const float* D = lds2 + buf * buf_floats + 32 * wi + l31;
+        const float* X = lds2 + buf * buf_floats + dy_dma * 256 + 32 * wj + l31;
+        // this lane's pixel of the pair: q = 2 s + khalf -> (r, c); patch offset ((r s) XC + c s) * 64 floats
+        int c = khalf, q = khalf;                                   // q = khalf < OW (OW >= 2)
+        int xoff = c * STRIDE * 64;
+        // operands of two pixel pairs; padding pixels (q >= P: dy is zero there) read the patch origin
+        // instead of running past its end
+        auto load_pairs = [&](float (&av)[2], float (&bv)[2][NTL]) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                av[u] = D[q * 64];
+                const int xo = q < a.P ? xoff : 0;
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) bv[u][t] = X[xo + tapoff[t]];
+                q += 2; c += 2; xoff += 2 * STRIDE * 64;
+                if (c >= a.OW) { c -= a.OW; xoff += wrap; }
+            }
+        };
+        auto mfma_pairs = [&](const float (&av)[2], const float (&bv)[2][NTL]) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < NTL; ++t)
+                    if (t < NTL - 1 || ntl == NTL)                  // the last slot is idle in the 4-tap group (wave-uniform)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][t], acc[t], 0, 0, 0);
+        };
+        auto issue_some = [&]() {
+            if (d_n < n_slots) { issue_slot(d_n); d_n += WAVES; }
+            if (a.dma_per_it > 1 && d_n < n_slots) { issue_slot(d_n); d_n += WAVES; }
+        };
+        // register double buffer: the LDS reads of iteration i + 1 are in flight during the MFMAs of iteration i.
+        // Every load is unconditional (iterations past the end re-read valid LDS and are never multiplied), so
+        // the two register sets stay distinct and no copy or early wait separates a read from its use.
+        float av0[2], bv0[2][NTL], av1[2], bv1[2][NTL];
+        load_pairs(av0, bv0);
+#pragma unroll 1
+        for (int it = 0; it < n_it; it += 2) {
+            load_pairs(av1, bv1);
+            mfma_pairs(av0, bv0);
+            issue_some();
+            load_pairs(av0, bv0);
+            if (it + 1 < n_it) mfma_pairs(av1, bv1);
+            issue_some();
+        }
+#pragma unroll 1
+        for (; d_n < n_slots; d_n += WAVES) issue_slot(d_n);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    // D layout: lane holds column ci = l31, rows co = 8 gq + 4 khalf + e in acc[t][4 gq + e]
+    float* out = a.part + (size_t)blockIdx.y * a.Cout * NT * a.Cin;
+    const int ci = ci0 + 32 * wj + l31;
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+        if (t < ntl) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + 32 * wi + 8 * (e >> 2) + 4 * khalf + (e & 3);
+                out[((size_t)co * NT + tap0 + t) * a.Cin + ci] = acc[t][e];
+            }
+        }
+}
+
+bool wgrad2_ok(int Cin, int Cout, int KH, int KW, int pad, int stride, int OW) {
+    if (option(OPT_CONV_PATH) != 1) return false;
+    if (Cin % 64 != 0 || Cout % 64 != 0 || OW < 2) return false;
+    return (KH == 3 && KW == 3 && pad == 1) || (KH == 1 && KW == 1 && pad == 0);
+}
+
+// rows per step: the largest R (<= OH) whose double-buffered tiles fit the LDS budget
+struct Wgrad2Plan { int R, P, Ppad, XR, XC, gpi, steps, tiles, groups, per_group; size_t lds_bytes; };
+Wgrad2Plan wgrad2_plan(int N, int OH, int OW, int Cin, int Cout, int KS, int stride) {
+    Wgrad2Plan p;
+    p.XC = (OW - 1) * stride + KS;
+    auto bytes = [&](int R) {
+        const int P = R * OW, Ppad = (P + 3) & ~3, XR = (R - 1) * stride + KS;
+        const size_t buf = (size_t)(((Ppad + 3) / 4 + (XR * p.XC + 3) / 4) * 256);
+        return 2 * buf * sizeof(float);
+    };
+    int R = 1;
+    // prefer an R that divides OH (no half-empty last group); pixels per step capped at 128
+    for (int cand = 1; cand <= OH; ++cand)
+        if (OH % cand == 0 && cand * OW <= 128 && bytes(cand) <= 150 * 1024) R = cand;
+    p.R = R; p.P = R * OW; p.Ppad = (p.P + 3) & ~3; p.XR = (R - 1) * stride + KS;
+    p.lds_bytes = bytes(R);
+    p.gpi = (OH + R - 1) / R;
+    p.steps = N * p.gpi;
+    p.tiles = (Cout / 64) * (Cin / 64);
+    int groups = 256 / p.tiles;
+    if (groups < 1) groups = 1;
+    if (groups > p.steps) groups = p.steps;
+    p.per_group = (p.steps + groups - 1) / groups;
+    p.groups = (p.steps + p.per_group - 1) / p.per_group;
+    return p;
+}
+
+template <int KS, int STRIDE>
+int launch_wgrad2(const float* x, const float* dy, float* dw, float* workspace, int N, int H, int W, int Cin, int Cout,
+                  int OH, int OW, hipStream_t s) {
+    const Wgrad2Plan p = wgrad2_plan(N, OH, OW, Cin, Cout, KS, STRIDE);
+    if (p.lds_bytes > 160 * 1024) return fail(DMC_E_INVALID, "conv_wgrad2: row of %d pixels does not fit the LDS", OW);
+    Wgrad2Args a;
+    a.x = x; a.dy = dy; a.part = p.groups > 1 ? workspace : dw;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout;
+    a.R = p.R; a.P = p.P; a.Ppad = p.Ppad; a.XR = p.XR; a.XC = p.XC;
+    a.groups_per_img = p.gpi; a.steps = p.steps; a.per_group = p.per_group; a.tiles_ci = Cin / 64;
+    a.inv_xc = (unsigned)((0x100000000ull + p.XC - 1) / p.XC);
+    a.inv_ow = (unsigned)((0x100000000ull + OW - 1) / OW);
+    {
+        const int slots = ((p.Ppad + 3) / 4 + (p.XR * p.XC + 3) / 4 + Wg2<KS>::WAVES - 1) / Wg2<KS>::WAVES, its = p.Ppad / 4;
+        a.dma_per_it = (slots + its - 1) / its;
+    }
+    // more than 64 KB of dynamic LDS needs the attribute; set once per instantiation (thread-safe static)
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad2_kernel<KS, STRIDE>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return fail(DMC_E_LAUNCH, "conv_wgrad2: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
+    conv_wgrad2_kernel<KS, STRIDE><<<dim3(p.tiles, p.groups), Wg2<KS>::WAVES * 64, p.lds_bytes, s>>>(a);
+    int rc = check_launch("conv_wgrad2");
+    if (rc || p.groups == 1) return rc;
+    const long numel = (long)Cout * KS * KS * Cin;
+    const long blocks = (numel + 63) / 64;
+    conv_wgrad_reduce_kernel<<<(int)(blocks > 4096 ? 4096 : blocks), 256, 0, s>>>(workspace, dw, p.groups, numel);
+    return check_launch("conv_wgrad_reduce");
+}
 
 int wgrad_slices(long M, int tiles) {
     // enough workgroups to fill 256 CUs about three times over, slices of at least 1024 pixels
@@ -588,10 +1091,39 @@ bool shape_supported(const ConvShape& s) {
     return (long)s.N * s.H * s.W * (s.Cin > s.Cout ? s.Cin : s.Cout) < (1L << 31);
 }
 
-int block_pixels(int cout, long M) {
+// ---- tile selection ---------------------------------------------------------------------------
+// Second-generation kernel (Cin % 32 == 0, Cout % 32 == 0): 128 x 64 tiles while they still give every CU
+// several workgroups, 64 x 64 below that (the 14 x 14 and 7 x 7 layers: 736 workgroups of 64 x 64 balance
+// over 256 CUs where 184 of 128 x 128 cannot).
+bool use_v2(int cin, int cout) { return option(OPT_CONV_PATH) == 1 && cin % 32 == 0 && cout % 32 == 0; }
+
+// configuration of the second-generation kernel: 0 = 128 x 32, 1 = 128 x 64, 2 = 64 x 64, 3 = 256 x 64,
+// 4 = 128 x 128, 5 = 64 x 128 (pixels x channels)
+int v2_choice(int cout, long M) {
+    if (cout % 64 != 0) return 0;
+    const int cfg = option(OPT_CONV_CFG);                  // measurement switch: 0 = automatic
+    if (cfg >= 1 && cfg <= 3) return cfg;
+    if ((cfg == 4 || cfg == 5) && cout % 128 == 0) return cfg;
+    // the largest tile that still gives the 256 CUs at least ~2.5 workgroups each (measured, N = 120: layer1
+    // 256 x 64, layer2 and the stride-2 convolutions 128 x 128, layer3 128 x 64, layer4 64 x 64)
+    const long need = 640;
+    if (cout % 128 == 0 && ((M + 127) / 128) * (cout / 128) >= need) return 4;
+    if (((M + 255) / 256) * (cout / 64) >= need) return 3;
+    if (((M + 127) / 128) * (cout / 64) >= need) return 1;
+    return 2;
+}
+
+int block_pixels_v2(int cout, long M) {
+    const int c = v2_choice(cout, M);
+    return c == 3 ? 256 : (c == 2 || c == 5) ? 64 : 128;
+}
+
+int block_pixels_v1(int cout, long M) {
     if (cout >= 64) return M >= 32768 ? 128 : 64;
     return cout == 32 ? 128 : 256;
 }
+
+int block_pixels(int cin, int cout, long M) { return use_v2(cin, cout) ? block_pixels_v2(cout, M) : block_pixels_v1(cout, M); }
 
 template <int BM, int BN, int BK, int WM, int WN>
 int launch_cfg(const ConvArgs& a, hipStream_t s) {
@@ -600,10 +1132,28 @@ int launch_cfg(const ConvArgs& a, hipStream_t s) {
     return check_launch("conv_nhwc");
 }
 
-int launch_conv(const ConvArgs& a, hipStream_t s) {
+template <int BM, int BN, int WM, int WN>
+int launch_cfg2(const ConvArgs& a, hipStream_t s) {
+    dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN);
+    conv2_kernel<BM, BN, WM, WN><<<grid, C2_THREADS, 0, s>>>(a);
+    return check_launch("conv2");
+}
+
+int launch_conv(ConvArgs a, hipStream_t s) {
     if (a.M <= 0) return DMC_OK;
+    a.ablate = option(OPT_CONV_ABLATE);
+    if (use_v2(a.Cin, a.Cout)) {
+        switch (v2_choice(a.Cout, a.M)) {
+            case 0: return launch_cfg2<128, 32, 4, 1>(a, s);
+            case 1: return launch_cfg2<128, 64, 2, 2>(a, s);
+            case 3: return launch_cfg2<256, 64, 4, 1>(a, s);
+            case 4: return launch_cfg2<128, 128, 2, 2>(a, s);
+            case 5: return launch_cfg2<64, 128, 1, 4>(a, s);
+            default: return launch_cfg2<64, 64, 2, 2>(a, s);
+        }
+    }
     const bool k32 = a.Cin % 32 == 0;
-    const int bm = block_pixels(a.Cout, a.M);
+    const int bm = block_pixels_v1(a.Cout, a.M);
     if (a.Cout >= 64) {
         if (bm == 128) return k32 ? launch_cfg<128, 64, 32, 2, 2>(a, s) : launch_cfg<128, 64, 16, 2, 2>(a, s);
         return k32 ? launch_cfg<64, 64, 32, 2, 2>(a, s) : launch_cfg<64, 64, 16, 2, 2>(a, s);
@@ -622,10 +1172,10 @@ int dmc_conv_nhwc_supported(int N, int H, int W, int Cin, int Cout, int KH, int 
 }
 
 // number of [Cout][2] double partial rows the forward writes when asked for statistics
-int dmc_conv_nhwc_stat_blocks(int N, int H, int W, int Cout, int KH, int stride, int pad) {
+int dmc_conv_nhwc_stat_blocks(int N, int H, int W, int Cin, int Cout, int KH, int stride, int pad) {
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
     const long M = (long)N * OH * OW;
-    const int bm = block_pixels(Cout, M);
+    const int bm = block_pixels(Cin, Cout, M);
     return (int)((M + bm - 1) / bm);
 }
 
@@ -709,6 +1259,10 @@ int dmc_conv_nhwc_stats_final(const double* partials, int nblk, int C, long coun
 size_t dmc_conv_nhwc_wgrad_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     if (wgrad_small_ok(Cin, KH, KW, pad)) return (size_t)512 * Cout * 9 * Cin * sizeof(float) + 16;
+    if (wgrad2_ok(Cin, Cout, KH, KW, pad, stride, OW)) {
+        const Wgrad2Plan p = wgrad2_plan(N, OH, OW, Cin, Cout, KH, stride);
+        return (size_t)(p.groups > 1 ? p.groups : 0) * Cout * KH * KW * Cin * sizeof(float) + 16;
+    }
     const int tiles = ((Cout + WG_T - 1) / WG_T) * ((Cin + WG_T - 1) / WG_T) * KH * KW;
     const int ns = wgrad_slices((long)N * OH * OW, tiles);
     return (size_t)(ns > 1 ? ns : 0) * Cout * KH * KW * Cin * sizeof(float) + 16;
@@ -732,6 +1286,12 @@ int dmc_conv_nhwc_wgrad(const float* x, const float* dy, float* dw, float* works
         if (stride == 1) return Cout % 32 == 0 ? launch_wgrad_small<32, 32, 1>(a, dw, workspace, s) : launch_wgrad_small<32, 16, 1>(a, dw, workspace, s);
         return Cout % 32 == 0 ? launch_wgrad_small<32, 32, 2>(a, dw, workspace, s) : launch_wgrad_small<32, 16, 2>(a, dw, workspace, s);
     }
+    if (wgrad2_ok(Cin, Cout, KH, KW, pad, stride, a.OW)) {
+        if (KH == 3) return stride == 1 ? launch_wgrad2<3, 1>(x, dy, dw, workspace, N, H, W, Cin, Cout, a.OH, a.OW, s)
+                                        : launch_wgrad2<3, 2>(x, dy, dw, workspace, N, H, W, Cin, Cout, a.OH, a.OW, s);
+        return stride == 1 ? launch_wgrad2<1, 1>(x, dy, dw, workspace, N, H, W, Cin, Cout, a.OH, a.OW, s)
+                           : launch_wgrad2<1, 2>(x, dy, dw, workspace, N, H, W, Cin, Cout, a.OH, a.OW, s);
+    }
     a.tiles_ci = (Cin + WG_T - 1) / WG_T; a.tiles_co = (Cout + WG_T - 1) / WG_T;
     const int tiles = a.tiles_ci * a.tiles_co * KH * KW;
     const int ns = wgrad_slices(a.M, tiles);
@@ -741,8 +1301,8 @@ int dmc_conv_nhwc_wgrad(const float* x, const float* dy, float* dw, float* works
     int rc = check_launch("conv_wgrad");
     if (rc || ns == 1) return rc;
     const long numel = (long)Cout * KH * KW * Cin;
-    const long blocks = (numel / 4 + 255) / 256;
-    conv_wgrad_reduce_kernel<<<(int)(blocks > 1024 ? 1024 : blocks), 256, 0, s>>>(workspace, dw, ns, numel);
+    const long blocks = (numel + 63) / 64;
+    conv_wgrad_reduce_kernel<<<(int)(blocks > 4096 ? 4096 : blocks), 256, 0, s>>>(workspace, dw, ns, numel);
     return check_launch("conv_wgrad_reduce");
 }
 

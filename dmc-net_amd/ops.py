@@ -510,7 +510,7 @@ def _conv_fwd(x, weight, bias, keep, stride, padding, act, want_stats):
     y = torch.empty((n, cout, oh, ow), dtype=torch.float32, device=x.device, memory_format=_CL)
     part, nblk = None, 0
     if want_stats:
-        nblk = lib.dmc_conv_nhwc_stat_blocks(n, h, w, cout, kh, stride, padding)
+        nblk = lib.dmc_conv_nhwc_stat_blocks(n, h, w, cin, cout, kh, stride, padding)
         part = torch.empty((nblk, cout, 2), dtype=torch.float64, device=x.device)
     _lib.check(lib.dmc_conv_nhwc_fwd(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(keep), _lib.ptr(y),
                                      _lib.ptr(part), n, h, w, cin, cout, kh, kw, stride, padding, int(act),
@@ -581,6 +581,99 @@ class _ConvNHWC(torch.autograd.Function):
 def conv_nhwc(x, weight, stride=1, padding=1):
     """conv2d(x, weight, None, stride, padding) for a channels_last ``x`` (see conv_nhwc_supported)."""
     return _ConvNHWC.apply(x, weight, int(stride), int(padding))
+
+
+class _ConvBnAct(torch.autograd.Function):
+    """relu?(BatchNorm2d(conv2d(x, w)) [+ residual]) in training mode: the ResNet's conv -> bn [-> add] [-> relu]
+    chains (torchvision BasicBlock / Bottleneck / downsample behind code/dmcnet/model.py:305,352) on the
+    matrix-core NHWC kernels.  The convolution's epilogue reduces the batch statistics (no separate pass
+    over its output), one streaming pass normalises / adds / rectifies; the backward runs the BatchNorm
+    backward (two passes) and feeds the data- and weight-gradient kernels (deterministic)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, residual, gamma, beta, running_mean, running_var, stride, padding, relu, eps,
+                momentum):
+        lib = _lib.load()
+        _need_cuda(x, weight, residual, gamma, beta)
+        x, wcl = _as_cl(x), _as_cl(weight)
+        cout = weight.shape[0]
+        with _span("conv_nhwc_fwd"):
+            y, part, nblk = _conv_fwd(x, wcl, None, None, stride, padding, 0, True)
+        n, _, oh, ow = y.shape
+        m = n * oh * ow
+        stats = _floats(lib.dmc_bn_act_stats_bytes(cout), x.device)
+        out = torch.empty_like(y)
+        mask = None
+        if relu and residual is not None:
+            residual = _as_cl(residual)
+            mask = torch.empty(m * (cout // 4), dtype=torch.uint8, device=x.device)
+        with _span("bn_apply_fwd"):
+            _lib.check(lib.dmc_conv_nhwc_stats_final(_lib.ptr(part), nblk, cout, m, _lib.ptr(stats),
+                                                     _lib.ptr(running_mean), _lib.ptr(running_var), float(eps),
+                                                     float(momentum), _stream()), "dmc_conv_nhwc_stats_final")
+            _lib.check(lib.dmc_bn_apply_act_nhwc(_lib.ptr(y), _lib.ptr(residual), _lib.ptr(gamma), _lib.ptr(beta),
+                                                 _lib.ptr(stats), _lib.ptr(out), _lib.ptr(mask), m, cout, int(relu),
+                                                 _stream()), "dmc_bn_apply_act_nhwc")
+        ctx.save_for_backward(x, weight, y, gamma, beta, stats, mask)
+        ctx.cfg = (int(stride), int(padding), bool(relu), residual is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, weight, y, gamma, beta, stats, mask = ctx.saved_tensors
+        stride, padding, relu, has_res = ctx.cfg
+        n, cout, oh, ow = y.shape
+        dout = _as_cl(dout)
+        dy = torch.empty_like(y)
+        want_dres = has_res and ctx.needs_input_grad[2]
+        dres = torch.empty_like(y) if (want_dres and relu) else None
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        scratch = _floats(lib.dmc_bn_act_scratch_bytes(cout), y.device)
+        with _span("bn_act_bwd"):
+            _lib.check(lib.dmc_bn_act_bwd(_lib.ptr(y), None, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(stats),
+                                          _lib.ptr(scratch), _lib.ptr(dout), _lib.ptr(dy), _lib.ptr(dres),
+                                          _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(mask), n * oh * ow, cout,
+                                          int(relu), _stream()), "dmc_bn_act_bwd")
+        if want_dres and not relu:
+            dres = dout
+        wcl = _as_cl(weight)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            with _span("conv_nhwc_dgrad"):
+                dx = _conv_dgrad(dy, wcl, x.shape, stride, padding)
+        if ctx.needs_input_grad[1]:
+            with _span("conv_nhwc_wgrad"):
+                dw = _grad_like(_conv_wgrad(x, dy, wcl, stride, padding), weight)
+        return dx, dw, dres, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+def conv_bn_act_supported(x, conv, bn):
+    """True if conv -> bn [-> add] [-> relu] can run as the fused NHWC training op."""
+    if not (torch.is_grad_enabled() and bn.training and bn.track_running_stats and bn.affine):
+        return False
+    if conv.bias is not None or conv.dilation != (1, 1) or conv.groups != 1 or conv.padding_mode != "zeros":
+        return False
+    if conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1]:
+        return False
+    if not _is_cl(x) or not conv_nhwc_supported(x, conv.weight, conv.stride[0], conv.padding[0]):
+        return False
+    n, _, h, w = x.shape
+    k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+    oh, ow = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    return bool(_lib.load().dmc_bn_act_supported(n * oh * ow, conv.out_channels))
+
+
+def conv_bn_act(x, conv, bn, residual=None, relu=True):
+    """relu?(bn(conv(x)) [+ residual]) for a channels_last ``x`` (see conv_bn_act_supported)."""
+    if bn.num_batches_tracked is not None:
+        if _PENDING_COUNTERS is not None:
+            _PENDING_COUNTERS.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked.add_(1)
+    return _ConvBnAct.apply(x, conv.weight, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                            conv.stride[0], conv.padding[0], relu, bn.eps,
+                            bn.momentum if bn.momentum is not None else 0.1)
 
 
 class _DiscBlock(torch.autograd.Function):

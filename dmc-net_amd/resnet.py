@@ -2,8 +2,10 @@
 
 The reference takes them from torchvision (``getattr(torchvision.models, base_model)``,
 code/dmcnet/model.py:305), which is not available here; the published architecture is restated
-with the same attribute names, so ``base_model.*`` state-dict keys match torchvision's.  The
-convolutions run on PyTorch-ROCm (MIOpen); BASELINE.json config 2 scopes them that way.
+with the same attribute names, so ``base_model.*`` state-dict keys match torchvision's.  The 3x3 /
+1x1 convolutions run on PyTorch-ROCm (MIOpen) by default, or, with ``OWN_CONV``, together with their
+BatchNorms on this package's NHWC matrix-core kernels (ops.conv_bn_act); BatchNorm / ReLU / add, the
+stem tail and the stem's weight gradient are HIP kernels either way.
 """
 import torch
 from torch import nn
@@ -21,6 +23,21 @@ def _bn_act(bn, x, residual=None, relu=True):
     if residual is not None:
         y = y + residual
     return torch.relu(y) if relu else y
+
+# True: the 3x3 / 1x1 convolutions run on this package's matrix-core NHWC kernels (fused conv -> bn op,
+# deterministic, no MIOpen) whenever the activation qualifies.  Default False = PyTorch-ROCm (MIOpen), which
+# BASELINE config 2 allows and which is still the faster of the two on MI355X (round 2, N = 120: 16.4 vs
+# 19.1 ms per step; per-layer table in DESIGN.md).  bench.py --own-conv 1 / DMC_OWN_CONV=1 switch it on.
+import os as _os
+OWN_CONV = _os.environ.get("DMC_OWN_CONV", "0") == "1"
+
+
+def _conv_bn_act(conv, bn, x, residual=None, relu=True):
+    """relu?(bn(conv(x)) [+ residual])"""
+    if OWN_CONV and x.is_cuda and ops.conv_bn_act_supported(x, conv, bn):
+        return ops.conv_bn_act(x, conv, bn, residual, relu)
+    return _bn_act(bn, conv(x), residual, relu)
+
 
 _CFG = {
     "resnet18": ("basic", (2, 2, 2, 2)),
@@ -59,12 +76,12 @@ class ResidualUnit(nn.Module):
         if self.downsample is None:
             shortcut = x
         else:
-            shortcut = _bn_act(self.downsample[1], self.downsample[0](x), relu=False)
-        y = _bn_act(self.bn1, self.conv1(x))
+            shortcut = _conv_bn_act(self.downsample[0], self.downsample[1], x, relu=False)
+        y = _conv_bn_act(self.conv1, self.bn1, x)
         if self.kind == "basic":
-            return _bn_act(self.bn2, self.conv2(y), residual=shortcut)
-        y = _bn_act(self.bn2, self.conv2(y))
-        return _bn_act(self.bn3, self.conv3(y), residual=shortcut)
+            return _conv_bn_act(self.conv2, self.bn2, y, residual=shortcut)
+        y = _conv_bn_act(self.conv2, self.bn2, y)
+        return _conv_bn_act(self.conv3, self.bn3, y, residual=shortcut)
 
 
 class ResNet(nn.Module):

@@ -189,6 +189,11 @@ int dmc_bn_act_bwd(const float* x, const float* residual, const float* gamma, co
  */
 int dmc_bn_apply_nhwc(const float* x, const float* gamma, const float* beta, const float* stats, float* y,
                       int M, int C, dmc_stream_t stream);
+/* the same apply pass with the residual add / ReLU / ReLU sign mask of dmc_bn_act_fwd: the second half of
+ * torchvision's `relu(bn(conv(x)) [+ identity])` when the convolution's epilogue reduced the statistics */
+int dmc_bn_apply_act_nhwc(const float* x, const float* residual, const float* gamma, const float* beta,
+                          const float* stats, float* y, unsigned char* relu_mask, int M, int C, int relu,
+                          dmc_stream_t stream);
 int dmc_bn_bwd_act_nhwc(const float* z, const float* gamma, const float* beta, const float* stats, void* scratch,
                         const float* dy, float* dpre, float* dgamma, float* dbeta, const float* keep, int hw,
                         float slope, int M, int C, dmc_stream_t stream);
@@ -270,7 +275,7 @@ int dmc_bn_relu_pool_bwd(const float* x, const float* gamma, const float* beta, 
  * workspace of dmc_conv_nhwc_wgrad_bytes().
  */
 int dmc_conv_nhwc_supported(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
-int dmc_conv_nhwc_stat_blocks(int N, int H, int W, int Cout, int KH, int stride, int pad);
+int dmc_conv_nhwc_stat_blocks(int N, int H, int W, int Cin, int Cout, int KH, int stride, int pad);
 int dmc_conv_nhwc_fwd(const float* x, const float* w, const float* bias, const float* keep, float* y,
                       double* stat_partials, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                       int pad, int act, dmc_stream_t stream);

@@ -320,10 +320,14 @@ def _watch(model, keys):
     return {k: (sd[k] if sd[k].numel() <= 4096 else sd[k].reshape(-1)[:4096]) for k in keys}
 
 
+@pytest.mark.parametrize("own_conv", [False, True])
 @pytest.mark.parametrize("tag,freeze", [("dmcnet", False), ("dmcnet_frozen", True)])
-def test_dmcnet_train_step_vs_reference_golden(golden, tag, freeze):
+def test_dmcnet_train_step_vs_reference_golden(golden, tag, freeze, own_conv, monkeypatch):
     """One iteration of the reference's own train() (golden G4) reproduced by the HIP path:
-    losses / consensus logits within 1e-4 relative, post-step weights close."""
+    losses / consensus logits within 1e-4 relative, post-step weights close.  own_conv: the classifier's
+    3x3 / 1x1 convolutions on this package's matrix-core kernels (fused conv -> bn op) instead of MIOpen."""
+    from dmcnet_amd import resnet
+    monkeypatch.setattr(resnet, "OWN_CONV", own_conv)
     g = golden("g4_train_steps")
     _, m = _product(False, 41)
     m.train()
@@ -794,6 +798,11 @@ CONV_CASES = [  # (N, Cin, H, W, Cout, k, stride)
     (3, 32, 56, 56, 32, 3, 1),
     (1, 32, 13, 11, 64, 3, 2),       # ragged: odd sizes, tiles ending inside the image
     (3, 48, 9, 7, 80, 3, 1),         # channel counts that are multiples of 16 only
+    (3, 64, 28, 28, 64, 3, 1),       # discriminator 3_2 / 3_3
+    (2, 128, 28, 28, 256, 1, 2),     # layer3.0.downsample
+    (3, 64, 13, 9, 128, 3, 2),       # second-generation kernels on ragged sizes (odd rows / columns, partial tiles)
+    (2, 64, 5, 3, 64, 3, 1),
+    (1, 128, 6, 2, 64, 1, 1),
 ]
 
 

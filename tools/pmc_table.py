@@ -10,6 +10,7 @@ for r in csv.DictReader(open(sys.argv[1])):
         continue
     agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 names = sorted({c for v in agg.values() for c in v})
-print("kernel," + ",".join(names))
+out = csv.writer(sys.stdout)
+out.writerow(["kernel"] + names)
 for k in sorted(agg):
-    print(k + "," + ",".join("%.4g" % (sum(agg[k][c]) / max(1, len(agg[k][c]))) for c in names))
+    out.writerow([k] + ["%.4g" % (sum(agg[k][c]) / max(1, len(agg[k][c]))) for c in names])
