@@ -140,52 +140,61 @@ def bench_prepare(dev, n_frames, flow_ds_factor, iters=20):
 def bench_i3d(args, rank, world, dev):
     """BASELINE config 5: I3D over the per-frame DMC generator; micro-batch of 3 clips x T frames,
     trunk under bf16 autocast, generator fp32; D and G phases alternate (iter_size 1)."""
-    from dmcnet_amd import ddp, i3d, ops
+    from dmcnet_amd import i3d, i3d_train, ops
     torch.manual_seed(0)
     b = 3 if args.batch == 40 else args.batch
     net = i3d.I3D(args.num_class, modality="flow+mp4", dropout_prob=0.85, arch_estimator="DenseNetTiny",
                   arch_d="Discriminator").to(dev).train()
     net.trunk_dtype = torch.bfloat16
-    stepper = i3d.I3DTrainStep(net, iter_size=1)
+    # the shipped recipe's optimizers / schedulers / two-stage policy; iter_size 1: every micro-step steps
+    # (and, with --gpus N, exchanges the stepping optimizers' gradients) -- the recipe's 32 would amortise both
+    trainer = i3d_train.recipe_trainer(net, batch_size=b, world_size=world, iter_size=1)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     data = torch.randn((b, 7, args.clip_length, 224, 224), generator=g, device=dev)
     target = torch.randint(0, args.num_class, (b,), generator=g, device=dev)
-    reducer = ddp.GradBucketReducer(list(net.parameters())) if world > 1 else None
+    counter = [0]
 
     def one():
-        if reducer is not None:
-            reducer.begin()
-        out = stepper.step(data, target)
-        if reducer is not None:
-            reducer.finish()
-        return out
+        out = trainer.step(data, target, 0, counter[0])
+        counter[0] += 1
+        return out[0], out[1], out[2]
 
-    if reducer is not None:
-        raise SystemExit("i3d config: gradient exchange must sit between backward and step; "
-                         "multi-GPU I3D is not wired this round")
     for _ in range(args.warmup):
         one()
-    probe = ops.EventProbe()
+    probe = ops.EventProbe(None if args.all_spans else ("gen_tiny_fwd", "gen_tiny_bwd"))
     ops.PROBE = probe
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         _, losses, _ = one()
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax)
     ops.PROBE = None
     spans = probe.summary()
+    if rank != 0:
+        dist.destroy_process_group()
+        return
     px = b * args.clip_length * 224 * 224
     fwd_ms = spans["gen_tiny_fwd"][0]
     tf = px * GEN_FLOP_PER_PX / (fwd_ms * 1e-3) / 1e12
     print(json.dumps({
         "metric": "clips/sec (%d-frame 224x224 clips) dmcnet_I3D train micro-step" % args.clip_length,
-        "value": round(b * args.steps / elapsed, 3), "unit": "clips/sec", "n_gpus": 1,
+        "value": round(world * b * args.steps / elapsed, 3), "unit": "clips/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 trunk / f32 generator",
         "data": "synthetic",
         "config": {"workload": "dmcnet_I3D HMDB-51, DenseNetTiny generator per frame + I3D trunk + Discriminator, "
-                               "micro-batch %d clips x %d frames, alternating D/G phases" % (b, args.clip_length),
+                               "micro-batch %d clips x %d frames per GPU, alternating D/G phases, the reference's 5-optimizer two-stage "
+                               "policy (stage 1), iter_size 1" % (b, args.clip_length),
+                   "global_batch": world * b, "parallelism": "dp%d" % world,
                    "final_losses": [round(float(l), 5) for l in losses]},
         "roofline": {"kernel": "dmc_gen_tiny_fwd (%d frames)" % (b * args.clip_length), "bound": "mfma",
                      "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -207,6 +216,9 @@ def main():
                     help="1 (default) = cudnn.benchmark as the reference's train.py:118 sets it: MIOpen "
                          "picks solvers by search, answered from the find-db shipped in "
                          "dmc-net_amd/miopen_db; 0 = MIOpen's heuristic picks")
+    ap.add_argument("--all-spans", action="store_true",
+                    help="HIP-event spans around every C-ABI call (kernels_ms lists them all); default: the "
+                         "generator forward / backward only, which the roofline object needs")
     ap.add_argument("--own-conv", type=int, default=0,
                     help="1 = the classifier's 3x3 / 1x1 convolutions on this package's matrix-core NHWC kernels "
                          "(fused conv -> bn op); 0 (default) = PyTorch-ROCm (MIOpen) convolutions, the faster of "
@@ -260,7 +272,7 @@ def main():
 
     for i in range(args.warmup):
         one(i)
-    probe = ops.EventProbe()
+    probe = ops.EventProbe(None if args.all_spans else ("gen_tiny_fwd", "gen_tiny_bwd"))
     ops.PROBE = probe
     if world > 1:
         dist.barrier()

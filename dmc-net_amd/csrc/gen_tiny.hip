@@ -508,6 +508,7 @@ __device__ __forceinline__ void dma_row16_s(unsigned long long sbase, unsigned v
 struct RingArgs {
     LayerArgs a;
     int tiles_y, ntiles;                              // row bands per frame, tiles in this launch
+    int ablate;                                       // measurement only (option gen_ablate): 1 = no transfers, 2 = no epilogue stores
 };
 
 // producer: stage chunk c of tile (n, ty0) -- 4 channels x 10 rows, one 1 KB row per instruction.
@@ -654,9 +655,9 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_layer_mfma_kernel(RingArgs ra
 #pragma unroll 1
         for (int q = 0; q < nitems; ++q) {
             // chunk q has landed (only chunk q+1 may still be in flight); consumers are done with q-1
-            if (q + 1 < nitems) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(G::DMA) : "memory");
+            if (q + 1 < nitems && !(ra.ablate & 1)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(G::DMA) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            if (q + 2 < nitems) {
+            if (q + 2 < nitems && !(ra.ablate & 1)) {
                 const int c2 = c + 2, tile2 = tile + (c2 / NCHUNK) * t_step, n2 = tile2 / ra.tiles_y;
                 int slot2 = slot + 2; slot2 = slot2 >= RING ? slot2 - RING : slot2;
                 ring_stage<MODE, K>(a, lds0 + (unsigned)slot2 * (P_BUF * 4), n2, (tile2 - n2 * ra.tiles_y) * PT_H,
@@ -754,7 +755,7 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_layer_mfma_kernel(RingArgs ra
                     v[e] *= ex[e] > 0.f ? 1.f : 0.1f;
                 }
             }
-            if (inside) {
+            if (inside && !(ra.ablate & 2)) {
                 const float4 o = make_float4(v[0], v[1], v[2], v[3]);
                 if (MODE == 0) *reinterpret_cast<float4*>(a.feat_out + ((size_t)n * NFEAT + (yoff(K) - NIN) + co) * HW + pix) = o;
                 else if (MODE == 1) *reinterpret_cast<float4*>(a.out + ((size_t)n * 2 + co) * HW + pix) = o;
@@ -1818,6 +1819,7 @@ int launch_layer(LayerArgs a, int n0, int N, hipStream_t s) {
     const int gpath = option(OPT_GEN_GATHER);
     if (GATHER_FORM && gpath == 1 && path == 1 && a.W % 4 == 0 && a.W <= P_MAXW) {
         RingArgs ra;
+        ra.ablate = 0;
         ra.a = a;
         ra.tiles_y = (a.H + GT_H - 1) / GT_H;
         ra.ntiles = ra.tiles_y * N;
@@ -1825,9 +1827,11 @@ int launch_layer(LayerArgs a, int n0, int N, hipStream_t s) {
         if constexpr (GATHER_FORM) gen_layer_gather_kernel<MODE, K><<<wgs, G_THREADS, 0, s>>>(ra);
     } else if (path == 1 && a.W % 4 == 0 && a.W <= P_MAXW) {
         RingArgs ra;
+        ra.ablate = 0;
         ra.a = a;
         ra.tiles_y = (a.H + PT_H - 1) / PT_H;
         ra.ntiles = ra.tiles_y * N;
+        ra.ablate = option(OPT_GEN_ABLATE);
         const int wgs = ra.ntiles < num_cus() ? ra.ntiles : num_cus();
         gen_layer_mfma_kernel<MODE, K><<<wgs, LTHREADS, 0, s>>>(ra);
     }
@@ -1884,6 +1888,7 @@ int dmc_gen_tiny_fwd(const float* mv, const float* res, const float* const* w,
         const int fuse45 = option(OPT_GEN_FUSE45), lpath = option(OPT_GEN_LAYER_PATH);
         if (fuse45 && lpath == 1 && W % 4 == 0 && W <= P_MAXW) {
             RingArgs ra;
+            ra.ablate = 0;
             ra.a = a;
             const size_t HWf = (size_t)H * W;
             ra.a.mv = mv + (size_t)n0 * 2 * HWf; ra.a.res = res + (size_t)n0 * 3 * HWf;

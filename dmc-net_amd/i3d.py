@@ -187,62 +187,3 @@ def i3d_losses(net, data, target, stage=None, detach=False):
                           data[:, 5:7].transpose(1, 2).reshape(-1, 2, h, w)), 0)
         losses.append(F.cross_entropy(net(d_in, node="D"), torch.cat((fake, valid), 0)))
     return output, losses
-
-
-class I3DTrainStep(object):
-    """Micro-batch accumulation of ``model.fit`` (code/dmcnet_I3D/train/model.py:354-491):
-    ``iter_size`` D-phase micro-batches (loss_cls + adv*loss_adv; trunk + discriminator step) then
-    ``iter_size`` G-phase micro-batches (loss_cls + mse + adv*loss_adv; generator step), gradients
-    divided by ``iter_size`` before each step.  Optimisers: Adam over the trunk, Adam(eps=1e-3)
-    over the discriminator and the generator (code/dmcnet_I3D/train_model.py:122-168)."""
-
-    def __init__(self, net, lr_base=4e-4, lr_d=2e-3, weight_decay=1e-4, adv=1.0, iter_size=1,
-                 detach=True):
-        self.net, self.adv, self.iter_size, self.detach = net, adv, iter_size, detach
-        trunk = [p for k, p in net.named_parameters()
-                 if not k.startswith("gen_flow_model") and not k.startswith("discriminator")]
-        self.optimizer = torch.optim.Adam(trunk, lr=lr_base, weight_decay=weight_decay)
-        self.optimizer_mse = torch.optim.Adam(net.gen_flow_model.parameters(), lr=lr_base,
-                                              weight_decay=weight_decay, eps=1e-3)
-        self.optimizer_d = None
-        if getattr(net, "arch_d", None) is not None and adv > 0:
-            self.optimizer_d = torch.optim.Adam(net.discriminator.parameters(), lr=lr_d,
-                                                weight_decay=weight_decay, eps=1e-3)
-        self.i_batch = 0
-        for o in (self.optimizer, self.optimizer_mse, self.optimizer_d):
-            if o is not None:
-                o.zero_grad(set_to_none=True)
-
-    def _finish(self, opts):
-        for o in opts:
-            if self.iter_size != 1:
-                for g in o.param_groups:
-                    for p in g["params"]:
-                        if p.grad is not None:
-                            p.grad /= self.iter_size
-            o.step()
-            o.zero_grad(set_to_none=True)
-
-    def step(self, data, target):
-        """One micro-batch; returns (logits, losses, phase)."""
-        gan = self.optimizer_d is not None
-        d_phase = gan and (self.i_batch % (2 * self.iter_size)) < self.iter_size
-        out, losses = i3d_losses(self.net, data, target, stage="D" if gan else None,
-                                 detach=self.detach)
-        if d_phase:
-            (losses[0] + self.adv * losses[2]).backward()
-        elif gan:
-            (losses[0] + losses[1] + self.adv * losses[2]).backward()
-        else:
-            (losses[0] + losses[1]).backward()
-        self.i_batch += 1
-        if self.i_batch % self.iter_size == 0:
-            if d_phase:
-                self._finish([self.optimizer, self.optimizer_d])
-                self.optimizer_mse.zero_grad(set_to_none=True)
-            else:
-                self._finish(([] if gan else [self.optimizer]) + [self.optimizer_mse])
-                self.optimizer.zero_grad(set_to_none=True)
-                if gan:
-                    self.optimizer_d.zero_grad(set_to_none=True)
-        return out.detach(), [l.detach() for l in losses], ("D" if d_phase else "G")

@@ -1,0 +1,272 @@
+"""Trainer policy of the I3D variant (BASELINE config 5): optimizer set, step-count LR schedule,
+two-stage switch, D / G alternation with gradient accumulation, and the data-parallel gradient exchange.
+
+Restates, with citations, what code/dmcnet_I3D/train_model.py:68-179,219-238 builds and what
+``model.fit`` (code/dmcnet_I3D/train/model.py:286-491) does per micro-batch; pinned bit-for-bit on the
+CPU by tests/golden/g10_i3d_trainer.npz, which the reference's own ``fit`` loop produced
+(tests/golden/make_golden_i3d.py).  Quirks are kept, not fixed -- they are listed where they occur.
+"""
+import torch
+import torch.distributed as dist
+
+from .i3d import i3d_losses
+
+
+class MultiFactorScheduler(object):
+    """Step-count LR schedule (code/dmcnet_I3D/train/lr_scheduler.py:22-61): ``lr *= factor`` each
+    time the step counter passes an entry of ``steps``; the first 99 updates return HALF the current
+    lr (warm-up, :59-60)."""
+
+    def __init__(self, steps, base_lr=0.01, factor=0.1, step_counter=0):
+        steps = list(steps)
+        if not steps:
+            raise ValueError("steps must be a non-empty increasing list")
+        for i, s in enumerate(steps):
+            if i != 0 and steps[i] <= steps[i - 1]:
+                raise ValueError("Schedule step must be an increasing integer list")
+            if s < 1:
+                raise ValueError("Schedule step must be greater or equal than 1 round")
+        if factor > 1.0:
+            raise ValueError("Factor must be no more than 1 to make lr reduce")
+        self.steps, self.factor = steps, factor
+        self.step_counter, self.base_lr = step_counter, base_lr
+        self.lr, self.cursor = base_lr, 0
+
+    def get_lr(self):
+        return self.lr
+
+    def update(self):
+        self.step_counter += 1
+        if self.cursor >= len(self.steps):
+            return self.lr
+        while self.steps[self.cursor] < self.step_counter:
+            self.lr *= self.factor
+            self.cursor += 1
+            if self.cursor >= len(self.steps):
+                return self.lr
+        if self.step_counter < 100:
+            return self.lr / 2.0
+        return self.lr
+
+
+def split_parameters(net, modality="flow+mp4", fine_tune=False):
+    """(base, new, generator, discriminator, lr_mul) by name prefix, code/dmcnet_I3D/train_model.py:68-106:
+    'flow+mp4': ``gen_flow_model*`` / ``discriminator*`` get their own optimizers, ``conv3d_0c_1x1*`` and
+    ``classifier*`` are the new layers (lr_mult 1), the rest of the trunk is base (lr_mult 0.5, or 0.2
+    when fine-tuning); other modalities: everything new unless fine-tuning."""
+    base, new, gf, d = [], [], [], []
+    for name, p in net.named_parameters():
+        head = name.startswith("conv3d_0c_1x1") or name.startswith("classifier")
+        if modality == "flow+mp4":
+            if name.startswith("gen_flow_model"):
+                gf.append(p)
+            elif name.startswith("discriminator"):
+                d.append(p)
+            elif head:
+                new.append(p)
+            else:
+                base.append(p)
+        elif fine_tune:
+            (new if head else base).append(p)
+        else:
+            new.append(p)
+    lr_mul = (0.2 if fine_tune else 0.5) if modality == "flow+mp4" else 0.2
+    return base, new, gf, d, lr_mul
+
+
+def make_optimizers(net, lr_base, lr_base2, optim="adam", adv=1.0, modality="flow+mp4", fine_tune=False,
+                    weight_decay=1e-4):
+    """The five optimizers of code/dmcnet_I3D/train_model.py:122-179 as a dict:
+    ``optimizer`` / ``optimizer_2`` (trunk, stage 1 / stage 2; groups base lr_mult, new 1.0),
+    ``optimizer_3`` (discriminator, Adam eps 1e-3, when adv > 0), ``optimizer_mse`` (generator, stage 1:
+    Adam eps 1e-8) / ``optimizer_mse_2`` (stage 2: Adam eps 1e-3) for 'flow+mp4'."""
+    base, new, gf, d, lr_mul = split_parameters(net, modality, fine_tune)
+
+    def trunk(lr):
+        groups = [{"params": base, "lr_mult": lr_mul}, {"params": new, "lr_mult": 1.0}]
+        if optim == "adam":
+            return torch.optim.Adam(groups, lr=lr, weight_decay=weight_decay)
+        return torch.optim.SGD(groups, lr=lr, momentum=0.9, weight_decay=weight_decay, nesterov=True)
+
+    def gen(lr, eps):
+        if optim == "adam":
+            return torch.optim.Adam(gf, lr=lr, weight_decay=weight_decay, eps=eps)
+        return torch.optim.SGD(gf, lr=lr, momentum=0.9, weight_decay=weight_decay, nesterov=True)
+
+    out = {"optimizer": trunk(lr_base), "optimizer_2": trunk(lr_base2), "optimizer_3": None,
+           "optimizer_mse": None, "optimizer_mse_2": None}
+    if adv > 0.0:
+        out["optimizer_3"] = torch.optim.Adam(d, lr=lr_base, weight_decay=weight_decay, eps=0.001)
+    if modality == "flow+mp4":
+        out["optimizer_mse"] = gen(lr_base, 1e-08)
+        out["optimizer_mse_2"] = gen(lr_base2, 0.001)
+    return out
+
+
+def adjust_learning_rate(optimizer, lr, epoch=0, epoch_thre=0):
+    """code/dmcnet_I3D/train/model.py:267-281: groups with lr_mult 0.2 / 0.5 (the pretrained trunk) are
+    frozen (lr 0) while ``epoch + 1 <= epoch_thre``; afterwards 0.5 becomes 1.0."""
+    for g in optimizer.param_groups:
+        m = g.get("lr_mult", 1.0)
+        if m == 0.2 or m == 0.5:
+            if epoch_thre > 0 and epoch + 1 <= epoch_thre:
+                m = 0.0
+            elif m == 0.5:
+                m = 1.0
+        g["lr"] = lr * m
+
+
+class I3DTrainer(object):
+    """``model.fit``'s training half, one micro-batch per :meth:`step`
+    (code/dmcnet_I3D/train/model.py:345-491).
+
+    Kept as written in the reference:
+      * the accumulation counter ``i`` is shared by the D and G phases and only stepping resets it;
+      * a phase divides by ``iter_size`` and steps only ITS optimizers and zeroes only THEIR gradients, so the
+        generator's gradients of a D phase are still there when the G phase steps it, and the trunk's /
+        discriminator's gradients of a G phase flow into the next D-phase step;
+      * with a discriminator, the G phase of epoch 0 multiplies the classification loss by 0 (:437);
+      * with a discriminator, the G phase re-uses the ``lr`` of the preceding D phase during stage 1 and
+        ``lr_d`` is only refreshed during stage 1 (:366-382,444-459);
+      * ``detach`` does not detach anything: ``fit`` never passes it to the forward, it only sets the trunk's
+        stage-1 learning rate to 0 (:371-374,449-452).
+    ``world_size > 1``: the gradients of the optimizers about to step are averaged over the ranks (one
+    flat all-reduce per optimizer) between the last backward of the window and the step -- the RCCL
+    counterpart of the nn.DataParallel wrap at code/dmcnet_I3D/train_model.py:120."""
+
+    def __init__(self, net, optimizers, lr_scheduler, lr_scheduler2=None, lr_scheduler3=None, adv=1.0,
+                 iter_size=1, epoch_thre=1, detach=False, group=None):
+        self.net, self.adv, self.iter_size = net, adv, iter_size
+        self.epoch_thre, self.detach, self.group = epoch_thre, detach, group
+        self.optimizer = optimizers["optimizer"]
+        self.optimizer_2 = optimizers.get("optimizer_2")
+        self.optimizer_3 = optimizers.get("optimizer_3")
+        self.optimizer_mse = optimizers.get("optimizer_mse")
+        self.optimizer_mse_2 = optimizers.get("optimizer_mse_2")
+        self.lr_scheduler, self.lr_scheduler2, self.lr_scheduler3 = lr_scheduler, lr_scheduler2, lr_scheduler3
+        self.i = 0
+        self.note = True
+        self.lr = self.lr_d = None
+        for o in (self.optimizer, self.optimizer_2, self.optimizer_mse, self.optimizer_mse_2, self.optimizer_3):
+            if o is not None:
+                o.zero_grad()
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if self.world > 1:
+            for p in net.parameters():
+                dist.broadcast(p.data, src=0, group=group)
+        self.exchanged = []          # [(optimizer attribute, bytes)] of the last stepping micro-batch
+
+    # ---------------------------------------------------------------------------------------
+    def _exchange(self, name, opt):
+        grads = [p.grad for g in opt.param_groups for p in g["params"] if p.grad is not None]
+        nbytes = sum(t.numel() * t.element_size() for t in grads)
+        self.exchanged.append((name, nbytes))
+        if self.world == 1 or not grads:
+            return
+        flat = torch.cat([t.reshape(-1) for t in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat.div_(self.world)
+        off = 0
+        for t in grads:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+
+    def _scale(self, opt):
+        if self.iter_size != 1:
+            for g in opt.param_groups:
+                for p in g["params"]:
+                    p.grad /= self.iter_size
+
+    def step(self, data, target, i_epoch, i_batch):
+        """One micro-batch of epoch ``i_epoch``; returns (logits, losses, phase, stepped)."""
+        net, gan, joint = self.net, self.optimizer_3 is not None, self.optimizer_mse is not None
+        if joint and i_epoch == self.epoch_thre and self.note:     # :348-352: second-stage optimizers
+            self.optimizer, self.optimizer_mse, self.note = self.optimizer_2, self.optimizer_mse_2, False
+        d_phase = gan and i_batch % (2 * self.iter_size) < self.iter_size
+        stage1 = i_epoch + 1 <= self.epoch_thre
+        self.exchanged = []
+        stepped = False
+        if joint:
+            # (fit() never forwards its ``detach`` flag to the network, :355,:414-416: the classifier always
+            # sees the undetached cue; ``detach`` only zeroes the trunk's stage-1 learning rate below)
+            out, losses = i3d_losses(net, data, target, stage="D" if gan else None, detach=False)
+        else:
+            out = net(data)
+            losses = [torch.nn.functional.cross_entropy(out, target)]
+        if d_phase:
+            (losses[0] + self.adv * losses[2]).backward()
+            if joint:
+                if stage1:
+                    self.lr = self.lr_scheduler.update()
+                    self.lr_scheduler2.update()
+                    self.lr_d = self.lr_scheduler3.update()
+                    lr1 = 0.0 if self.detach else self.lr
+                else:
+                    self.lr = self.lr_scheduler2.update()
+                    lr1 = self.lr
+                adjust_learning_rate(self.optimizer, lr1, i_epoch, self.epoch_thre)
+                adjust_learning_rate(self.optimizer_3, self.lr_d)
+            else:
+                adjust_learning_rate(self.optimizer, self.lr_scheduler.update())
+            self.i += 1
+            if self.i % self.iter_size == 0:
+                self._exchange("optimizer", self.optimizer)
+                self._exchange("optimizer_3", self.optimizer_3)
+                self._scale(self.optimizer)
+                self._scale(self.optimizer_3)
+                self.optimizer.step(); self.optimizer.zero_grad()
+                self.optimizer_3.step(); self.optimizer_3.zero_grad()
+                self.i, stepped = 0, True
+            return out.detach(), [l.detach() for l in losses], "D", stepped
+        # ---- G phase (or the only phase without a discriminator) ----
+        if len(losses) == 1:
+            losses[0].backward()
+        elif not gan:
+            (losses[0] + losses[1]).backward()
+        elif i_epoch < 1:
+            (0.0 * losses[0] + losses[1] + self.adv * losses[2]).backward()
+        else:
+            (losses[0] + losses[1] + self.adv * losses[2]).backward()
+        if joint:
+            if stage1:
+                if not gan:
+                    self.lr = self.lr_scheduler.update()
+                self.lr_scheduler2.update()
+                lr1 = 0.0 if self.detach else self.lr
+            else:
+                self.lr = self.lr_scheduler2.update()
+                lr1 = self.lr
+            if not gan:
+                adjust_learning_rate(self.optimizer, lr1, i_epoch, self.epoch_thre)
+            adjust_learning_rate(self.optimizer_mse, self.lr)
+        else:
+            adjust_learning_rate(self.optimizer, self.lr_scheduler.update())
+        self.i += 1
+        if self.i % self.iter_size == 0:
+            if not gan:
+                self._exchange("optimizer", self.optimizer)
+            if joint:
+                self._exchange("optimizer_mse", self.optimizer_mse)
+            if not gan:
+                self._scale(self.optimizer)
+            if joint:
+                self._scale(self.optimizer_mse)
+            if not gan:
+                self.optimizer.step(); self.optimizer.zero_grad()
+            if joint:
+                self.optimizer_mse.step(); self.optimizer_mse.zero_grad()
+            self.i, stepped = 0, True
+        return out.detach(), [l.detach() for l in losses], "G", stepped
+
+
+def recipe_trainer(net, batch_size=3, world_size=1, lr_base=4e-4, lr_base2=4e-4, lr_d=2e-3, lr_factor=0.2,
+                   lr_steps=(400000, 800000), iter_size=32, adv=1.0, epoch_thre=6, detach=True, optim="adam",
+                   group=None):
+    """Trainer with the shipped recipe's settings (code/dmcnet_I3D/train.sh: batch 3, iter-size 32, Adam,
+    lr-base / lr-base2 4e-4, lr-d 2e-3, lr-factor 0.2, adv 1, epoch-thre 6, detach 1) and the schedulers as
+    code/dmcnet_I3D/train_model.py:219-238 builds them (steps in samples / (batch * workers))."""
+    opts = make_optimizers(net, lr_base, lr_base2, optim=optim, adv=adv)
+    steps = [int(x / (batch_size * world_size)) for x in lr_steps]
+    mk = lambda base: MultiFactorScheduler(steps, base_lr=base, factor=lr_factor)
+    return I3DTrainer(net, opts, mk(lr_base), mk(lr_base2), mk(lr_d), adv=adv, iter_size=iter_size,
+                      epoch_thre=epoch_thre, detach=detach, group=group)

@@ -14,8 +14,9 @@ class EventProbe(object):
     current stream).  bench.py installs one over the timed region to obtain the generator
     kernels' average duration; ``summary()`` synchronises."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.pairs = {}
+        self.only = None if only is None else frozenset(only)   # restrict to these span names (fewer event records)
 
     def span(self, name):
         return _Span(self, name)
@@ -55,7 +56,9 @@ DEBUG_DISC_Z = None
 
 
 def _span(name):
-    return PROBE.span(name) if PROBE is not None else _NoSpan()
+    if PROBE is None or (PROBE.only is not None and name not in PROBE.only):
+        return _NoSpan()
+    return PROBE.span(name)
 
 
 def _stream():

@@ -695,17 +695,21 @@ def test_i3d_train_step_phases():
     torch.manual_seed(0)
     net = i3d.I3D(51, modality="flow+mp4", dropout_prob=0, arch_estimator="DenseNetTiny",
                   arch_d="Discriminator").to(DEV).train()
-    step = i3d.I3DTrainStep(net, iter_size=1)
+    from dmcnet_amd import i3d_train
+    step = i3d_train.recipe_trainer(net, batch_size=1, iter_size=1)
     data, tgt = rnd(83, (1, 7, 16, 224, 224)).to(DEV), torch.tensor([3], device=DEV)
     w_gen = net.gen_flow_model.predict_flow.weight.detach().clone()
     w_d = net.discriminator.adv_layer.weight.detach().clone()
-    _, losses, phase = step.step(data, tgt)
-    assert phase == "D" and len(losses) == 3 and all(torch.isfinite(l) for l in losses)
+    w_trunk = net.conv3d_1a_7x7.conv3d.weight.detach().clone() if hasattr(net.conv3d_1a_7x7, "conv3d") else None
+    _, losses, phase, stepped = step.step(data, tgt, 0, 0)
+    assert phase == "D" and stepped and len(losses) == 3 and all(torch.isfinite(l) for l in losses)
     assert torch.equal(net.gen_flow_model.predict_flow.weight, w_gen)      # D phase: G untouched
     assert not torch.equal(net.discriminator.adv_layer.weight, w_d)
+    if w_trunk is not None:                                                # stage 1 + detach: pretrained trunk frozen (lr 0)
+        assert torch.equal(net.conv3d_1a_7x7.conv3d.weight, w_trunk)
     w_d = net.discriminator.adv_layer.weight.detach().clone()
-    _, _, phase = step.step(data, tgt)
-    assert phase == "G"
+    _, _, phase, stepped = step.step(data, tgt, 0, 1)
+    assert phase == "G" and stepped
     assert not torch.equal(net.gen_flow_model.predict_flow.weight, w_gen)
     assert torch.equal(net.discriminator.adv_layer.weight, w_d)
 

@@ -490,3 +490,98 @@ def test_geometry_plan_matches_applied_transforms():
     with pytest.raises(ValueError):
         transforms.geometry_plan(transforms.Compose([transforms.GroupScale(256), transforms.GroupScale(224)]),
                                  (240, 320, 7))
+
+
+# ------------------------------------------------------------------ I3D trainer policy (BASELINE config 5)
+def _i3d_cfg(golden):
+    g = golden("g10_i3d_trainer")
+    return g, eval(str(g["cfg"]))
+
+
+def _make_i3d_trainer(c, net, group=None):
+    from dmcnet_amd import i3d_train as IT
+    opts = IT.make_optimizers(net, c["lr_base"], c["lr_base2"], optim="adam", adv=c["adv"])
+    mk = lambda base: IT.MultiFactorScheduler(list(c["sched_steps"]), base_lr=base, factor=c["lr_factor"])
+    tr = IT.I3DTrainer(net, opts, mk(c["lr_base"]), mk(c["lr_base2"]), mk(c["lr_d"]), adv=c["adv"],
+                       iter_size=c["iter_size"], epoch_thre=c["epoch_thre"], detach=c["detach"], group=group)
+    return tr, opts
+
+
+def test_i3d_scheduler_matches_reference_table(golden):
+    """MultiFactorScheduler against the table the reference's class produced (warm-up halving for the
+    first 99 updates, factor steps)."""
+    from dmcnet_amd import i3d_train as IT
+    g = golden("g10_i3d_trainer")
+    s = IT.MultiFactorScheduler([2, 14, 18], base_lr=0.1, factor=0.1, step_counter=2)
+    np.testing.assert_array_equal(np.array([s.update() for _ in range(130)]), g["sched_table"])
+
+
+def test_i3d_trainer_policy_vs_reference_fit(golden):
+    """The reference's own ``model.fit`` (3 epochs x 8 micro-batches, iter_size 2, two stages, D / G
+    alternation) against I3DTrainer on the same tiny network: optimizer group layout, every learning
+    rate and EVERY parameter after every micro-batch, bit for bit: same torch CPU ops in the same order, on ONE
+    thread like the golden run (the summation order of the CPU convolution backward depends on the thread
+    count, and Adam(eps 1e-8) amplifies a 1-ulp difference in a near-zero gradient to a full +-lr step)."""
+    from tests.golden import tiny_i3d
+    g, c = _i3d_cfg(golden)
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    net = tiny_i3d.build(c["seed_net"])
+    np.testing.assert_array_equal(tiny_i3d.snapshot(net), g["init"])
+    tr, opts = _make_i3d_trainer(c, net)
+    layout = [(k, len(opts[k].param_groups), [len(gr["params"]) for gr in opts[k].param_groups],
+               [gr.get("lr_mult", 1.0) for gr in opts[k].param_groups]) for k in sorted(opts)]
+    assert repr(layout) == str(g["group_layout"])
+    assert opts["optimizer_3"].defaults["eps"] == 0.001 and opts["optimizer_mse"].defaults["eps"] == 1e-08
+    assert opts["optimizer_mse_2"].defaults["eps"] == 0.001 and opts["optimizer_2"].defaults["lr"] == c["lr_base2"]
+    data = tiny_i3d.batches(c["seed_data"], c["epochs"], c["per_epoch"])
+    k, phases = 0, []
+    for ep in range(c["epochs"]):
+        for ib, (x, t) in enumerate(data[ep]):
+            _, _, phase, stepped = tr.step(x, t, ep, ib)
+            phases.append((phase, stepped))
+            np.testing.assert_array_equal(tiny_i3d.snapshot(net), g["params"][k], err_msg="epoch %d batch %d" % (ep, ib))
+            lrs = [gr["lr"] for name in sorted(opts) for gr in opts[name].param_groups]
+            np.testing.assert_array_equal(np.array(lrs), g["lrs"][k], err_msg="lr, epoch %d batch %d" % (ep, ib))
+            k += 1
+    torch.set_num_threads(nthreads)
+    assert phases[:8] == [("D", False), ("D", True), ("G", False), ("G", True)] * 2
+    assert tr.optimizer is opts["optimizer_2"] and tr.optimizer_mse is opts["optimizer_mse_2"]   # stage 2 took over
+
+
+def _i3d_ddp_worker(rank, world, port, out_dir, cfg):
+    from tests.golden import tiny_i3d
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = tiny_i3d.build(300 + rank)                   # different init per rank: the trainer broadcasts
+    tr, _ = _make_i3d_trainer(cfg, net)
+    data = tiny_i3d.batches(77, 2, 4, b=2)
+    log = []
+    for ep in range(2):
+        for ib, (x, t) in enumerate(data[ep]):
+            sh = slice(rank, rank + 1)                 # one clip of each two-clip micro-batch per rank
+            tr.step(x[sh], t[sh], ep, ib)
+            log.append(list(tr.exchanged))
+    torch.save({"params": tiny_i3d.snapshot(net), "log": log}, os.path.join(out_dir, "i%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_i3d_trainer_two_ranks_gloo_equals_full_micro_batches(golden, tmp_path):
+    """Two ranks, one clip each, against one process on the two-clip micro-batches (the losses are
+    means over clips, so averaged gradients are the full-batch gradients); the exchange happens only on
+    stepping micro-batches and only for the optimizers that step."""
+    from tests.golden import tiny_i3d
+    _, c = _i3d_cfg(golden)
+    port = _free_port()
+    mp.spawn(_i3d_ddp_worker, args=(2, port, str(tmp_path), c), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp_path, "i%d.pt" % r), weights_only=False) for r in (0, 1))
+    np.testing.assert_array_equal(r0["params"], r1["params"])
+    net = tiny_i3d.build(300)
+    tr, _ = _make_i3d_trainer(c, net)
+    data = tiny_i3d.batches(77, 2, 4, b=2)
+    for ep in range(2):
+        for ib, (x, t) in enumerate(data[ep]):
+            tr.step(x, t, ep, ib)
+    np.testing.assert_allclose(r0["params"], tiny_i3d.snapshot(net), rtol=2e-4, atol=2e-6)
+    names = [[n for n, _ in e] for e in r0["log"]]
+    assert names[0] == [] and names[1] == ["optimizer", "optimizer_3"] and names[2] == [] and names[3] == ["optimizer_mse"]
