@@ -216,6 +216,11 @@ def main():
                     help="1 (default) = cudnn.benchmark as the reference's train.py:118 sets it: MIOpen "
                          "picks solvers by search, answered from the find-db shipped in "
                          "dmc-net_amd/miopen_db; 0 = MIOpen's heuristic picks")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="1 = capture the whole training step (forward, losses, backward, Adam) in a hipGraph after the "
+                         "warm-up and time graph replays (single GPU): removes the launch gaps between the ~290 kernels "
+                         "of a step.  The generator kernels' durations are then taken from eager steps run right after "
+                         "the timed region (events cannot be recorded inside a replay)")
     ap.add_argument("--all-spans", action="store_true",
                     help="HIP-event spans around every C-ABI call (kernels_ms lists them all); default: the "
                          "generator forward / backward only, which the roofline object needs")
@@ -273,7 +278,25 @@ def main():
     for i in range(args.warmup):
         one(i)
     probe = ops.EventProbe(None if args.all_spans else ("gen_tiny_fwd", "gen_tiny_bwd"))
-    ops.PROBE = probe
+    graphs = None
+    if args.graph and world == 1:
+        # whole-step capture: one graph per distinct step kind (GAN: the D step and the G step).  Inputs are
+        # the resident synthetic batch, every workspace comes from the graph's private pool, the fused Adam
+        # kernels keep their step counters on the device, learning rates are baked in (constant here).
+        try:
+            torch.cuda.synchronize()
+            graphs, gouts = [], []
+            for kind in range(2 if gan else 1):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    gouts.append(one(kind))
+                graphs.append(g)
+            torch.cuda.synchronize()
+        except Exception as e:                       # capture is an optimisation, never a requirement
+            sys.stderr.write("bench: hipGraph capture failed (%s: %s); timing eager steps\n" % (type(e).__name__, e))
+            graphs = None
+    if graphs is None:
+        ops.PROBE = probe
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -284,13 +307,22 @@ def main():
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
-        out = one(i)
+        if graphs is None:
+            out = one(i)
+        else:
+            graphs[i % len(graphs)].replay()
+            out = gouts[i % len(graphs)]
         marks[i + 1].record()
     ops.profile_mark()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if graphs is not None:                           # kernel durations: eager steps right after the timed replays
+        ops.PROBE = probe
+        for i in range(6):
+            one(i)
+        torch.cuda.synchronize()
     ops.PROBE = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -337,6 +369,9 @@ def main():
                         "traffic_source": traffic_src,
                         "traffic_gbs": None if traffic is None else round(traffic / (fwd_ms * 1e-3) / 1e9, 1)}},
             "kernels_ms": {k: round(v[0], 4) for k, v in spans.items()},
+            "launch": ("hipGraph replay of the captured step; roofline.launch_ms from HIP events around the same "
+                       "C-ABI call in 6 eager steps run right after the timed region") if graphs is not None else
+                      "eager (one launch per kernel); roofline.launch_ms from HIP events inside the timed region",
         }
         if world == 1:
             line["prepare_inputs"] = bench_prepare(dev, n_frames, 0 if gan else 16)

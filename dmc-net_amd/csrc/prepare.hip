@@ -148,107 +148,196 @@ __device__ __forceinline__ int resized_u8(const CropArgs& a, const unsigned char
     return (int)v;
 }
 
-// one wave per (frame, flow channel, block): integer sum of the block's resized + flipped pixels
-__global__ __launch_bounds__(256) void crop_block_mean_kernel(CropArgs a) {
-    const long total = (long)a.N * 2 * a.bh * a.bw;
-    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= total) return;
-    const int lane = threadIdx.x & 63;
-    const int bx = (int)(i % a.bw), by = (int)((i / a.bw) % a.bh);
-    const int c = (int)((i / ((long)a.bw * a.bh)) % 2), n = (int)(i / ((long)a.bw * a.bh * 2));
-    const bool flipped = a.flip && a.flip[n];
-    const Box b = box_of(a, n);
-    const unsigned char* fr = a.frames + (size_t)n * a.H0 * a.W0 * 7;
-    int sum = 0;
-    for (int k = lane; k < a.factor * a.factor; k += 64) {
-        const int y = by * a.factor + k / a.factor, x = bx * a.factor + k % a.factor;
-        if (y < a.OH && x < a.OW) {
+// Values of 4 consecutive output pixels (y, x0 .. x0 + 3), all 7 channels, after crop / resize / flip:
+// identity-size boxes read their 28 source bytes as aligned dwords + byte alignment (no byte loads).
+__device__ __forceinline__ void quad_values(const CropArgs& a, const unsigned char* fr, const Box& b, int y, int x0,
+                                            bool flipped, int (&v)[4][7]) {
+    const bool identity = b.h == b.rh && b.w == b.rw;
+    if (identity && x0 + 3 < a.OW) {
+        // source pixels xs .. xs+3 (ascending in memory): 28 contiguous bytes
+        const int xs = flipped ? a.OW - 4 - x0 : x0;
+        const size_t off = ((size_t)(b.y0 + b.cy + y) * a.W0 + (b.x0 + b.cx + xs)) * 7;
+        const size_t base = (size_t)(fr - a.frames) + off;
+        const unsigned* w32 = reinterpret_cast<const unsigned*>(a.frames + (base & ~(size_t)3));
+        const unsigned sh = (unsigned)(base & 3);
+        unsigned d[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = w32[k];              // (the 8th dword is inside the buffer's 16-byte tail pad)
+        unsigned char bytes[28];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const unsigned u = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sh);
+            bytes[4 * k + 0] = u & 255; bytes[4 * k + 1] = (u >> 8) & 255;
+            bytes[4 * k + 2] = (u >> 16) & 255; bytes[4 * k + 3] = u >> 24;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int js = flipped ? 3 - j : j;
+#pragma unroll
+            for (int c = 0; c < 7; ++c) v[j][c] = flip_value(bytes[js * 7 + c], c, flipped);
+        }
+    } else if (identity) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = x0 + j < a.OW ? x0 + j : a.OW - 1;
             const int xs = flipped ? a.OW - 1 - x : x;
-            sum += flip_value(resized_u8(a, fr, b, y, xs, c), c, flipped);
+#pragma unroll
+            for (int c = 0; c < 7; ++c) v[j][c] = flip_value(resized_u8(a, fr, b, y, xs, c), c, flipped);
+        }
+    } else {
+        // bilinear resize: the taps are computed once per pixel (not per channel) and the two horizontally
+        // adjacent source pixels of a row (14 contiguous bytes) arrive as 5 aligned dwords + byte
+        // alignment instead of 14 byte loads -- the byte gathers were the kernel's bottleneck.  The
+        // arithmetic is resized_u8's, operation for operation.
+        const Tap ty = tap_of(y + b.cy, b.rh, b.h);
+        const unsigned char* row0 = fr + ((size_t)(b.y0 + ty.lo) * a.W0 + b.x0) * 7;
+        const unsigned char* row1 = fr + ((size_t)(b.y0 + ty.hi) * a.W0 + b.x0) * 7;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = x0 + j < a.OW ? x0 + j : a.OW - 1;
+            const int xs = flipped ? a.OW - 1 - x : x;
+            const Tap tx = tap_of(xs + b.cx, b.rw, b.w);
+            const int hi_off = (tx.hi - tx.lo) * 7;               // 7, or 0 at the clamped right edge
+            unsigned char pb[2][16];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const size_t base = (size_t)((r ? row1 : row0) + (size_t)tx.lo * 7 - a.frames);
+                const unsigned* w32 = reinterpret_cast<const unsigned*>(a.frames + (base & ~(size_t)3));
+                const unsigned sh = (unsigned)(base & 3);
+                unsigned d[5];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) d[k] = w32[k];          // (at most 6 bytes past the pair: inside the tail pad)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned u = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sh);
+                    pb[r][4 * k + 0] = u & 255; pb[r][4 * k + 1] = (u >> 8) & 255;
+                    pb[r][4 * k + 2] = (u >> 16) & 255; pb[r][4 * k + 3] = u >> 24;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 7; ++c) {
+                const double p00 = (double)pb[0][c], p01 = (double)(hi_off ? pb[0][7 + c] : pb[0][c]);
+                const double p10 = (double)pb[1][c], p11 = (double)(hi_off ? pb[1][7 + c] : pb[1][c]);
+                const double top = p00 * (1.0 - tx.f) + p01 * tx.f;
+                const double bot = p10 * (1.0 - tx.f) + p11 * tx.f;
+                double r = rint(top * (1.0 - ty.f) + bot * ty.f);
+                r = r < 0.0 ? 0.0 : (r > 255.0 ? 255.0 : r);
+                v[j][c] = flip_value((int)r, c, flipped);
+            }
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
-    if (lane == 0) a.block_mean[i] = (float)((double)sum / (double)(a.factor * a.factor));
 }
 
-// 4 consecutive output pixels per thread, float4 stores into the seven planes.  Identity-size
-// boxes read their 28 source bytes as aligned dwords + byte alignment (no byte loads).
+// normalised outputs of a quad: channels 2..6 (mv, residual) from the table, the two flow channels either from
+// the table (factor == 0) or from the given block means
+struct Lut { float t[4][257]; };
+__device__ __forceinline__ void fill_lut(const CropArgs& a, Lut& lut) {
+    // (u / 255 - 0.5) / std has 257 possible results per standard deviation (256 - v for a flipped x-component,
+    // code/dmcnet/transforms.py:54-56, reaches 256): one table per std, filled with exactly that expression,
+    // replaces two IEEE divisions per value (56 per quad)
+    for (int i = threadIdx.x; i < 257; i += blockDim.x) {
+        const float u = (float)i;
+        lut.t[0][i] = (u / 255.0f - 0.5f) / a.std_mean;
+        lut.t[1][i] = (u / 255.0f - 0.5f) / a.std_r;
+        lut.t[2][i] = (u / 255.0f - 0.5f) / a.std_g;
+        lut.t[3][i] = (u / 255.0f - 0.5f) / a.std_b;
+    }
+}
+
+__device__ __forceinline__ void store_plane_quad(const CropArgs& a, float* dst, size_t pix, int x0, const float (&o)[4]) {
+    if ((a.OW & 3) == 0) {
+        *reinterpret_cast<float4*>(dst + pix) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (x0 + j < a.OW) dst[pix + j] = o[j];
+    }
+}
+
+__device__ __forceinline__ float* plane_of(const CropArgs& a, int n, int c, size_t OHW) {
+    return c < 2 ? a.flow + ((size_t)n * 2 + c) * OHW
+         : c < 4 ? a.mv + ((size_t)n * 2 + (c - 2)) * OHW
+                 : a.res + ((size_t)n * 3 + (c - 4)) * OHW;
+}
+
+// flow_ds_factor == 0: 4 consecutive output pixels per thread, float4 stores into the seven planes
 __global__ __launch_bounds__(256) void prepare_crop_kernel(CropArgs a) {
+    __shared__ Lut lut;
+    fill_lut(a, lut);
+    __syncthreads();
     const int qw = (a.OW + 3) / 4;                                  // 4-pixel groups per row
     const size_t OHW = (size_t)a.OH * a.OW;
     const size_t total = (size_t)a.N * a.OH * qw;
-    const bool vec_ok = (a.OW & 3) == 0;
     for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
         const int n = (int)(g / ((size_t)a.OH * qw));
         const int rem = (int)(g - (size_t)n * a.OH * qw);
         const int y = rem / qw, x0 = (rem - y * qw) * 4;
         const bool flipped = a.flip && a.flip[n];
         const Box b = box_of(a, n);
-        const unsigned char* fr = a.frames + (size_t)n * a.H0 * a.W0 * 7;
         int v[4][7];
-        const bool identity = b.h == b.rh && b.w == b.rw;
-        if (identity && x0 + 3 < a.OW) {
-            // source pixels xs .. xs+3 (ascending in memory): 28 contiguous bytes
-            const int xs = flipped ? a.OW - 4 - x0 : x0;
-            const size_t off = ((size_t)(b.y0 + b.cy + y) * a.W0 + (b.x0 + b.cx + xs)) * 7;
-            const size_t base = (size_t)(fr - a.frames) + off;
-            const unsigned* w32 = reinterpret_cast<const unsigned*>(a.frames + (base & ~(size_t)3));
-            const unsigned sh = (unsigned)(base & 3);
-            unsigned d[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) d[k] = w32[k];              // (the 8th dword is inside the buffer's 16-byte tail pad)
-            unsigned char bytes[28];
-#pragma unroll
-            for (int k = 0; k < 7; ++k) {
-                const unsigned u = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sh);
-                bytes[4 * k + 0] = u & 255; bytes[4 * k + 1] = (u >> 8) & 255;
-                bytes[4 * k + 2] = (u >> 16) & 255; bytes[4 * k + 3] = u >> 24;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int js = flipped ? 3 - j : j;
-#pragma unroll
-                for (int c = 0; c < 7; ++c) v[j][c] = flip_value(bytes[js * 7 + c], c, flipped);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int x = x0 + j < a.OW ? x0 + j : a.OW - 1;
-                const int xs = flipped ? a.OW - 1 - x : x;
-#pragma unroll
-                for (int c = 0; c < 7; ++c) v[j][c] = flip_value(resized_u8(a, fr, b, y, xs, c), c, flipped);
-            }
-        }
-        float o[7][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int x = x0 + j < a.OW ? x0 + j : a.OW - 1;
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const float f = a.factor > 0
-                    ? a.block_mean[(((size_t)n * 2 + c) * a.bh + y / a.factor) * a.bw + x / a.factor]
-                    : (float)v[j][c];
-                o[c][j] = (f / 255.0f - 0.5f) / a.std_mean;
-                o[2 + c][j] = ((float)v[j][2 + c] / 255.0f - 0.5f) / a.std_mean;
-            }
-            o[4][j] = ((float)v[j][4] / 255.0f - 0.5f) / a.std_r;
-            o[5][j] = ((float)v[j][5] / 255.0f - 0.5f) / a.std_g;
-            o[6][j] = ((float)v[j][6] / 255.0f - 0.5f) / a.std_b;
-        }
+        quad_values(a, a.frames + (size_t)n * a.H0 * a.W0 * 7, b, y, x0, flipped, v);
         const size_t pix = (size_t)y * a.OW + x0;
 #pragma unroll
         for (int c = 0; c < 7; ++c) {
-            float* dst = c < 2 ? a.flow + ((size_t)n * 2 + c) * OHW
-                       : c < 4 ? a.mv + ((size_t)n * 2 + (c - 2)) * OHW
-                               : a.res + ((size_t)n * 3 + (c - 4)) * OHW;
-            if (vec_ok) {
-                *reinterpret_cast<float4*>(dst + pix) = make_float4(o[c][0], o[c][1], o[c][2], o[c][3]);
-            } else {
+            const int k = c < 4 ? 0 : c - 3;
+            const float o[4] = {lut.t[k][v[0][c]], lut.t[k][v[1][c]], lut.t[k][v[2][c]], lut.t[k][v[3][c]]};
+            store_plane_quad(a, plane_of(a, n, c, OHW), pix, x0, o);
+        }
+    }
+}
+
+// flow_ds_factor > 0 (the dmcnet recipes' 16): one workgroup per (frame, band of `factor` output rows), ONE pass
+// over the source: every quad's mv / residual planes are written at once, its flow values are added to
+// the band's per-block integer sums in LDS, and after a barrier the flow planes are written from the block
+// means (ragged edge blocks divide by factor^2, as skimage.measure.block_reduce's zero padding does).
+// HBM traffic = the algorithmic 7 B per sampled source pixel + 28 B per output pixel; the earlier two-kernel
+// form read the flow channels twice and round-tripped the block means.
+__global__ __launch_bounds__(256) void prepare_crop_band_kernel(CropArgs a) {
+    __shared__ Lut lut;
+    extern __shared__ int bsum[];                                    // [bw][2]
+    fill_lut(a, lut);
+    for (int i = threadIdx.x; i < 2 * a.bw; i += 256) bsum[i] = 0;
+    __syncthreads();
+    const int n = blockIdx.x / a.bh, by = blockIdx.x - n * a.bh;
+    const int qw = (a.OW + 3) / 4;
+    const size_t OHW = (size_t)a.OH * a.OW;
+    const bool flipped = a.flip && a.flip[n];
+    const Box b = box_of(a, n);
+    const unsigned char* fr = a.frames + (size_t)n * a.H0 * a.W0 * 7;
+    const int y_begin = by * a.factor, rows = (a.OH - y_begin < a.factor) ? a.OH - y_begin : a.factor;
+    for (int g = threadIdx.x; g < rows * qw; g += 256) {
+        const int y = y_begin + g / qw, x0 = (g % qw) * 4;
+        int v[4][7];
+        quad_values(a, fr, b, y, x0, flipped, v);
+        const size_t pix = (size_t)y * a.OW + x0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (x0 + j < a.OW) dst[pix + j] = o[c][j];
+        for (int c = 2; c < 7; ++c) {
+            const int k = c < 4 ? 0 : c - 3;
+            const float o[4] = {lut.t[k][v[0][c]], lut.t[k][v[1][c]], lut.t[k][v[2][c]], lut.t[k][v[3][c]]};
+            store_plane_quad(a, plane_of(a, n, c, OHW), pix, x0, o);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (x0 + j < a.OW) {
+                atomicAdd(&bsum[2 * ((x0 + j) / a.factor) + 0], v[j][0]);
+                atomicAdd(&bsum[2 * ((x0 + j) / a.factor) + 1], v[j][1]);
             }
+    }
+    __syncthreads();
+    const double denom = (double)(a.factor * a.factor);
+    for (int g = threadIdx.x; g < rows * qw; g += 256) {
+        const int y = y_begin + g / qw, x0 = (g % qw) * 4;
+        const size_t pix = (size_t)y * a.OW + x0;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int x = x0 + j < a.OW ? x0 + j : a.OW - 1;
+                const float mean = (float)((double)bsum[2 * (x / a.factor) + c] / denom);
+                o[j] = (mean / 255.0f - 0.5f) / a.std_mean;
+            }
+            store_plane_quad(a, plane_of(a, n, c, OHW), pix, x0, o);
         }
     }
 }
@@ -310,11 +399,9 @@ int dmc_prepare_inputs_crop(const unsigned char* frames_u8, const int* boxes, co
     a.bh = flow_ds_factor ? (OH + flow_ds_factor - 1) / flow_ds_factor : 0;
     a.bw = flow_ds_factor ? (OW + flow_ds_factor - 1) / flow_ds_factor : 0;
     a.std_mean = std4_host[0]; a.std_r = std4_host[1]; a.std_g = std4_host[2]; a.std_b = std4_host[3];
-    int rc;
     if (flow_ds_factor > 0) {
-        const long total = (long)N * 2 * a.bh * a.bw;
-        crop_block_mean_kernel<<<(int)((total + 3) / 4), 256, 0, s>>>(a);
-        if ((rc = check_launch("prepare_crop_block_mean"))) return rc;
+        prepare_crop_band_kernel<<<N * a.bh, 256, (size_t)2 * a.bw * sizeof(int), s>>>(a);
+        return check_launch("prepare_inputs_crop_band");
     }
     const size_t want = ((size_t)N * OH * ((OW + 3) / 4) + 255) / 256;
     prepare_crop_kernel<<<(int)(want > 16384 ? 16384 : want), 256, 0, s>>>(a);

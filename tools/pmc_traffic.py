@@ -50,8 +50,12 @@ def main():
         print("# generator %s total: %.1f MB calibrated = %.1f B/px (algorithmic: fwd 28 B/px fused, "
               "140 B/px with saved features)" % (g, v / 1e6, v / px))
     if len(sys.argv) > 4:
+        import hashlib
         import json
+        import os
+        src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dmc-net_amd", "csrc", "gen_tiny.hip")
         json.dump({"frames": n, "fetch_scale": kr, "write_scale": kw,
+                   "kernel_source_sha16": hashlib.sha256(open(src, "rb").read()).hexdigest()[:16],
                    "gen_fwd_bytes_per_px": tot["fwd"] / px, "gen_bwd_bytes_per_px": tot["bwd"] / px,
                    "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
                              "tools/gen_microbench.py, calibrated on flow_mse kernels of known traffic"},
