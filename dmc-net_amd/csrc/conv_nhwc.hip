@@ -291,13 +291,13 @@ __device__ __forceinline__ void dma16_v(const void* src, unsigned lds_byte_addr)
                  :: "v"((unsigned long long)src), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)) : "memory");
 }
 
-constexpr int C2_THREADS = 256;
-
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(C2_THREADS) void conv2_kernel(ConvArgs a) {
+__global__ __launch_bounds__(WM * WN * 64) void conv2_kernel(ConvArgs a) {
+    constexpr int NW = WM * WN;                            // waves: 4, or 8 (smaller wave tiles, twice the waves per SIMD)
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;   // 32 x 32 tiles per wave: pixels x channels
-    static_assert(WM * WN == 4 && BM % (32 * WM) == 0 && BN % (32 * WN) == 0, "wave layout");
-    constexpr int NDP = BM / 32, NDW = BN / 32;            // DMA instructions per wave and step: pixel rows, weight rows
+    static_assert((NW == 4 || NW == 8) && BM % (32 * WM) == 0 && BN % (32 * WN) == 0, "wave layout");
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "transfer split");
+    constexpr int NDP = BM / 8 / NW, NDW = BN / 8 / NW;    // DMA instructions per wave and step: pixel rows, weight rows
     constexpr int ND = NDP + NDW;
     constexpr int BUF = (BM + BN) * 128;                   // bytes per buffer: tile rows of 32 floats
     __shared__ __attribute__((aligned(1024))) float lds[2 * (BM + BN) * 32];
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(C2_THREADS) void conv2_kernel(ConvArgs a) {
     const unsigned lds0 = lds_addr_of(lds);
     const unsigned long long zeros = (unsigned long long)g_zeros;
 
-    // ---- this lane's share of the transfers: instruction d = wave + 4 j moves tile rows 8 d .. 8 d + 7,
+    // ---- this lane's share of the transfers: instruction d = wave + NW j moves tile rows 8 d .. 8 d + 7,
     // lane -> (row 8 d + lane / 8, slot lane % 8), source quad = slot ^ ((row >> 1) & 7).  Per pixel row the
     // lane keeps the address of its quad at tap offset (0, 0) and a bit mask of the taps that fall inside
     // the image, so a step costs one add and one select per transfer ----
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(C2_THREADS) void conv2_kernel(ConvArgs a) {
     unsigned p_mask[NDP];
 #pragma unroll
     for (int j = 0; j < NDP; ++j) {
-        const int row = 8 * (wave + 4 * j) + rr;
+        const int row = 8 * (wave + NW * j) + rr;
         const int q = sl ^ ((row >> 1) & 7);
         const int m = m0 + row;
         p_mask[j] = 0; p_addr[j] = zeros;
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(C2_THREADS) void conv2_kernel(ConvArgs a) {
     unsigned long long w_addr[NDW];   // (co, tap 0, ci 0) + the lane's quad; Cout % BN == 0: every row exists
 #pragma unroll
     for (int j = 0; j < NDW; ++j) {
-        const int row = 8 * (wave + 4 * j) + rr;            // row within the weight tile
+        const int row = 8 * (wave + NW * j) + rr;           // row within the weight tile
         const int q = sl ^ ((row >> 1) & 7);
         w_addr[j] = (unsigned long long)a.w + ((long)(co0 + row) * a.KK * a.Cin + 4 * q) * 4;
     }
@@ -355,11 +355,11 @@ __global__ __launch_bounds__(C2_THREADS) void conv2_kernel(ConvArgs a) {
         if (j < NDP) {
             const bool ok = (p_mask[j < NDP ? j : 0] >> tap_n) & 1;
             const unsigned long long src = ok ? p_addr[j < NDP ? j : 0] + (unsigned long long)toff : zeros;
-            dma16_v(reinterpret_cast<const void*>(src), base + (wave + 4 * j) * 1024);
+            dma16_v(reinterpret_cast<const void*>(src), base + (wave + NW * j) * 1024);
         } else {
             const int jw = j - NDP;
             dma16_v(reinterpret_cast<const void*>(w_addr[jw >= 0 && jw < NDW ? jw : 0] + (unsigned long long)woff),
-                    base + BM * 128 + (wave + 4 * jw) * 1024);
+                    base + BM * 128 + (wave + NW * jw) * 1024);
         }
     };
 
@@ -396,23 +396,31 @@ __global__ __launch_bounds__(C2_THREADS) void conv2_kernel(ConvArgs a) {
         const bool more = t + 1 < T_steps;
         if (more) set_step();
         const char* base = reinterpret_cast<const char*>(lds) + buf * BUF;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float4 xa[TM], wa[TN];
+        // fragment registers are double-buffered over the four k-groups: the LDS reads of group g + 1 are issued
+        // before the MFMAs of group g (with one register set every group started by waiting ~100 cycles for
+        // its operands with a single MFMA left in the pipe)
+        float4 xa[2][TM], wa[2][TN];
+        auto load_frags = [&](int g, int sel) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                xa[i] = *reinterpret_cast<const float4*>(base + (prow0 + 32 * i) * 128 + foff[g]);
+                xa[sel][i] = *reinterpret_cast<const float4*>(base + (prow0 + 32 * i) * 128 + foff[g]);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                wa[j] = *reinterpret_cast<const float4*>(base + (crow0 + 32 * j) * 128 + foff[g]);
+                wa[sel][j] = *reinterpret_cast<const float4*>(base + (crow0 + 32 * j) * 128 + foff[g]);
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cur = g & 1;
+            if (g + 1 < 4) load_frags(g + 1, cur ^ 1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j].x, xa[i].x, acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[cur][j].x, xa[cur][i].x, acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j].y, xa[i].y, acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[cur][j].y, xa[cur][i].y, acc[i][j], 0, 0, 0);
             // the next step's transfers, a quarter of them behind each k-group's MFMAs (they land during the
             // remaining groups; nothing is issued, or waited for, in front of the step's first MFMA).  A
             // dedicated producer wave was measured too: its ~40 transfers per step serialise on one wave's
@@ -424,11 +432,11 @@ __global__ __launch_bounds__(C2_THREADS) void conv2_kernel(ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j].z, xa[i].z, acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[cur][j].z, xa[cur][i].z, acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j].w, xa[i].w, acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[cur][j].w, xa[cur][i].w, acc[i][j], 0, 0, 0);
         }
         if (more) {
             ci_n += 32;
@@ -1098,24 +1106,25 @@ bool shape_supported(const ConvShape& s) {
 bool use_v2(int cin, int cout) { return option(OPT_CONV_PATH) == 1 && cin % 32 == 0 && cout % 32 == 0; }
 
 // configuration of the second-generation kernel: 0 = 128 x 32, 1 = 128 x 64, 2 = 64 x 64, 3 = 256 x 64,
-// 4 = 128 x 128, 5 = 64 x 128 (pixels x channels)
+// 4 = 128 x 128, 5 = 64 x 128 (pixels x channels), 4 waves each; 6 = 128 x 128, 7 = 256 x 64, 8 = 128 x 64 with 8 waves
 int v2_choice(int cout, long M) {
     if (cout % 64 != 0) return 0;
     const int cfg = option(OPT_CONV_CFG);                  // measurement switch: 0 = automatic
-    if (cfg >= 1 && cfg <= 3) return cfg;
-    if ((cfg == 4 || cfg == 5) && cout % 128 == 0) return cfg;
+    if ((cfg >= 1 && cfg <= 3) || cfg == 7 || cfg == 8) return cfg;
+    if ((cfg == 4 || cfg == 5 || cfg == 6) && cout % 128 == 0) return cfg;
     // the largest tile that still gives the 256 CUs at least ~2.5 workgroups each (measured, N = 120: layer1
-    // 256 x 64, layer2 and the stride-2 convolutions 128 x 128, layer3 128 x 64, layer4 64 x 64)
+    // 256 x 64 with 4 waves; layer2 and the stride-2 convolutions 128 x 128 with 8 waves; layer3 128 x 64 with 8
+    // waves; layer4 64 x 64)
     const long need = 640;
-    if (cout % 128 == 0 && ((M + 127) / 128) * (cout / 128) >= need) return 4;
+    if (cout % 128 == 0 && ((M + 127) / 128) * (cout / 128) >= need) return 6;
     if (((M + 255) / 256) * (cout / 64) >= need) return 3;
-    if (((M + 127) / 128) * (cout / 64) >= need) return 1;
+    if (((M + 127) / 128) * (cout / 64) >= need) return 8;
     return 2;
 }
 
 int block_pixels_v2(int cout, long M) {
     const int c = v2_choice(cout, M);
-    return c == 3 ? 256 : (c == 2 || c == 5) ? 64 : 128;
+    return (c == 3 || c == 7) ? 256 : (c == 2 || c == 5) ? 64 : 128;
 }
 
 int block_pixels_v1(int cout, long M) {
@@ -1135,7 +1144,7 @@ int launch_cfg(const ConvArgs& a, hipStream_t s) {
 template <int BM, int BN, int WM, int WN>
 int launch_cfg2(const ConvArgs& a, hipStream_t s) {
     dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN);
-    conv2_kernel<BM, BN, WM, WN><<<grid, C2_THREADS, 0, s>>>(a);
+    conv2_kernel<BM, BN, WM, WN><<<grid, WM * WN * 64, 0, s>>>(a);
     return check_launch("conv2");
 }
 
@@ -1149,6 +1158,9 @@ int launch_conv(ConvArgs a, hipStream_t s) {
             case 3: return launch_cfg2<256, 64, 4, 1>(a, s);
             case 4: return launch_cfg2<128, 128, 2, 2>(a, s);
             case 5: return launch_cfg2<64, 128, 1, 4>(a, s);
+            case 6: return launch_cfg2<128, 128, 2, 4>(a, s);
+            case 7: return launch_cfg2<256, 64, 4, 2>(a, s);
+            case 8: return launch_cfg2<128, 64, 4, 2>(a, s);
             default: return launch_cfg2<64, 64, 2, 2>(a, s);
         }
     }
