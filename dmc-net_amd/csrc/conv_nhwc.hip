@@ -538,16 +538,23 @@ __global__ __launch_bounds__(256) void conv_stats_final_kernel(const double* __r
                                                                float* __restrict__ running_mean,
                                                                float* __restrict__ running_var, float eps,
                                                                float momentum) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (c >= C) return;
+    // one workgroup per channel: 256 lanes stride over the (up to ~12,000) workgroup partials, then a fixed-order
+    // tree (a single wave per channel walked them in 180 dependent-latency steps: 20 us per call)
+    __shared__ double red[2][4];
+    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double s = 0.0, ss = 0.0;
-    for (int b = lane; b < nblk; b += 64) {
-        s += part[((size_t)b * C + c) * 2 + 0];
-        ss += part[((size_t)b * C + c) * 2 + 1];
+    for (int b = threadIdx.x; b < nblk; b += 256) {
+        const double2 v = *reinterpret_cast<const double2*>(part + ((size_t)b * C + c) * 2);
+        s += v.x;
+        ss += v.y;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o, 64); ss += __shfl_down(ss, o, 64); }
-    if (lane != 0) return;
+    if (lane == 0) { red[0][wave] = s; red[1][wave] = ss; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    ss = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     const double mean = s / (double)count;
     double var = ss / (double)count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -1261,7 +1268,7 @@ int dmc_conv_nhwc_stats_final(const double* partials, int nblk, int C, long coun
                               dmc_stream_t stream) {
     if (!partials || !stats || !running_mean || !running_var || nblk <= 0 || C <= 0 || count <= 0)
         return fail(DMC_E_INVALID, "dmc_conv_nhwc_stats_final: bad argument");
-    conv_stats_final_kernel<<<(C + 3) / 4, 256, 0, (hipStream_t)stream>>>(partials, nblk, C, count, stats,
+    conv_stats_final_kernel<<<C, 256, 0, (hipStream_t)stream>>>(partials, nblk, C, count, stats,
                                                                           running_mean, running_var, eps, momentum);
     return check_launch("conv_stats_final");
 }
