@@ -26,6 +26,8 @@ SIGNATURES = {
     "dmc_gen_tiny_gbuf_bytes": (_Z, [_I, _I, _I]),
     "dmc_gen_tiny_partials_bytes": (_Z, [_I, _I, _I]),
     "dmc_gen_tiny_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dmc_gen_tiny_mse_partials_bytes": (_Z, []),
+    "dmc_gen_tiny_fwd_mse": (_I, [_P] * 10 + [_I, _I, _I, _I, _P]),
     "dmc_gen_tiny_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "dmc_flow_mse_partials_bytes": (_Z, []),
     "dmc_flow_mse_fwd": (_I, [_P, _P, _P, _P, _Z, _P]),

@@ -97,6 +97,8 @@ struct LayerArgs {
     const float* pk;      // packed parameters
     float* out;           // [N,2,H,W]                        (MODE 1)
     int H, W, add_mv;
+    const float* mse_flow;   // [N,2,H,W] flow target: the fused layer-4+5 kernel also reduces sum((out - flow)^2) ...
+    double* mse_part;        // ... into one double per workgroup (null: no loss)
 };
 
 template <int MODE, int K>
@@ -956,6 +958,7 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_l45_kernel(RingArgs ra) {
     const float bias4[2] = {a.pk[bf_off(4) + 0], a.pk[bf_off(4) + 1]};
     const float bias5[2] = {a.pk[bf_off(5) + 0], a.pk[bf_off(5) + 1]};
 
+    float mse_acc = 0.f;                              // this lane's sum of (out - flow)^2 over the workgroup's tiles
     int tile = t_begin, c = 0, slot = 0;
 #pragma unroll 1
     for (int q = 0; q < nitems; ++q) {
@@ -999,13 +1002,16 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_l45_kernel(RingArgs ra) {
         const size_t tile_pix = (size_t)ty0 * a.W;
         // the delta-mode mv values of the layer-5 epilogue: one batch of loads, issued now so that
         // their latency hides behind the layer-4 epilogue and the y4 K-steps
-        float mvv[F_S5][2];
+        float mvv[F_S5][2], mse_f[F_S5][2];
 #pragma unroll
         for (int s = 0; s < F_S5; ++s) {
             const int p = r * (F_S5 * 64) + s * 64 + lane;
             const size_t pp = p < pmax ? tile_pix + p : 0;
 #pragma unroll
-            for (int co = 0; co < 2; ++co) mvv[s][co] = a.add_mv ? a.mv[((size_t)n * 2 + co) * HW + pp] : 0.f;
+            for (int co = 0; co < 2; ++co) {
+                mvv[s][co] = a.add_mv ? a.mv[((size_t)n * 2 + co) * HW + pp] : 0.f;
+                mse_f[s][co] = a.mse_flow ? a.mse_flow[((size_t)n * 2 + co) * HW + pp] : 0.f;
+            }
         }
         // ---- layer 4: combine, bias, LeakyReLU; y4 -> HBM (owned rows) and LDS tile (10 rows, 0 outside) ----
         push_edges<F_S5, 3, 0>(acc, xchg4, r, lane);
@@ -1060,8 +1066,14 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_l45_kernel(RingArgs ra) {
             const int p = r * (F_S5 * 64) + s * 64 + lane;
             if (p < pmax) {
 #pragma unroll
-                for (int co = 0; co < 2; ++co)
-                    a.out[((size_t)n * 2 + co) * HW + tile_pix + p] = o5[s][co] + bias5[co] + mvv[s][co];
+                for (int co = 0; co < 2; ++co) {
+                    const float v = o5[s][co] + bias5[co] + mvv[s][co];
+                    a.out[((size_t)n * 2 + co) * HW + tile_pix + p] = v;
+                    if (a.mse_flow) {                                        // wave-uniform
+                        const float d = v - mse_f[s][co];
+                        mse_acc = fmaf(d, d, mse_acc);
+                    }
+                }
             }
         }
 #pragma unroll
@@ -1070,6 +1082,14 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_l45_kernel(RingArgs ra) {
             for (int t = 0; t < 3; ++t) acc[s][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         acc4e[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc4e[0][1] = acc4e[0][0];
         tile += t_step;
+    }
+    if (a.mse_part) {
+        // one partial per consumer wave (no barrier: the producer wave may already have left): fp32 per lane over
+        // the ~100 values it produced, fp64 across the lanes, fixed order -> deterministic
+        double d = (double)mse_acc;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o, 64);
+        if (lane == 0) a.mse_part[(size_t)blockIdx.x * P_CONS + r] = d;
     }
 }
 
@@ -1776,6 +1796,19 @@ __global__ void gen_bwd_weight_reduce_kernel(const float* __restrict__ partials,
         G.b[k][co] = s;
 }
 
+// loss = sum of the fused kernel's per-wave partials / numel (fixed order)
+__global__ __launch_bounds__(256) void gen_mse_final_kernel(const double* __restrict__ part, int n,
+                                                            float* __restrict__ loss_out, double numel) {
+    __shared__ double sm[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *loss_out = (float)((sm[0] + sm[1] + sm[2] + sm[3]) / numel);
+}
+
 int wgrad_groups(int N, int H, int W) {
     const long tiles = (long)N * ((H + WT_H - 1) / WT_H) * ((W + WT_W - 1) / WT_W);
     return (int)(tiles < WGRAD_MAX_GROUPS ? tiles : WGRAD_MAX_GROUPS);
@@ -1866,9 +1899,12 @@ size_t dmc_gen_tiny_partials_bytes(int N, int H, int W) {
     return (size_t)(wgrad_groups(N, H, W) + RED_CHUNKS) * WPART * sizeof(float);
 }
 
-int dmc_gen_tiny_fwd(const float* mv, const float* res, const float* const* w,
-                     const float* const* b, float* out, float* saved, float* workspace, int N,
-                     int H, int W, int add_mv_delta, dmc_stream_t stream) {
+// flow != null: also reduce sum((out - flow)^2) into mse_part (the fused kernel's epilogue); *fused_wgs receives
+// the number of workgroups that wrote partials, 0 if the shape took a path without the fused epilogue
+static int gen_tiny_fwd_impl(const float* mv, const float* res, const float* const* w,
+                             const float* const* b, float* out, float* saved, float* workspace, int N,
+                             int H, int W, int add_mv_delta, const float* flow, double* mse_part, int* fused_wgs,
+                             dmc_stream_t stream) {
     if (!mv || !res || !w || !b || !out || !saved || !workspace)
         return fail(DMC_E_INVALID, "dmc_gen_tiny_fwd: null pointer");
     if (N <= 0 || H <= 0 || W <= 0) return fail(DMC_E_INVALID, "dmc_gen_tiny_fwd: bad shape");
@@ -1878,6 +1914,8 @@ int dmc_gen_tiny_fwd(const float* mv, const float* res, const float* const* w,
     LayerArgs a;
     a.mv = mv; a.res = res; a.feat = saved; a.feat_out = saved; a.gout = nullptr; a.gbuf = nullptr;
     a.pk = workspace; a.out = out; a.H = H; a.W = W; a.add_mv = add_mv_delta;
+    a.mse_flow = nullptr; a.mse_part = nullptr;
+    if (fused_wgs) *fused_wgs = 0;
     const int step = frames_per_pass(N, H, W);
     for (int n0 = 0; n0 < N; n0 += step) {
         const int nn = (N - n0) < step ? (N - n0) : step;
@@ -1897,6 +1935,10 @@ int dmc_gen_tiny_fwd(const float* mv, const float* res, const float* const* w,
             ra.tiles_y = (H + PT_H - 1) / PT_H;
             ra.ntiles = ra.tiles_y * nn;
             const int wgs = ra.ntiles < num_cus() ? ra.ntiles : num_cus();
+            if (flow && mse_part && step >= N) {              // (one pass over all frames: one partial set)
+                ra.a.mse_flow = flow; ra.a.mse_part = mse_part;
+                if (fused_wgs) *fused_wgs = wgs;
+            }
             gen_l45_kernel<<<wgs, LTHREADS, 0, s>>>(ra);
             if ((rc = check_launch("gen_l45"))) return rc;
         } else {
@@ -1905,6 +1947,34 @@ int dmc_gen_tiny_fwd(const float* mv, const float* res, const float* const* w,
         }
     }
     return DMC_OK;
+}
+
+int dmc_gen_tiny_fwd(const float* mv, const float* res, const float* const* w,
+                     const float* const* b, float* out, float* saved, float* workspace, int N,
+                     int H, int W, int add_mv_delta, dmc_stream_t stream) {
+    return gen_tiny_fwd_impl(mv, res, w, b, out, saved, workspace, N, H, W, add_mv_delta, nullptr, nullptr, nullptr,
+                             stream);
+}
+
+size_t dmc_gen_tiny_mse_partials_bytes(void) {
+    const size_t fused = (size_t)num_cus() * P_CONS * sizeof(double), plain = dmc_flow_mse_partials_bytes();
+    return fused > plain ? fused : plain;
+}
+
+int dmc_gen_tiny_fwd_mse(const float* mv, const float* res, const float* const* w, const float* const* b,
+                         const float* flow, float* out, float* saved, float* workspace, float* loss_out,
+                         void* mse_partials, int N, int H, int W, int add_mv_delta, dmc_stream_t stream) {
+    if (!flow || !loss_out || !mse_partials) return fail(DMC_E_INVALID, "dmc_gen_tiny_fwd_mse: null pointer");
+    int wgs = 0;
+    int rc = gen_tiny_fwd_impl(mv, res, w, b, out, saved, workspace, N, H, W, add_mv_delta, flow,
+                               static_cast<double*>(mse_partials), &wgs, stream);
+    if (rc) return rc;
+    const size_t numel = (size_t)N * 2 * H * W;
+    if (wgs == 0)       // this shape took a path without the fused epilogue: the streaming reduction instead
+        return dmc_flow_mse_fwd(out, flow, loss_out, static_cast<float*>(mse_partials), numel, stream);
+    gen_mse_final_kernel<<<1, 256, 0, (hipStream_t)stream>>>(static_cast<const double*>(mse_partials), wgs * P_CONS,
+                                                            loss_out, (double)numel);
+    return check_launch("gen_mse_final");
 }
 
 int dmc_gen_tiny_bwd(const float* mv, const float* res, const float* const* w, const float* saved,
@@ -1925,6 +1995,7 @@ int dmc_gen_tiny_bwd(const float* mv, const float* res, const float* const* w, c
     LayerArgs la;
     la.mv = mv; la.res = res; la.feat = saved; la.feat_out = nullptr; la.gout = grad_out; la.gbuf = gbuf;
     la.pk = workspace; la.out = nullptr; la.H = H; la.W = W; la.add_mv = 0;
+    la.mse_flow = nullptr; la.mse_part = nullptr;
     const int step = frames_per_pass(N, H, W);
     for (int n0 = 0; n0 < N; n0 += step) {
         const int nn = (N - n0) < step ? (N - n0) : step;

@@ -72,6 +72,11 @@ class EstimatorDenseNetTiny(DenseEstimatorBase):
         ws, bs = self._params()
         return ops.gen_tiny(mv, res, ws, bs, add_mv)
 
+    def forward_mv_res_mse(self, mv, res, flow, add_mv=False):
+        """(gen_flow, nn.MSELoss()(gen_flow, flow)): the loss is reduced in the forward's last kernel."""
+        ws, bs = self._params()
+        return ops.gen_tiny_mse(mv, res, flow, ws, bs, add_mv)
+
     def forward(self, x):
         return self.forward_mv_res(x[:, :2].contiguous(), x[:, 2:].contiguous(), False)
 
@@ -349,6 +354,22 @@ class Model(nn.Module):
                 d_in = torch.cat((gen_flow, input_flow), 0)
             outputs = (self.base_model(gen_flow), self.discriminator(d_in), gen_flow)
         return outputs + ((att_flow,) if self.att == 1 else ())
+
+    def forward_with_flow_mse(self, input_mv, input_residual, input_flow):
+        """dmcnet variant only: ``forward(input_mv, input_residual)`` plus the reconstruction loss the reference
+        computes right after it (``criterion_mse(gen_flow, input_flow)``, code/dmcnet/train.py:236,245) as a third
+        output, reduced inside the generator's last kernel when the generator is the HIP DenseNetTiny at full
+        resolution; any other configuration computes it with ops.flow_mse afterwards.  Same values either way."""
+        if self.arch_d is not None or self.att == 1:
+            raise TypeError("forward_with_flow_mse serves the dmcnet variant without attention")
+        flow = input_flow.reshape((-1,) + tuple(input_flow.shape[-3:]))
+        if isinstance(self.gen_flow_model, EstimatorDenseNetTiny) and self.gen_flow_ds_factor == 0:
+            mv = input_mv.reshape((-1,) + tuple(input_mv.shape[-3:]))
+            res = input_residual.reshape((-1,) + tuple(input_residual.shape[-3:]))
+            gen_flow, loss_mse = self.gen_flow_model.forward_mv_res_mse(mv, res, flow, add_mv=self.gen_flow_or_delta == 1)
+            return self.base_model(gen_flow.detach()), gen_flow, loss_mse
+        base_out, gen_flow = self.forward(input_mv, input_residual)
+        return base_out, gen_flow, ops.flow_mse(gen_flow, flow)
 
     @property
     def crop_size(self):

@@ -131,6 +131,72 @@ class _GenTiny(torch.autograd.Function):
         return (None, None, None) + tuple(dws) + tuple(dbs)
 
 
+class _GenTinyMSE(torch.autograd.Function):
+    """(gen_flow, MSELoss(gen_flow, flow)) with the loss reduced in the epilogue of the kernel that writes
+    gen_flow: EstimatorDenseNetTiny(cat(mv, res)) [+ mv] (code/dmcnet/model.py:187-194,341-346) followed by
+    ``criterion_mse(gen_flow, input_flow)`` (code/dmcnet/train.py:167,245).  Backward = the flow-MSE gradient
+    (plus whatever else reaches gen_flow) through the generator's backward, as with the separate ops."""
+
+    @staticmethod
+    def forward(ctx, mv, res, flow, add_mv, *params):
+        lib = _lib.load()
+        _need_cuda(mv, res, flow, *params)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise NotImplementedError("no gradients w.r.t. the MV / residual / flow inputs")
+        mv, res, flow = mv.contiguous(), res.contiguous(), flow.contiguous()
+        ws, bs = [p.contiguous() for p in params[:6]], [p.contiguous() for p in params[6:]]
+        n, _, h, w = mv.shape
+        if tuple(flow.shape) != (n, 2, h, w):
+            raise ValueError("flow target %s does not match the generator output %s" % (tuple(flow.shape), (n, 2, h, w)))
+        out = torch.empty((n, 2, h, w), dtype=torch.float32, device=mv.device)
+        loss = torch.empty((), dtype=torch.float32, device=mv.device)
+        saved = _floats(lib.dmc_gen_tiny_saved_bytes(n, h, w), mv.device)
+        work = _floats(lib.dmc_gen_tiny_workspace_bytes(), mv.device)
+        part = _floats(lib.dmc_gen_tiny_mse_partials_bytes(), mv.device)
+        with _span("gen_tiny_fwd"):
+            _lib.check(lib.dmc_gen_tiny_fwd_mse(_lib.ptr(mv), _lib.ptr(res), _lib.ptr_array(ws), _lib.ptr_array(bs),
+                                                _lib.ptr(flow), _lib.ptr(out), _lib.ptr(saved), _lib.ptr(work),
+                                                _lib.ptr(loss), _lib.ptr(part), n, h, w, int(add_mv), _stream()),
+                       "dmc_gen_tiny_fwd_mse")
+        ctx.save_for_backward(mv, res, saved, out, flow, *ws)
+        ctx.bias_like = [(b.shape, b.dtype) for b in bs]
+        ctx.set_materialize_grads(False)
+        return out, loss
+
+    @staticmethod
+    def backward(ctx, grad_out, grad_loss):
+        lib = _lib.load()
+        mv, res, saved, out, flow = ctx.saved_tensors[:5]
+        ws = list(ctx.saved_tensors[5:])
+        n, _, h, w = mv.shape
+        g = None
+        if grad_loss is not None:
+            g = torch.empty_like(out)
+            with _span("flow_mse_bwd"):
+                _lib.check(lib.dmc_flow_mse_bwd(_lib.ptr(out), _lib.ptr(flow), _lib.ptr(grad_loss.contiguous().float()),
+                                                _lib.ptr(g), out.numel(), _stream()), "dmc_flow_mse_bwd")
+        if grad_out is not None:
+            g = grad_out.contiguous() if g is None else g.add_(grad_out)
+        if g is None:
+            return (None,) * (4 + 12)
+        dws = [torch.empty_like(x) for x in ws]
+        dbs = [torch.empty(s, dtype=d, device=mv.device) for s, d in ctx.bias_like]
+        gbuf = _floats(lib.dmc_gen_tiny_gbuf_bytes(n, h, w), mv.device)
+        partials = _floats(lib.dmc_gen_tiny_partials_bytes(n, h, w), mv.device)
+        work = _floats(lib.dmc_gen_tiny_workspace_bytes(), mv.device)
+        with _span("gen_tiny_bwd"):
+            _lib.check(lib.dmc_gen_tiny_bwd(_lib.ptr(mv), _lib.ptr(res), _lib.ptr_array(ws), _lib.ptr(saved),
+                                            _lib.ptr(g), _lib.ptr_array(dws), _lib.ptr_array(dbs), _lib.ptr(gbuf),
+                                            _lib.ptr(partials), _lib.ptr(work), n, h, w, _stream()),
+                       "dmc_gen_tiny_bwd")
+        return (None, None, None, None) + tuple(dws) + tuple(dbs)
+
+
+def gen_tiny_mse(mv, res, flow, weights, biases, add_mv=False):
+    """(gen_flow [N,2,H,W], mean((gen_flow - flow)^2)) in one forward launch sequence (see _GenTinyMSE)."""
+    return _GenTinyMSE.apply(mv, res, flow, bool(add_mv), *weights, *biases)
+
+
 def gen_tiny(mv, res, weights, biases, add_mv=False):
     """mv [N,2,H,W], res [N,3,H,W], 6 weights + 6 biases (reference layout) -> [N,2,H,W]."""
     return _GenTiny.apply(mv, res, bool(add_mv), *weights, *biases)

@@ -190,11 +190,16 @@ class DmcnetTrainStep(object):
         flow = input_flow.reshape((-1,) + tuple(input_mv.shape[-3:]))
         self.optimizer_cls.zero_grad(set_to_none=True)
         self.optimizer_gf.zero_grad(set_to_none=True)
-        outs = self.model(input_mv, input_residual)
-        output, gen_flow = outs[0], outs[1]
-        att_flow = outs[2] if self.att == 1 else None
-        loss_cls, consensus = ops.consensus_ce(output, target, self.num_segments)
-        loss_mse = flow_loss(self.loss_mse, gen_flow, flow, att_flow)
+        if self.loss_mse == "MSELoss" and self.att == 0 and hasattr(self.model, "forward_with_flow_mse"):
+            # the MSE is reduced in the epilogue of the kernel that writes gen_flow (no re-read of it)
+            output, gen_flow, loss_mse = self.model.forward_with_flow_mse(input_mv, input_residual, flow)
+            loss_cls, consensus = ops.consensus_ce(output, target, self.num_segments)
+        else:
+            outs = self.model(input_mv, input_residual)
+            output, gen_flow = outs[0], outs[1]
+            att_flow = outs[2] if self.att == 1 else None
+            loss_cls, consensus = ops.consensus_ce(output, target, self.num_segments)
+            loss_mse = flow_loss(self.loss_mse, gen_flow, flow, att_flow)
         loss = loss_cls * self.lr_cls + loss_mse * self.lr_mse
         if self.reducer is not None:
             self.reducer.begin()

@@ -83,6 +83,19 @@ int dmc_gen_tiny_fwd(const float* mv, const float* res, const float* const* w,
                      const float* const* b, float* out, float* saved, float* workspace, int N,
                      int H, int W, int add_mv_delta, dmc_stream_t stream);
 
+/*
+ * Forward + flow-reconstruction loss in one go: as dmc_gen_tiny_fwd, and additionally
+ * *loss_out = mean((out - flow)^2) = nn.MSELoss()(gen_flow, input_flow), code/dmcnet/train.py:167,245,
+ * reduced in the epilogue of the kernel that produces `out` (the separate loss kernel would read `out`
+ * back from HBM).  flow [N,2,H,W]; loss_out: one float on the device; mse_partials: workspace of
+ * dmc_gen_tiny_mse_partials_bytes().  Shapes that do not take the fused kernel (W % 4 != 0, W > 224)
+ * fall back to dmc_flow_mse_fwd internally.  The gradient is dmc_flow_mse_bwd's, unchanged.
+ */
+size_t dmc_gen_tiny_mse_partials_bytes(void);
+int dmc_gen_tiny_fwd_mse(const float* mv, const float* res, const float* const* w, const float* const* b,
+                         const float* flow, float* out, float* saved, float* workspace, float* loss_out,
+                         void* mse_partials, int N, int H, int W, int add_mv_delta, dmc_stream_t stream);
+
 /* Bytes of the gradient-feature buffer (`gbuf`) and of the per-workgroup weight-gradient
  * partials (`partials`) that the backward needs. */
 size_t dmc_gen_tiny_gbuf_bytes(int N, int H, int W);

@@ -151,6 +151,34 @@ def test_flow_mse(numel):
     assert rel_err(ag.grad, ao.grad) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(6, 224, 224), (3, 40, 40), (2, 19, 37), (120, 224, 224)])
+def test_generator_fused_flow_mse_equals_separate_ops(shape):
+    """ops.gen_tiny_mse (loss reduced in the forward's last kernel) against gen_tiny + flow_mse: identical
+    gen_flow, the same loss to fp32 rounding of a different (both fixed) summation order, the same parameter
+    gradients for loss-only, output-only and mixed upstream gradients; W % 4 != 0 takes the internal fallback."""
+    n, h, w = shape
+    torch.manual_seed(5)
+    gen = dmcnet_amd.model.EstimatorDenseNetTiny(5).to(DEV)
+    mv, res, flow = rnd(301, (n, 2, h, w)).to(DEV), rnd(302, (n, 3, h, w)).to(DEV), rnd(303, (n, 2, h, w)).to(DEV)
+    r = rnd(304, (n, 2, h, w)).to(DEV)
+    params = list(gen.parameters())
+    for lw, ow in ((10.0, 0.0), (0.0, 1.0), (10.0, 0.5)):
+        gen.zero_grad()
+        y0 = gen.forward_mv_res(mv, res, True)
+        l0 = ops.flow_mse(y0, flow)
+        (lw * l0 + ow * (y0 * r).sum()).backward()
+        g0 = [p.grad.clone() for p in params]
+        gen.zero_grad()
+        y1, l1 = gen.forward_mv_res_mse(mv, res, flow, True)
+        (lw * l1 + ow * (y1 * r).sum()).backward()
+        assert torch.equal(y0, y1)
+        assert abs(float(l0) - float(l1)) <= 2e-6 * abs(float(l0))
+        for a, b in zip([p.grad for p in params], g0):
+            assert rel_err(a, b) < 1e-6
+    y2, l2 = gen.forward_mv_res_mse(mv, res, flow, True)
+    assert torch.equal(y1, y2) and float(l1) == float(l2)          # deterministic
+
+
 @pytest.mark.parametrize("B,S,C", [(40, 3, 51), (2, 3, 51), (1, 25, 101), (5, 1, 2), (17, 3, 400)])
 def test_consensus_ce(B, S, C):
     x = rnd(5, (B * S, C)) * 3
