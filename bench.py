@@ -228,6 +228,10 @@ def main():
                     help="1 = the classifier's 3x3 / 1x1 convolutions on this package's matrix-core NHWC kernels "
                          "(fused conv -> bn op); 0 (default) = PyTorch-ROCm (MIOpen) convolutions, the faster of "
                          "the two so far")
+    ap.add_argument("--conv-arith", type=int, default=0,
+                    help="arithmetic of this package's NHWC convolutions (option conv_arith): 0 = fp32 MFMA, 1 = bf16x3 "
+                         "(fp32 operands as three bf16 slices, six bf16 MFMAs per product block, fp32 accumulate: "
+                         "fp32-level error at a multiple of the fp32 instruction's rate)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -251,6 +255,7 @@ def main():
     import dmcnet_amd
     from dmcnet_amd import dataset, ddp, miopen, ops, resnet, train
     resnet.OWN_CONV = bool(args.own_conv)
+    dmcnet_amd._lib.check(dmcnet_amd._lib.load().dmc_set_option(b"conv_arith", int(args.conv_arith)), "dmc_set_option")
     if args.miopen_find:
         miopen.enable_find()          # before the first convolution of the process
     if args.config == "i3d":

@@ -28,6 +28,7 @@
 // (sum, sum of squares) partials of the result for the BatchNorm that follows (fp64 across lanes,
 // waves and workgroups, fixed order).
 #include "dmc_common.h"
+#include <type_traits>
 
 using namespace dmc;
 
@@ -291,6 +292,128 @@ __device__ __forceinline__ void dma16_v(const void* src, unsigned lds_byte_addr)
                  :: "v"((unsigned long long)src), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)) : "memory");
 }
 
+// Epilogue shared by the implicit-GEMM kernels on 32 x 32 tiles: + bias, LeakyReLU(0.2), Dropout2d keep mask, the
+// store, and the per-channel (sum, sum of squares) partials of the stored values for the BatchNorm that follows.
+template <int BM, int BN, int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void conv_tile_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], void* lds, int m0, int co0,
+                                                   int wm, int wn, int l31, int khalf, int tid) {
+    const int prow0 = wm * (BM / WM);
+    // ---- lane holds pixel column l31 of tile i; channels 8 gq + 4 khalf + e of tile j in acc[4 gq + e] ----
+    // one channel tile j at a time, so that only 2 x 16 statistics accumulators are live next to acc
+    long opix[TM];
+    int nimg[TM];
+    bool mok[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + prow0 + 32 * i + l31;
+        mok[i] = m < a.M;
+        nimg[i] = 0; opix[i] = 0;
+        if (mok[i]) {
+            const int n = m / (a.OHs * a.OWs);
+            const int rem = m - n * (a.OHs * a.OWs);
+            const int yy = rem / a.OWs, xx = rem - yy * a.OWs;
+            nimg[i] = n;
+            opix[i] = ((long)n * a.OH + (a.oy0 + yy * a.ostep)) * a.OW + (a.ox0 + xx * a.ostep);
+        }
+    }
+    double* red = reinterpret_cast<double*>(lds);             // [WM][BN][2]
+    if (a.stat_part) __syncthreads();                         // every wave is done with the operand tiles
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        float s1[16], s2[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int co = co0 + wn * (BN / WN) + 32 * j + 8 * gq + 4 * khalf;
+                if (co >= a.Cout) continue;
+                float v[4] = {acc[i][j][4 * gq], acc[i][j][4 * gq + 1], acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]};
+                if (a.bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(a.bias + co);
+                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                }
+                if (a.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+                }
+                if (a.keep && mok[i]) {
+                    const float4 kv = *reinterpret_cast<const float4*>(a.keep + (long)nimg[i] * a.Cout + co);
+                    v[0] *= kv.x; v[1] *= kv.y; v[2] *= kv.z; v[3] *= kv.w;
+                }
+                if (mok[i]) {
+                    *reinterpret_cast<float4*>(a.y + opix[i] * a.Cout + co) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { s1[4 * gq + e] += v[e]; s2[4 * gq + e] += v[e] * v[e]; }
+                }
+            }
+        if (a.stat_part) {
+            // per-channel sums of this workgroup's tile: 32 pixel lanes -> waves (WM) -> one store per channel
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                double d1 = (double)s1[e], d2 = (double)s2[e];
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) {
+                    d1 += __shfl_xor(d1, o, 64);
+                    d2 += __shfl_xor(d2, o, 64);
+                }
+                if (l31 == 0) {
+                    const int c = wn * (BN / WN) + 32 * j + 8 * (e >> 2) + 4 * khalf + (e & 3);
+                    red[(wm * BN + c) * 2 + 0] = d1;
+                    red[(wm * BN + c) * 2 + 1] = d2;
+                }
+            }
+        }
+    }
+    if (a.stat_part) {
+        __syncthreads();
+        for (int c = tid; c < BN; c += WM * WN * 64)
+            if (co0 + c < a.Cout) {
+                double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) { d1 += red[(w * BN + c) * 2 + 0]; d2 += red[(w * BN + c) * 2 + 1]; }
+                double* dst = a.stat_part + ((size_t)blockIdx.x * a.Cout + co0 + c) * 2;
+                dst[0] = d1; dst[1] = d2;
+            }
+    }
+}
+
+// ---- fp32 products from bf16 matrix-core instructions ("bf16x3") -----------------------------------
+// An fp32 value is the exact sum of three bf16 values: s0 = its upper 16 bits (sign, exponent, 7 mantissa bits:
+// 8 significant bits, truncated), s1 = the upper 16 bits of the (exact) remainder, s2 = the second remainder,
+// which has at most 8 significant bits left and is therefore a bf16 value itself.  The product of two such
+// sums is formed from six of the nine slice products, (0,0) (0,1) (1,0) (0,2) (2,0) (1,1) -- each one exact in
+// the fp32 accumulator's input precision -- and the three omitted ones are below 2^-23 of |a||b|, the size of
+// one fp32 rounding of the product.  v_mfma_f32_32x32x16_bf16 retires 16 k-values per 32 cycles where
+// v_mfma_f32_32x32x2_f32 retires 2 per 64: six of them per 16 k-values are 2.67x the fp32 instruction's rate.
+// (Inf inputs become NaN, values below 2^-110 lose their low slices: neither occurs in a finite training run.)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct Split3 { u32x4 s[3]; };
+__device__ __forceinline__ Split3 split_bf16x3(const f32x4& lo, const f32x4& hi) {
+    const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    unsigned u0[8], u1[8], u2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        u0[e] = __float_as_uint(v[e]);
+        const float r1 = v[e] - __uint_as_float(u0[e] & 0xffff0000u);
+        u1[e] = __float_as_uint(r1);
+        u2[e] = __float_as_uint(r1 - __uint_as_float(u1[e] & 0xffff0000u));
+    }
+    Split3 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {                         // (upper half of value 2e+1, upper half of value 2e)
+        r.s[0][e] = __builtin_amdgcn_perm(u0[2 * e + 1], u0[2 * e], 0x07060302u);
+        r.s[1][e] = __builtin_amdgcn_perm(u1[2 * e + 1], u1[2 * e], 0x07060302u);
+        r.s[2][e] = __builtin_amdgcn_perm(u2[2 * e + 1], u2[2 * e], 0x07060302u);
+    }
+    return r;
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64) void conv2_kernel(ConvArgs a) {
     constexpr int NW = WM * WN;                            // waves: 4, or 8 (smaller wave tiles, twice the waves per SIMD)
@@ -446,77 +569,245 @@ __global__ __launch_bounds__(WM * WN * 64) void conv2_kernel(ConvArgs a) {
         __builtin_amdgcn_s_barrier();                              // ... everyone's; and nobody reads buf any more
     }
 
-    // ---- epilogue: lane holds pixel column l31 of tile i; channels 8 gq + 4 khalf + e of tile j in acc[4 gq + e] ----
-    float s1[TN][16], s2[TN][16];
+    conv_tile_epilogue<BM, BN, WM, WN, TM, TN>(a, acc, lds, m0, co0, wm, wn, l31, khalf, tid);
+}
+
+// ------------------------------------------------------------------------------------------
+// Third generation: the same implicit GEMM in bf16x3 arithmetic (above) for Cin % 32 == 0, Cout % 64 == 0.
+//   * weights arrive already split (conv_split_w_kernel: three bf16 slices [3][Cout][KK][Cin], a few microseconds per
+//     call), so only the activation fragments are split in registers (11 VALU instructions per pair of values,
+//     overlapped with the matrix pipe); activations stay fp32 in HBM and LDS: nothing upstream changes;
+//   * K-step = one tap x 32 channels = two k-blocks of 16; per buffer BM pixel rows of 128 bytes (slot swizzle as in
+//     conv2) + 3 x BN weight rows of 64 bytes (four 16-byte slots, slot = quad ^ ((row >> 2) & 3): rows r, r+4, r+8,
+//     r+12 share their banks and take different slots, so a ds_read_b128 of 16 rows is conflict-free);
+//   * the loop is software-pipelined across k-blocks AND steps: while the six-MFMA groups of one k-block run, the
+//     next block's fragments are read and split; the step's only barrier stands in front of its LAST k-block, where
+//     this wave's transfers of step t+1 were issued a whole step earlier (nobody waits for memory there), and
+//     the first fragments of step t+1 are read from the other buffer during that last block; the transfers of
+//     step t+2 go into the buffer the barrier just freed.
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void conv3_kernel(ConvArgs a) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static_assert(BM % (32 * WM) == 0 && BN % (32 * WN) == 0 && BM % (8 * NW) == 0 && BN % 16 == 0, "tile layout");
+    constexpr int NDP = BM / 8 / NW;                       // pixel transfers per wave and step (8 rows of 128 B)
+    constexpr int WD = 3 * BN / 16;                        // weight transfers per step (16 rows of 64 B), whole workgroup
+    constexpr int NDW = (WD + NW - 1) / NW;
+    constexpr int PIXB = BM * 128, BUF = PIXB + 3 * BN * 64;
+    extern __shared__ __attribute__((aligned(1024))) float lds3[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int m0 = blockIdx.x * BM, co0 = blockIdx.y * BN;
+    const unsigned lds0 = lds_addr_of(lds3);
+    const unsigned long long zeros = (unsigned long long)g_zeros;
+
+    // ---- transfers ----
+    const int rr = lane >> 3, sl = lane & 7;
+    unsigned long long p_addr[NDP];
+    unsigned p_mask[NDP];
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { s1[j][e] = 0.f; s2[j][e] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + prow0 + 32 * i + l31;
-        const bool mok = m < a.M;
-        int n = 0;
-        long opix = 0;
-        if (mok) {
-            n = m / (a.OHs * a.OWs);
-            const int rem = m - n * (a.OHs * a.OWs);
+    for (int j = 0; j < NDP; ++j) {
+        const int row = 8 * (wave + NW * j) + rr;
+        const int q = sl ^ ((row >> 1) & 7);
+        const int m = m0 + row;
+        p_mask[j] = 0; p_addr[j] = zeros;
+        if (m < a.M) {
+            const int n = m / (a.OHs * a.OWs), rem = m - n * (a.OHs * a.OWs);
             const int yy = rem / a.OWs, xx = rem - yy * a.OWs;
-            opix = ((long)n * a.OH + (a.oy0 + yy * a.ostep)) * a.OW + (a.ox0 + xx * a.ostep);
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int co = co0 + wn * (BN / WN) + 32 * j + 8 * gq + 4 * khalf;
-                if (co >= a.Cout) continue;
-                float v[4] = {acc[i][j][4 * gq], acc[i][j][4 * gq + 1], acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]};
-                if (a.bias) {
-                    const float4 bv = *reinterpret_cast<const float4*>(a.bias + co);
-                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-                }
-                if (a.act == 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
-                }
-                if (a.keep && mok) {
-                    const float4 kv = *reinterpret_cast<const float4*>(a.keep + (long)n * a.Cout + co);
-                    v[0] *= kv.x; v[1] *= kv.y; v[2] *= kv.z; v[3] *= kv.w;
-                }
-                if (mok) {
-                    *reinterpret_cast<float4*>(a.y + opix * a.Cout + co) = make_float4(v[0], v[1], v[2], v[3]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { s1[j][4 * gq + e] += v[e]; s2[j][4 * gq + e] += v[e] * v[e]; }
-                }
+            const int iy0 = yy * a.stride, ix0 = xx * a.stride;
+            p_addr[j] = (unsigned long long)a.x + ((((long)n * a.H + iy0) * a.W + ix0) * a.Cin + 4 * q) * 4;
+            for (int t = 0; t < a.ntaps; ++t) {
+                const int iy = iy0 + (int)((a.tap_dy >> (4 * t)) & 15) - 8, ix = ix0 + (int)((a.tap_dx >> (4 * t)) & 15) - 8;
+                if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) p_mask[j] |= 1u << t;
             }
+        }
     }
-    if (a.stat_part) {
-        // per-channel sums of this workgroup's tile: 32 pixel lanes -> waves (WM) -> one store per channel
-        double* red = reinterpret_cast<double*>(lds);         // [WM][BN][2]; the operand tiles are dead (last barrier)
+    // weight transfer e moves rows 16 e .. 16 e + 15 of the stacked [3][BN] tile: lane -> (row 16 e + lane / 4, slot lane % 4)
+    unsigned long long w_addr[NDW];
+#pragma unroll
+    for (int j = 0; j < NDW; ++j) {
+        const int R = 16 * (wave + NW * j) + (lane >> 2);
+        const int slice = R / BN, c = R - slice * BN;
+        const int q = (lane & 3) ^ ((c >> 2) & 3);
+        w_addr[j] = (unsigned long long)a.w + (((long)(slice < 3 ? slice : 0) * a.Cout + co0 + c) * a.KK * a.Cin + 8 * q) * 2;
+    }
+
+    int tap_n = 0, ci_n = 0;
+    long toff = 0, woff = 0;
+    auto set_step = [&]() {
+        const int dy = (int)((a.tap_dy >> (4 * tap_n)) & 15) - 8, dx = (int)((a.tap_dx >> (4 * tap_n)) & 15) - 8;
+        const int tw = (int)((a.tap_w >> (4 * tap_n)) & 15);
+        toff = (((long)dy * a.W + dx) * a.Cin + ci_n) * 4;
+        woff = ((long)tw * a.Cin + ci_n) * 2;
+    };
+    auto advance = [&]() {
+        ci_n += 32;
+        if (ci_n == a.Cin) { ci_n = 0; ++tap_n; }
+    };
+    auto issue_all = [&](int buf) {
+        const unsigned base = lds0 + buf * BUF;
+#pragma unroll
+        for (int j = 0; j < NDP; ++j) {
+            const bool ok = (p_mask[j] >> tap_n) & 1;
+            const unsigned long long src = ok ? p_addr[j] + (unsigned long long)toff : zeros;
+            dma16_v(reinterpret_cast<const void*>(src), base + (wave + NW * j) * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < NDW; ++j)
+            if (WD % NW == 0 || wave + NW * j < WD)
+                dma16_v(reinterpret_cast<const void*>(w_addr[j] + (unsigned long long)woff), base + PIXB + (wave + NW * j) * 1024);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                double d1 = (double)s1[j][e], d2 = (double)s2[j][e];
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // ---- fragment addressing (byte offsets inside a buffer) ----
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int prow0 = wm * (BM / WM), crow0 = wn * (BN / WN);
+    int xoff[2][2], wfo[2];                                // [k-block][quad of the pair] / [k-block]
 #pragma unroll
-                for (int o = 1; o < 32; o <<= 1) {
-                    d1 += __shfl_xor(d1, o, 64);
-                    d2 += __shfl_xor(d2, o, 64);
-                }
-                if (l31 == 0) {
-                    const int c = wn * (BN / WN) + 32 * j + 8 * (e >> 2) + 4 * khalf + (e & 3);
-                    red[(wm * BN + c) * 2 + 0] = d1;
-                    red[(wm * BN + c) * 2 + 1] = d2;
-                }
-            }
-        __syncthreads();
-        if (tid < BN && co0 + tid < a.Cout) {
-            double d1 = 0.0, d2 = 0.0;
+    for (int kb = 0; kb < 2; ++kb) {
+        xoff[kb][0] = (prow0 + l31) * 128 + (((4 * kb + 2 * khalf) ^ ((l31 >> 1) & 7)) << 4);
+        xoff[kb][1] = (prow0 + l31) * 128 + (((4 * kb + 2 * khalf + 1) ^ ((l31 >> 1) & 7)) << 4);
+        wfo[kb] = PIXB + (crow0 + l31) * 64 + (((2 * kb + khalf) ^ ((l31 >> 2) & 3)) << 4);
+    }
+    // fragment reads: per-lane byte offsets (swizzled slots) + compile-time buffer / tile offsets, so that every
+    // ds_read_b128 is "lane address + immediate"
+    typedef const __attribute__((address_space(3))) char* lds_cptr;
+    lds_cptr const L = (lds_cptr)lds3;
+    struct Raw { f32x4 lo[TM], hi[TM]; };
+    auto load_raw = [&](auto bufc, auto kbc, Raw& r) {
+        constexpr int buf = decltype(bufc)::value, kb = decltype(kbc)::value;
 #pragma unroll
-            for (int w = 0; w < WM; ++w) { d1 += red[(w * BN + tid) * 2 + 0]; d2 += red[(w * BN + tid) * 2 + 1]; }
-            double* dst = a.stat_part + ((size_t)blockIdx.x * a.Cout + co0 + tid) * 2;
-            dst[0] = d1; dst[1] = d2;
+        for (int i = 0; i < TM; ++i) {
+            r.lo[i] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(L + xoff[kb][0] + (buf * BUF + i * 32 * 128));
+            r.hi[i] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(L + xoff[kb][1] + (buf * BUF + i * 32 * 128));
         }
+    };
+    u32x4 wf[TN][3];                                       // weight fragments: ONE set; a slice is re-read for the next
+                                                           // k-block right after its last MFMA of this one
+    auto load_w = [&](auto bufc, auto kbc, int sidx) {
+        constexpr int buf = decltype(bufc)::value, kb = decltype(kbc)::value;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            wf[j][sidx] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(L + wfo[kb] + (buf * BUF + (sidx * BN + 32 * j) * 64));
+    };
+    auto split_all = [&](const Raw& r, Split3 (&xs)[TM]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xs[i] = split_bf16x3(r.lo[i], r.hi[i]);
+    };
+    auto mfma_terms = [&](const Split3 (&xs)[TM], int wsl, int xlo, int xhi) {   // weight slice wsl x input slices xhi .. xlo
+#pragma unroll
+        for (int xsl = xhi; xsl >= xlo; --xsl)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(wf[j][wsl], xs[i].s[xsl], acc[i][j]);
+    };
+    // the six slice products of a k-block, grouped by weight slice: (0,2) (0,1) (0,0) | (1,1) (1,0) | (2,0); each weight
+    // slice of the next block is read right behind its last product of this one.  The split of the NEXT block's
+    // activations (11 VALU instructions per value pair) is spread evenly behind this block's MFMAs by
+    // sched_group_barriers -- one MFMA (32 cycles of the matrix pipe), then a few VALU instructions (4 cycles of
+    // issue each): bunched up, as the compiler schedules them on its own, a wave issues VALU work for longer than
+    // its MFMAs last and the pipe drains; `skip` leading MFMAs carry no VALU work (they cover the LDS latency of
+    // fragments read just in front of the block)
+    constexpr int NMF = 6 * TM * TN, NVALU = 44 * TM;
+    auto block = [&](const Split3 (&xs)[TM], bool have_next, auto nbuf, auto nkb, const Raw& r, Split3 (&xn)[TM], auto skipc) {
+        constexpr int skip = decltype(skipc)::value;
+        constexpr int per = (NVALU + (NMF - skip) - 1) / (NMF - skip);
+        mfma_terms(xs, 0, 0, 2);
+        if (have_next) load_w(nbuf, nkb, 0);
+        if (have_next) split_all(r, xn);
+        mfma_terms(xs, 1, 0, 1);
+        if (have_next) load_w(nbuf, nkb, 1);
+        mfma_terms(xs, 2, 0, 0);
+        if (have_next) load_w(nbuf, nkb, 2);
+        if (have_next) {                                   // materialise the slices HERE (they are used beyond the barrier
+#pragma unroll                                             // and would be sunk to their use otherwise)
+            for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(xn[i].s[0]), "+v"(xn[i].s[1]), "+v"(xn[i].s[2]));
+#pragma unroll
+            for (int k = 0; k < NMF; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (k >= skip) __builtin_amdgcn_sched_group_barrier(0x002, per, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using ISKIP = std::integral_constant<int, (NMF >= 12 ? 4 : 2)>;
+
+    const int T_steps = a.ntaps * (a.Cin >> 5);
+    const bool dma_on = !(a.ablate & 1);
+    if (T_steps == 0) {                                    // a parity class of a strided data gradient without taps: zeros
+        conv_tile_epilogue<BM, BN, WM, WN, TM, TN>(a, acc, lds3, m0, co0, wm, wn, l31, khalf, tid);
+        return;
+    }
+    Raw raw0, raw1;                                        // fp32 fragments of the next step's two k-blocks
+    Split3 x0[TM], x1[TM];
+    set_step(); issue_all(0); advance();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    load_raw(I0{}, I0{}, raw0);
+    load_raw(I0{}, I1{}, raw1);
+    load_w(I0{}, I0{}, 0); load_w(I0{}, I0{}, 1); load_w(I0{}, I0{}, 2);
+    if (T_steps > 1) { set_step(); issue_all(1); advance(); }
+    split_all(raw0, x0);
+    // one step on buffer `buf` (compile-time).  k-block 0 runs while block 1's fragments (read a block ago) are split;
+    // then the step's only barrier -- this wave's transfers of step t+1 were issued a step ago, its reads of `buf` are
+    // complete --; k-block 1 runs while BOTH fragments of step t+1 are read from the other buffer, its first block
+    // is split, and the transfers of step t+2 are issued into the buffer just released
+    auto step = [&](auto bufc, auto lastc, int t) {
+        constexpr int buf = decltype(bufc)::value;
+        constexpr bool more = !decltype(lastc)::value;         // compile-time: the loop body has no conditional reads
+        using NB = std::integral_constant<int, buf ^ 1>;
+        block(x0, true, bufc, I1{}, raw1, x1, I0{});
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (more) { load_raw(NB{}, I0{}, raw0); load_raw(NB{}, I1{}, raw1); }
+        if (t + 2 < T_steps && dma_on) { set_step(); issue_all(buf); advance(); }
+        block(x1, more, NB{}, I0{}, raw0, x0, ISKIP{});
+    };
+    // T_steps is even (Cin % 64 == 0): pairs of steps on buffers 0 and 1; the last pair is peeled
+    int t = 0;
+#pragma unroll 1
+    for (; t + 2 < T_steps; t += 2) {
+        step(I0{}, I0{}, t);
+        step(I1{}, I0{}, t + 1);
+    }
+    step(I0{}, I0{}, t);
+    step(I1{}, I1{}, t + 1);
+    conv_tile_epilogue<BM, BN, WM, WN, TM, TN>(a, acc, lds3, m0, co0, wm, wn, l31, khalf, tid);
+}
+
+// weights as three bf16 slices: ws[s][row][tap][col] (16-bit words); rows / cols = (co, ci) of w[co][tap][ci], or,
+// transposed, (ci, co) for the data gradient (the conv_pack_wt_kernel order)
+__global__ __launch_bounds__(256) void conv_split_w_kernel(const float* __restrict__ w, unsigned short* __restrict__ ws,
+                                                           int Cout, int KK, int Cin, int transposed) {
+    const long total = (long)Cout * KK * Cin;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        float v;
+        if (transposed) {
+            const int co = (int)(i % Cout), tap = (int)((i / Cout) % KK), ci = (int)(i / ((long)Cout * KK));
+            v = w[((long)co * KK + tap) * Cin + ci];
+        } else {
+            v = w[i];
+        }
+        const unsigned u0 = __float_as_uint(v);
+        const float r1 = v - __uint_as_float(u0 & 0xffff0000u);
+        const unsigned u1 = __float_as_uint(r1);
+        const unsigned u2 = __float_as_uint(r1 - __uint_as_float(u1 & 0xffff0000u));
+        ws[i] = (unsigned short)(u0 >> 16);
+        ws[total + i] = (unsigned short)(u1 >> 16);
+        ws[2 * total + i] = (unsigned short)(u2 >> 16);
     }
 }
 
@@ -1086,6 +1377,251 @@ int launch_wgrad2(const float* x, const float* dy, float* dw, float* workspace, 
     return check_launch("conv_wgrad_reduce");
 }
 
+// ------------------------------------------------------------------------------------------
+// Weight gradient in bf16x3 arithmetic (option conv_arith = 1; 3x3, Cin % 64 == 0, Cout % 64 == 0).
+// The GEMM contracts over PIXELS, and v_mfma_f32_32x32x16_bf16 wants eight consecutive k-values of one row in
+// one lane -- eight pixels of one channel, which in NHWC tiles are 256 bytes apart.  So a lane gathers its
+// eight pixels with eight ds_read_b32 (conflict-free: the 32 lanes of a half-wave read 32 consecutive
+// channels), splits them into bf16 slices and packs pairs with v_perm.  What keeps the VALU work below the
+// matrix pipe's time is the choice of the eight pixels: they are consecutive in ONE output row, so the three
+// horizontal taps of a tap row read the shifted windows [c, c+8), [c+1, c+9), [c+2, c+10) of one patch row:
+// ten values are read and split once (stride 2: 17) and packed three times -- 120 VALU instructions next to
+// 18 MFMAs of 32 cycles per 16 pixels.  Rows are padded to a multiple of 8 pixels in LDS (the padding's dy
+// rows are transferred from the zero block).
+//   workgroup = 64 co x 64 ci block of dw, all nine taps, a run of steps (R output rows of one image each);
+//   12 waves = 4 quarters (32 co x 32 ci) x 3 tap rows, three per SIMD; 3 x 16 accumulators per wave.
+// Staging (dy tile + input patch per step, LDS-DMA, double-buffered), partials and their fixed-order
+// reduction are those of conv_wgrad2_kernel.
+// ------------------------------------------------------------------------------------------
+struct Wgrad3Args {
+    const float* x;        // [N][H][W][Cin]
+    const float* dy;       // [N][OH][OW][Cout]
+    float* part;           // [groups][Cout][9][Cin]
+    int N, H, W, Cin, OH, OW, Cout;
+    int R, OWp;            // output rows per step; row length padded to a multiple of 8
+    int G, gpr;            // 8-pixel groups per step (R * OWp / 8), per row
+    int dyrows;            // pixel rows of the dy tile: 16 * ceil(G / 2)
+    int XR, XC;            // patch rows / columns: (R - 1) s + 3, (OWp - 1) s + 3
+    int groups_per_img, steps, per_group, tiles_ci;
+    int dma_per_it;
+    unsigned inv_xc, inv_owp;
+};
+
+template <int STRIDE>
+__global__ __launch_bounds__(768) void conv_wgrad3_kernel(Wgrad3Args a) {
+    constexpr int WAVES = 12, NRAW = 7 * STRIDE + 3;               // patch values per lane and k-block
+    extern __shared__ __attribute__((aligned(1024))) float lds4[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int quarter = wave & 3, trow = wave >> 2;                // tap row: taps 3 trow .. 3 trow + 2
+    const int wi = quarter & 1, wj = quarter >> 1;
+    const int tci = blockIdx.x % a.tiles_ci, tco = blockIdx.x / a.tiles_ci;
+    const int co0 = tco * 64, ci0 = tci * 64;
+    const int x_rows = a.XR * a.XC;
+    const int dy_dma = a.dyrows >> 2, x_dma = (x_rows + 3) >> 2;    // 1 KB transfers (4 pixel rows each)
+    const int buf_floats = (dy_dma + x_dma) * 256;
+    const unsigned lds0 = lds_addr_of(lds4);
+    const char* zeros = reinterpret_cast<const char*>(g_zeros);
+
+    const int s_begin = blockIdx.y * a.per_group;
+    const int s_end = s_begin + a.per_group < a.steps ? s_begin + a.per_group : a.steps;
+    const int sub = lane >> 4, q16 = lane & 15;
+
+    const int n_slots = dy_dma + x_dma;
+    const char* dyb = nullptr;
+    const char* xb = nullptr;
+    int rows_left = 0, iy0 = 0;
+    unsigned ibase = 0;
+    auto set_step = [&](int step, int buf) {
+        const int n = step / a.groups_per_img, oy0 = (step - n * a.groups_per_img) * a.R;
+        ibase = lds0 + (unsigned)buf * buf_floats * 4;
+        dyb = reinterpret_cast<const char*>(a.dy + (((long)n * a.OH + oy0) * a.OW) * a.Cout + co0 + 4 * q16);
+        rows_left = a.OH - oy0 < a.R ? a.OH - oy0 : a.R;
+        iy0 = oy0 * STRIDE - 1;
+        xb = reinterpret_cast<const char*>(a.x + ((long)n * a.H * a.W) * a.Cin + ci0 + 4 * q16);
+    };
+    auto issue_slot = [&](int d) {
+        if (d < dy_dma) {                                           // wave-uniform
+            const int p = 4 * d + sub;
+            const int r = (int)(((unsigned long long)p * a.inv_owp) >> 32), c = p - r * a.OWp;
+            const bool ok = r < rows_left && c < a.OW;
+            dma16_v(ok ? dyb + ((long)r * a.OW + c) * a.Cout * 4 : zeros, ibase + d * 1024);
+        } else {
+            const int pp = 4 * (d - dy_dma) + sub;
+            const int pr = (int)(((unsigned long long)pp * a.inv_xc) >> 32), pc = pp - pr * a.XC;
+            const int iy = iy0 + pr, ix = pc - 1;
+            const bool ok = pp < x_rows && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            dma16_v(ok ? xb + ((long)iy * a.W + ix) * a.Cin * 4 : zeros, ibase + d * 1024);
+        }
+    };
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    if (s_begin < s_end) {
+        set_step(s_begin, 0);
+#pragma unroll 1
+        for (int d = wave; d < n_slots; d += WAVES) issue_slot(d);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int n_kb = (a.G + 1) >> 1;                                // k-blocks (pairs of 8-pixel groups) per step
+#pragma unroll 1
+    for (int step = s_begin; step < s_end; ++step) {
+        const int buf = (step - s_begin) & 1;
+        const bool more = step + 1 < s_end;
+        if (more) set_step(step + 1, buf ^ 1);
+        int d_n = more ? wave : n_slots;
+        const float* D = lds4 + buf * buf_floats + 32 * wi + l31;
+        const float* X = lds4 + buf * buf_floats + dy_dma * 256 + trow * a.XC * 64 + 32 * wj + l31;
+        // this lane's group of the pair: g = 2 kb + khalf -> (row r, first column 8 cg)
+        int g = khalf, r = 0, cg = khalf;
+        if (cg >= a.gpr) { cg -= a.gpr; ++r; }
+        struct Raw { float d[8], x[NRAW]; };
+        auto load_raw = [&](Raw& w) {
+            const float* dp = D + (g < 2 * n_kb ? g : 0) * 512;     // g < dyrows / 8
+            const float* xp = X + (g < a.G ? (r * STRIDE * a.XC + cg * 8 * STRIDE) * 64 : 0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w.d[j] = dp[j * 64];
+#pragma unroll
+            for (int j = 0; j < NRAW; ++j) w.x[j] = xp[j * 64];
+            g += 2; cg += 2;
+            if (cg >= a.gpr) { cg -= a.gpr; ++r; }
+            if (cg >= a.gpr) { cg -= a.gpr; ++r; }
+        };
+        auto process = [&](const Raw& w) {
+            unsigned a0[8], a1[8], a2[8], b0[NRAW], b1[NRAW], b2[NRAW];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                a0[j] = __float_as_uint(w.d[j]);
+                const float r1 = w.d[j] - __uint_as_float(a0[j] & 0xffff0000u);
+                a1[j] = __float_as_uint(r1);
+                a2[j] = __float_as_uint(r1 - __uint_as_float(a1[j] & 0xffff0000u));
+            }
+#pragma unroll
+            for (int j = 0; j < NRAW; ++j) {
+                b0[j] = __float_as_uint(w.x[j]);
+                const float r1 = w.x[j] - __uint_as_float(b0[j] & 0xffff0000u);
+                b1[j] = __float_as_uint(r1);
+                b2[j] = __float_as_uint(r1 - __uint_as_float(b1[j] & 0xffff0000u));
+            }
+            u32x4 A0, A1, A2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                A0[e] = __builtin_amdgcn_perm(a0[2 * e + 1], a0[2 * e], 0x07060302u);
+                A1[e] = __builtin_amdgcn_perm(a1[2 * e + 1], a1[2 * e], 0x07060302u);
+                A2[e] = __builtin_amdgcn_perm(a2[2 * e + 1], a2[2 * e], 0x07060302u);
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {                           // horizontal tap t: pixel j reads patch value j s + t
+                u32x4 B0, B1, B2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    B0[e] = __builtin_amdgcn_perm(b0[(2 * e + 1) * STRIDE + t], b0[2 * e * STRIDE + t], 0x07060302u);
+                    B1[e] = __builtin_amdgcn_perm(b1[(2 * e + 1) * STRIDE + t], b1[2 * e * STRIDE + t], 0x07060302u);
+                    B2[e] = __builtin_amdgcn_perm(b2[(2 * e + 1) * STRIDE + t], b2[2 * e * STRIDE + t], 0x07060302u);
+                }
+                acc[t] = mfma_bf16(A0, B2, acc[t]);
+                acc[t] = mfma_bf16(A2, B0, acc[t]);
+                acc[t] = mfma_bf16(A1, B1, acc[t]);
+                acc[t] = mfma_bf16(A0, B1, acc[t]);
+                acc[t] = mfma_bf16(A1, B0, acc[t]);
+                acc[t] = mfma_bf16(A0, B0, acc[t]);
+            }
+        };
+        auto issue_some = [&]() {
+#pragma unroll 1
+            for (int i = 0; i < a.dma_per_it && d_n < n_slots; ++i, d_n += WAVES) issue_slot(d_n);
+        };
+        Raw w0, w1;
+        load_raw(w0);
+#pragma unroll 1
+        for (int kb = 0; kb < n_kb; kb += 2) {
+            load_raw(w1);                                           // past the end: valid LDS, never multiplied
+            process(w0);
+            issue_some();
+            load_raw(w0);
+            if (kb + 1 < n_kb) process(w1);
+            issue_some();
+        }
+#pragma unroll 1
+        for (; d_n < n_slots; d_n += WAVES) issue_slot(d_n);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    float* out = a.part + (size_t)blockIdx.y * a.Cout * 9 * a.Cin;
+    const int ci = ci0 + 32 * wj + l31;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = co0 + 32 * wi + 8 * (e >> 2) + 4 * khalf + (e & 3);
+            out[((size_t)co * 9 + 3 * trow + t) * a.Cin + ci] = acc[t][e];
+        }
+}
+
+bool wgrad3_ok(int Cin, int Cout, int KH, int KW, int pad, int stride) {
+    if (option(OPT_CONV_PATH) != 1 || option(OPT_CONV_ARITH) != 1) return false;
+    return Cin % 64 == 0 && Cout % 64 == 0 && KH == 3 && KW == 3 && pad == 1 && (stride == 1 || stride == 2);
+}
+
+struct Wgrad3Plan { int R, OWp, G, dyrows, XR, XC, gpi, steps, tiles, groups, per_group; size_t lds_bytes; };
+Wgrad3Plan wgrad3_plan(int N, int OH, int OW, int Cin, int Cout, int stride) {
+    Wgrad3Plan p;
+    p.OWp = (OW + 7) & ~7;
+    p.XC = (p.OWp - 1) * stride + 3;
+    auto bytes = [&](int R) {
+        const int G = R * p.OWp / 8, dyrows = 16 * ((G + 1) / 2), XR = (R - 1) * stride + 3;
+        return (size_t)2 * (dyrows / 4 + (XR * p.XC + 3) / 4) * 1024;
+    };
+    int R = 1;
+    for (int cand = 1; cand <= OH; ++cand)
+        if (OH % cand == 0 && cand * p.OWp <= 128 && bytes(cand) <= 150 * 1024) R = cand;
+    p.R = R; p.G = R * p.OWp / 8; p.dyrows = 16 * ((p.G + 1) / 2); p.XR = (R - 1) * stride + 3;
+    p.lds_bytes = bytes(R);
+    p.gpi = (OH + R - 1) / R;
+    p.steps = N * p.gpi;
+    p.tiles = (Cout / 64) * (Cin / 64);
+    int groups = 256 / p.tiles;
+    if (groups < 1) groups = 1;
+    if (groups > p.steps) groups = p.steps;
+    p.per_group = (p.steps + groups - 1) / groups;
+    p.groups = (p.steps + p.per_group - 1) / p.per_group;
+    return p;
+}
+
+template <int STRIDE>
+int launch_wgrad3(const float* x, const float* dy, float* dw, float* workspace, int N, int H, int W, int Cin, int Cout,
+                  int OH, int OW, hipStream_t s) {
+    const Wgrad3Plan p = wgrad3_plan(N, OH, OW, Cin, Cout, STRIDE);
+    if (p.lds_bytes > 160 * 1024) return fail(DMC_E_INVALID, "conv_wgrad3: row of %d pixels does not fit the LDS", OW);
+    Wgrad3Args a;
+    a.x = x; a.dy = dy; a.part = p.groups > 1 ? workspace : dw;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout;
+    a.R = p.R; a.OWp = p.OWp; a.G = p.G; a.gpr = p.OWp / 8; a.dyrows = p.dyrows; a.XR = p.XR; a.XC = p.XC;
+    a.groups_per_img = p.gpi; a.steps = p.steps; a.per_group = p.per_group; a.tiles_ci = Cin / 64;
+    a.inv_xc = (unsigned)((0x100000000ull + p.XC - 1) / p.XC);
+    a.inv_owp = (unsigned)((0x100000000ull + p.OWp - 1) / p.OWp);
+    {
+        const int slots = (p.dyrows / 4 + (p.XR * p.XC + 3) / 4 + 11) / 12, its = (p.G + 1) / 2;
+        a.dma_per_it = (slots + its - 1) / its;
+    }
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3_kernel<STRIDE>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return fail(DMC_E_LAUNCH, "conv_wgrad3: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
+    conv_wgrad3_kernel<STRIDE><<<dim3(p.tiles, p.groups), 768, p.lds_bytes, s>>>(a);
+    int rc = check_launch("conv_wgrad3");
+    if (rc || p.groups == 1) return rc;
+    const long numel = (long)Cout * 9 * Cin;
+    const long blocks = (numel + 63) / 64;
+    conv_wgrad_reduce_kernel<<<(int)(blocks > 4096 ? 4096 : blocks), 256, 0, s>>>(workspace, dw, p.groups, numel);
+    return check_launch("conv_wgrad_reduce");
+}
+
 int wgrad_slices(long M, int tiles) {
     // enough workgroups to fill 256 CUs about three times over, slices of at least 1024 pixels
     long want = (768 + tiles - 1) / tiles;
@@ -1139,7 +1675,67 @@ int block_pixels_v1(int cout, long M) {
     return cout == 32 ? 128 : 256;
 }
 
-int block_pixels(int cin, int cout, long M) { return use_v2(cin, cout) ? block_pixels_v2(cout, M) : block_pixels_v1(cout, M); }
+// Third-generation kernel (bf16x3 arithmetic, option conv_arith = 1): Cin % 64 == 0 (an even number of K-steps), Cout % 64 == 0.
+bool use_v3(int cin, int cout) { return option(OPT_CONV_PATH) == 1 && option(OPT_CONV_ARITH) == 1 && cin % 64 == 0 && cout % 64 == 0; }
+
+// wave tiles are wide in channels (TN = 2 .. 4 tiles): the weights arrive split, the activation fragments are split by the
+// wave that reads them, so the VALU work per MFMA falls with the number of channels a wave covers
+//   0 = 256 x 128 (8 x 1 waves), 1 = 256 x 64 (8 x 1), 2 = 128 x 128 (4 x 2), 3 = 128 x 256 (4 x 2), 4 = 64 x 128 (2 x 2),
+//   5 = 128 x 64 (4 x 1)
+int v3_choice(int cout, long M) {
+    const int cfg = option(OPT_CONV_CFG);                  // measurement switch: 0 = automatic, 1 + configuration otherwise
+    if (cfg >= 1 && cfg <= 6) {
+        const int c = cfg - 1;
+        if ((c == 1 || c == 5) || (c == 3 ? cout % 256 == 0 : cout % 128 == 0)) return c;
+    }
+    const long need = 512;
+    if (cout % 128 == 0 && ((M + 255) / 256) * (cout / 128) >= need) return 0;
+    if (cout % 128 == 0 && ((M + 127) / 128) * (cout / 128) >= need) return 2;
+    if (cout % 128 != 0) return ((M + 255) / 256) * (cout / 64) >= need ? 1 : 5;
+    return 4;
+}
+
+int block_pixels_v3(int cout, long M) {
+    const int c = v3_choice(cout, M);
+    return (c == 0 || c == 1) ? 256 : c == 4 ? 64 : 128;
+}
+
+int block_pixels(int cin, int cout, long M) {
+    if (use_v3(cin, cout)) return block_pixels_v3(cout, M);
+    return use_v2(cin, cout) ? block_pixels_v2(cout, M) : block_pixels_v1(cout, M);
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_cfg3(const ConvArgs& a, hipStream_t s) {
+    constexpr size_t lds_bytes = 2 * (BM * 128 + 3 * BN * 64);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_kernel<BM, BN, WM, WN>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (attr != hipSuccess) return fail(DMC_E_LAUNCH, "conv3: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
+    dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN);
+    conv3_kernel<BM, BN, WM, WN><<<grid, WM * WN * 64, lds_bytes, s>>>(a);
+    return check_launch("conv3");
+}
+
+// a.w = the split weights (conv_split_w_kernel)
+int launch_conv3(ConvArgs a, hipStream_t s) {
+    if (a.M <= 0) return DMC_OK;
+    a.ablate = option(OPT_CONV_ABLATE);
+    switch (v3_choice(a.Cout, a.M)) {
+        case 0: return launch_cfg3<256, 128, 8, 1>(a, s);
+        case 1: return launch_cfg3<256, 64, 8, 1>(a, s);
+        case 2: return launch_cfg3<128, 128, 4, 2>(a, s);
+        case 3: return launch_cfg3<128, 256, 4, 2>(a, s);
+        case 4: return launch_cfg3<64, 128, 2, 2>(a, s);
+        default: return launch_cfg3<128, 64, 4, 1>(a, s);
+    }
+}
+
+int split_weights(const float* w, void* wpack, int Cout, int KK, int Cin, int transposed, hipStream_t s) {
+    const long total = (long)Cout * KK * Cin;
+    const long blocks = (total + 255) / 256;
+    conv_split_w_kernel<<<(int)(blocks > 2048 ? 2048 : blocks), 256, 0, s>>>(w, reinterpret_cast<unsigned short*>(wpack), Cout, KK, Cin, transposed);
+    return check_launch("conv_split_w");
+}
 
 template <int BM, int BN, int BK, int WM, int WN>
 int launch_cfg(const ConvArgs& a, hipStream_t s) {
@@ -1198,7 +1794,7 @@ int dmc_conv_nhwc_stat_blocks(int N, int H, int W, int Cin, int Cout, int KH, in
     return (int)((M + bm - 1) / bm);
 }
 
-int dmc_conv_nhwc_fwd(const float* x, const float* w, const float* bias, const float* keep, float* y,
+int dmc_conv_nhwc_fwd(const float* x, const float* w, void* wpack, const float* bias, const float* keep, float* y,
                       double* stat_partials, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                       int pad, int act, dmc_stream_t stream) {
     if (!x || !w || !y) return fail(DMC_E_INVALID, "dmc_conv_nhwc_fwd: null pointer");
@@ -1219,10 +1815,18 @@ int dmc_conv_nhwc_fwd(const float* x, const float* w, const float* bias, const f
             a.set_tap(t, ky - pad, kx - pad, t);
         }
     a.M = N * a.OH * a.OW;
+    if (use_v3(Cin, Cout)) {
+        if (!wpack) return fail(DMC_E_INVALID, "dmc_conv_nhwc_fwd: the bf16x3 arithmetic needs the weight workspace");
+        int rc = split_weights(w, wpack, Cout, a.KK, Cin, 0, (hipStream_t)stream);
+        if (rc) return rc;
+        a.w = reinterpret_cast<const float*>(wpack);
+        return launch_conv3(a, (hipStream_t)stream);
+    }
     return launch_conv(a, (hipStream_t)stream);
 }
 
-size_t dmc_conv_nhwc_wt_bytes(int Cin, int Cout, int KH, int KW) { return (size_t)Cin * Cout * KH * KW * sizeof(float); }
+// packed-weight workspace of the forward and the data gradient: fp32 transposed weights or three bf16 slices
+size_t dmc_conv_nhwc_wt_bytes(int Cin, int Cout, int KH, int KW) { return (size_t)Cin * Cout * KH * KW * 6; }
 
 // dx [N,H,W,Cin] from dy [N,OH,OW,Cout]; wt: workspace of dmc_conv_nhwc_wt_bytes() (the packed weights)
 int dmc_conv_nhwc_dgrad(const float* dy, const float* w, float* wt, float* dx, int N, int H, int W, int Cin,
@@ -1233,8 +1837,14 @@ int dmc_conv_nhwc_dgrad(const float* dy, const float* w, float* wt, float* dx, i
     hipStream_t s = (hipStream_t)stream;
     const int KK = KH * KW;
     const long total = (long)Cin * Cout * KK;
-    conv_pack_wt_kernel<<<(int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256), 256, 0, s>>>(w, wt, Cout, KK, Cin);
-    int rc = check_launch("conv_pack_wt");
+    const bool v3 = use_v3(Cout, Cin);                    // the GEMM contracts over Cout and produces Cin channels
+    int rc;
+    if (v3) {
+        rc = split_weights(w, wt, Cout, KK, Cin, 1, s);
+    } else {
+        conv_pack_wt_kernel<<<(int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256), 256, 0, s>>>(w, wt, Cout, KK, Cin);
+        rc = check_launch("conv_pack_wt");
+    }
     if (rc) return rc;
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     ConvArgs a;
@@ -1256,7 +1866,7 @@ int dmc_conv_nhwc_dgrad(const float* dy, const float* w, float* wt, float* dx, i
                 }
             a.ntaps = nt;
             a.M = N * a.OHs * a.OWs;
-            if ((rc = launch_conv(a, s))) return rc;
+            if ((rc = v3 ? launch_conv3(a, s) : launch_conv(a, s))) return rc;
         }
     return DMC_OK;
 }
@@ -1278,6 +1888,10 @@ int dmc_conv_nhwc_stats_final(const double* partials, int nblk, int C, long coun
 size_t dmc_conv_nhwc_wgrad_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     if (wgrad_small_ok(Cin, KH, KW, pad)) return (size_t)512 * Cout * 9 * Cin * sizeof(float) + 16;
+    if (wgrad3_ok(Cin, Cout, KH, KW, pad, stride)) {
+        const Wgrad3Plan p = wgrad3_plan(N, OH, OW, Cin, Cout, stride);
+        return (size_t)(p.groups > 1 ? p.groups : 0) * Cout * KH * KW * Cin * sizeof(float) + 16;
+    }
     if (wgrad2_ok(Cin, Cout, KH, KW, pad, stride, OW)) {
         const Wgrad2Plan p = wgrad2_plan(N, OH, OW, Cin, Cout, KH, stride);
         return (size_t)(p.groups > 1 ? p.groups : 0) * Cout * KH * KW * Cin * sizeof(float) + 16;
@@ -1305,6 +1919,9 @@ int dmc_conv_nhwc_wgrad(const float* x, const float* dy, float* dw, float* works
         if (stride == 1) return Cout % 32 == 0 ? launch_wgrad_small<32, 32, 1>(a, dw, workspace, s) : launch_wgrad_small<32, 16, 1>(a, dw, workspace, s);
         return Cout % 32 == 0 ? launch_wgrad_small<32, 32, 2>(a, dw, workspace, s) : launch_wgrad_small<32, 16, 2>(a, dw, workspace, s);
     }
+    if (wgrad3_ok(Cin, Cout, KH, KW, pad, stride))
+        return stride == 1 ? launch_wgrad3<1>(x, dy, dw, workspace, N, H, W, Cin, Cout, a.OH, a.OW, s)
+                           : launch_wgrad3<2>(x, dy, dw, workspace, N, H, W, Cin, Cout, a.OH, a.OW, s);
     if (wgrad2_ok(Cin, Cout, KH, KW, pad, stride, a.OW)) {
         if (KH == 3) return stride == 1 ? launch_wgrad2<3, 1>(x, dy, dw, workspace, N, H, W, Cin, Cout, a.OH, a.OW, s)
                                         : launch_wgrad2<3, 2>(x, dy, dw, workspace, N, H, W, Cin, Cout, a.OH, a.OW, s);

@@ -581,7 +581,8 @@ def _conv_fwd(x, weight, bias, keep, stride, padding, act, want_stats):
     if want_stats:
         nblk = lib.dmc_conv_nhwc_stat_blocks(n, h, w, cin, cout, kh, stride, padding)
         part = torch.empty((nblk, cout, 2), dtype=torch.float64, device=x.device)
-    _lib.check(lib.dmc_conv_nhwc_fwd(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(keep), _lib.ptr(y),
+    wpack = _floats(lib.dmc_conv_nhwc_wt_bytes(cin, cout, kh, kw), x.device)
+    _lib.check(lib.dmc_conv_nhwc_fwd(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(wpack), _lib.ptr(bias), _lib.ptr(keep), _lib.ptr(y),
                                      _lib.ptr(part), n, h, w, cin, cout, kh, kw, stride, padding, int(act),
                                      _stream()), "dmc_conv_nhwc_fwd")
     return y, part, nblk

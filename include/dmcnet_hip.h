@@ -283,13 +283,20 @@ int dmc_bn_relu_pool_bwd(const float* x, const float* gamma, const float* beta, 
  * of y per workgroup row, [dmc_conv_nhwc_stat_blocks()][Cout][2] doubles, which
  * dmc_conv_nhwc_stats_final() turns into the (mean, invstd) pair [2*C] and the running-statistics
  * update of the nn.BatchNorm2d that follows (count = N*OH*OW).
+ * wpack: workspace of dmc_conv_nhwc_wt_bytes() bytes for the weights as the kernel wants them (needed when the
+ * option "conv_arith" is 1; may be NULL otherwise).
  * dgrad: dx = conv_transpose(dy, w); wt = workspace of dmc_conv_nhwc_wt_bytes().
+ * Arithmetic (option "conv_arith"): 0 = v_mfma_f32_32x32x2_f32 (fp32 operands, fp32 accumulate); 1 = "bf16x3" for
+ * Cin % 32 == 0, Cout % 64 == 0: every fp32 operand is the exact sum of three bf16 slices, each product is formed
+ * from six slice products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (the omitted three are below 2^-23 of
+ * |a||b|) -- the error against an fp64 evaluation is that of the fp32 instruction or below
+ * (tools/conv_x3_check.py, tests), at 2.67x its rate.
  * wgrad: dw (OHWI) = sum over pixels, deterministic (fixed-order split-K reduction, no atomics);
  * workspace of dmc_conv_nhwc_wgrad_bytes().
  */
 int dmc_conv_nhwc_supported(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 int dmc_conv_nhwc_stat_blocks(int N, int H, int W, int Cin, int Cout, int KH, int stride, int pad);
-int dmc_conv_nhwc_fwd(const float* x, const float* w, const float* bias, const float* keep, float* y,
+int dmc_conv_nhwc_fwd(const float* x, const float* w, void* wpack, const float* bias, const float* keep, float* y,
                       double* stat_partials, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                       int pad, int act, dmc_stream_t stream);
 int dmc_conv_nhwc_stats_final(const double* partials, int nblk, int C, long count, float* stats,

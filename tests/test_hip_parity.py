@@ -348,14 +348,26 @@ def _watch(model, keys):
     return {k: (sd[k] if sd[k].numel() <= 4096 else sd[k].reshape(-1)[:4096]) for k in keys}
 
 
-@pytest.mark.parametrize("own_conv", [False, True])
-@pytest.mark.parametrize("tag,freeze", [("dmcnet", False), ("dmcnet_frozen", True)])
-def test_dmcnet_train_step_vs_reference_golden(golden, tag, freeze, own_conv, monkeypatch):
-    """One iteration of the reference's own train() (golden G4) reproduced by the HIP path:
-    losses / consensus logits within 1e-4 relative, post-step weights close.  own_conv: the classifier's
-    3x3 / 1x1 convolutions on this package's matrix-core kernels (fused conv -> bn op) instead of MIOpen."""
+@pytest.fixture
+def conv_mode(request, monkeypatch):
+    """Classifier convolution path for one test: "miopen", "own_f32" (this package's kernels, fp32 MFMA) or
+    "own_x3" (the same in bf16x3 arithmetic)."""
     from dmcnet_amd import resnet
-    monkeypatch.setattr(resnet, "OWN_CONV", own_conv)
+    lib = dmcnet_amd._lib.load()
+    before = lib.dmc_get_option(b"conv_arith")
+    monkeypatch.setattr(resnet, "OWN_CONV", request.param != "miopen")
+    dmcnet_amd._lib.check(lib.dmc_set_option(b"conv_arith", int(request.param == "own_x3")), "dmc_set_option")
+    yield request.param
+    dmcnet_amd._lib.check(lib.dmc_set_option(b"conv_arith", before), "dmc_set_option")
+
+
+@pytest.mark.parametrize("conv_mode", ["miopen", "own_f32", "own_x3"], indirect=True)
+@pytest.mark.parametrize("tag,freeze", [("dmcnet", False), ("dmcnet_frozen", True)])
+def test_dmcnet_train_step_vs_reference_golden(golden, tag, freeze, conv_mode):
+    """One iteration of the reference's own train() (golden G4) reproduced by the HIP path:
+    losses / consensus logits within 1e-4 relative, post-step weights close.  conv_mode: the classifier's
+    3x3 / 1x1 convolutions on MIOpen or on this package's matrix-core kernels (fused conv -> bn op) in
+    either arithmetic."""
     g = golden("g4_train_steps")
     _, m = _product(False, 41)
     m.train()
@@ -838,11 +850,23 @@ CONV_CASES = [  # (N, Cin, H, W, Cout, k, stride)
 ]
 
 
+@pytest.fixture
+def conv_arith(request):
+    """Option conv_arith for one test: 0 = fp32 MFMA, 1 = bf16x3 (fp32 products from three bf16 slices)."""
+    lib = dmcnet_amd._lib.load()
+    before = lib.dmc_get_option(b"conv_arith")
+    dmcnet_amd._lib.check(lib.dmc_set_option(b"conv_arith", int(request.param)), "dmc_set_option")
+    yield int(request.param)
+    dmcnet_amd._lib.check(lib.dmc_set_option(b"conv_arith", before), "dmc_set_option")
+
+
+@pytest.mark.parametrize("conv_arith", [0, 1], indirect=True)
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_nhwc_fwd_dgrad_wgrad_vs_fp64(case):
+def test_conv_nhwc_fwd_dgrad_wgrad_vs_fp64(case, conv_arith):
     """The matrix-core NHWC convolution and both gradients against an fp64 evaluation of
     F.conv2d (the arithmetic the reference's nn.Conv2d performs), for the ResNet-18 and discriminator
-    shapes; results are deterministic (two runs bit-identical)."""
+    shapes, in both arithmetics (the bar is the same: bf16x3 is an fp32-accurate product); results are
+    deterministic (two runs bit-identical)."""
     n, cin, h, w, cout, k, stride = case
     pad = k // 2
     x, wt = rnd(201, (n, cin, h, w)), rnd(202, (cout, cin, k, k)) * 0.1
