@@ -224,11 +224,10 @@ def main():
     ap.add_argument("--all-spans", action="store_true",
                     help="HIP-event spans around every C-ABI call (kernels_ms lists them all); default: the "
                          "generator forward / backward only, which the roofline object needs")
-    ap.add_argument("--own-conv", type=int, default=0,
-                    help="1 = the classifier's 3x3 / 1x1 convolutions on this package's matrix-core NHWC kernels "
-                         "(fused conv -> bn op); 0 (default) = PyTorch-ROCm (MIOpen) convolutions, the faster of "
-                         "the two so far")
-    ap.add_argument("--conv-arith", type=int, default=0,
+    ap.add_argument("--own-conv", type=int, default=1,
+                    help="1 (default) = the classifier's 3x3 / 1x1 convolutions on this package's matrix-core NHWC "
+                         "kernels (fused conv -> bn op); 0 = PyTorch-ROCm (MIOpen) convolutions")
+    ap.add_argument("--conv-arith", type=int, default=1,
                     help="arithmetic of this package's NHWC convolutions (option conv_arith): 0 = fp32 MFMA, 1 = bf16x3 "
                          "(fp32 operands as three bf16 slices, six bf16 MFMAs per product block, fp32 accumulate: "
                          "fp32-level error at a multiple of the fp32 instruction's rate)")
@@ -360,7 +359,12 @@ def main():
                                     "generator, delta mode, MSE x10") +
                                    ", batch %d clips/GPU, random-init weights" % args.batch,
                        "global_batch": world * args.batch, "num_class": args.num_class,
-                       "parallelism": "dp%d" % world, "final_loss": round(loss, 6)},
+                       "parallelism": "dp%d" % world, "final_loss": round(loss, 6),
+                       "classifier_convs": ("libdmcnet_hip conv_nhwc, " + ("bf16x3 arithmetic (fp32 tensors; every fp32 "
+                                            "product formed from three bf16 slices by six bf16 MFMAs, fp32 accumulate: "
+                                            "error vs fp64 <= the fp32 MFMA's, tools/conv_x3_check.py)"
+                                            if args.conv_arith else "fp32 MFMA")) if args.own_conv
+                                           else "PyTorch-ROCm (MIOpen fp32, NHWC, solver search)"},
             "roofline": {
                 "kernel": "dmc_gen_tiny_fwd (EstimatorDenseNetTiny forward, %d frames)" % n_frames,
                 # the fused fp32 generator is FMA-bound (325 FLOP/B >> ridge 20 FLOP/B): the binding

@@ -3,7 +3,7 @@
 The reference takes them from torchvision (``getattr(torchvision.models, base_model)``,
 code/dmcnet/model.py:305), which is not available here; the published architecture is restated
 with the same attribute names, so ``base_model.*`` state-dict keys match torchvision's.  The 3x3 /
-1x1 convolutions run on PyTorch-ROCm (MIOpen) by default, or, with ``OWN_CONV``, together with their
+1x1 convolutions run, with ``OWN_CONV`` (the default), together with their
 BatchNorms on this package's NHWC matrix-core kernels (ops.conv_bn_act); BatchNorm / ReLU / add, the
 stem tail and the stem's weight gradient are HIP kernels either way.
 """
@@ -24,12 +24,14 @@ def _bn_act(bn, x, residual=None, relu=True):
         y = y + residual
     return torch.relu(y) if relu else y
 
-# True: the 3x3 / 1x1 convolutions run on this package's matrix-core NHWC kernels (fused conv -> bn op,
-# deterministic, no MIOpen) whenever the activation qualifies.  Default False = PyTorch-ROCm (MIOpen), which
-# BASELINE config 2 allows and which is still the faster of the two on MI355X (round 2, N = 120: 16.4 vs
-# 19.1 ms per step; per-layer table in DESIGN.md).  bench.py --own-conv 1 / DMC_OWN_CONV=1 switch it on.
+# True (default): the 3x3 / 1x1 convolutions run on this package's matrix-core NHWC kernels (fused conv -> bn op,
+# deterministic, no MIOpen) whenever the activation qualifies -- in bf16x3 arithmetic (library option conv_arith = 1,
+# the default: fp32 products from three bf16 slices, error <= the fp32 MFMA's) they are the faster path on MI355X
+# (round 2, N = 120: 14.96 ms per step vs 15.97 with MIOpen's searched fp32 solvers; with conv_arith = 0, the fp32
+# MFMA, 19.1 ms).  False = PyTorch-ROCm (MIOpen), which BASELINE config 2 allows.  bench.py --own-conv 0 /
+# DMC_OWN_CONV=0 switch it off.
 import os as _os
-OWN_CONV = _os.environ.get("DMC_OWN_CONV", "0") == "1"
+OWN_CONV = _os.environ.get("DMC_OWN_CONV", "1") != "0"
 
 
 def _conv_bn_act(conv, bn, x, residual=None, relu=True):
