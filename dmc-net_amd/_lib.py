@@ -13,6 +13,7 @@ _P = ctypes.c_void_p
 _I = ctypes.c_int
 _F = ctypes.c_float
 _Z = ctypes.c_size_t
+_L = ctypes.c_long
 
 #: name -> (restype, argtypes); must list every symbol include/dmcnet_hip.h declares
 SIGNATURES = {
@@ -69,6 +70,13 @@ SIGNATURES = {
     "dmc_stem_wgrad_supported": (_I, [_I, _I]),
     "dmc_stem_wgrad_partials_bytes": (_Z, [_I, _I, _I]),
     "dmc_stem_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "dmc_conv3d_bf16_supported": (_I, [_I] * 9),
+    "dmc_conv3d_bf16_wpack_bytes": (_Z, [_I] * 5),
+    "dmc_conv3d_bf16_stat_blocks": (_I, [_I] * 5),
+    "dmc_conv3d_bf16_fwd": (_I, [_P, _P, _L, _L, _L, _P, _P, _P] + [_I] * 9 + [_P]),
+    "dmc_conv3d_bf16_dgrad": (_I, [_P, _P, _L, _L, _L, _P, _P] + [_I] * 9 + [_P]),
+    "dmc_conv3d_bf16_wgrad_bytes": (_Z, [_I] * 9),
+    "dmc_conv3d_bf16_wgrad": (_I, [_P] * 4 + [_I] * 9 + [_P]),
 }
 
 _lib = None

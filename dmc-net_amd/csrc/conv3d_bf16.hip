@@ -1,0 +1,585 @@
+// NDHWC bf16 3-D convolutions of the I3D trunk on the gfx950 matrix cores
+// (v_mfma_f32_32x32x16_bf16, fp32 accumulate) -- BASELINE config 5, SURVEY 8(f)4.
+//
+// Replaces nn.Conv3d inside the reference's Unit3Dpy (code/dmcnet_I3D/network/i3d.py:328-403) for the
+// trunk's stride-1 "SAME" convolutions: every 1x1x1 and 3x3x3 Unit3Dpy of conv3d_2b / 2c and of the nine
+// Mixed blocks (:421-455), i.e. all of the trunk except the 2-channel 7x7x7 stride-2 stem.
+//
+//   forward        y[p][co]  = sum_{tap,ci} x[p + off(tap)][ci] * w[co][ci][tap]       (zero outside the volume)
+//   data gradient  the same kernel on dy with the weights packed as wt[ci][mirror(tap)][co]
+//   weight grad.   dw[co][ci][tap] = sum_p dy[p][co] * x[p + off(tap)][ci]             (conv3d_wgrad_kernel below)
+//
+// Activations are the memory of a channels_last_3d bf16 tensor, [N][D][H][W][C]; the fp32 master weights are packed
+// per call into bf16 [rows_pad][taps][Cp] (rows = output channels of the GEMM padded to 128, Cp = contraction
+// channels padded to 32, zero filled -- so the weight tile needs no masks and odd channel counts (16, 24, 48, 112,
+// 144, 208, 528 ... the Inception branch widths) only cost zero columns in their last 32-channel chunk).
+//
+// GEMM view: rows = output channels (A operand = weights), columns = output pixels (B operand = the input at the
+// tap-shifted pixel), K = (tap, ci).  A workgroup owns BM pixels x BN channels; a K-step is one tap x 32 channels =
+// two MFMA k-blocks.  Both operand tiles are rows of 64 bytes (32 bf16) and go global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: 64 lanes x 16 bytes = sixteen rows per instruction), double-buffered; the 16-byte quad q
+// of tile row r is stored in slot q ^ ((r >> 2) & 3) -- applied to the source address, and again by the fragment
+// reads -- so that a ds_read_b128 of 16 consecutive rows is conflict-free.  Per pixel row a lane keeps one address
+// and a 27-bit mask of the taps that fall inside the volume; masked taps and channels >= Cin read 16 zero bytes.
+// Epilogue: fp32 -> bf16 (round to nearest even), 8-byte stores of 4 consecutive channels, and, when asked, the
+// per-channel (sum, sum of squares) of the ROUNDED values in fp32 per workgroup for the BatchNorm3d that follows.
+#include "dmc_common.h"
+#include <type_traits>
+
+using namespace dmc;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short bf16_t;
+
+__device__ __attribute__((aligned(16))) unsigned g_zeros3d[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ void dma16(const void* src, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"((unsigned long long)src), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)) : "memory");
+}
+
+__device__ __forceinline__ unsigned f2bf(float v) {        // round to nearest even, as torch's .to(bfloat16)
+    unsigned u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // NaN stays NaN
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf2f(unsigned h) { return __uint_as_float(h << 16); }
+
+struct C3dArgs {
+    const bf16_t* x;       // [N][D][H][W][Cin]
+    const bf16_t* w;       // packed [rows_pad][T][Cp]
+    bf16_t* y;             // [N][D][H][W][Cout]
+    float* stat_part;      // [gridDim.x][Cout][2] or null
+    int N, D, H, W, Cin, Cout, Cp;
+    int KD, KH, KW;        // odd extents; tap (kz, ky, kx) reads the pixel at offset (kz - KD/2, ky - KH/2, kx - KW/2)
+    long M;                // N * D * H * W
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void conv3d_bf16_kernel(C3dArgs a) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static_assert(BM % (32 * WM) == 0 && BN % (32 * WN) == 0 && BM % 16 == 0 && BN % 16 == 0, "tile layout");
+    constexpr int IP = BM / 16, IW = BN / 16;              // DMA instructions per step: pixel rows, weight rows
+    constexpr int NDP = (IP + NW - 1) / NW, NDW = (IW + NW - 1) / NW;
+    constexpr int PIXB = BM * 64, BUF = (BM + BN) * 64;
+    __shared__ __attribute__((aligned(1024))) char lds[2 * BUF];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const long m0 = (long)blockIdx.x * BM;
+    const int co0 = blockIdx.y * BN;
+    const unsigned lds0 = lds_addr_of(lds);
+    const unsigned long long zeros = (unsigned long long)g_zeros3d;
+    const int T = a.KD * a.KH * a.KW;
+
+    // ---- transfers: instruction e moves tile rows 16 e .. 16 e + 15; lane -> (row 16 e + lane / 4, slot lane % 4),
+    // source quad = slot ^ ((row >> 2) & 3) = (lane & 3) ^ ((lane >> 4) & 3) ----
+    const int rr = lane >> 2;
+    const int q = (lane & 3) ^ ((lane >> 4) & 3);
+    unsigned long long p_addr[NDP];
+    unsigned p_mask[NDP];
+#pragma unroll
+    for (int j = 0; j < NDP; ++j) {
+        const int e = wave + NW * j;
+        const long m = m0 + 16 * e + rr;
+        p_mask[j] = 0; p_addr[j] = zeros;
+        if (e < IP && m < a.M) {
+            const long hw = (long)a.H * a.W;
+            const long nd = m / hw;
+            const int rem = (int)(m - nd * hw);
+            const int hh = rem / a.W, ww = rem - hh * a.W;
+            const int dd = (int)(nd % a.D);
+            p_addr[j] = (unsigned long long)a.x + ((unsigned long long)m * a.Cin + 8 * q) * 2;
+            int t = 0;
+            for (int kz = 0; kz < a.KD; ++kz)
+                for (int ky = 0; ky < a.KH; ++ky)
+                    for (int kx = 0; kx < a.KW; ++kx, ++t) {
+                        const int z = dd + kz - a.KD / 2, yv = hh + ky - a.KH / 2, xv = ww + kx - a.KW / 2;
+                        if (z >= 0 && z < a.D && yv >= 0 && yv < a.H && xv >= 0 && xv < a.W) p_mask[j] |= 1u << t;
+                    }
+        }
+    }
+    unsigned long long w_addr[NDW];
+#pragma unroll
+    for (int j = 0; j < NDW; ++j) {
+        const int e = wave + NW * j;
+        w_addr[j] = (unsigned long long)a.w + ((unsigned long long)(co0 + 16 * e + rr) * T * a.Cp + 8 * q) * 2;
+    }
+
+    // step state of the transfers being issued: tap (kz, ky, kx) = index tap_n, channel chunk ci_n; all scalar
+    int tap_n = 0, kz_n = 0, ky_n = 0, kx_n = 0, ci_n = 0;
+    auto issue = [&](int buf) {
+        const long toff = ((((long)(kz_n - a.KD / 2) * a.H + (ky_n - a.KH / 2)) * a.W + (kx_n - a.KW / 2)) * a.Cin + ci_n) * 2;
+        const long woff = ((long)tap_n * a.Cp + ci_n) * 2;
+        const bool cok = ci_n + 8 * q < a.Cin;
+        const unsigned base = lds0 + buf * BUF;
+#pragma unroll
+        for (int j = 0; j < NDP; ++j) {
+            if (IP % NW != 0 && wave + NW * j >= IP) continue;
+            const bool ok = ((p_mask[j] >> tap_n) & 1) && cok;
+            const unsigned long long src = ok ? p_addr[j] + (unsigned long long)toff : zeros;
+            dma16(reinterpret_cast<const void*>(src), base + (wave + NW * j) * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < NDW; ++j) {
+            if (IW % NW != 0 && wave + NW * j >= IW) continue;
+            dma16(reinterpret_cast<const void*>(w_addr[j] + (unsigned long long)woff), base + PIXB + (wave + NW * j) * 1024);
+        }
+    };
+    auto advance = [&]() {
+        ci_n += 32;
+        if (ci_n >= a.Cp) {
+            ci_n = 0; ++tap_n;
+            if (++kx_n == a.KW) { kx_n = 0; if (++ky_n == a.KH) { ky_n = 0; ++kz_n; } }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragment reads: lane -> tile row l31, quad 2 kb + khalf, stored in slot quad ^ ((row >> 2) & 3)
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int prow0 = wm * (BM / WM), crow0 = wn * (BN / WN);
+    int xoff[2], wfo[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int slot = ((2 * kb + khalf) ^ ((l31 >> 2) & 3)) << 4;
+        xoff[kb] = (prow0 + l31) * 64 + slot;
+        wfo[kb] = PIXB + (crow0 + l31) * 64 + slot;
+    }
+
+    const int T_steps = T * (a.Cp >> 5);
+    issue(0); advance();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+    for (int t = 0; t < T_steps; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < T_steps) { issue(buf ^ 1); advance(); }
+        const char* base = lds + buf * BUF;
+        u32x4 xf[2][TM], wf[2][TN];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) xf[kb][i] = *reinterpret_cast<const u32x4*>(base + xoff[kb] + i * 32 * 64);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wf[kb][j] = *reinterpret_cast<const u32x4*>(base + wfo[kb] + j * 32 * 64);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[kb][j]),
+                                                                        __builtin_bit_cast(bf16x8, xf[kb][i]), acc[i][j], 0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- epilogue: lane holds pixel column l31 of tile i, channels 8 gq + 4 khalf + e of tile j in acc[4 gq + e] ----
+    float* red = reinterpret_cast<float*>(lds);               // [WM][BN][2]
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        float s1[16], s2[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const long m = m0 + prow0 + 32 * i + l31;
+            const bool mok = m < a.M;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int co = co0 + crow0 + 32 * j + 8 * gq + 4 * khalf;
+                if (co >= a.Cout || !mok) continue;
+                unsigned h[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    h[e] = f2bf(acc[i][j][4 * gq + e]);
+                    const float r = bf2f(h[e]);
+                    s1[4 * gq + e] += r; s2[4 * gq + e] += r * r;
+                }
+                uint2 pk = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                *reinterpret_cast<uint2*>(a.y + (unsigned long long)m * a.Cout + co) = pk;
+            }
+        }
+        if (a.stat_part) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float d1 = s1[e], d2 = s2[e];
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) {
+                    d1 += __shfl_xor(d1, o, 64);
+                    d2 += __shfl_xor(d2, o, 64);
+                }
+                if (l31 == 0) {
+                    const int c = crow0 + 32 * j + 8 * (e >> 2) + 4 * khalf + (e & 3);
+                    red[(wm * BN + c) * 2 + 0] = d1;
+                    red[(wm * BN + c) * 2 + 1] = d2;
+                }
+            }
+        }
+    }
+    if (a.stat_part) {
+        __syncthreads();
+        for (int c = tid; c < BN; c += NW * 64)
+            if (co0 + c < a.Cout) {
+                float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) { d1 += red[(w * BN + c) * 2 + 0]; d2 += red[(w * BN + c) * 2 + 1]; }
+                float* dst = a.stat_part + ((size_t)blockIdx.x * a.Cout + co0 + c) * 2;
+                dst[0] = d1; dst[1] = d2;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient: dw[co][ci][tap] = sum_p dy[p][co] * x[p + off(tap)][ci], a GEMM over pixels.  Both MFMA operands
+// must hold 8 consecutive k (= pixels) of one channel per lane, while memory is pixel-major, so the tiles are
+// transposed on their way into LDS: every thread loads the 8 channels (16 bytes) of one pixel and writes them with
+// eight ds_write_b16 into [channel][pixel] rows of 32 pixels (64 bytes, the forward's slot swizzle), from which the
+// fragments are read with ds_read_b128.  A workgroup owns CT x CT channels (CT = 32 TM: 64 or 128) of dw for NT taps --
+// the 9 in-plane taps of one kz for the 3x3x3 layers (the dy tile is staged once per 9 x tiles), or the single tap of a
+// 1x1x1 layer with 128 x 128 tiles -- and a contiguous run of pixels; split-K partials [split][Cout][T][Cin] are
+// summed in fixed order by conv3d_wgrad_reduce_kernel (deterministic, no atomics), which also writes the
+// parameter's [Cout][Cin][T] layout.  Out-of-volume taps and pixels beyond the run contribute zeros.
+// ------------------------------------------------------------------------------------------
+struct C3dWgradArgs {
+    const bf16_t* x;       // [N][D][H][W][Cin]
+    const bf16_t* dy;      // [N][D][H][W][Cout]
+    float* part;           // [splits][Cout][T][Cin]
+    int N, D, H, W, Cin, Cout;
+    int KD, KH, KW;
+    long M;
+    long per_split;        // pixels per split (multiple of 32)
+    int tiles_ci;          // ceil(Cin / CT)
+};
+
+template <int NT, int TM>
+__global__ __launch_bounds__(256) void conv3d_wgrad_kernel(C3dWgradArgs a) {
+    constexpr int CT = 64 * TM;                            // channels per tile side (2 x 2 waves of TM x TM 32 x 32 tiles)
+    constexpr int LPT = CT / 64;                           // 16-byte loads per thread and tile (32 pixels x CT channels)
+    __shared__ __attribute__((aligned(1024))) char lds[2 * CT * 64];   // dyT [CT][32 px] | xT [CT][32 px]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave & 1, wc = wave >> 1;               // wave tile: rows (co) 32 TM wr.., columns (ci) 32 TM wc..
+    const int tile = blockIdx.x;
+    const int co0 = (tile / a.tiles_ci) * CT, ci0 = (tile % a.tiles_ci) * CT;
+    const int kz = blockIdx.y;                             // NT == 9: the depth tap; NT == 1: 0
+    const int T = a.KD * a.KH * a.KW;
+    const long p_begin = (long)blockIdx.z * a.per_split;
+    long p_end = p_begin + a.per_split;
+    if (p_end > a.M) p_end = a.M;
+
+    // staging map: load l of this thread covers pixel (tid >> 3) + 32 * 0 .. and channel octet (tid & 7) + 8 l
+    const int sp = tid >> 3;                               // pixel within the 32-pixel step
+    const int so = tid & 7;                                // channel octet
+    auto lds_elem = [&](int row, int px) -> int {          // byte offset of (channel row, pixel) in a [CT][32] tile
+        return row * 64 + ((((px >> 3) ^ ((row >> 2) & 3) ^ ((row >> 4) & 3)) & 3) << 4) + (px & 7) * 2;
+    };
+    auto put = [&](char* tileb, int oct, const u32x4& v) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned short h = (unsigned short)((j & 1) ? (v[j >> 1] >> 16) : (v[j >> 1] & 0xffffu));
+            *reinterpret_cast<unsigned short*>(tileb + lds_elem(8 * oct + j, sp)) = h;
+        }
+    };
+
+    f32x16 acc[NT][TM][TM];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[t][i][j][e] = 0.f;
+
+    const int l31 = lane & 31, khalf = lane >> 5;
+    int foff[2][2][TM];                                    // [operand][k-block][tile] byte offset of this lane's fragment
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int ra = wr * 32 * TM + 32 * i + l31, rb = wc * 32 * TM + 32 * i + l31;
+            foff[0][kb][i] = ra * 64 + ((((2 * kb + khalf) ^ ((ra >> 2) & 3) ^ ((ra >> 4) & 3)) & 3) << 4);
+            foff[1][kb][i] = CT * 64 + rb * 64 + ((((2 * kb + khalf) ^ ((rb >> 2) & 3) ^ ((rb >> 4) & 3)) & 3) << 4);
+        }
+    const long hw = (long)a.H * a.W;
+    const int dzo = (NT == 9 ? kz - a.KD / 2 : 0);
+
+#pragma unroll 1
+    for (long p0 = p_begin; p0 < p_end; p0 += 32) {
+        const long m = p0 + sp;
+        const bool mok = m < p_end;
+        int dd = 0, hh = 0, ww = 0;
+        if (mok) {
+            const long nd = m / hw;
+            const int rem = (int)(m - nd * hw);
+            hh = rem / a.W; ww = rem - hh * a.W; dd = (int)(nd % a.D);
+        }
+        // dy tile (shared by the NT taps)
+        u32x4 gv[LPT];
+#pragma unroll
+        for (int l = 0; l < LPT; ++l) {
+            const int c = co0 + 8 * (so + 8 * l);
+            gv[l] = u32x4{0u, 0u, 0u, 0u};
+            if (mok && c < a.Cout) gv[l] = *reinterpret_cast<const u32x4*>(a.dy + (unsigned long long)m * a.Cout + c);
+        }
+        __syncthreads();                                   // previous step's fragment reads are done
+#pragma unroll
+        for (int l = 0; l < LPT; ++l) put(lds, so + 8 * l, gv[l]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int dyo = (NT == 9 ? t / 3 - 1 : 0), dxo = (NT == 9 ? t % 3 - 1 : 0);
+            const int z = dd + dzo, yv = hh + dyo, xv = ww + dxo;
+            const bool ok = mok && z >= 0 && z < a.D && yv >= 0 && yv < a.H && xv >= 0 && xv < a.W;
+            const long ms = m + (long)dzo * hw + dyo * a.W + dxo;
+            u32x4 xv4[LPT];
+#pragma unroll
+            for (int l = 0; l < LPT; ++l) {
+                const int c = ci0 + 8 * (so + 8 * l);
+                xv4[l] = u32x4{0u, 0u, 0u, 0u};
+                if (ok && c < a.Cin) xv4[l] = *reinterpret_cast<const u32x4*>(a.x + (unsigned long long)ms * a.Cin + c);
+            }
+            if (t > 0) __syncthreads();                    // the previous tap's fragment reads of the x tile are done
+#pragma unroll
+            for (int l = 0; l < LPT; ++l) put(lds + CT * 64, so + 8 * l, xv4[l]);
+            __syncthreads();
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                u32x4 af[TM], bf[TM];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const u32x4*>(lds + foff[0][kb][i]);
+#pragma unroll
+                for (int j = 0; j < TM; ++j) bf[j] = *reinterpret_cast<const u32x4*>(lds + foff[1][kb][j]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j)
+                        acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]),
+                                                                               __builtin_bit_cast(bf16x8, bf[j]), acc[t][i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // partials: lane holds column l31 (ci) of tile j, rows 8 gq + 4 khalf + e (co) of tile i
+    float* part = a.part + (size_t)blockIdx.z * a.Cout * T * a.Cin;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tap = (NT == 9 ? kz * 9 + t : 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int ci = ci0 + wc * 32 * TM + 32 * j + l31;
+                if (ci >= a.Cin) continue;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int co = co0 + wr * 32 * TM + 32 * i + 8 * (e >> 2) + 4 * khalf + (e & 3);
+                    if (co < a.Cout) part[((size_t)co * T + tap) * a.Cin + ci] = acc[t][i][j][e];
+                }
+            }
+    }
+}
+
+// dw[co][ci][t] (the parameter's contiguous layout) = sum over splits of part[s][co][t][ci], fixed order
+__global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                  int splits, int Cout, int T, int Cin) {
+    const long total = (long)Cout * T * Cin;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += part[(size_t)k * total + i];
+        const int ci = (int)(i % Cin);
+        const int t = (int)((i / Cin) % T);
+        const int co = (int)(i / ((long)Cin * T));
+        dw[((size_t)co * Cin + ci) * T + t] = s;
+    }
+}
+
+struct C3dWgradPlan { int nt, ct, tiles_co, tiles_ci, groups, splits; long per_split; };
+C3dWgradPlan c3d_wgrad_plan(long M, int Cin, int Cout, int KD, int KH, int KW) {
+    C3dWgradPlan p;
+    const bool k3 = KD == 3 && KH == 3 && KW == 3;
+    p.nt = k3 ? 9 : 1;
+    p.ct = k3 ? 64 : 128;
+    if (!k3 && (Cin <= 64 || Cout <= 64)) p.ct = 64;
+    p.tiles_co = (Cout + p.ct - 1) / p.ct; p.tiles_ci = (Cin + p.ct - 1) / p.ct;
+    p.groups = k3 ? 3 : 1;
+    const long base = (long)p.tiles_co * p.tiles_ci * p.groups;
+    long splits = (1536 + base - 1) / base;                 // ~6 workgroups per CU
+    const long max_splits = (M + 511) / 512;                // at least 512 pixels per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    p.per_split = ((M + splits - 1) / splits + 31) / 32 * 32;
+    p.splits = (int)((M + p.per_split - 1) / p.per_split);
+    return p;
+}
+
+// fp32 weights (any strides) -> packed bf16 [rows_pad][T][Cp], zero padded; tap index mirrored for the data gradient
+__global__ __launch_bounds__(256) void conv3d_pack_w_kernel(const float* __restrict__ w, bf16_t* __restrict__ wp, int rows,
+                                                            int rows_pad, int cols, int Cp, int T, long s_row, long s_col,
+                                                            long s_tap, int mirror) {
+    const long total = (long)rows_pad * T * Cp;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % Cp);
+        const int t = (int)((i / Cp) % T);
+        const int r = (int)(i / ((long)Cp * T));
+        unsigned v = 0;
+        if (r < rows && c < cols) v = f2bf(w[r * s_row + c * s_col + (mirror ? T - 1 - t : t) * s_tap]);
+        wp[i] = (bf16_t)v;
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_c3d(const C3dArgs& a, hipStream_t s) {
+    dim3 grid((unsigned)((a.M + BM - 1) / BM), (a.Cout + BN - 1) / BN);
+    conv3d_bf16_kernel<BM, BN, WM, WN><<<grid, WM * WN * 64, 0, s>>>(a);
+    return check_launch("conv3d_bf16");
+}
+
+// tile choice: 0 = 128 x 128 (2 x 2 waves, 64 x 64 per wave), 1 = 128 x 64 (2 x 2), 2 = 64 x 64 (2 x 2), 3 = 128 x 32 (4 x 1),
+// 4 = 256 x 128 (4 x 2)
+int c3d_choice(int cout, long M) {
+    const int cfg = option(OPT_CONV_CFG);
+    if (cfg >= 1 && cfg <= 5) return cfg - 1;
+    if (cout <= 32) return 3;
+    const long need = 512;
+    if (cout > 64 && ((M + 255) / 256) * ((cout + 127) / 128) >= need && cout % 128 == 0) return 4;
+    if (cout > 64 && (cout % 128 == 0 || cout % 128 > 64) && ((M + 127) / 128) * ((cout + 127) / 128) >= need) return 0;
+    if (((M + 127) / 128) * ((cout + 63) / 64) >= need) return 1;
+    return 2;
+}
+int c3d_block_pixels(int cout, long M) {
+    const int c = c3d_choice(cout, M);
+    return c == 4 ? 256 : c == 2 ? 64 : 128;
+}
+
+int launch_conv3d(const C3dArgs& a, hipStream_t s) {
+    if (a.M <= 0) return DMC_OK;
+    switch (c3d_choice(a.Cout, a.M)) {
+        case 0: return launch_c3d<128, 128, 2, 2>(a, s);
+        case 1: return launch_c3d<128, 64, 2, 2>(a, s);
+        case 2: return launch_c3d<64, 64, 2, 2>(a, s);
+        case 3: return launch_c3d<128, 32, 4, 1>(a, s);
+        default: return launch_c3d<256, 128, 4, 2>(a, s);
+    }
+}
+
+bool c3d_supported(int N, int D, int H, int W, int Cin, int Cout, int KD, int KH, int KW) {
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return false;
+    if (Cin % 8 != 0 || Cout % 8 != 0) return false;
+    if (!((KD == 1 || KD == 3) && (KH == 1 || KH == 3) && (KW == 1 || KW == 3))) return false;
+    return (long)N * D * H * W * (Cin > Cout ? Cin : Cout) < (1L << 40);
+}
+
+int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+extern "C" {
+
+int dmc_conv3d_bf16_supported(int N, int D, int H, int W, int Cin, int Cout, int KD, int KH, int KW) {
+    return c3d_supported(N, D, H, W, Cin, Cout, KD, KH, KW) ? 1 : 0;
+}
+
+// bytes of the packed-weight workspace of one forward or data-gradient call
+size_t dmc_conv3d_bf16_wpack_bytes(int Cin, int Cout, int KD, int KH, int KW) {
+    const size_t T = (size_t)KD * KH * KW;
+    const size_t f = (size_t)pad_to(Cout, 128) * T * pad_to(Cin, 32), b = (size_t)pad_to(Cin, 128) * T * pad_to(Cout, 32);
+    return 2 * (f > b ? f : b) + 16;
+}
+
+// number of [Cout][2] float partial rows the forward writes when asked for statistics
+int dmc_conv3d_bf16_stat_blocks(int N, int D, int H, int W, int Cout) {
+    const long M = (long)N * D * H * W;
+    const int bm = c3d_block_pixels(Cout, M);
+    return (int)((M + bm - 1) / bm);
+}
+
+// y [N,D,H,W,Cout] bf16 = conv3d(x [N,D,H,W,Cin] bf16, w fp32 [Cout][Cin][KD][KH][KW] given by its element strides),
+// stride 1, "SAME" zero padding (odd kernel extents).  wpack: dmc_conv3d_bf16_wpack_bytes().
+int dmc_conv3d_bf16_fwd(const void* x, const float* w, long w_s_co, long w_s_ci, long w_s_tap, void* wpack, void* y,
+                        float* stat_partials, int N, int D, int H, int W, int Cin, int Cout, int KD, int KH, int KW,
+                        dmc_stream_t stream) {
+    if (!x || !w || !wpack || !y) return fail(DMC_E_INVALID, "dmc_conv3d_bf16_fwd: null pointer");
+    if (!c3d_supported(N, D, H, W, Cin, Cout, KD, KH, KW))
+        return fail(DMC_E_INVALID, "dmc_conv3d_bf16_fwd: unsupported shape N=%d D=%d H=%d W=%d Cin=%d Cout=%d k=%dx%dx%d",
+                    N, D, H, W, Cin, Cout, KD, KH, KW);
+    hipStream_t s = (hipStream_t)stream;
+    const int T = KD * KH * KW, Cp = pad_to(Cin, 32), rows_pad = pad_to(Cout, 128);
+    const long total = (long)rows_pad * T * Cp;
+    conv3d_pack_w_kernel<<<(int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256), 256, 0, s>>>(
+        w, (bf16_t*)wpack, Cout, rows_pad, Cin, Cp, T, w_s_co, w_s_ci, w_s_tap, 0);
+    int rc = check_launch("conv3d_pack_w");
+    if (rc) return rc;
+    C3dArgs a;
+    a.x = (const bf16_t*)x; a.w = (const bf16_t*)wpack; a.y = (bf16_t*)y; a.stat_part = stat_partials;
+    a.N = N; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.Cp = Cp; a.KD = KD; a.KH = KH; a.KW = KW;
+    a.M = (long)N * D * H * W;
+    return launch_conv3d(a, s);
+}
+
+// dx [N,D,H,W,Cin] bf16 from dy [N,D,H,W,Cout] bf16
+int dmc_conv3d_bf16_dgrad(const void* dy, const float* w, long w_s_co, long w_s_ci, long w_s_tap, void* wpack, void* dx,
+                          int N, int D, int H, int W, int Cin, int Cout, int KD, int KH, int KW, dmc_stream_t stream) {
+    if (!dy || !w || !wpack || !dx) return fail(DMC_E_INVALID, "dmc_conv3d_bf16_dgrad: null pointer");
+    if (!c3d_supported(N, D, H, W, Cin, Cout, KD, KH, KW)) return fail(DMC_E_INVALID, "dmc_conv3d_bf16_dgrad: unsupported shape");
+    hipStream_t s = (hipStream_t)stream;
+    const int T = KD * KH * KW, Cp = pad_to(Cout, 32), rows_pad = pad_to(Cin, 128);
+    const long total = (long)rows_pad * T * Cp;
+    conv3d_pack_w_kernel<<<(int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256), 256, 0, s>>>(
+        w, (bf16_t*)wpack, Cin, rows_pad, Cout, Cp, T, w_s_ci, w_s_co, w_s_tap, 1);
+    int rc = check_launch("conv3d_pack_w");
+    if (rc) return rc;
+    C3dArgs a;
+    a.x = (const bf16_t*)dy; a.w = (const bf16_t*)wpack; a.y = (bf16_t*)dx; a.stat_part = nullptr;
+    a.N = N; a.D = D; a.H = H; a.W = W; a.Cin = Cout; a.Cout = Cin; a.Cp = Cp; a.KD = KD; a.KH = KH; a.KW = KW;
+    a.M = (long)N * D * H * W;
+    return launch_conv3d(a, s);
+}
+
+// bytes of the split-K partials of the weight gradient
+size_t dmc_conv3d_bf16_wgrad_bytes(int N, int D, int H, int W, int Cin, int Cout, int KD, int KH, int KW) {
+    const C3dWgradPlan p = c3d_wgrad_plan((long)N * D * H * W, Cin, Cout, KD, KH, KW);
+    return (size_t)p.splits * Cout * KD * KH * KW * Cin * sizeof(float) + 16;
+}
+
+// dw fp32 [Cout][Cin][KD][KH][KW] (contiguous, the parameter's layout) from x, dy bf16 NDHWC; deterministic
+int dmc_conv3d_bf16_wgrad(const void* x, const void* dy, float* dw, float* workspace, int N, int D, int H, int W, int Cin,
+                          int Cout, int KD, int KH, int KW, dmc_stream_t stream) {
+    if (!x || !dy || !dw || !workspace) return fail(DMC_E_INVALID, "dmc_conv3d_bf16_wgrad: null pointer");
+    if (!c3d_supported(N, D, H, W, Cin, Cout, KD, KH, KW) || !((KD == 3 && KH == 3 && KW == 3) || (KD == 1 && KH == 1 && KW == 1)))
+        return fail(DMC_E_INVALID, "dmc_conv3d_bf16_wgrad: unsupported shape");
+    hipStream_t s = (hipStream_t)stream;
+    const long M = (long)N * D * H * W;
+    const C3dWgradPlan p = c3d_wgrad_plan(M, Cin, Cout, KD, KH, KW);
+    C3dWgradArgs a;
+    a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.part = workspace;
+    a.N = N; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KD = KD; a.KH = KH; a.KW = KW;
+    a.M = M; a.per_split = p.per_split; a.tiles_ci = p.tiles_ci;
+    dim3 grid(p.tiles_co * p.tiles_ci, p.groups, p.splits);
+    if (p.nt == 9) conv3d_wgrad_kernel<9, 1><<<grid, 256, 0, s>>>(a);
+    else if (p.ct == 128) conv3d_wgrad_kernel<1, 2><<<grid, 256, 0, s>>>(a);
+    else conv3d_wgrad_kernel<1, 1><<<grid, 256, 0, s>>>(a);
+    int rc = check_launch("conv3d_wgrad");
+    if (rc) return rc;
+    const int T = KD * KH * KW;
+    const long total = (long)Cout * T * Cin;
+    conv3d_wgrad_reduce_kernel<<<(int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256), 256, 0, s>>>(
+        workspace, dw, p.splits, Cout, T, Cin);
+    return check_launch("conv3d_wgrad_reduce");
+}
+
+}  // extern "C"

@@ -5,14 +5,21 @@ Same module/attribute names and state-dict keys as the reference's
 ``code/dmcnet_I3D/network/i3d.py`` (``Unit3Dpy`` :328-403, ``MaxPool3dTFPadding`` :406-418,
 ``Mixed`` :421-455, ``I3D`` :458-601) and the loss assembly of
 ``code/dmcnet_I3D/train/model.py:135-188``.  The per-frame generator is the HIP path
-(``EstimatorDenseNetTiny``); the 3-D convolutions run on PyTorch-ROCm (MIOpen), optionally under
-bf16 autocast (the generator stays fp32).
+(``EstimatorDenseNetTiny``); with a bf16 trunk (``trunk_dtype``) the stride-1 1x1x1 / 3x3x3 convolutions run on this
+package's bf16 matrix-core kernels (``ops.conv3d_bf16``, NDHWC), the rest on PyTorch-ROCm (the generator stays fp32).
 """
 import torch
 from torch import nn
 import torch.nn.functional as F
 
 from . import model as _m
+from . import ops
+
+#: True (default): inside a bf16 trunk the stride-1 1x1x1 / 3x3x3 Unit3Dpy convolutions run on this package's
+#: matrix-core kernels (csrc/conv3d_bf16.hip: NDHWC bf16, fp32 accumulate, deterministic weight gradient) instead of
+#: MIOpen; the 2-channel 7x7x7 stem and the biased classifier head stay on PyTorch-ROCm.  DMC_OWN_CONV3D=0 switches off.
+import os as _os
+OWN_CONV3D = _os.environ.get("DMC_OWN_CONV3D", "1") != "0"
 
 
 def _same_pad(kernel, stride):
@@ -51,7 +58,12 @@ class Unit3Dpy(nn.Module):
     def forward(self, x):
         if self.pad is not None:
             x = self.pad(x)
-        x = self.conv3d(x)
+        c = self.conv3d
+        if (OWN_CONV3D and self.pad is None and c.bias is None and x.is_cuda and x.dtype == torch.bfloat16
+                and ops.conv3d_bf16_supported(x, c.weight, c.stride, c.padding)):
+            x = ops.conv3d_bf16(x, c.weight)            # bf16 NDHWC implicit GEMM on the matrix cores
+        else:
+            x = c(x)
         if self.use_bn:
             x = self.batch3d(x)
         if self.relu:

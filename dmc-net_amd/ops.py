@@ -941,3 +941,87 @@ def prepare_inputs(frames_u8, flip=None, flow_ds_factor=0, boxes=None, out_size=
                                                int(flow_ds_factor), ctypes.cast(std4, ctypes.c_void_p),
                                                _stream()), "dmc_prepare_inputs_crop")
     return flow, mv, res
+
+
+# ------------------------------------------------------------------ I3D trunk: bf16 Conv3d (conv3d_bf16.hip)
+_CL3 = torch.channels_last_3d
+
+
+def _as_cl3(t, dtype=torch.bfloat16):
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t if t.is_contiguous(memory_format=_CL3) else t.contiguous(memory_format=_CL3)
+
+
+def conv3d_bf16_supported(x, weight, stride=(1, 1, 1), padding=None):
+    """True if ``conv3d(x, weight)`` (bf16 ``x`` [N,Cin,D,H,W], fp32 ``weight``, stride 1, padding k // 2, kernel
+    extents 1 or 3, channels multiples of 8) can run on the HIP implicit-GEMM kernels; the weight gradient
+    additionally needs a 1x1x1 or 3x3x3 kernel."""
+    if not (x.is_cuda and x.dim() == 5 and x.dtype == torch.bfloat16 and weight.dtype == torch.float32):
+        return False
+    if tuple(stride) != (1, 1, 1) or x.shape[1] != weight.shape[1]:
+        return False
+    kd, kh, kw = weight.shape[2:]
+    if padding is not None and tuple(padding) != (kd // 2, kh // 2, kw // 2):
+        return False
+    if not ((kd, kh, kw) == (1, 1, 1) or (kd, kh, kw) == (3, 3, 3)):
+        return False
+    n, cin, d, h, w = x.shape
+    return bool(_lib.load().dmc_conv3d_bf16_supported(n, d, h, w, cin, weight.shape[0], kd, kh, kw))
+
+
+class _Conv3dBf16(torch.autograd.Function):
+    """nn.Conv3d(bias=False, stride 1, TF-"SAME") of the I3D trunk's Unit3Dpy
+    (code/dmcnet_I3D/network/i3d.py:372-393) on the bf16 matrix cores: bf16 NDHWC activations, fp32 master
+    weights rounded to bf16 per call, fp32 accumulation; deterministic weight gradient in fp32."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        lib = _lib.load()
+        if not (x.is_cuda and weight.is_cuda):
+            raise _lib.DmcHipError("conv3d_bf16 runs on the HIP extension only (no CPU fallback)")
+        x = _as_cl3(x)
+        wc = weight.detach().contiguous()
+        n, cin, d, h, w = x.shape
+        cout, _, kd, kh, kw = wc.shape
+        t = kd * kh * kw
+        y = torch.empty((n, cout, d, h, w), dtype=torch.bfloat16, device=x.device, memory_format=_CL3)
+        wpack = _floats(lib.dmc_conv3d_bf16_wpack_bytes(cin, cout, kd, kh, kw), x.device)
+        with _span("conv3d_bf16_fwd"):
+            _lib.check(lib.dmc_conv3d_bf16_fwd(_lib.ptr(x), _lib.ptr(wc), cin * t, t, 1, _lib.ptr(wpack), _lib.ptr(y),
+                                               None, n, d, h, w, cin, cout, kd, kh, kw, _stream()),
+                       "dmc_conv3d_bf16_fwd")
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, weight = ctx.saved_tensors
+        dy = _as_cl3(dy)
+        wc = weight.detach().contiguous()
+        n, cin, d, h, w = x.shape
+        cout, _, kd, kh, kw = wc.shape
+        t = kd * kh * kw
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            wpack = _floats(lib.dmc_conv3d_bf16_wpack_bytes(cin, cout, kd, kh, kw), x.device)
+            with _span("conv3d_bf16_dgrad"):
+                _lib.check(lib.dmc_conv3d_bf16_dgrad(_lib.ptr(dy), _lib.ptr(wc), cin * t, t, 1, _lib.ptr(wpack),
+                                                     _lib.ptr(dx), n, d, h, w, cin, cout, kd, kh, kw, _stream()),
+                           "dmc_conv3d_bf16_dgrad")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(wc)
+            work = _floats(lib.dmc_conv3d_bf16_wgrad_bytes(n, d, h, w, cin, cout, kd, kh, kw), x.device)
+            with _span("conv3d_bf16_wgrad"):
+                _lib.check(lib.dmc_conv3d_bf16_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(work), n, d, h, w,
+                                                     cin, cout, kd, kh, kw, _stream()), "dmc_conv3d_bf16_wgrad")
+            dw = dw.view_as(weight)
+        return dx, dw
+
+
+def conv3d_bf16(x, weight):
+    """conv3d(x, weight, None, 1, k // 2) for a bf16 ``x`` (see conv3d_bf16_supported); returns a bf16
+    channels_last_3d tensor."""
+    return _Conv3dBf16.apply(x, weight)

@@ -341,6 +341,33 @@ size_t dmc_stem_wgrad_partials_bytes(int N, int H, int W);
 int dmc_stem_wgrad(const float* x, const float* dy, float* dw, float* partials, int N, int H, int W,
                    dmc_stream_t stream);
 
+/* ---- I3D trunk: bf16 3-D convolutions on the matrix cores (BASELINE config 5) -------------------------
+ * Replace nn.Conv3d and its autograd inside the reference's Unit3Dpy, code/dmcnet_I3D/network/i3d.py:328-403
+ * (self.conv3d at :372-388, run at :393), for the trunk's stride-1 TF-"SAME" units: conv3d_2b_1x1, conv3d_2c_3x3
+ * (:484-486) and the 1x1x1 / 3x3x3 branches of the nine Mixed blocks (:421-455, built at :491-513), as the
+ * reference runs them in bf16/fp16-style mixed precision (fp32 master weights, 16-bit activations).
+ * Layouts: activations bf16 NDHWC ([N][D][H][W][C], the memory of a channels_last_3d tensor); weights fp32
+ * [Cout][Cin][KD][KH][KW] addressed by element strides (w_s_co, w_s_ci, w_s_tap: 1 for a contiguous parameter),
+ * rounded to bf16 (nearest even) on the way into the packed workspace; fp32 accumulation; bf16 results rounded to
+ * nearest even.  Kernel extents 1 or 3 per dimension, stride 1, zero padding k/2; Cin, Cout multiples of 8.
+ * fwd: y = conv3d(x, w); if stat_partials != NULL also per-channel (sum, sum of squares) of the rounded y per
+ * workgroup row, [dmc_conv3d_bf16_stat_blocks()][Cout][2] floats (for the BatchNorm3d that follows).
+ * dgrad: dx = conv_transpose3d(dy, w).  wgrad: dw fp32 [Cout][Cin][KD][KH][KW] contiguous = sum over pixels
+ * (1x1x1 and 3x3x3 only), deterministic split-K reduction; workspace of dmc_conv3d_bf16_wgrad_bytes().
+ * wpack: workspace of dmc_conv3d_bf16_wpack_bytes() bytes.
+ */
+int dmc_conv3d_bf16_supported(int N, int D, int H, int W, int Cin, int Cout, int KD, int KH, int KW);
+size_t dmc_conv3d_bf16_wpack_bytes(int Cin, int Cout, int KD, int KH, int KW);
+int dmc_conv3d_bf16_stat_blocks(int N, int D, int H, int W, int Cout);
+int dmc_conv3d_bf16_fwd(const void* x, const float* w, long w_s_co, long w_s_ci, long w_s_tap, void* wpack, void* y,
+                        float* stat_partials, int N, int D, int H, int W, int Cin, int Cout, int KD, int KH, int KW,
+                        dmc_stream_t stream);
+int dmc_conv3d_bf16_dgrad(const void* dy, const float* w, long w_s_co, long w_s_ci, long w_s_tap, void* wpack, void* dx,
+                          int N, int D, int H, int W, int Cin, int Cout, int KD, int KH, int KW, dmc_stream_t stream);
+size_t dmc_conv3d_bf16_wgrad_bytes(int N, int D, int H, int W, int Cin, int Cout, int KD, int KH, int KW);
+int dmc_conv3d_bf16_wgrad(const void* x, const void* dy, float* dw, float* workspace, int N, int D, int H, int W, int Cin,
+                          int Cout, int KD, int KH, int KW, dmc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

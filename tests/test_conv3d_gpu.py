@@ -1,0 +1,120 @@
+"""GPU parity of the I3D trunk's bf16 3-D convolutions (csrc/conv3d_bf16.hip, ops.conv3d_bf16) against an fp64
+evaluation of F.conv3d on the same bf16-rounded operands -- the arithmetic nn.Conv3d performs under bf16 autocast
+in the reference's Unit3Dpy (code/dmcnet_I3D/network/i3d.py:372-393) up to the accumulation precision.
+
+Tolerances: outputs are bf16 (8 significant bits): |y - ref| <= 2^-8 |ref| + a little absolute slack for
+cancellation; the weight gradient is fp32 from fp32 accumulation: 2e-5 of its largest element."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import dmcnet_amd
+from dmcnet_amd import i3d, ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+CL3 = torch.channels_last_3d
+
+
+def rnd(seed, shape):
+    return torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32))
+
+
+def bf16_close(got, ref, what):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    tol = ref.abs() * 2.0 ** -8 + 2.0 ** -9 * ref.abs().mean()
+    bad = (got - ref).abs() > tol
+    assert not bool(bad.any()), "%s: %d of %d outside the bf16 rounding bar, max err %.3e (ref max %.3e)" % (
+        what, int(bad.sum()), bad.numel(), float((got - ref).abs().max()), float(ref.abs().max()))
+
+
+@pytest.fixture
+def conv_cfg(request):
+    lib = dmcnet_amd._lib.load()
+    before = lib.dmc_get_option(b"conv_cfg")
+    dmcnet_amd._lib.check(lib.dmc_set_option(b"conv_cfg", int(request.param)), "dmc_set_option")
+    yield int(request.param)
+    dmcnet_amd._lib.check(lib.dmc_set_option(b"conv_cfg", before), "dmc_set_option")
+
+
+# (N, Cin, D, H, W, Cout, k): Inception branch widths incl. the odd ones (16, 24, 48, 112, 144, 208), volumes whose
+# pixel count is no multiple of any tile, a depth of 1 and 2 (every tap masked somewhere)
+CASES = [
+    (2, 64, 4, 9, 7, 192, 3),       # conv3d_2c: 64 -> 192
+    (1, 192, 3, 6, 5, 16, 1),       # mixed_3b branch_2 reduce: Cout 16 (32-channel tile)
+    (2, 16, 2, 7, 7, 32, 3),        # 16 -> 32: half-empty K chunk
+    (1, 24, 3, 5, 6, 64, 3),        # 24 -> 64: Cin % 16 != 0
+    (1, 112, 2, 4, 5, 224, 3),      # mixed_4c: 112 -> 224
+    (1, 528, 1, 7, 7, 160, 1),      # mixed_4f reduce, depth 1
+    (2, 144, 2, 3, 3, 288, 3),      # mixed_4e
+    (1, 208, 5, 4, 3, 48, 1),       # odd widths both sides
+    (3, 64, 8, 14, 14, 64, 1),      # conv3d_2b-like, several pixel tiles
+    (1, 96, 6, 12, 12, 128, 3),     # mixed_3b branch_1, >= 2 workgroup rows
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv3d_bf16_fwd_dgrad_wgrad_vs_fp64(case):
+    n, cin, d, h, w, cout, k = case
+    x = rnd(301, (n, cin, d, h, w)).bfloat16()
+    wt = rnd(302, (cout, cin, k, k, k)) * (2.0 / (cin * k ** 3)) ** 0.5
+    xo = x.double().requires_grad_(True)
+    wo = wt.bfloat16().double().requires_grad_(True)          # the kernel rounds the fp32 master weights to bf16
+    yo = F.conv3d(xo, wo, None, 1, k // 2)
+    go = rnd(303, tuple(yo.shape)).bfloat16()
+    (yo * go.double()).sum().backward()
+
+    xg = x.to(DEV).contiguous(memory_format=CL3).requires_grad_(True)
+    wg = wt.to(DEV).requires_grad_(True)
+    assert ops.conv3d_bf16_supported(xg, wg)
+    y = ops.conv3d_bf16(xg, wg)
+    assert y.dtype == torch.bfloat16 and y.shape == yo.shape and y.is_contiguous(memory_format=CL3)
+    y.backward(go.to(DEV).contiguous(memory_format=CL3))
+    bf16_close(y, yo, "forward")
+    bf16_close(xg.grad, xo.grad, "data gradient")
+    assert wg.grad.dtype == torch.float32 and wg.grad.shape == wg.shape
+    err = float((wg.grad.double().cpu() - wo.grad).abs().max() / wo.grad.abs().max())
+    assert err < 2e-5, err
+    # deterministic: a second run is bit-identical
+    g1, d1, y1 = wg.grad.clone(), xg.grad.clone(), y.detach().clone()
+    xg.grad = wg.grad = None
+    y2 = ops.conv3d_bf16(xg, wg)
+    y2.backward(go.to(DEV).contiguous(memory_format=CL3))
+    assert torch.equal(y1, y2) and torch.equal(g1, wg.grad) and torch.equal(d1, xg.grad)
+
+
+@pytest.mark.parametrize("conv_cfg", [1, 2, 3, 4, 5], indirect=True)
+def test_conv3d_bf16_every_tile_configuration(conv_cfg):
+    """Each forward tile configuration (option conv_cfg) on a shape with ragged pixel and channel edges."""
+    n, cin, d, h, w, cout, k = 2, 48, 3, 11, 9, 160, 3
+    x = rnd(311, (n, cin, d, h, w)).bfloat16()
+    wt = rnd(312, (cout, cin, k, k, k)) * 0.05
+    yo = F.conv3d(x.double(), wt.bfloat16().double(), None, 1, 1)
+    y = ops.conv3d_bf16(x.to(DEV).contiguous(memory_format=CL3), wt.to(DEV))
+    bf16_close(y, yo, "forward cfg %d" % conv_cfg)
+
+
+def test_unit3d_takes_the_hip_path_and_matches_stock():
+    """Unit3Dpy inside a bf16 trunk: the own convolution against the stock module (MIOpen under autocast), forward
+    output and the gradients of input, convolution weight and BatchNorm parameters."""
+    torch.manual_seed(5)
+    unit = i3d.Unit3Dpy(96, 128, (3, 3, 3)).to(DEV).train()
+    x = torch.randn(2, 96, 4, 14, 14, device=DEV).bfloat16()
+    g = torch.randn(2, 128, 4, 14, 14, device=DEV).bfloat16()
+    res = {}
+    for own in (True, False):
+        i3d.OWN_CONV3D = own
+        try:
+            unit.zero_grad()
+            unit.batch3d.running_mean.zero_(); unit.batch3d.running_var.fill_(1.0)
+            xi = x.clone().contiguous(memory_format=CL3).requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = unit(xi)
+            y.backward(g)
+            res[own] = (y.float(), xi.grad.float(), unit.conv3d.weight.grad.clone(), unit.batch3d.weight.grad.clone())
+        finally:
+            i3d.OWN_CONV3D = True
+    for a, b, name, tol in zip(res[True], res[False], ("y", "dx", "dw", "dgamma"), (0.03, 0.05, 0.03, 0.03)):
+        err = float((a - b).abs().max() / b.abs().max())
+        assert err < tol, (name, err)
