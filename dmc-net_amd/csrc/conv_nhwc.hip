@@ -1681,10 +1681,11 @@ bool use_v3(int cin, int cout) { return option(OPT_CONV_PATH) == 1 && option(OPT
 // wave tiles are wide in channels (TN = 2 .. 4 tiles): the weights arrive split, the activation fragments are split by the
 // wave that reads them, so the VALU work per MFMA falls with the number of channels a wave covers
 //   0 = 256 x 128 (8 x 1 waves), 1 = 256 x 64 (8 x 1), 2 = 128 x 128 (4 x 2), 3 = 128 x 256 (4 x 2), 4 = 64 x 128 (2 x 2),
-//   5 = 128 x 64 (4 x 1)
+//   5 = 128 x 64 (4 x 1), 6 = 128 x 128 (4 x 1: 32 x 128 per wave), 7 = 64 x 128 (2 x 1),
+//   8 = 256 x 128 (4 x 1: 64 x 128 per wave), 9 = 128 x 128 (2 x 1)
 int v3_choice(int cout, long M) {
     const int cfg = option(OPT_CONV_CFG);                  // measurement switch: 0 = automatic, 1 + configuration otherwise
-    if (cfg >= 1 && cfg <= 6) {
+    if (cfg >= 1 && cfg <= 10) {
         const int c = cfg - 1;
         if ((c == 1 || c == 5) || (c == 3 ? cout % 256 == 0 : cout % 128 == 0)) return c;
     }
@@ -1692,12 +1693,12 @@ int v3_choice(int cout, long M) {
     if (cout % 128 == 0 && ((M + 255) / 256) * (cout / 128) >= need) return 0;
     if (cout % 128 == 0 && ((M + 127) / 128) * (cout / 128) >= need) return 2;
     if (cout % 128 != 0) return ((M + 255) / 256) * (cout / 64) >= need ? 1 : 5;
-    return 4;
+    return 6;                                              // layer3 / layer4: 32 x 128 per wave (147 -> 167, 156 -> 162 TFLOP/s vs 64 x 128 on 2 x 2 waves)
 }
 
 int block_pixels_v3(int cout, long M) {
     const int c = v3_choice(cout, M);
-    return (c == 0 || c == 1) ? 256 : c == 4 ? 64 : 128;
+    return (c == 0 || c == 1 || c == 8) ? 256 : (c == 4 || c == 7) ? 64 : 128;
 }
 
 int block_pixels(int cin, int cout, long M) {
@@ -1726,6 +1727,10 @@ int launch_conv3(ConvArgs a, hipStream_t s) {
         case 2: return launch_cfg3<128, 128, 4, 2>(a, s);
         case 3: return launch_cfg3<128, 256, 4, 2>(a, s);
         case 4: return launch_cfg3<64, 128, 2, 2>(a, s);
+        case 6: return launch_cfg3<128, 128, 4, 1>(a, s);
+        case 7: return launch_cfg3<64, 128, 2, 1>(a, s);
+        case 8: return launch_cfg3<256, 128, 4, 1>(a, s);
+        case 9: return launch_cfg3<128, 128, 2, 1>(a, s);
         default: return launch_cfg3<128, 64, 4, 1>(a, s);
     }
 }

@@ -81,8 +81,11 @@ class MaxPool3dTFPadding(nn.Module):
         pads = _same_pad(kernel_size, stride)
         self.pad = nn.ConstantPad3d(pads[2] + pads[1] + pads[0], 0)
         self.pool = nn.MaxPool3d(kernel_size, stride, ceil_mode=True)
+        self.kernel_size, self.stride = tuple(kernel_size), tuple(stride)
 
     def forward(self, x):
+        if OWN_CONV3D and x.is_cuda and x.dtype == torch.bfloat16 and ops.maxpool3d_tf_supported(x, self.kernel_size, self.stride):
+            return ops.maxpool3d_tf(x, self.kernel_size, self.stride)   # pad + pool in one NDHWC pass (csrc/pool3d_bf16.hip)
         return self.pool(self.pad(x))
 
 

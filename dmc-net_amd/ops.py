@@ -980,6 +980,7 @@ class _Conv3dBf16(torch.autograd.Function):
         lib = _lib.load()
         if not (x.is_cuda and weight.is_cuda):
             raise _lib.DmcHipError("conv3d_bf16 runs on the HIP extension only (no CPU fallback)")
+        ctx.x_was_cl3 = x.is_contiguous(memory_format=_CL3)
         x = _as_cl3(x)
         wc = weight.detach().contiguous()
         n, cin, d, h, w = x.shape
@@ -1011,6 +1012,8 @@ class _Conv3dBf16(torch.autograd.Function):
                 _lib.check(lib.dmc_conv3d_bf16_dgrad(_lib.ptr(dy), _lib.ptr(wc), cin * t, t, 1, _lib.ptr(wpack),
                                                      _lib.ptr(dx), n, d, h, w, cin, cout, kd, kh, kw, _stream()),
                            "dmc_conv3d_bf16_dgrad")
+            if not ctx.x_was_cl3:          # hand the gradient back in the producer's layout (a stock op's backward --
+                dx = dx.contiguous()       # e.g. MIOpen's stem convolution -- then sees the problem it saw in the forward)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(wc)
             work = _floats(lib.dmc_conv3d_bf16_wgrad_bytes(n, d, h, w, cin, cout, kd, kh, kw), x.device)
@@ -1025,3 +1028,55 @@ def conv3d_bf16(x, weight):
     """conv3d(x, weight, None, 1, k // 2) for a bf16 ``x`` (see conv3d_bf16_supported); returns a bf16
     channels_last_3d tensor."""
     return _Conv3dBf16.apply(x, weight)
+
+
+def maxpool3d_tf_supported(x, kernel, stride):
+    """True if MaxPool3dTFPadding(kernel, stride)(x) can run on the HIP kernels (bf16 CUDA [N,C,D,H,W], C % 8 == 0)."""
+    if not (x.is_cuda and x.dim() == 5 and x.dtype == torch.bfloat16):
+        return False
+    n, c, d, h, w = x.shape
+    return bool(_lib.load().dmc_maxpool3d_tf_out_shape(d, h, w, c, *[int(k) for k in kernel], *[int(s) for s in stride],
+                                                       None, None, None))
+
+
+class _MaxPool3dTF(torch.autograd.Function):
+    """MaxPool3dTFPadding (code/dmcnet_I3D/network/i3d.py:406-418) on bf16 NDHWC tensors: zero padding to the
+    TF-"SAME" extent and MaxPool3d(ceil_mode=True) in one pass; the backward gathers from the stored winning taps."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, stride):
+        import ctypes
+        lib = _lib.load()
+        ctx.x_was_cl3 = x.is_contiguous(memory_format=_CL3)
+        x = _as_cl3(x)
+        n, c, d, h, w = x.shape
+        od, oh, ow = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        if not lib.dmc_maxpool3d_tf_out_shape(d, h, w, c, *kernel, *stride, ctypes.byref(od), ctypes.byref(oh), ctypes.byref(ow)):
+            raise _lib.DmcHipError("maxpool3d_tf: unsupported shape %s kernel %s stride %s" % (tuple(x.shape), kernel, stride))
+        y = torch.empty((n, c, od.value, oh.value, ow.value), dtype=torch.bfloat16, device=x.device, memory_format=_CL3)
+        code = torch.empty(y.numel(), dtype=torch.uint8, device=x.device)
+        with _span("maxpool3d_fwd"):
+            _lib.check(lib.dmc_maxpool3d_tf_bf16_fwd(_lib.ptr(x), _lib.ptr(y), _lib.ptr(code), n, d, h, w, c, *kernel, *stride,
+                                                     _stream()), "dmc_maxpool3d_tf_bf16_fwd")
+        ctx.save_for_backward(code)
+        ctx.geom = (tuple(x.shape), kernel, stride)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (code,) = ctx.saved_tensors
+        (n, c, d, h, w), kernel, stride = ctx.geom
+        dy = _as_cl3(dy)
+        dx = torch.empty((n, c, d, h, w), dtype=torch.bfloat16, device=dy.device, memory_format=_CL3)
+        with _span("maxpool3d_bwd"):
+            _lib.check(lib.dmc_maxpool3d_tf_bf16_bwd(_lib.ptr(dy), _lib.ptr(code), _lib.ptr(dx), n, d, h, w, c, *kernel, *stride,
+                                                     _stream()), "dmc_maxpool3d_tf_bf16_bwd")
+        if not ctx.x_was_cl3:
+            dx = dx.contiguous()
+        return dx, None, None
+
+
+def maxpool3d_tf(x, kernel, stride):
+    """MaxPool3dTFPadding(kernel, stride)(x) for a bf16 ``x`` (see maxpool3d_tf_supported); channels_last_3d result."""
+    return _MaxPool3dTF.apply(x, tuple(int(k) for k in kernel), tuple(int(s) for s in stride))

@@ -368,6 +368,21 @@ size_t dmc_conv3d_bf16_wgrad_bytes(int N, int D, int H, int W, int Cin, int Cout
 int dmc_conv3d_bf16_wgrad(const void* x, const void* dy, float* dw, float* workspace, int N, int D, int H, int W, int Cin,
                           int Cout, int KD, int KH, int KW, dmc_stream_t stream);
 
+/* ---- I3D trunk: MaxPool3dTFPadding on bf16 NDHWC tensors -------------------------------------------
+ * Replaces the reference's MaxPool3dTFPadding, code/dmcnet_I3D/network/i3d.py:406-418 (ConstantPad3d with zeros
+ * to the TF-"SAME" extent, then nn.MaxPool3d(kernel, stride, ceil_mode=True)), and its autograd, as used at
+ * :482,:488,:494,:505 and in every Mixed block (:441-443).  x [N,D,H,W,C] bf16 (channels_last_3d memory), C % 8 == 0;
+ * front padding = max(k - s, 0) / 2 per dimension; the scan order and tie rule are nn.MaxPool3d's.  fwd also writes
+ * one byte per output value (the winning tap; 255 = a padding zero) which bwd gathers from: no atomics,
+ * deterministic, fp32 sums rounded once.  dmc_maxpool3d_tf_out_shape() returns 0 for unsupported arguments.
+ */
+int dmc_maxpool3d_tf_out_shape(int D, int H, int W, int C, int kd, int kh, int kw, int sd, int sh, int sw, int* od, int* oh,
+                               int* ow);
+int dmc_maxpool3d_tf_bf16_fwd(const void* x, void* y, void* code, int N, int D, int H, int W, int C, int kd, int kh, int kw,
+                              int sd, int sh, int sw, dmc_stream_t stream);
+int dmc_maxpool3d_tf_bf16_bwd(const void* dy, const void* code, void* dx, int N, int D, int H, int W, int C, int kd, int kh,
+                              int kw, int sd, int sh, int sw, dmc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -118,3 +118,35 @@ def test_unit3d_takes_the_hip_path_and_matches_stock():
     for a, b, name, tol in zip(res[True], res[False], ("y", "dx", "dw", "dgamma"), (0.03, 0.05, 0.03, 0.03)):
         err = float((a - b).abs().max() / b.abs().max())
         assert err < tol, (name, err)
+
+
+POOLS = [((1, 3, 3), (1, 2, 2), (2, 64, 4, 16, 14)),      # maxPool3d_2a / 3a
+         ((3, 3, 3), (2, 2, 2), (1, 480, 6, 9, 8)),       # maxPool3d_4a, odd extents
+         ((2, 2, 2), (2, 2, 2), (2, 832, 4, 7, 7)),       # maxPool3d_5a: ceil_mode windows past the edge
+         ((3, 3, 3), (1, 1, 1), (1, 192, 5, 7, 6)),       # Mixed branch_3
+         ((3, 3, 3), (1, 1, 1), (2, 16, 1, 3, 2))]        # depth 1: every window mostly padding
+
+
+@pytest.mark.parametrize("kernel,stride,shape", POOLS)
+def test_maxpool3d_tf_matches_the_stock_module_bit_for_bit(kernel, stride, shape):
+    """MaxPool3dTFPadding on the HIP kernels against ConstantPad3d + nn.MaxPool3d (the reference's module,
+    code/dmcnet_I3D/network/i3d.py:406-418) on rectified inputs (many exact zeros: ties with each other and with the
+    padding zeros): the output bit for bit; the input gradient equal to an fp32 evaluation of the stock backward
+    rounded once (the stock bf16 backward rounds after every atomic add)."""
+    pool = i3d.MaxPool3dTFPadding(kernel, stride)
+    x = torch.relu(rnd(321, shape)).bfloat16().to(DEV)
+    i3d.OWN_CONV3D = False
+    try:
+        xs = x.clone().float().requires_grad_(True)
+        ys = pool(xs)
+        g = rnd(322, tuple(ys.shape)).bfloat16().to(DEV)
+        ys.backward(g.float())
+    finally:
+        i3d.OWN_CONV3D = True
+    xo = x.clone().contiguous(memory_format=CL3).requires_grad_(True)
+    assert ops.maxpool3d_tf_supported(xo, kernel, stride)
+    yo = pool(xo)
+    assert yo.dtype == torch.bfloat16 and yo.shape == ys.shape and yo.is_contiguous(memory_format=CL3)
+    yo.backward(g)
+    assert torch.equal(yo.float(), ys)
+    assert torch.equal(xo.grad.float(), xs.grad.bfloat16().float())
