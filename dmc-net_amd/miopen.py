@@ -22,6 +22,13 @@ def enable_find(use_shipped_db=True):
     somewhere, ``MIOPEN_USER_DB_PATH`` = a writable copy of the shipped find-db.  Call before the
     first convolution of the process (MIOpen reads the variable when its handle is created)."""
     torch.backends.cudnn.benchmark = True
+    # MIOpen's reference ("naive") direct solvers take part in every search they apply to; for the I3D stem's data
+    # gradient (2 <- 64 channels, 7x7x7, stride 2) one evaluation of ConvDirectNaiveConvBwd lasts 69 s, and the search
+    # is repeated by every new process even with the result in the find-db (~10 minutes before the first step).
+    # They never win a search here, so they are switched off unless the user has set the variables.
+    for var in ("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_BWD",
+                "MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_WRW"):
+        os.environ.setdefault(var, "0")
     if not use_shipped_db or "MIOPEN_USER_DB_PATH" in os.environ or not os.path.isdir(_DB_DIR):
         return os.environ.get("MIOPEN_USER_DB_PATH")
     path = _DB_DIR
