@@ -586,7 +586,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv2_kernel(ConvArgs a) {
 //     the first fragments of step t+1 are read from the other buffer during that last block; the transfers of
 //     step t+2 go into the buffer the barrier just freed.
 // ------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int ABL = 0>     // ABL: measurement only (option conv_ablate bits 4, 8)
 __global__ __launch_bounds__(WM * WN * 64) void conv3_kernel(ConvArgs a) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -684,8 +684,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3_kernel(ConvArgs a) {
     typedef const __attribute__((address_space(3))) char* lds_cptr;
     lds_cptr const L = (lds_cptr)lds3;
     struct Raw { f32x4 lo[TM], hi[TM]; };
+    bool first_reads = true;
     auto load_raw = [&](auto bufc, auto kbc, Raw& r) {
         constexpr int buf = decltype(bufc)::value, kb = decltype(kbc)::value;
+        if ((ABL & 8) && !first_reads) return;             // ablation: fragments read once (results wrong)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             r.lo[i] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(L + xoff[kb][0] + (buf * BUF + i * 32 * 128));
@@ -696,13 +698,21 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3_kernel(ConvArgs a) {
                                                            // k-block right after its last MFMA of this one
     auto load_w = [&](auto bufc, auto kbc, int sidx) {
         constexpr int buf = decltype(bufc)::value, kb = decltype(kbc)::value;
+        if ((ABL & 8) && !first_reads) return;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
             wf[j][sidx] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(L + wfo[kb] + (buf * BUF + (sidx * BN + 32 * j) * 64));
     };
     auto split_all = [&](const Raw& r, Split3 (&xs)[TM]) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) xs[i] = split_bf16x3(r.lo[i], r.hi[i]);
+        for (int i = 0; i < TM; ++i) {
+            if constexpr (ABL & 4) {                       // ablation: no split (results wrong)
+                xs[i].s[0] = __builtin_bit_cast(u32x4, r.lo[i]); xs[i].s[1] = __builtin_bit_cast(u32x4, r.hi[i]);
+                xs[i].s[2] = __builtin_bit_cast(u32x4, r.lo[i]);
+            } else {
+                xs[i] = split_bf16x3(r.lo[i], r.hi[i]);
+            }
+        }
     };
     auto mfma_terms = [&](const Split3 (&xs)[TM], int wsl, int xlo, int xhi) {   // weight slice wsl x input slices xhi .. xlo
 #pragma unroll
@@ -760,6 +770,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3_kernel(ConvArgs a) {
     load_raw(I0{}, I1{}, raw1);
     load_w(I0{}, I0{}, 0); load_w(I0{}, I0{}, 1); load_w(I0{}, I0{}, 2);
     if (T_steps > 1) { set_step(); issue_all(1); advance(); }
+    first_reads = false;
     split_all(raw0, x0);
     // one step on buffer `buf` (compile-time).  k-block 0 runs while block 1's fragments (read a block ago) are split;
     // then the step's only barrier -- this wave's transfers of step t+1 were issued a step ago, its reads of `buf` are
@@ -1682,10 +1693,12 @@ bool use_v3(int cin, int cout) { return option(OPT_CONV_PATH) == 1 && option(OPT
 // wave that reads them, so the VALU work per MFMA falls with the number of channels a wave covers
 //   0 = 256 x 128 (8 x 1 waves), 1 = 256 x 64 (8 x 1), 2 = 128 x 128 (4 x 2), 3 = 128 x 256 (4 x 2), 4 = 64 x 128 (2 x 2),
 //   5 = 128 x 64 (4 x 1), 6 = 128 x 128 (4 x 1: 32 x 128 per wave), 7 = 64 x 128 (2 x 1),
-//   8 = 256 x 128 (4 x 1: 64 x 128 per wave), 9 = 128 x 128 (2 x 1)
+//   8 = 256 x 128 (4 x 1: 64 x 128 per wave), 9 = 128 x 128 (2 x 1),
+//   10 = 384 x 128 (4 x 2: 96 x 64 per wave), 11 = 192 x 128 (2 x 2), 12 = 96 x 128 (3 x 1): pixel extents that divide
+//   the layer2 / layer3 / layer4 problems of a 120-frame batch into ~one workgroup per CU
 int v3_choice(int cout, long M) {
     const int cfg = option(OPT_CONV_CFG);                  // measurement switch: 0 = automatic, 1 + configuration otherwise
-    if (cfg >= 1 && cfg <= 10) {
+    if (cfg >= 1 && cfg <= 13) {
         const int c = cfg - 1;
         if ((c == 1 || c == 5) || (c == 3 ? cout % 256 == 0 : cout % 128 == 0)) return c;
     }
@@ -1693,12 +1706,13 @@ int v3_choice(int cout, long M) {
     if (cout % 128 == 0 && ((M + 255) / 256) * (cout / 128) >= need) return 0;
     if (cout % 128 == 0 && ((M + 127) / 128) * (cout / 128) >= need) return 2;
     if (cout % 128 != 0) return ((M + 255) / 256) * (cout / 64) >= need ? 1 : 5;
+    if (cout % 128 == 0 && ((M + 191) / 192) * (cout / 128) >= 200) return 11;   // layer3: 246 workgroups of 192 x 128 (176 TFLOP/s; 167 with 32 x 128 wave tiles)
     return 6;                                              // layer3 / layer4: 32 x 128 per wave (147 -> 167, 156 -> 162 TFLOP/s vs 64 x 128 on 2 x 2 waves)
 }
 
 int block_pixels_v3(int cout, long M) {
     const int c = v3_choice(cout, M);
-    return (c == 0 || c == 1 || c == 8) ? 256 : (c == 4 || c == 7) ? 64 : 128;
+    return (c == 0 || c == 1 || c == 8) ? 256 : (c == 4 || c == 7) ? 64 : c == 10 ? 384 : c == 11 ? 192 : c == 12 ? 96 : 128;
 }
 
 int block_pixels(int cin, int cout, long M) {
@@ -1713,6 +1727,18 @@ int launch_cfg3(const ConvArgs& a, hipStream_t s) {
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (attr != hipSuccess) return fail(DMC_E_LAUNCH, "conv3: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
     dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN);
+    if constexpr (BM == 128 && BN == 128 && WM == 4 && WN == 2) {       // ablation variants of ONE configuration (measurement only)
+        const int abl = a.ablate & 12;
+        if (abl) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_kernel<BM, BN, WM, WN, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_kernel<BM, BN, WM, WN, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_kernel<BM, BN, WM, WN, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (abl == 4) conv3_kernel<BM, BN, WM, WN, 4><<<grid, WM * WN * 64, lds_bytes, s>>>(a);
+            else if (abl == 8) conv3_kernel<BM, BN, WM, WN, 8><<<grid, WM * WN * 64, lds_bytes, s>>>(a);
+            else conv3_kernel<BM, BN, WM, WN, 12><<<grid, WM * WN * 64, lds_bytes, s>>>(a);
+            return check_launch("conv3 (ablation)");
+        }
+    }
     conv3_kernel<BM, BN, WM, WN><<<grid, WM * WN * 64, lds_bytes, s>>>(a);
     return check_launch("conv3");
 }
@@ -1731,6 +1757,9 @@ int launch_conv3(ConvArgs a, hipStream_t s) {
         case 7: return launch_cfg3<64, 128, 2, 1>(a, s);
         case 8: return launch_cfg3<256, 128, 4, 1>(a, s);
         case 9: return launch_cfg3<128, 128, 2, 1>(a, s);
+        case 10: return launch_cfg3<384, 128, 4, 2>(a, s);
+        case 11: return launch_cfg3<192, 128, 2, 2>(a, s);
+        case 12: return launch_cfg3<96, 128, 3, 1>(a, s);
         default: return launch_cfg3<128, 64, 4, 1>(a, s);
     }
 }

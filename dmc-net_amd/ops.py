@@ -1047,6 +1047,8 @@ class _MaxPool3dTF(torch.autograd.Function):
     def forward(ctx, x, kernel, stride):
         import ctypes
         lib = _lib.load()
+        if not (x.is_cuda and x.dtype == torch.bfloat16):
+            raise _lib.DmcHipError("maxpool3d_tf runs on the HIP extension only: bf16 CUDA tensors (no CPU fallback)")
         ctx.x_was_cl3 = x.is_contiguous(memory_format=_CL3)
         x = _as_cl3(x)
         n, c, d, h, w = x.shape

@@ -85,3 +85,34 @@ def test_other_backbones_construct():
     assert list(m.state_dict().keys()) == list(o.state_dict().keys())
     with pytest.raises(ValueError):
         dmcnet_amd.Model(51, 3, "mv", base_model="vgg16")
+
+
+def test_i3d_3d_ops_host_side_without_gpu():
+    """Host-only parts of the I3D 3-D entry points: MaxPool3dTFPadding output extents equal the stock module's
+    (ConstantPad3d + MaxPool3d(ceil_mode=True), code/dmcnet_I3D/network/i3d.py:406-418) on the trunk's pools,
+    workspace sizes, argument validation; on the CPU the predicates are False and the ops raise (no fallback);
+    the I3D modules themselves stay constructible and runnable with the stock ops."""
+    import ctypes
+    from dmcnet_amd import i3d, ops
+    lib = _lib.load()
+    od, oh, ow = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    for kernel, stride, (d, h, w) in [((1, 3, 3), (1, 2, 2), (32, 112, 112)), ((3, 3, 3), (2, 2, 2), (32, 28, 28)),
+                                      ((2, 2, 2), (2, 2, 2), (16, 14, 14)), ((2, 2, 2), (2, 2, 2), (5, 7, 7)),
+                                      ((3, 3, 3), (1, 1, 1), (8, 7, 7)), ((3, 3, 3), (2, 2, 2), (9, 13, 6))]:
+        assert lib.dmc_maxpool3d_tf_out_shape(d, h, w, 64, *kernel, *stride, ctypes.byref(od), ctypes.byref(oh), ctypes.byref(ow)) == 1
+        ref = i3d.MaxPool3dTFPadding(kernel, stride)(torch.zeros(1, 8, d, h, w))
+        assert (od.value, oh.value, ow.value) == tuple(ref.shape[2:]), (kernel, stride, (d, h, w))
+    assert lib.dmc_maxpool3d_tf_out_shape(8, 8, 8, 12, 3, 3, 3, 1, 1, 1, None, None, None) == 0      # C % 8 != 0
+    assert lib.dmc_conv3d_bf16_supported(3, 32, 56, 56, 64, 192, 3, 3, 3) == 1
+    assert lib.dmc_conv3d_bf16_supported(3, 32, 56, 56, 2, 64, 7, 7, 7) == 0                         # the stem stays stock
+    assert lib.dmc_conv3d_bf16_supported(3, 32, 56, 56, 20, 64, 3, 3, 3) == 0                        # Cin % 8 != 0
+    assert lib.dmc_conv3d_bf16_wpack_bytes(64, 192, 3, 3, 3) >= 2 * 256 * 27 * 64
+    assert lib.dmc_conv3d_bf16_wgrad_bytes(3, 32, 56, 56, 64, 192, 3, 3, 3) >= 192 * 27 * 64 * 4
+    rc = lib.dmc_conv3d_bf16_fwd(None, None, 1, 1, 1, None, None, None, 1, 1, 1, 1, 8, 8, 1, 1, 1, None)
+    assert rc == -1 and b"dmc_conv3d_bf16_fwd" in lib.dmc_last_error()
+    x = torch.zeros(1, 16, 2, 4, 4, dtype=torch.bfloat16)
+    assert not ops.conv3d_bf16_supported(x, torch.zeros(8, 16, 3, 3, 3)) and not ops.maxpool3d_tf_supported(x, (3, 3, 3), (1, 1, 1))
+    with pytest.raises(_lib.DmcHipError):
+        ops.conv3d_bf16(x, torch.zeros(8, 16, 3, 3, 3))
+    unit = i3d.Unit3Dpy(16, 8, (3, 3, 3))
+    assert unit(torch.zeros(1, 16, 2, 4, 4)).shape == (1, 8, 2, 4, 4)                                # stock path on the CPU
