@@ -188,6 +188,113 @@ __global__ void stem_reduce2_kernel(const float* __restrict__ partials, int grou
     dw[i] = s;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Forward of the same convolution: y[n][oy][ox][co] = sum_k w[co][k] x[n][ci][2 oy + ky - 3][2 ox + kx - 3],
+// k = (ci, ky, kx), 98 values.  GEMM on v_mfma_f32_32x32x2_f32 (exact fp32): rows = the 64 output channels (two
+// tiles), columns = 32 consecutive output pixels of a row, 49 k-pairs.  A wave keeps ALL weights as A operands in
+// registers for the whole launch (2 x 49 VGPRs: lane (row, half) holds w[32 ct + row][2 kp + half]) and walks
+// 32-pixel tiles; the B operand of k-pair kp is ONE input value per lane, x at this lane's pixel and tap
+// (2 kp + half), read straight from global memory (lanes of a half read every second float of an input row: the
+// whole 2-channel input is 48 MB and lives in L2 / MALL), the next tile's 49 values are in flight during the 98
+// MFMAs of the current one.  No LDS, no barriers.  Output NHWC (a lane holds 4 consecutive channels of its pixel:
+// 16-byte stores).  Replaces MIOpen's implicit-GEMM forward (0.25 ms at 120 frames), the last library convolution of
+// config 2.
+// ------------------------------------------------------------------------------------------
+typedef float stem_f32x16 __attribute__((ext_vector_type(16)));
+
+struct StemFwdArgs {
+    const float* x;        // [N, 2, H, W]
+    const float* w;        // [64, 2, 7, 7] by element strides
+    float* y;              // [N, OH, OW, 64]
+    int N, H, W, OH, OW, tiles_x;
+    long ws_co, ws_ci, ws_ky, ws_kx;
+};
+
+__device__ __forceinline__ void stem_tap(int k, int& ci, int& ky, int& kx) {
+    ci = k / 49; const int r = k - ci * 49; ky = r / 7; kx = r - ky * 7;
+}
+
+__global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemFwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int l31 = lane & 31, half = lane >> 5;
+    const long HW = (long)a.H * a.W;
+
+    float wr[2][49];
+#pragma unroll
+    for (int kp = 0; kp < 49; ++kp) {
+        int ci0, ky0, kx0, ci1, ky1, kx1;
+        stem_tap(2 * kp, ci0, ky0, kx0); stem_tap(2 * kp + 1, ci1, ky1, kx1);
+        const long o = half ? ci1 * a.ws_ci + ky1 * a.ws_ky + kx1 * a.ws_kx : ci0 * a.ws_ci + ky0 * a.ws_ky + kx0 * a.ws_kx;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) wr[ct][kp] = a.w[(32 * ct + l31) * a.ws_co + o];
+    }
+
+    const long ntiles = (long)a.N * a.OH * a.tiles_x;
+    const long stride = (long)gridDim.x * 4;
+    auto load_tile = [&](long tile, float (&xv)[49]) {
+        const int xt = (int)(tile % a.tiles_x);
+        const long r = tile / a.tiles_x;
+        const int oy = (int)(r % a.OH);
+        const long n = r / a.OH;
+        const int ox = 32 * xt + l31;
+        const int iy0 = 2 * oy - 3, ix0 = 2 * ox - 3;
+        const float* base = a.x + n * 2 * HW;
+        const bool interior = iy0 >= 0 && iy0 + 6 < a.H && 64 * xt - 3 >= 0 && 64 * xt + 62 + 3 < a.W;   // wave-uniform
+        if (interior) {
+            const long p0 = (long)iy0 * a.W + ix0;
+#pragma unroll
+            for (int kp = 0; kp < 49; ++kp) {
+                int ci0, ky0, kx0, ci1, ky1, kx1;
+                stem_tap(2 * kp, ci0, ky0, kx0); stem_tap(2 * kp + 1, ci1, ky1, kx1);
+                const long o = half ? ci1 * HW + (long)ky1 * a.W + kx1 : ci0 * HW + (long)ky0 * a.W + kx0;
+                xv[kp] = base[p0 + o];
+            }
+        } else {
+#pragma unroll
+            for (int kp = 0; kp < 49; ++kp) {
+                int ci0, ky0, kx0, ci1, ky1, kx1;
+                stem_tap(2 * kp, ci0, ky0, kx0); stem_tap(2 * kp + 1, ci1, ky1, kx1);
+                const int ci = half ? ci1 : ci0, iy = iy0 + (half ? ky1 : ky0), ix = ix0 + (half ? kx1 : kx0);
+                const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                xv[kp] = ok ? base[ci * HW + (long)iy * a.W + ix] : 0.f;
+            }
+        }
+    };
+
+    long tile = (long)blockIdx.x * 4 + wave;
+    float xc[49], xn[49];
+    if (tile < ntiles) load_tile(tile, xc);
+    for (; tile < ntiles; tile += stride) {
+        const long next = tile + stride;
+        if (next < ntiles) load_tile(next, xn);
+        stem_f32x16 acc[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
+#pragma unroll
+        for (int kp = 0; kp < 49; ++kp)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[ct][kp], xc[kp], acc[ct], 0, 0, 0);
+        const int xt = (int)(tile % a.tiles_x);
+        const long r = tile / a.tiles_x;
+        const int ox = 32 * xt + l31;
+        if (ox < a.OW) {
+            float* dst = a.y + (r * a.OW + ox) * S_CO;            // r = n * OH + oy
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(dst + 32 * ct + 8 * g + 4 * half) =
+                        make_float4(acc[ct][4 * g], acc[ct][4 * g + 1], acc[ct][4 * g + 2], acc[ct][4 * g + 3]);
+        }
+#pragma unroll
+        for (int kp = 0; kp < 49; ++kp) xc[kp] = xn[kp];
+    }
+}
+
 int stem_groups(int N, int H, int W) {
     const int OH = (H + 1) / 2, OW = (W + 1) / 2;
     const long tiles = (long)N * ((OH + S_TH - 1) / S_TH) * ((OW + S_TW - 1) / S_TW);
@@ -223,6 +330,23 @@ int dmc_stem_wgrad(const float* x, const float* dy, float* dw, float* partials, 
     if ((rc = check_launch("stem_reduce1"))) return rc;
     stem_reduce2_kernel<<<(S_CO * S_NCOL + 255) / 256, 256, 0, s>>>(partials, groups, dw);
     return check_launch("stem_reduce2");
+}
+
+// y [N, OH, OW, 64] (NHWC: the memory of a channels_last [N,64,OH,OW] tensor) = conv2d(x [N,2,H,W], w, stride 2,
+// padding 3); w [64,2,7,7] addressed by its element strides (contiguous or channels_last)
+int dmc_stem_fwd(const float* x, const float* w, long ws_co, long ws_ci, long ws_ky, long ws_kx, float* y, int N, int H, int W,
+                 dmc_stream_t stream) {
+    if (!x || !w || !y) return fail(DMC_E_INVALID, "dmc_stem_fwd: null pointer");
+    if (N <= 0 || H <= 0 || W <= 0) return fail(DMC_E_INVALID, "dmc_stem_fwd: bad shape");
+    StemFwdArgs a;
+    a.x = x; a.w = w; a.y = y; a.N = N; a.H = H; a.W = W; a.OH = (H + 1) / 2; a.OW = (W + 1) / 2;
+    a.tiles_x = (a.OW + 31) / 32;
+    a.ws_co = ws_co; a.ws_ci = ws_ci; a.ws_ky = ws_ky; a.ws_kx = ws_kx;
+    const long tiles = (long)N * a.OH * a.tiles_x;
+    long blocks = (tiles + 3) / 4;
+    if (blocks > 512) blocks = 512;                       // two workgroups per CU, every wave walks many tiles
+    stem_fwd_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(a);
+    return check_launch("stem_fwd");
 }
 
 }  // extern "C"

@@ -495,18 +495,33 @@ def bn_relu_pool(x, bn):
                              bn.momentum if bn.momentum is not None else 0.1)
 
 
+#: True (default): conv1's forward on dmc_stem_fwd (exact fp32 MFMA, no LDS); False = F.conv2d (MIOpen)
+STEM_FWD_HIP = True
+
+
 class _StemConv(torch.autograd.Function):
     """conv1 of the classifier for the 2-channel flow input (code/dmcnet/model.py:285-294): the
-    forward convolution is MIOpen's; with 2 input channels MIOpen's implicit-GEMM *gradients*
-    degenerate (weight gradient 0.80 ms, data gradient 2.1 ms at 120 frames), so
+    forward convolution is dmc_stem_fwd (fp32 MFMA with the weights resident in registers); with 2 input
+    channels MIOpen's implicit-GEMM *gradients* degenerate (weight gradient 0.80 ms, data gradient 2.1 ms at
+    120 frames), so
       * the weight gradient is dmc_stem_wgrad (0.24 ms, deterministic);
       * the data gradient (needed only by the GAN variant, whose classifier loss reaches the
         generator) is a batched GEMM  W^T[98,64] x dy[64, OH*OW]  followed by ``fold`` (col2im)."""
 
     @staticmethod
     def forward(ctx, x, weight):
-        y = torch.nn.functional.conv2d(x, weight, None, 2, 3)
-        ctx.save_for_backward(x.detach().contiguous(), weight)
+        xc = x.detach().contiguous()
+        if STEM_FWD_HIP:
+            n, _, h, w = xc.shape
+            y = torch.empty((n, 64, (h + 1) // 2, (w + 1) // 2), dtype=torch.float32, device=x.device,
+                            memory_format=torch.channels_last)
+            so, si, sy, sx = weight.stride()
+            with _span("stem_fwd"):
+                _lib.check(_lib.load().dmc_stem_fwd(_lib.ptr(xc), _lib.ptr(weight), so, si, sy, sx, _lib.ptr(y), n, h, w,
+                                                    _stream()), "dmc_stem_fwd")
+        else:
+            y = torch.nn.functional.conv2d(x, weight, None, 2, 3)
+        ctx.save_for_backward(xc, weight)
         return y
 
     @staticmethod

@@ -340,6 +340,11 @@ int dmc_stem_wgrad_supported(int H, int W);
 size_t dmc_stem_wgrad_partials_bytes(int N, int H, int W);
 int dmc_stem_wgrad(const float* x, const float* dy, float* dw, float* partials, int N, int H, int W,
                    dmc_stream_t stream);
+/* forward of the same convolution (replaces F.conv2d(x, conv1.weight, None, 2, 3) behind base_model(input),
+ * code/dmcnet/model.py:352): y [N,OH,OW,64] NHWC fp32; w [64,2,7,7] by element strides (contiguous: 98, 49, 7, 1;
+ * channels_last: 98, 1, 14, 2).  Exact fp32 (v_mfma_f32_32x32x2_f32), any H, W. */
+int dmc_stem_fwd(const float* x, const float* w, long ws_co, long ws_ci, long ws_ky, long ws_kx, float* y, int N, int H, int W,
+                 dmc_stream_t stream);
 
 /* ---- I3D trunk: bf16 3-D convolutions on the matrix cores (BASELINE config 5) -------------------------
  * Replace nn.Conv3d and its autograd inside the reference's Unit3Dpy, code/dmcnet_I3D/network/i3d.py:328-403

@@ -129,7 +129,11 @@ def test_gan_step_pair_full_batch_vs_oracle():
         assert got["validity"].shape == ((240, 2) if i == 0 else (120, 2))
         # weights that stepped in this phase: D step -> classifier + discriminator, G step -> generator
         keys = [k for k in WATCH + WATCH_D if ("gen_flow_model" in k) == (i == 1)]
-        _check_post_step(m, o, keys, 0.25)
+        # G step: the two networks already differ by the D step's Adam-normalised rounding noise (their logits agree to
+        # 9e-5 instead of 1e-6), and Adam's first step turns a gradient difference dg into lr * dg / eps for the many
+        # generator weights with |g| <~ eps: every convolution path lands at 0.2-0.3 of a step on the watched generator
+        # weights (measured: MIOpen 0.23, fp32 MFMA 0.30, bf16x3 0.28; tools/_diag.py in round 2) -- the bar is half a step
+        _check_post_step(m, o, keys, 0.5 if i == 1 else 0.25)
 
 
 @pytest.mark.parametrize("weights", ["generic"])
