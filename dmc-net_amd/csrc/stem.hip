@@ -193,9 +193,9 @@ __global__ void stem_reduce2_kernel(const float* __restrict__ partials, int grou
 // Forward of the same convolution: y[n][oy][ox][co] = sum_k w[co][k] x[n][ci][2 oy + ky - 3][2 ox + kx - 3],
 // k = (ci, ky, kx), 98 values.  GEMM on v_mfma_f32_32x32x2_f32 (exact fp32): rows = the 64 output channels (two
 // tiles), columns = 32 consecutive output pixels of a row, 49 k-pairs.  A wave keeps ALL weights as A operands in
-// registers for the whole launch (2 x 49 VGPRs: lane (row, half) holds w[32 ct + row][2 kp + half]) and walks
+// registers for the whole launch (2 x 49 VGPRs: lane (row, half) holds w[32 ct + row][ci = half][ky][kx]) and walks
 // 32-pixel tiles; the B operand of k-pair kp is ONE input value per lane, x at this lane's pixel and tap
-// (2 kp + half), read straight from global memory (lanes of a half read every second float of an input row: the
+// (ky, kx) of channel `half`, read straight from global memory (lanes read every second float of an input row: the
 // whole 2-channel input is 48 MB and lives in L2 / MALL), the next tile's 49 values are in flight during the 98
 // MFMAs of the current one.  No LDS, no barriers.  Output NHWC (a lane holds 4 consecutive channels of its pixel:
 // 16-byte stores).  Replaces MIOpen's implicit-GEMM forward (0.25 ms at 120 frames), the last library convolution of
@@ -211,22 +211,18 @@ struct StemFwdArgs {
     long ws_co, ws_ci, ws_ky, ws_kx;
 };
 
-__device__ __forceinline__ void stem_tap(int k, int& ci, int& ky, int& kx) {
-    ci = k / 49; const int r = k - ci * 49; ky = r / 7; kx = r - ky * 7;
-}
-
 __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemFwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int l31 = lane & 31, half = lane >> 5;
-    const long HW = (long)a.H * a.W;
+    const int HW = a.H * a.W;
 
+    // k-pair kp = (ky, kx), the two k-values of the pair are the two input channels: lane half = ci, so both halves
+    // of a wave read the same tap of their own channel plane (one per-lane base, a wave-uniform tap offset)
     float wr[2][49];
 #pragma unroll
     for (int kp = 0; kp < 49; ++kp) {
-        int ci0, ky0, kx0, ci1, ky1, kx1;
-        stem_tap(2 * kp, ci0, ky0, kx0); stem_tap(2 * kp + 1, ci1, ky1, kx1);
-        const long o = half ? ci1 * a.ws_ci + ky1 * a.ws_ky + kx1 * a.ws_kx : ci0 * a.ws_ci + ky0 * a.ws_ky + kx0 * a.ws_kx;
+        const long o = half * a.ws_ci + (kp / 7) * a.ws_ky + (kp % 7) * a.ws_kx;
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) wr[ct][kp] = a.w[(32 * ct + l31) * a.ws_co + o];
     }
@@ -237,28 +233,33 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemFwdArgs a) {
         const int xt = (int)(tile % a.tiles_x);
         const long r = tile / a.tiles_x;
         const int oy = (int)(r % a.OH);
-        const long n = r / a.OH;
+        const int n = (int)(r / a.OH);
         const int ox = 32 * xt + l31;
         const int iy0 = 2 * oy - 3, ix0 = 2 * ox - 3;
-        const float* base = a.x + n * 2 * HW;
-        const bool interior = iy0 >= 0 && iy0 + 6 < a.H && 64 * xt - 3 >= 0 && 64 * xt + 62 + 3 < a.W;   // wave-uniform
-        if (interior) {
-            const long p0 = (long)iy0 * a.W + ix0;
+        const float* plane = a.x + ((long)n * 2 + half) * HW;                  // this lane's channel plane
+        const bool cols_inside = 64 * xt - 3 >= 0 && 64 * xt + 62 + 3 < a.W;    // wave-uniform: no column of the tile is clipped
+        unsigned cm = 0;                                                        // per lane: taps kx whose column exists
 #pragma unroll
-            for (int kp = 0; kp < 49; ++kp) {
-                int ci0, ky0, kx0, ci1, ky1, kx1;
-                stem_tap(2 * kp, ci0, ky0, kx0); stem_tap(2 * kp + 1, ci1, ky1, kx1);
-                const long o = half ? ci1 * HW + (long)ky1 * a.W + kx1 : ci0 * HW + (long)ky0 * a.W + kx0;
-                xv[kp] = base[p0 + o];
+        for (int kx = 0; kx < 7; ++kx) cm |= (ix0 + kx >= 0 && ix0 + kx < a.W) ? 1u << kx : 0u;
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) {
+            const int iy = iy0 + ky;                                            // wave-uniform
+            if (iy < 0 || iy >= a.H) {
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) xv[ky * 7 + kx] = 0.f;
+                continue;
             }
-        } else {
+            const int rowoff = iy * a.W + ix0;
+            if (cols_inside) {
 #pragma unroll
-            for (int kp = 0; kp < 49; ++kp) {
-                int ci0, ky0, kx0, ci1, ky1, kx1;
-                stem_tap(2 * kp, ci0, ky0, kx0); stem_tap(2 * kp + 1, ci1, ky1, kx1);
-                const int ci = half ? ci1 : ci0, iy = iy0 + (half ? ky1 : ky0), ix = ix0 + (half ? kx1 : kx0);
-                const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-                xv[kp] = ok ? base[ci * HW + (long)iy * a.W + ix] : 0.f;
+                for (int kx = 0; kx < 7; ++kx) xv[ky * 7 + kx] = plane[rowoff + kx];
+            } else {
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) {
+                    const bool ok = (cm >> kx) & 1;
+                    const float v = plane[ok ? rowoff + kx : iy * a.W];
+                    xv[ky * 7 + kx] = ok ? v : 0.f;
+                }
             }
         }
     };

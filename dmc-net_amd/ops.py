@@ -496,7 +496,7 @@ def bn_relu_pool(x, bn):
 
 
 #: True (default): conv1's forward on dmc_stem_fwd (exact fp32 MFMA, no LDS); False = F.conv2d (MIOpen)
-STEM_FWD_HIP = True
+STEM_FWD_HIP = __import__("os").environ.get("DMC_STEM_FWD", "1") != "0"
 
 
 class _StemConv(torch.autograd.Function):

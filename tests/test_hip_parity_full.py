@@ -129,11 +129,14 @@ def test_gan_step_pair_full_batch_vs_oracle():
         assert got["validity"].shape == ((240, 2) if i == 0 else (120, 2))
         # weights that stepped in this phase: D step -> classifier + discriminator, G step -> generator
         keys = [k for k in WATCH + WATCH_D if ("gen_flow_model" in k) == (i == 1)]
-        # G step: the two networks already differ by the D step's Adam-normalised rounding noise (their logits agree to
-        # 9e-5 instead of 1e-6), and Adam's first step turns a gradient difference dg into lr * dg / eps for the many
-        # generator weights with |g| <~ eps: every convolution path lands at 0.2-0.3 of a step on the watched generator
-        # weights (measured: MIOpen 0.23, fp32 MFMA 0.30, bf16x3 0.28; tools/_diag.py in round 2) -- the bar is half a step
-        _check_post_step(m, o, keys, 0.5 if i == 1 else 0.25)
+        _check_post_step(m, o, keys, 0.25)
+        if i == 0:
+            # The G step is checked from IDENTICAL weights: after the D step the two classifiers differ by Adam-normalised
+            # rounding noise (<= 0.16 of a step), which the G step's Adam (lr * dg / eps for |g| <~ eps) turns into 0.2-0.6 of
+            # a step on the generator weights whatever the convolution path (measured with tools/gan_full_batch_diag.py:
+            # MIOpen 0.23, fp32 MFMA 0.30, bf16x3 0.28) -- a property of the comparison, not of the kernels.  The
+            # generator's optimizer has not stepped yet, so no optimizer state is lost.
+            m.load_state_dict(o.state_dict())
 
 
 @pytest.mark.parametrize("weights", ["generic"])
