@@ -270,7 +270,7 @@ template <int NT, int TM>
 __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(C3dWgradArgs a) {
     constexpr int CT = 64 * TM;                            // channels per tile side (2 x 2 waves of TM x TM 32 x 32 tiles)
     constexpr int LPT = CT / 64;                           // 16-byte loads per thread and tile (32 pixels x CT channels)
-    __shared__ __attribute__((aligned(1024))) char lds[2 * CT * 64];   // dyT [CT][32 px] | xT [CT][32 px]
+    __shared__ __attribute__((aligned(1024))) char lds[3 * CT * 64];   // dyT [CT][32 px] | xT [CT][32 px] x 2 (double-buffered over the taps)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave & 1, wc = wave >> 1;               // wave tile: rows (co) 32 TM wr.., columns (ci) 32 TM wc..
@@ -337,39 +337,48 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(C3dWgradArgs a) {
             gv[l] = u32x4{0u, 0u, 0u, 0u};
             if (mok && c < a.Cout) gv[l] = *reinterpret_cast<const u32x4*>(a.dy + (unsigned long long)m * a.Cout + c);
         }
-        __syncthreads();                                   // previous step's fragment reads are done
-#pragma unroll
-        for (int l = 0; l < LPT; ++l) put(lds, so + 8 * l, gv[l]);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
+        // the x tile is double-buffered over the taps: tap t + 1 is loaded while tap t's MFMAs run and written to the
+        // other buffer behind them -- one barrier per tap, no global-load latency in front of the MFMAs (the first
+        // version loaded, waited, wrote and synchronised twice per tap: 19 barriers and 10 exposed loads per 18 MFMAs)
+        u32x4 xv4[LPT];
+        auto load_x = [&](int t) {
             const int dyo = (NT == 9 ? t / 3 - 1 : 0), dxo = (NT == 9 ? t % 3 - 1 : 0);
             const int z = dd + dzo, yv = hh + dyo, xv = ww + dxo;
             const bool ok = mok && z >= 0 && z < a.D && yv >= 0 && yv < a.H && xv >= 0 && xv < a.W;
             const long ms = m + (long)dzo * hw + dyo * a.W + dxo;
-            u32x4 xv4[LPT];
 #pragma unroll
             for (int l = 0; l < LPT; ++l) {
                 const int c = ci0 + 8 * (so + 8 * l);
                 xv4[l] = u32x4{0u, 0u, 0u, 0u};
                 if (ok && c < a.Cin) xv4[l] = *reinterpret_cast<const u32x4*>(a.x + (unsigned long long)ms * a.Cin + c);
             }
-            if (t > 0) __syncthreads();                    // the previous tap's fragment reads of the x tile are done
+        };
+        load_x(0);
+        __syncthreads();                                   // previous step's fragment reads are done
 #pragma unroll
-            for (int l = 0; l < LPT; ++l) put(lds + CT * 64, so + 8 * l, xv4[l]);
-            __syncthreads();
+        for (int l = 0; l < LPT; ++l) { put(lds, so + 8 * l, gv[l]); put(lds + CT * 64, so + 8 * l, xv4[l]); }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t + 1 < NT) load_x(t + 1);
+            __syncthreads();                               // dyT and xT[t & 1] visible; xT[(t + 1) & 1] free
+            const int xoff = (t & 1) * CT * 64;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 u32x4 af[TM], bf[TM];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const u32x4*>(lds + foff[0][kb][i]);
 #pragma unroll
-                for (int j = 0; j < TM; ++j) bf[j] = *reinterpret_cast<const u32x4*>(lds + foff[1][kb][j]);
+                for (int j = 0; j < TM; ++j) bf[j] = *reinterpret_cast<const u32x4*>(lds + xoff + foff[1][kb][j]);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TM; ++j)
                         acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]),
                                                                                __builtin_bit_cast(bf16x8, bf[j]), acc[t][i][j], 0, 0, 0);
+            }
+            if (t + 1 < NT) {
+#pragma unroll
+                for (int l = 0; l < LPT; ++l) put(lds + CT * 64 + ((t + 1) & 1) * CT * 64, so + 8 * l, xv4[l]);
             }
         }
     }
