@@ -137,6 +137,41 @@ def bench_prepare(dev, n_frames, flow_ds_factor, iters=20):
     return out
 
 
+def classifier_conv_roofline(conv_spans, n_frames, conv_arith, hw=224):
+    """The ResNet-18 3x3 / 1x1 convolutions (everything but conv1) as one kernel family: algorithmic FLOPs of the
+    forward, data-gradient and weight-gradient GEMMs of a step (2 x MACs each) over the HIP-event time of their C-ABI
+    calls, against the matrix peak of the arithmetic they run in: bf16x3 = six bf16 MFMAs per fp32 product block
+    (2,500 / 6 TFLOP/s fp32-equivalent, MI355X_MICROARCH.md dense bf16 peak), fp32 MFMA = 157.3."""
+    if not conv_spans:
+        return None
+    macs, cin, res = 0, 64, hw // 4
+    for i, cout in enumerate((64, 128, 256, 512)):
+        if i:
+            res //= 2
+            macs += res * res * cout * cin * (9 + 1)              # stride-2 3x3 + the 1x1 shortcut
+            macs += 3 * res * res * cout * cout * 9
+        else:
+            macs += 4 * res * res * cout * cin * 9
+        cin = cout
+    flop = 2.0 * macs * n_frames
+    out = {"unit": "TFLOP/s (fp32-equivalent)", "bound": "mfma",
+           "peak": round(2500.0 / 6, 1) if conv_arith else FP32_PEAK_TFLOPS,
+           "arithmetic": "bf16x3" if conv_arith else "fp32 MFMA", "gflop_per_pass": round(flop / 1e9, 1)}
+    tot_ms = 0.0
+    for name, key in (("forward", "conv_nhwc_fwd"), ("data_gradient", "conv_nhwc_dgrad"), ("weight_gradient", "conv_nhwc_wgrad")):
+        if key in conv_spans:
+            ms = conv_spans[key][0] * conv_spans[key][1] / 6.0      # average call x calls per step (6 probed steps)
+            out[name] = {"ms_per_step": round(ms, 3), "achieved": round(flop / (ms * 1e-3) / 1e12, 1)}
+            tot_ms += ms
+    if tot_ms > 0:
+        out["ms_per_step"] = round(tot_ms, 3)
+        out["achieved"] = round(3 * flop / (tot_ms * 1e-3) / 1e12, 1)
+        out["frac"] = round(out["achieved"] / out["peak"], 4)
+    out["note"] = ("HIP events around the C-ABI calls (weight split / pack launches included) in 6 steps after the timed "
+                   "region; the span names are ops.conv_nhwc_*")
+    return out
+
+
 def bench_i3d(args, rank, world, dev):
     """BASELINE config 5: I3D over the per-frame DMC generator; micro-batch of 3 clips x T frames,
     trunk under bf16 autocast, generator fp32; D and G phases alternate (iter_size 1)."""
@@ -328,6 +363,16 @@ def main():
             one(i)
         torch.cuda.synchronize()
     ops.PROBE = None
+    conv_spans = None
+    if args.own_conv and not gan and world == 1:
+        # classifier convolutions (the step's dominant kernel family): HIP-event spans around their C-ABI calls in 6
+        # extra steps right AFTER the timed region (57 spans per step would cost the timed steps ~2 %)
+        cprobe = ops.EventProbe(("conv_nhwc_fwd", "conv_nhwc_dgrad", "conv_nhwc_wgrad"))
+        ops.PROBE = cprobe
+        for i in range(6):
+            one(i)
+        conv_spans = cprobe.summary()
+        ops.PROBE = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -378,6 +423,7 @@ def main():
                         "traffic_source": traffic_src,
                         "traffic_gbs": None if traffic is None else round(traffic / (fwd_ms * 1e-3) / 1e9, 1)}},
             "kernels_ms": {k: round(v[0], 4) for k, v in spans.items()},
+            "roofline_classifier_convs": classifier_conv_roofline(conv_spans, n_frames, args.conv_arith),
             "launch": ("hipGraph replay of the captured step; roofline.launch_ms from HIP events around the same "
                        "C-ABI call in 6 eager steps run right after the timed region") if graphs is not None else
                       "eager (one launch per kernel); roofline.launch_ms from HIP events inside the timed region",
