@@ -1646,6 +1646,44 @@ __device__ __forceinline__ void wgrad_stage(const WgradArgs& a, float* buf, unsi
     }
 }
 
+// bf16x3 helpers (see conv_nhwc.hip: an fp32 value = the exact sum of three bf16 slices; six slice products per
+// fp32 product on the bf16 matrix cores, fp32 accumulate, error <= one fp32 rounding of the product)
+typedef __bf16 gen_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned gen_u32x4 __attribute__((ext_vector_type(4)));
+struct GenSplit3 { gen_u32x4 s[3]; };
+__device__ __forceinline__ GenSplit3 gen_split_bf16x3(const float (&v)[8]) {
+    unsigned u0[8], u1[8], u2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        u0[e] = __float_as_uint(v[e]);
+        const float r1 = v[e] - __uint_as_float(u0[e] & 0xffff0000u);
+        u1[e] = __float_as_uint(r1);
+        u2[e] = __float_as_uint(r1 - __uint_as_float(u1[e] & 0xffff0000u));
+    }
+    GenSplit3 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        r.s[0][e] = __builtin_amdgcn_perm(u0[2 * e + 1], u0[2 * e], 0x07060302u);
+        r.s[1][e] = __builtin_amdgcn_perm(u1[2 * e + 1], u1[2 * e], 0x07060302u);
+        r.s[2][e] = __builtin_amdgcn_perm(u2[2 * e + 1], u2[2 * e], 0x07060302u);
+    }
+    return r;
+}
+__device__ __forceinline__ f32x4 gen_mfma_x3(const GenSplit3& a, const GenSplit3& b, f32x4 c) {
+    // small terms first: (0,2) (2,0) (1,1) (0,1) (1,0) (0,0)
+    auto mm = [&](int i, int j, f32x4 acc) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gen_bf16x8, a.s[i]), __builtin_bit_cast(gen_bf16x8, b.s[j]), acc, 0, 0, 0);
+    };
+    c = mm(0, 2, c); c = mm(2, 0, c); c = mm(1, 1, c); c = mm(0, 1, c); c = mm(1, 0, c); c = mm(0, 0, c);
+    return c;
+}
+
+// X3 = true: the same GEMM in bf16x3 arithmetic -- one v_mfma_f32_16x16x32_bf16 k-block = the 32 pixels of a tile row
+// (lane (j, kq) holds pixels 8 kq .. 8 kq + 7 of its gradient plane / its (ci, tap) column: eight consecutive floats of an
+// LDS row), six MFMAs of 16 cycles per accumulator tile and row where the fp32 form issues eight of 32: 2.67x fewer
+// matrix cycles; the split of a fragment (44 VALU instructions) is shared by the two row tiles.  Same C layout, same
+// reductions.
+template <bool X3>
 __global__ __launch_bounds__(512, 2) void gen_bwd_weight_pc_kernel(WgradArgs a) {
     __shared__ __attribute__((aligned(16))) float lds2[2 * PW_BUF];
     const int lane = threadIdx.x & 63;
@@ -1696,6 +1734,34 @@ __global__ __launch_bounds__(512, 2) void gen_bwd_weight_pc_kernel(WgradArgs a) 
         asm volatile("s_barrier" ::: "memory");
         for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
             const float* lds = lds2 + (it & 1) * PW_BUF;
+            if constexpr (X3) {
+                // fragments: 8 consecutive pixels 8 kq .. 8 kq + 7 of this wave's tile row (offA / offB carry + kq: + 7 kq more)
+                const int sA = wave * WT_W + 7 * kq, sB = wave * WX_PITCH + 7 * kq;
+                float av[8];
+                const float4 p0 = *reinterpret_cast<const float4*>(lds + offA0 + sA), p1 = *reinterpret_cast<const float4*>(lds + offA0 + sA + 4);
+                av[0] = p0.x; av[1] = p0.y; av[2] = p0.z; av[3] = p0.w; av[4] = p1.x; av[5] = p1.y; av[6] = p1.z; av[7] = p1.w;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bias_a += av[e];
+                const GenSplit3 a0s = gen_split_bf16x3(av);
+                const float4 q0 = *reinterpret_cast<const float4*>(lds + offA1 + sA), q1 = *reinterpret_cast<const float4*>(lds + offA1 + sA + 4);
+                av[0] = q0.x; av[1] = q0.y; av[2] = q0.z; av[3] = q0.w; av[4] = q1.x; av[5] = q1.y; av[6] = q1.z; av[7] = q1.w;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) av[e] = rowB ? av[e] : 0.f;
+                const GenSplit3 a1s = gen_split_bf16x3(av);
+#pragma unroll
+                for (int t = 0; t < NT_B; ++t) {
+                    float bv[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bv[e] = lds[offB[t] + sB + e];
+                    if (t == 18 && ones) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) bv[e] = 1.f;
+                    }
+                    const GenSplit3 bs = gen_split_bf16x3(bv);
+                    if (t < 8) accA[t] = gen_mfma_x3(a0s, bs, accA[t]);
+                    accB[t] = gen_mfma_x3(a1s, bs, accB[t]);
+                }
+            } else
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const int sA = wave * WT_W + g * 4, sB = wave * WX_PITCH + g * 4;
@@ -2012,9 +2078,10 @@ int dmc_gen_tiny_bwd(const float* mv, const float* res, const float* const* w, c
     a.tiles_x = (W + WT_W - 1) / WT_W;
     const int groups = wgrad_groups(N, H, W);
     const int wpath = option(OPT_GEN_WGRAD_PATH);
-    if (W % 4 == 0 && wpath == 1) {
+    if (W % 4 == 0 && (wpath == 1 || wpath == 2)) {
         a.tiles_y = (H + PW_H - 1) / PW_H;
-        gen_bwd_weight_pc_kernel<<<groups, 512, 0, s>>>(a);
+        if (wpath == 2) gen_bwd_weight_pc_kernel<true><<<groups, 512, 0, s>>>(a);
+        else gen_bwd_weight_pc_kernel<false><<<groups, 512, 0, s>>>(a);
     } else {
         a.tiles_y = (H + WT_H - 1) / WT_H;
         if (W % 4 == 0) gen_bwd_weight_kernel<true><<<groups, 512, 0, s>>>(a, workspace + PACKED_TOTAL);
