@@ -201,9 +201,11 @@ def bench_i3d(args, rank, world, dev):
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    ops.profile_mark()                               # brackets the timed region in a rocprofv3 trace (tools/rocprof_region.py)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         _, losses, _ = one()
+    ops.profile_mark()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

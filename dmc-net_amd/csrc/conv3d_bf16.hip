@@ -427,7 +427,8 @@ C3dWgradPlan c3d_wgrad_plan(long M, int Cin, int Cout, int KD, int KH, int KW) {
     p.tiles_co = (Cout + p.ct - 1) / p.ct; p.tiles_ci = (Cin + p.ct - 1) / p.ct;
     p.groups = k3 ? 3 : 1;
     const long base = (long)p.tiles_co * p.tiles_ci * p.groups;
-    long splits = (1536 + base - 1) / base;                 // ~6 workgroups per CU
+    long splits = (512 + base - 1) / base;                  // ~2 rounds of one workgroup per CU (144 accumulator registers: one wave per SIMD); more splits only
+                                                            // grow the partials (conv3d_2c: 171 splits = 227 MB written and read back)
     const long max_splits = (M + 511) / 512;                // at least 512 pixels per split
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;

@@ -59,8 +59,12 @@ class Unit3Dpy(nn.Module):
         if self.pad is not None:
             x = self.pad(x)
         c = self.conv3d
-        if (OWN_CONV3D and self.pad is None and c.bias is None and x.is_cuda and x.dtype == torch.bfloat16
-                and ops.conv3d_bf16_supported(x, c.weight, c.stride, c.padding)):
+        own = (OWN_CONV3D and self.pad is None and c.bias is None and x.is_cuda and x.dtype == torch.bfloat16
+               and ops.conv3d_bf16_supported(x, c.weight, c.stride, c.padding))
+        if own and self.use_bn and not self.squeeze and ops.conv_bn_relu3d_supported(x, c, self.batch3d):
+            # conv (batch statistics in its epilogue) -> BatchNorm3d -> ReLU as one op on the bf16 kernels
+            return ops.conv_bn_relu3d(x, c, self.batch3d, self.relu)
+        if own:
             x = ops.conv3d_bf16(x, c.weight)            # bf16 NDHWC implicit GEMM on the matrix cores
         else:
             x = c(x)

@@ -1097,3 +1097,94 @@ class _MaxPool3dTF(torch.autograd.Function):
 def maxpool3d_tf(x, kernel, stride):
     """MaxPool3dTFPadding(kernel, stride)(x) for a bf16 ``x`` (see maxpool3d_tf_supported); channels_last_3d result."""
     return _MaxPool3dTF.apply(x, tuple(int(k) for k in kernel), tuple(int(s) for s in stride))
+
+
+class _ConvBnRelu3d(torch.autograd.Function):
+    """relu?(BatchNorm3d(conv3d(x, w))) of a Unit3Dpy in training mode (code/dmcnet_I3D/network/i3d.py:390-398) on the
+    bf16 kernels: the convolution's epilogue reduces the batch statistics, one streaming pass normalises and rectifies;
+    the backward runs the ReLU + BatchNorm backward in two passes and feeds the data / weight gradient kernels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, eps, momentum, relu):
+        lib = _lib.load()
+        if not (x.is_cuda and weight.is_cuda):
+            raise _lib.DmcHipError("conv_bn_relu3d runs on the HIP extension only (no CPU fallback)")
+        ctx.x_was_cl3 = x.is_contiguous(memory_format=_CL3)
+        x = _as_cl3(x)
+        wc = weight.detach().contiguous()
+        n, cin, d, h, w = x.shape
+        cout, _, kd, kh, kw = wc.shape
+        t = kd * kh * kw
+        m = n * d * h * w
+        y = torch.empty((n, cout, d, h, w), dtype=torch.bfloat16, device=x.device, memory_format=_CL3)
+        nblk = lib.dmc_conv3d_bf16_stat_blocks(n, d, h, w, cout)
+        part = torch.empty((nblk, cout, 2), dtype=torch.float32, device=x.device)
+        wpack = _floats(lib.dmc_conv3d_bf16_wpack_bytes(cin, cout, kd, kh, kw), x.device)
+        with _span("conv3d_bf16_fwd"):
+            _lib.check(lib.dmc_conv3d_bf16_fwd(_lib.ptr(x), _lib.ptr(wc), cin * t, t, 1, _lib.ptr(wpack), _lib.ptr(y),
+                                               _lib.ptr(part), n, d, h, w, cin, cout, kd, kh, kw, _stream()),
+                       "dmc_conv3d_bf16_fwd")
+        stats = torch.empty(2 * cout, dtype=torch.float32, device=x.device)
+        out = torch.empty_like(y)
+        with _span("bn3d_fwd"):
+            _lib.check(lib.dmc_bn3d_bf16_fwd(_lib.ptr(y), _lib.ptr(part), nblk, _lib.ptr(gamma), _lib.ptr(beta),
+                                             _lib.ptr(stats), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(out),
+                                             m, cout, int(relu), float(eps), float(momentum), _stream()), "dmc_bn3d_bf16_fwd")
+        ctx.save_for_backward(x, weight, y, gamma, beta, stats)
+        ctx.relu = bool(relu)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, weight, y, gamma, beta, stats = ctx.saved_tensors
+        dout = _as_cl3(dout)
+        wc = weight.detach().contiguous()
+        n, cin, d, h, w = x.shape
+        cout, _, kd, kh, kw = wc.shape
+        t = kd * kh * kw
+        m = n * d * h * w
+        dy = torch.empty_like(y)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        scratch = _floats(lib.dmc_bn3d_bf16_scratch_bytes(cout), y.device)
+        with _span("bn3d_bwd"):
+            _lib.check(lib.dmc_bn3d_bf16_bwd(_lib.ptr(dout), _lib.ptr(y), _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta),
+                                             _lib.ptr(scratch), _lib.ptr(dy), _lib.ptr(dgamma), _lib.ptr(dbeta), m, cout,
+                                             int(ctx.relu), _stream()), "dmc_bn3d_bf16_bwd")
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            wpack = _floats(lib.dmc_conv3d_bf16_wpack_bytes(cin, cout, kd, kh, kw), x.device)
+            with _span("conv3d_bf16_dgrad"):
+                _lib.check(lib.dmc_conv3d_bf16_dgrad(_lib.ptr(dy), _lib.ptr(wc), cin * t, t, 1, _lib.ptr(wpack),
+                                                     _lib.ptr(dx), n, d, h, w, cin, cout, kd, kh, kw, _stream()),
+                           "dmc_conv3d_bf16_dgrad")
+            if not ctx.x_was_cl3:
+                dx = dx.contiguous()
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(wc)
+            work = _floats(lib.dmc_conv3d_bf16_wgrad_bytes(n, d, h, w, cin, cout, kd, kh, kw), x.device)
+            with _span("conv3d_bf16_wgrad"):
+                _lib.check(lib.dmc_conv3d_bf16_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(work), n, d, h, w,
+                                                     cin, cout, kd, kh, kw, _stream()), "dmc_conv3d_bf16_wgrad")
+            dw = dw.view_as(weight)
+        return dx, dw, dgamma, dbeta, None, None, None, None, None
+
+
+def conv_bn_relu3d_supported(x, conv, bn):
+    """True if conv -> BatchNorm3d (training) [-> ReLU] of a Unit3Dpy can run as the fused bf16 op."""
+    if not (torch.is_grad_enabled() and bn.training and bn.track_running_stats and bn.affine and bn.momentum is not None):
+        return False
+    if bn.weight.dtype != torch.float32 or not conv3d_bf16_supported(x, conv.weight, conv.stride, conv.padding):
+        return False
+    n, _, d, h, w = x.shape
+    return bool(_lib.load().dmc_bn3d_bf16_supported(n * d * h * w, conv.out_channels))
+
+
+def conv_bn_relu3d(x, conv, bn, relu=True):
+    """relu?(bn(conv(x))) for a bf16 ``x`` (see conv_bn_relu3d_supported); updates the running statistics and
+    ``num_batches_tracked`` as nn.BatchNorm3d does."""
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _ConvBnRelu3d.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum,
+                               bool(relu))

@@ -150,3 +150,47 @@ def test_maxpool3d_tf_matches_the_stock_module_bit_for_bit(kernel, stride, shape
     yo.backward(g)
     assert torch.equal(yo.float(), ys)
     assert torch.equal(xo.grad.float(), xs.grad.bfloat16().float())
+
+
+@pytest.mark.parametrize("shape,cout,k,relu", [((2, 64, 4, 14, 14), 192, 3, True), ((1, 192, 3, 7, 6), 16, 1, True),
+                                               ((3, 48, 2, 9, 5), 208, 3, False), ((2, 832, 2, 7, 7), 384, 1, True)])
+def test_conv_bn_relu3d_vs_fp32_batchnorm_on_the_same_conv_output(shape, cout, k, relu):
+    """The fused conv -> BatchNorm3d -> ReLU op against torch's fp32 BatchNorm + ReLU applied to the SAME bf16
+    convolution output (so only the BatchNorm / ReLU kernels differ): output within one bf16 rounding, running
+    statistics to 1e-5, dgamma / dbeta to 2e-3 of their largest element (bf16 inputs, fp32 vs fp64 sums), the
+    gradient handed to the convolution within bf16 rounding of the fp32 one."""
+    torch.manual_seed(7)
+    n, cin = shape[0], shape[1]
+    unit = i3d.Unit3Dpy(cin, cout, (k, k, k), activation="relu" if relu else None).to(DEV).train()
+    with torch.no_grad():
+        unit.batch3d.weight.uniform_(0.5, 1.5); unit.batch3d.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(*shape, device=DEV).bfloat16().contiguous(memory_format=CL3)
+    g = torch.randn(n, cout, *shape[2:], device=DEV).bfloat16().contiguous(memory_format=CL3)
+    assert ops.conv_bn_relu3d_supported(x, unit.conv3d, unit.batch3d)
+    out = unit(x)                                                     # fused path
+    assert out.dtype == torch.bfloat16 and out.is_contiguous(memory_format=CL3)
+    out.backward(g)
+    got = dict(out=out.float(), dgamma=unit.batch3d.weight.grad.clone(), dbeta=unit.batch3d.bias.grad.clone(),
+               dw=unit.conv3d.weight.grad.clone(), rm=unit.batch3d.running_mean.clone(), rv=unit.batch3d.running_var.clone())
+    assert int(unit.batch3d.num_batches_tracked) == 1
+    # reference: the same convolution kernel, then fp32 BatchNorm / ReLU by torch
+    unit.zero_grad()
+    bn = torch.nn.BatchNorm3d(cout).to(DEV).train()
+    bn.load_state_dict({k_: v for k_, v in unit.batch3d.state_dict().items()})
+    with torch.no_grad():
+        bn.running_mean.zero_(); bn.running_var.fill_(1.0); bn.num_batches_tracked.zero_()
+    y = ops.conv3d_bf16(x, unit.conv3d.weight)
+    yf = y.detach().float().requires_grad_(True)
+    ref = bn(yf)
+    ref = torch.relu(ref) if relu else ref
+    ref.backward(g.float())
+    tol = ref.abs() * 2.0 ** -8 + 1e-3
+    assert bool(((got["out"] - ref).abs() <= tol).all())
+    assert float((got["rm"] - bn.running_mean).abs().max()) < 1e-5 and float((got["rv"] - bn.running_var).abs().max() / bn.running_var.abs().max()) < 1e-5
+    for name, a, b in (("dgamma", got["dgamma"], bn.weight.grad), ("dbeta", got["dbeta"], bn.bias.grad)):
+        assert float((a - b).abs().max() / b.abs().max()) < 2e-3, name
+    # the convolution's weight gradient from the fused op's dy against the one from the fp32 dy rounded to bf16
+    y2 = ops.conv3d_bf16(x, unit.conv3d.weight)
+    y2.backward(yf.grad.bfloat16())
+    err = float((got["dw"] - unit.conv3d.weight.grad).abs().max() / unit.conv3d.weight.grad.abs().max())
+    assert err < 5e-3, err
