@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void bn3d_apply_kernel(const bf16_t* __restric
 __global__ __launch_bounds__(256) void bn3d_bwd_partial_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ y,
                                                                const float* __restrict__ stats, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float* __restrict__ part, long M,
-                                                               int C, int relu) {
+                                                               int C, int relu, long dout_ld) {
     __shared__ float red[256 * 16];
     const int C8 = C >> 3, P = 256 / C8;
     const int chunk = threadIdx.x % C8, pl = threadIdx.x / C8;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void bn3d_bwd_partial_kernel(const bf16_t* __r
         }
         for (long m = (long)blockIdx.x * P + pl; m < M; m += (long)gridDim.x * P) {
             float g[8], v[8];
-            unpack8(*reinterpret_cast<const u32x4*>(dout + m * C + 8 * chunk), g);
+            unpack8(*reinterpret_cast<const u32x4*>(dout + m * dout_ld + 8 * chunk), g);
             unpack8(*reinterpret_cast<const u32x4*>(y + m * C + 8 * chunk), v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void bn3d_bwd_final_kernel(const float* __rest
 __global__ __launch_bounds__(256) void bn3d_bwd_apply_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ y,
                                                              const float* __restrict__ stats, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float* __restrict__ coef,
-                                                             bf16_t* __restrict__ dy, long M, int C, int relu) {
+                                                             bf16_t* __restrict__ dy, long M, int C, int relu, long dout_ld) {
     const int C8 = C >> 3, P = 256 / C8;
     const int chunk = threadIdx.x % C8, pl = threadIdx.x / C8;
     if (pl >= P) return;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void bn3d_bwd_apply_kernel(const bf16_t* __res
     }
     for (long m = (long)blockIdx.x * P + pl; m < M; m += (long)gridDim.x * P) {
         float g[8], v[8];
-        unpack8(*reinterpret_cast<const u32x4*>(dout + m * C + 8 * chunk), g);
+        unpack8(*reinterpret_cast<const u32x4*>(dout + m * dout_ld + 8 * chunk), g);
         unpack8(*reinterpret_cast<const u32x4*>(y + m * C + 8 * chunk), v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -227,21 +227,23 @@ int dmc_bn3d_bf16_fwd(const void* y, const float* partials, int nblk, const floa
     return check_launch("bn3d_apply");
 }
 
-// dy (gradient of the convolution output), dgamma, dbeta from dout; scratch: dmc_bn3d_bf16_scratch_bytes(C)
-int dmc_bn3d_bf16_bwd(const void* dout, const void* y, const float* stats, const float* gamma, const float* beta, float* scratch,
-                      void* dy, float* dgamma, float* dbeta, long M, int C, int relu, dmc_stream_t stream) {
+// dy (gradient of the convolution output), dgamma, dbeta from dout; scratch: dmc_bn3d_bf16_scratch_bytes(C).
+// dout_ld: elements between consecutive pixels of dout (C for a dense tensor; the width of the concatenated tensor
+// when dout is a channel slice of an Inception block's gradient, which is then read in place)
+int dmc_bn3d_bf16_bwd(const void* dout, long dout_ld, const void* y, const float* stats, const float* gamma, const float* beta,
+                      float* scratch, void* dy, float* dgamma, float* dbeta, long M, int C, int relu, dmc_stream_t stream) {
     if (!dout || !y || !stats || !gamma || !beta || !scratch || !dy || !dgamma || !dbeta)
         return fail(DMC_E_INVALID, "dmc_bn3d_bf16_bwd: null pointer");
-    if (!bn3_ok(M, C)) return fail(DMC_E_INVALID, "dmc_bn3d_bf16_bwd: unsupported shape M=%ld C=%d", M, C);
+    if (!bn3_ok(M, C) || dout_ld < C || dout_ld % 8 != 0) return fail(DMC_E_INVALID, "dmc_bn3d_bf16_bwd: unsupported shape M=%ld C=%d ld=%ld", M, C, dout_ld);
     hipStream_t s = (hipStream_t)stream;
     const int nblk = bn3_blocks(M, C);
     float* coef = scratch + (size_t)BN3_MAXBLK * C * 2;
-    bn3d_bwd_partial_kernel<<<nblk, 256, 0, s>>>((const bf16_t*)dout, (const bf16_t*)y, stats, gamma, beta, scratch, M, C, relu);
+    bn3d_bwd_partial_kernel<<<nblk, 256, 0, s>>>((const bf16_t*)dout, (const bf16_t*)y, stats, gamma, beta, scratch, M, C, relu, dout_ld);
     int rc = check_launch("bn3d_bwd_partial");
     if (rc) return rc;
     bn3d_bwd_final_kernel<<<C, 256, 0, s>>>(scratch, nblk, C, M, dgamma, dbeta, coef);
     if ((rc = check_launch("bn3d_bwd_final"))) return rc;
-    bn3d_bwd_apply_kernel<<<nblk, 256, 0, s>>>((const bf16_t*)dout, (const bf16_t*)y, stats, gamma, beta, coef, (bf16_t*)dy, M, C, relu);
+    bn3d_bwd_apply_kernel<<<nblk, 256, 0, s>>>((const bf16_t*)dout, (const bf16_t*)y, stats, gamma, beta, coef, (bf16_t*)dy, M, C, relu, dout_ld);
     return check_launch("bn3d_bwd_apply");
 }
 

@@ -173,7 +173,7 @@ class I3D(nn.Module):
             inp = self.generate(inp)
         x = inp.detach() if detach else inp
         if self.trunk_dtype is not None and x.is_cuda:
-            with torch.autocast("cuda", dtype=self.trunk_dtype):
+            with torch.autocast("cuda", dtype=self.trunk_dtype), ops.batched_bn_counters():
                 for nm in self._ORDER:
                     x = getattr(self, nm)(x)
             x = x.float()

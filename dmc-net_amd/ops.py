@@ -1138,17 +1138,21 @@ class _ConvBnRelu3d(torch.autograd.Function):
     def backward(ctx, dout):
         lib = _lib.load()
         x, weight, y, gamma, beta, stats = ctx.saved_tensors
-        dout = _as_cl3(dout)
         wc = weight.detach().contiguous()
         n, cin, d, h, w = x.shape
         cout, _, kd, kh, kw = wc.shape
         t = kd * kh * kw
         m = n * d * h * w
+        # a channel slice of a concatenated (Inception) gradient is read in place: NDHWC memory with a wider pixel stride
+        ld = dout.stride(4) if dout.dim() == 5 else 0
+        if not (dout.dtype == torch.bfloat16 and ld >= cout and ld % 8 == 0 and dout.storage_offset() % 8 == 0
+                and dout.stride() == (d * h * w * ld, 1, h * w * ld, w * ld, ld)):
+            dout, ld = _as_cl3(dout), cout
         dy = torch.empty_like(y)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         scratch = _floats(lib.dmc_bn3d_bf16_scratch_bytes(cout), y.device)
         with _span("bn3d_bwd"):
-            _lib.check(lib.dmc_bn3d_bf16_bwd(_lib.ptr(dout), _lib.ptr(y), _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta),
+            _lib.check(lib.dmc_bn3d_bf16_bwd(_lib.ptr(dout), ld, _lib.ptr(y), _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta),
                                              _lib.ptr(scratch), _lib.ptr(dy), _lib.ptr(dgamma), _lib.ptr(dbeta), m, cout,
                                              int(ctx.relu), _stream()), "dmc_bn3d_bf16_bwd")
         dx = dw = None
@@ -1185,6 +1189,9 @@ def conv_bn_relu3d(x, conv, bn, relu=True):
     """relu?(bn(conv(x))) for a bf16 ``x`` (see conv_bn_relu3d_supported); updates the running statistics and
     ``num_batches_tracked`` as nn.BatchNorm3d does."""
     if bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        if _PENDING_COUNTERS is not None:
+            _PENDING_COUNTERS.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked.add_(1)
     return _ConvBnRelu3d.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum,
                                bool(relu))

@@ -394,7 +394,8 @@ int dmc_maxpool3d_tf_bf16_bwd(const void* dy, const void* code, void* dx, int N,
  * that ran dmc_conv3d_bf16_fwd with stat_partials: y [M,C] bf16 (M = N*D*H*W), partials [nblk][C][2] floats.
  * fwd: stats [2*C] = (mean, invstd) (biased variance + eps), running_mean / running_var updated with `momentum`
  * (unbiased variance; NULL to skip), out = relu?(gamma * (y - mean) * invstd + beta) in bf16.
- * bwd: dy = gradient of y, dgamma, dbeta (fp32) from dout; scratch of dmc_bn3d_bf16_scratch_bytes(C).  fp32 per
+ * bwd: dy = gradient of y, dgamma, dbeta (fp32) from dout (pixel stride dout_ld elements: C, or the width of the
+ * concatenated Inception output when dout is a channel slice of its gradient); scratch of dmc_bn3d_bf16_scratch_bytes(C).  fp32 per
  * element, fp64 per-channel sums in fixed order (deterministic).  C % 8 == 0, C <= 2048.
  */
 int dmc_bn3d_bf16_supported(long M, int C);
@@ -402,8 +403,8 @@ size_t dmc_bn3d_bf16_scratch_bytes(int C);
 int dmc_bn3d_bf16_fwd(const void* y, const float* partials, int nblk, const float* gamma, const float* beta, float* stats,
                       float* running_mean, float* running_var, void* out, long M, int C, int relu, float eps, float momentum,
                       dmc_stream_t stream);
-int dmc_bn3d_bf16_bwd(const void* dout, const void* y, const float* stats, const float* gamma, const float* beta, float* scratch,
-                      void* dy, float* dgamma, float* dbeta, long M, int C, int relu, dmc_stream_t stream);
+int dmc_bn3d_bf16_bwd(const void* dout, long dout_ld, const void* y, const float* stats, const float* gamma, const float* beta,
+                      float* scratch, void* dy, float* dgamma, float* dbeta, long M, int C, int relu, dmc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -194,3 +194,23 @@ def test_conv_bn_relu3d_vs_fp32_batchnorm_on_the_same_conv_output(shape, cout, k
     y2.backward(yf.grad.bfloat16())
     err = float((got["dw"] - unit.conv3d.weight.grad).abs().max() / unit.conv3d.weight.grad.abs().max())
     assert err < 5e-3, err
+
+
+def test_conv_bn_relu3d_reads_a_concatenation_slice_gradient_in_place():
+    """The gradient of an Inception branch is a channel slice of the concatenated gradient (NDHWC memory with a wider
+    pixel stride): the fused op reads it in place; results are bit-identical to those from a dense copy."""
+    torch.manual_seed(9)
+    unit = i3d.Unit3Dpy(32, 48, (3, 3, 3)).to(DEV).train()
+    x = torch.randn(2, 32, 3, 6, 5, device=DEV).bfloat16().contiguous(memory_format=CL3)
+    wide = torch.randn(2, 16 + 48 + 24, 3, 6, 5, device=DEV).bfloat16().contiguous(memory_format=CL3)
+    res = []
+    for dense in (False, True):
+        unit.zero_grad()
+        xi = x.clone().contiguous(memory_format=CL3).requires_grad_(True)
+        out = unit(xi)
+        g = wide[:, 16:64]
+        assert not g.is_contiguous(memory_format=CL3)
+        out.backward(g.clone().contiguous(memory_format=CL3) if dense else g)
+        res.append((xi.grad.clone(), unit.conv3d.weight.grad.clone(), unit.batch3d.weight.grad.clone(), unit.batch3d.bias.grad.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
