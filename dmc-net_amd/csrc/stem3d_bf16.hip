@@ -1,0 +1,219 @@
+// Forward of the I3D stem on the bf16 matrix cores (BASELINE config 5).
+//
+// Replaces the convolution of `conv3d_1a_7x7 = Unit3Dpy(in_channels, 64, (7, 7, 7), (2, 2, 2))`, built at
+// code/dmcnet_I3D/network/i3d.py:480-481, run through Unit3Dpy.forward (:390-393: ConstantPad3d to the TF-"SAME"
+// extent, front 2 / back 3 per dimension, then nn.Conv3d with padding 0) on the 2-channel DMC cue, as the reference
+// runs it in 16-bit mixed precision: 106 GFLOP for 3 clips x 64 frames x 224^2, K = 2 x 343 = 686.
+//
+// With 2 input channels the contraction is arranged by (kz, ky): one MFMA k-block of 16 = the 7 taps kx x 2 channels
+// of an input row segment (14 values) + 2 zero-weight slots -- 49 k-blocks, 87.5 % useful.  The cue is first
+// converted to a zero-padded bf16 volume [n][T+5][H+5][Wp][2] (stem3d_prep_kernel; Wp a multiple of 4 pixels), in
+// which the 16 values of a k-block for output pixel ox are 32 CONTIGUOUS bytes starting at pixel 2 ox of row
+// (2 od + kz, 2 oh + ky): lane (pixel, half) loads its 16 bytes straight from global memory (the volume is 44 MB
+// and stays in L2 / MALL), no LDS staging of activations.  The packed weights [49][64][16] (100 KB) are loaded into
+// LDS once per workgroup; rows = the 64 output channels (two 32-row tiles), columns = 32 consecutive output pixels.
+// Persistent workgroups of 8 waves walk the pixel tiles.  Epilogue: bf16 NDHWC stores and, per wave, the per-channel
+// (sum, sum of squares) of the rounded outputs for the BatchNorm3d that follows (dmc_bn3d_bf16_fwd).
+// The stem's data and weight gradients stay on MIOpen (dmc-net_amd/ops.py: _Stem3d).
+#include "dmc_common.h"
+
+using namespace dmc;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short bf16_t;
+
+__device__ __forceinline__ unsigned f2bf(float v) {
+    unsigned u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf2f(unsigned h) { return __uint_as_float(h << 16); }
+
+constexpr int S3_CO = 64, S3_K = 7, S3_KB = 49, S3_WAVES = 8;
+constexpr int S3_WLDS = S3_KB * S3_CO * 16 * 2;           // 100,352 bytes
+
+// x fp32 [N][2][T][H][W] -> xq [N][Tp][Hp][Wp] dwords, dword = (bf16 channel 0) | (bf16 channel 1) << 16, zero borders
+__global__ __launch_bounds__(256) void stem3d_prep_kernel(const float* __restrict__ x, unsigned* __restrict__ xq, int N, int T, int H,
+                                                          int W, int Tp, int Hp, int Wp) {
+    const long total = (long)N * Tp * Hp * Wp;
+    const long plane = (long)T * H * W;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int xx = (int)(i % Wp);
+        long r = i / Wp;
+        const int yy = (int)(r % Hp); r /= Hp;
+        const int zz = (int)(r % Tp);
+        const int n = (int)(r / Tp);
+        const int t = zz - 2, h = yy - 2, w = xx - 2;
+        unsigned v = 0;
+        if (t >= 0 && t < T && h >= 0 && h < H && w >= 0 && w < W) {
+            const long o = ((long)n * 2) * plane + ((long)t * H + h) * W + w;
+            v = f2bf(x[o]) | (f2bf(x[o + plane]) << 16);
+        }
+        xq[i] = v;
+    }
+}
+
+// w fp32 [64][2][7][7][7] (contiguous) -> wp bf16 [49][64][16]: slot 2 kx + c, slots 14, 15 zero
+__global__ __launch_bounds__(256) void stem3d_pack_w_kernel(const float* __restrict__ w, bf16_t* __restrict__ wp) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S3_KB * S3_CO * 16) return;
+    const int j = i & 15, co = (i >> 4) % S3_CO, kb = i / (16 * S3_CO);
+    unsigned v = 0;
+    if (j < 14) {
+        const int kx = j >> 1, c = j & 1;
+        v = f2bf(w[((co * 2 + c) * 343) + kb * 7 + kx]);       // kb = kz * 7 + ky
+    }
+    wp[i] = (bf16_t)v;
+}
+
+struct Stem3dArgs {
+    const unsigned* xq;    // [N][Tp][Hp][Wp] dwords
+    const bf16_t* wp;      // [49][64][16]
+    bf16_t* y;             // [N][OD][OH][OW][64]
+    float* stat_part;      // [gridDim.x * 8][64][2] or null
+    int N, OD, OH, OW, Tp, Hp, Wp, tiles_x;
+};
+
+__global__ __launch_bounds__(S3_WAVES * 64) void stem3d_fwd_kernel(Stem3dArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char wlds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    for (int i = tid; i < S3_WLDS / 16; i += S3_WAVES * 64)
+        reinterpret_cast<u32x4*>(wlds)[i] = reinterpret_cast<const u32x4*>(a.wp)[i];
+    __syncthreads();
+
+    const long ntiles = (long)a.N * a.OD * a.OH * a.tiles_x;
+    const long stride = (long)gridDim.x * S3_WAVES;
+    const int woff = l31 * 32 + half * 16;                 // this lane's A fragment inside a [64][16] slab (+ 1024 for tile 1)
+    float s1[2][16], s2[2][16];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s1[ct][e] = 0.f; s2[ct][e] = 0.f; }
+
+    for (long tile = (long)blockIdx.x * S3_WAVES + wave; tile < ntiles; tile += stride) {
+        const int xt = (int)(tile % a.tiles_x);
+        long r = tile / a.tiles_x;                          // (n * OD + od) * OH + oh
+        const int oh = (int)(r % a.OH);
+        const long nd = r / a.OH;
+        const int od = (int)(nd % a.OD);
+        const int n = (int)(nd / a.OD);
+        const int ox = 32 * xt + l31;
+        const int oxc = ox < a.OW ? ox : a.OW - 1;          // clipped lanes read a valid pixel and do not store
+        // dword index of (row z = 2 od, y = 2 oh, pixel 2 ox + 4 half)
+        const unsigned* base = a.xq + (((long)n * a.Tp + 2 * od) * a.Hp + 2 * oh) * a.Wp + 2 * oxc + 4 * half;
+        f32x16 acc[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
+#pragma unroll
+        for (int kz = 0; kz < S3_K; ++kz) {
+            u32x4 xb[S3_K];
+#pragma unroll
+            for (int ky = 0; ky < S3_K; ++ky) {
+                const unsigned* p = base + ((long)kz * a.Hp + ky) * a.Wp;
+                const u32x2 lo = *reinterpret_cast<const u32x2*>(p), hi = *reinterpret_cast<const u32x2*>(p + 2);
+                xb[ky] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+#pragma unroll
+            for (int ky = 0; ky < S3_K; ++ky) {
+                const char* wk = wlds + (kz * S3_K + ky) * (S3_CO * 32) + woff;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const u32x4 wf = *reinterpret_cast<const u32x4*>(wk + ct * 1024);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xb[ky]),
+                                                                      acc[ct], 0, 0, 0);
+                }
+            }
+        }
+        // lane holds pixel column l31, channels 32 ct + 8 g + 4 half + e in acc[ct][4 g + e]
+        if (ox < a.OW) {
+            bf16_t* dst = a.y + (r * a.OW + ox) * S3_CO;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    unsigned h[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        h[e] = f2bf(acc[ct][4 * g + e]);
+                        const float rv = bf2f(h[e]);
+                        s1[ct][4 * g + e] += rv; s2[ct][4 * g + e] += rv * rv;
+                    }
+                    *reinterpret_cast<u32x2*>(dst + 32 * ct + 8 * g + 4 * half) = u32x2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+                }
+        }
+    }
+    if (a.stat_part) {
+        float* dst = a.stat_part + ((size_t)blockIdx.x * S3_WAVES + wave) * S3_CO * 2;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float d1 = s1[ct][e], d2 = s2[ct][e];
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) { d1 += __shfl_xor(d1, o, 64); d2 += __shfl_xor(d2, o, 64); }
+                if (l31 == 0) {
+                    const int c = 32 * ct + 8 * (e >> 2) + 4 * half + (e & 3);
+                    dst[2 * c] = d1; dst[2 * c + 1] = d2;
+                }
+            }
+    }
+}
+
+int s3_blocks(long tiles) {
+    long b = (tiles + S3_WAVES - 1) / S3_WAVES;
+    return (int)(b > 256 ? 256 : (b < 1 ? 1 : b));         // one 100 KB workgroup per CU
+}
+
+}  // namespace
+
+extern "C" {
+
+// bytes of the workspace: padded bf16 volume + packed weights
+size_t dmc_stem3d_bf16_workspace_bytes(int N, int T, int H, int W) {
+    const long Wp = (W + 5 + 1 + 3) / 4 * 4;
+    return (size_t)N * (T + 5) * (H + 5) * Wp * 4 + (size_t)S3_KB * S3_CO * 16 * 2 + 64;
+}
+// rows of [64][2] float partials the forward writes when asked for statistics
+int dmc_stem3d_bf16_stat_blocks(int N, int T, int H, int W) {
+    const int OD = (T + 5 - 7) / 2 + 1, OH = (H + 5 - 7) / 2 + 1, OW = (W + 5 - 7) / 2 + 1;
+    return s3_blocks((long)N * OD * OH * ((OW + 31) / 32)) * S3_WAVES;
+}
+
+// y [N,OD,OH,OW,64] bf16 (NDHWC) = conv3d(pad_SAME(x [N,2,T,H,W] fp32), w [64,2,7,7,7] fp32 contiguous, stride 2);
+// OD = (T + 5 - 7) / 2 + 1 etc.  x and w are rounded to bf16 (nearest even), fp32 accumulation.
+int dmc_stem3d_bf16_fwd(const float* x, const float* w, void* workspace, void* y, float* stat_partials, int N, int T, int H, int W,
+                        dmc_stream_t stream) {
+    if (!x || !w || !workspace || !y) return fail(DMC_E_INVALID, "dmc_stem3d_bf16_fwd: null pointer");
+    if (N <= 0 || T < 2 || H < 2 || W < 2) return fail(DMC_E_INVALID, "dmc_stem3d_bf16_fwd: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const int Tp = T + 5, Hp = H + 5, Wp = (W + 5 + 1 + 3) / 4 * 4;
+    unsigned* xq = (unsigned*)workspace;
+    bf16_t* wp = (bf16_t*)((char*)workspace + (size_t)N * Tp * Hp * Wp * 4);
+    const long total = (long)N * Tp * Hp * Wp;
+    stem3d_prep_kernel<<<(int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256), 256, 0, s>>>(x, xq, N, T, H, W, Tp, Hp, Wp);
+    int rc = check_launch("stem3d_prep");
+    if (rc) return rc;
+    stem3d_pack_w_kernel<<<(S3_KB * S3_CO * 16 + 255) / 256, 256, 0, s>>>(w, wp);
+    if ((rc = check_launch("stem3d_pack_w"))) return rc;
+    Stem3dArgs a;
+    a.xq = xq; a.wp = wp; a.y = (bf16_t*)y; a.stat_part = stat_partials;
+    a.N = N; a.OD = (T + 5 - 7) / 2 + 1; a.OH = (H + 5 - 7) / 2 + 1; a.OW = (W + 5 - 7) / 2 + 1;
+    a.Tp = Tp; a.Hp = Hp; a.Wp = Wp; a.tiles_x = (a.OW + 31) / 32;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&stem3d_fwd_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, S3_WLDS);
+    if (attr != hipSuccess) return fail(DMC_E_LAUNCH, "stem3d: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
+    const long tiles = (long)N * a.OD * a.OH * a.tiles_x;
+    stem3d_fwd_kernel<<<s3_blocks(tiles), S3_WAVES * 64, S3_WLDS, s>>>(a);
+    return check_launch("stem3d_fwd");
+}
+
+}  // extern "C"

@@ -56,9 +56,13 @@ class Unit3Dpy(nn.Module):
         self.use_bn = use_bn
 
     def forward(self, x):
+        c = self.conv3d
+        if (OWN_CONV3D and self.pad is not None and self.use_bn and not self.squeeze and c.kernel_size == (7, 7, 7)
+                and ops.stem3d_supported(x, c, self.batch3d)):
+            # the 2-channel stem: forward on the bf16 matrix cores with the BatchNorm3d statistics in its epilogue
+            return ops.stem3d_bn_relu(x, c, self.batch3d, self.relu)
         if self.pad is not None:
             x = self.pad(x)
-        c = self.conv3d
         own = (OWN_CONV3D and self.pad is None and c.bias is None and x.is_cuda and x.dtype == torch.bfloat16
                and ops.conv3d_bf16_supported(x, c.weight, c.stride, c.padding))
         if own and self.use_bn and not self.squeeze and ops.conv_bn_relu3d_supported(x, c, self.batch3d):

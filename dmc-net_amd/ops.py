@@ -1195,3 +1195,84 @@ def conv_bn_relu3d(x, conv, bn, relu=True):
             bn.num_batches_tracked.add_(1)
     return _ConvBnRelu3d.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum,
                                bool(relu))
+
+
+class _Stem3dBnRelu(torch.autograd.Function):
+    """relu(BatchNorm3d(conv3d_1a_7x7(x))) of the I3D stem in a bf16 trunk (code/dmcnet_I3D/network/i3d.py:480-481,
+    :390-398): forward on dmc_stem3d_bf16_fwd (statistics in its epilogue) + the fused BatchNorm3d / ReLU pass; the
+    BatchNorm / ReLU backward on bn3d_bf16.hip, the convolution's data and weight gradients on PyTorch-ROCm (MIOpen)
+    with the tensors the stock path would hand it (bf16, NCDHW, explicitly padded)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, eps, momentum, relu):
+        lib = _lib.load()
+        if not (x.is_cuda and weight.is_cuda):
+            raise _lib.DmcHipError("stem3d runs on the HIP extension only (no CPU fallback)")
+        xc = x.detach().float().contiguous()
+        wc = weight.detach().float().contiguous()
+        n, _, t, h, w = xc.shape
+        od, oh, ow = (t - 2) // 2 + 1, (h - 2) // 2 + 1, (w - 2) // 2 + 1
+        y = torch.empty((n, 64, od, oh, ow), dtype=torch.bfloat16, device=x.device, memory_format=_CL3)
+        work = _floats(lib.dmc_stem3d_bf16_workspace_bytes(n, t, h, w), x.device)
+        nblk = lib.dmc_stem3d_bf16_stat_blocks(n, t, h, w)
+        part = torch.empty((nblk, 64, 2), dtype=torch.float32, device=x.device)
+        with _span("stem3d_fwd"):
+            _lib.check(lib.dmc_stem3d_bf16_fwd(_lib.ptr(xc), _lib.ptr(wc), _lib.ptr(work), _lib.ptr(y), _lib.ptr(part), n, t, h, w,
+                                               _stream()), "dmc_stem3d_bf16_fwd")
+        stats = torch.empty(128, dtype=torch.float32, device=x.device)
+        out = torch.empty_like(y)
+        m = n * od * oh * ow
+        with _span("bn3d_fwd"):
+            _lib.check(lib.dmc_bn3d_bf16_fwd(_lib.ptr(y), _lib.ptr(part), nblk, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(stats),
+                                             _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(out), m, 64, int(relu),
+                                             float(eps), float(momentum), _stream()), "dmc_bn3d_bf16_fwd")
+        ctx.save_for_backward(xc.bfloat16(), weight, y, gamma, beta, stats)
+        ctx.relu = bool(relu)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        xb, weight, y, gamma, beta, stats = ctx.saved_tensors
+        n, _, od, oh, ow = y.shape
+        m = n * od * oh * ow
+        dout = _as_cl3(dout)
+        dy = torch.empty_like(y)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        scratch = _floats(lib.dmc_bn3d_bf16_scratch_bytes(64), y.device)
+        with _span("bn3d_bwd"):
+            _lib.check(lib.dmc_bn3d_bf16_bwd(_lib.ptr(dout), 64, _lib.ptr(y), _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta),
+                                             _lib.ptr(scratch), _lib.ptr(dy), _lib.ptr(dgamma), _lib.ptr(dbeta), m, 64,
+                                             int(ctx.relu), _stream()), "dmc_bn3d_bf16_bwd")
+        t, h, w = xb.shape[2:]
+        xpad = torch.nn.functional.pad(xb, (2, 3, 2, 3, 2, 3))
+        with _span("stem3d_bwd"):
+            dxp, dw, _ = torch.ops.aten.convolution_backward(
+                dy.contiguous(), xpad, weight.detach().bfloat16(), None, (2, 2, 2), (0, 0, 0), (1, 1, 1), False, (0, 0, 0), 1,
+                (bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), False))
+        dx = dxp[:, :, 2:2 + t, 2:2 + h, 2:2 + w].float() if dxp is not None else None
+        dw = dw.to(weight.dtype) if dw is not None else None
+        return dx, dw, dgamma, dbeta, None, None, None, None, None
+
+
+def stem3d_supported(x, conv, bn):
+    """True if the I3D stem unit (2 -> 64 channels, 7x7x7, stride 2, TF-"SAME") can take the bf16 HIP forward: a CUDA
+    fp32 / bf16 cue inside a bf16 autocast region, BatchNorm3d in training mode."""
+    if not (x.is_cuda and x.dim() == 5 and x.shape[1] == 2 and torch.is_autocast_enabled()
+            and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+        return False
+    if tuple(conv.weight.shape) != (64, 2, 7, 7, 7) or tuple(conv.stride) != (2, 2, 2) or conv.bias is not None:
+        return False
+    if not (torch.is_grad_enabled() and bn.training and bn.track_running_stats and bn.affine and bn.momentum is not None):
+        return False
+    return all(int(s) >= 2 and int(s) % 2 == 0 for s in x.shape[2:])
+
+
+def stem3d_bn_relu(x, conv, bn, relu=True):
+    if bn.num_batches_tracked is not None:
+        if _PENDING_COUNTERS is not None:
+            _PENDING_COUNTERS.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked.add_(1)
+    return _Stem3dBnRelu.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum,
+                               bool(relu))

@@ -406,6 +406,19 @@ int dmc_bn3d_bf16_fwd(const void* y, const float* partials, int nblk, const floa
 int dmc_bn3d_bf16_bwd(const void* dout, long dout_ld, const void* y, const float* stats, const float* gamma, const float* beta,
                       float* scratch, void* dy, float* dgamma, float* dbeta, long M, int C, int relu, dmc_stream_t stream);
 
+/* ---- I3D stem: forward of conv3d_1a_7x7 on the bf16 matrix cores -----------------------------------------
+ * Replaces ConstantPad3d(TF-"SAME": front 2, back 3) + nn.Conv3d(2, 64, 7, stride 2) of the stem Unit3Dpy,
+ * code/dmcnet_I3D/network/i3d.py:480-481 via :390-393, as run in 16-bit mixed precision: x [N,2,T,H,W] fp32 (the DMC
+ * cue) and w [64,2,7,7,7] fp32 contiguous are rounded to bf16, fp32 accumulation, y [N,OD,OH,OW,64] bf16 NDHWC with
+ * OD = (T + 5 - 7) / 2 + 1 (likewise OH, OW); stat_partials (NULL to skip): [dmc_stem3d_bf16_stat_blocks()][64][2]
+ * floats = per-channel (sum, sum of squares) of the rounded outputs, for dmc_bn3d_bf16_fwd.  workspace:
+ * dmc_stem3d_bf16_workspace_bytes().  (The stem's gradients stay on PyTorch-ROCm.)
+ */
+size_t dmc_stem3d_bf16_workspace_bytes(int N, int T, int H, int W);
+int dmc_stem3d_bf16_stat_blocks(int N, int T, int H, int W);
+int dmc_stem3d_bf16_fwd(const float* x, const float* w, void* workspace, void* y, float* stat_partials, int N, int T, int H, int W,
+                        dmc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

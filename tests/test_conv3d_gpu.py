@@ -214,3 +214,45 @@ def test_conv_bn_relu3d_reads_a_concatenation_slice_gradient_in_place():
         res.append((xi.grad.clone(), unit.conv3d.weight.grad.clone(), unit.batch3d.weight.grad.clone(), unit.batch3d.bias.grad.clone()))
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shape", [(2, 2, 8, 32, 24), (1, 2, 4, 18, 70), (1, 2, 16, 64, 64)])
+def test_i3d_stem_forward_and_unit_vs_stock(shape):
+    """conv3d_1a_7x7 (2 -> 64, 7x7x7, stride 2, TF-"SAME"): dmc_stem3d_bf16_fwd against an fp64 evaluation of the
+    stock pad + conv3d on the same bf16-rounded operands; then the whole stem unit (conv -> BatchNorm3d -> ReLU, own
+    forward, MIOpen convolution gradients) against the stock unit under bf16 autocast: output and the gradients of
+    the cue, the convolution weight and the BatchNorm parameters."""
+    torch.manual_seed(11)
+    unit = i3d.Unit3Dpy(2, 64, (7, 7, 7), (2, 2, 2)).to(DEV).train()
+    x = torch.randn(*shape, device=DEV)
+    lib = dmcnet_amd._lib.load()
+    n, _, t, h, w = shape
+    od, oh, ow = t // 2, h // 2, w // 2
+    y = torch.empty((n, 64, od, oh, ow), dtype=torch.bfloat16, device=DEV, memory_format=CL3)
+    work = torch.empty(lib.dmc_stem3d_bf16_workspace_bytes(n, t, h, w), dtype=torch.uint8, device=DEV)
+    wt = unit.conv3d.weight.detach().contiguous()
+    dmcnet_amd._lib.check(lib.dmc_stem3d_bf16_fwd(dmcnet_amd._lib.ptr(x), dmcnet_amd._lib.ptr(wt), dmcnet_amd._lib.ptr(work),
+                                                  dmcnet_amd._lib.ptr(y), None, n, t, h, w, None), "dmc_stem3d_bf16_fwd")
+    torch.cuda.synchronize()
+    ref = F.conv3d(F.pad(x.bfloat16().double(), (2, 3, 2, 3, 2, 3)), wt.bfloat16().double(), None, 2, 0)
+    assert tuple(ref.shape) == tuple(y.shape)
+    bf16_close(y, ref, "stem forward")
+    g = torch.randn(n, 64, od, oh, ow, device=DEV).bfloat16()
+    res = {}
+    for own in (True, False):
+        i3d.OWN_CONV3D = own
+        try:
+            unit.zero_grad()
+            with torch.no_grad():
+                unit.batch3d.running_mean.zero_(); unit.batch3d.running_var.fill_(1.0)
+            xi = x.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = unit(xi)
+            out.backward(g)
+            res[own] = (out.float(), xi.grad.float(), unit.conv3d.weight.grad.clone(), unit.batch3d.weight.grad.clone(),
+                        unit.batch3d.running_var.clone())
+        finally:
+            i3d.OWN_CONV3D = True
+    for a, b, name, tol in zip(res[True], res[False], ("out", "dx", "dw", "dgamma", "running_var"), (0.03, 0.06, 0.03, 0.03, 1e-3)):
+        err = float((a - b).abs().max() / b.abs().max())
+        assert err < tol, (name, err)
