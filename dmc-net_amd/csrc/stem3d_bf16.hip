@@ -113,25 +113,33 @@ __global__ __launch_bounds__(S3_WAVES * 64) void stem3d_fwd_kernel(Stem3dArgs a)
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
-#pragma unroll
-        for (int kz = 0; kz < S3_K; ++kz) {
-            u32x4 xb[S3_K];
+        // one kz plane (7 rows x 16 bytes per lane) in flight ahead of the 14 MFMAs of the current one; the loop is NOT
+        // unrolled over kz: fully unrolled, the compiler hoisted all 98 loads and spilled (256 VGPRs + 1 KB of scratch)
+        u32x4 cur[S3_K], nxt[S3_K];
+        auto load_plane = [&](int kz, u32x4 (&xb)[S3_K]) {
 #pragma unroll
             for (int ky = 0; ky < S3_K; ++ky) {
                 const unsigned* p = base + ((long)kz * a.Hp + ky) * a.Wp;
                 const u32x2 lo = *reinterpret_cast<const u32x2*>(p), hi = *reinterpret_cast<const u32x2*>(p + 2);
                 xb[ky] = u32x4{lo[0], lo[1], hi[0], hi[1]};
             }
+        };
+        load_plane(0, cur);
+#pragma unroll 1
+        for (int kz = 0; kz < S3_K; ++kz) {
+            if (kz + 1 < S3_K) load_plane(kz + 1, nxt);
 #pragma unroll
             for (int ky = 0; ky < S3_K; ++ky) {
                 const char* wk = wlds + (kz * S3_K + ky) * (S3_CO * 32) + woff;
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
                     const u32x4 wf = *reinterpret_cast<const u32x4*>(wk + ct * 1024);
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xb[ky]),
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, cur[ky]),
                                                                       acc[ct], 0, 0, 0);
                 }
             }
+#pragma unroll
+            for (int ky = 0; ky < S3_K; ++ky) cur[ky] = nxt[ky];
         }
         // lane holds pixel column l31, channels 32 ct + 8 g + 4 half + e in acc[ct][4 g + e]
         if (ox < a.OW) {
@@ -167,6 +175,155 @@ __global__ __launch_bounds__(S3_WAVES * 64) void stem3d_fwd_kernel(Stem3dArgs a)
             }
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient of the stem: dw[co][c][kz][ky][kx] = sum over output pixels of dy[px][co] * x[2 od + kz][2 oh + ky][2 ow + kx][c],
+// a GEMM over pixels with rows = the forward's k index (49 k-blocks x 16 slots = 784 rows, 25 tiles of 32), columns = the 64
+// channels.  Both operands must hold 8 consecutive pixels per lane, so a 32-pixel row segment is transposed on its way into
+// LDS: dy [32 px][64] -> dyT [64][32 px] (eight ds_write_b16 per 16-byte load) and, from the padded volume of the forward,
+// xT [784][32 px]: every input dword (both channels of one input pixel) is written to the <= 4 (output pixel, tap kx) positions
+// that use it -- the (k-block, input pixel) work items and their LDS targets are fixed per thread for the whole launch.  Four
+// waves share the 25 row tiles (6-7 tiles x 2 column tiles of fp32 accumulators each); a workgroup walks a contiguous run of
+// segments and writes one partial [800][64]; stem3d_wgrad_reduce_kernel sums the partials in fixed order (deterministic).
+// ------------------------------------------------------------------------------------------
+constexpr int S3_ROWS = 800;                               // 25 x 32 (rows 784 .. 799 stay zero)
+constexpr int S3_ITEMS = S3_KB * 70;                       // (k-block, input pixel q = 0 .. 69) work items per segment
+constexpr int S3_IPT = (S3_ITEMS + 255) / 256;             // 14 per thread
+
+struct Stem3dWgArgs {
+    const unsigned* xq;    // [N][Tp][Hp][Wp] dwords
+    const bf16_t* dy;      // [N][OD][OH][OW][64]
+    float* part;           // [gridDim.x][800][64]
+    int N, OD, OH, OW, Tp, Hp, Wp, tiles_x;
+    long nseg, per_wg;
+};
+
+__device__ __forceinline__ int s3_lds(int row, int px) { return row * 64 + ((((px >> 3) ^ ((row >> 2) & 3)) & 3) << 4) + (px & 7) * 2; }
+
+__global__ __launch_bounds__(256) void stem3d_wgrad_kernel(Stem3dWgArgs a) {
+    __shared__ __attribute__((aligned(1024))) char lds[(S3_ROWS + 64) * 64];   // xT [800][32 px] | dyT [64][32 px]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    for (int i = tid; i < (S3_ROWS + 64) * 4; i += 256) reinterpret_cast<u32x4*>(lds)[i] = u32x4{0u, 0u, 0u, 0u};
+    char* dyT = lds + S3_ROWS * 64;
+
+    // this thread's work items: item = tid + 256 i -> (kb, q); input pixel q of the segment's row feeds output pixel
+    // ow = (q - kx) / 2 for the taps kx = q & 1, (q & 1) + 2, ... with 0 <= ow < 32
+    int it_kb[S3_IPT], it_q[S3_IPT];
+#pragma unroll
+    for (int i = 0; i < S3_IPT; ++i) {
+        const int item = tid + 256 * i;
+        it_kb[i] = item < S3_ITEMS ? item / 70 : -1;
+        it_q[i] = item % 70;
+    }
+    const int dpx = tid >> 3, doct = tid & 7;              // dy staging: pixel, channel octet
+
+    f32x16 acc[7][2];
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    int fa[7], fb[2][2];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) fa[i] = (32 * (wave + 4 * i) + l31) * 64;       // row of tile wave + 4 i (tile 28 does not exist: i = 6 only for wave 0)
+    const int swz = (l31 >> 2) & 3;
+
+    long seg = (long)blockIdx.x * a.per_wg;
+    long seg_end = seg + a.per_wg;
+    if (seg_end > a.nseg) seg_end = a.nseg;
+    __syncthreads();
+#pragma unroll 1
+    for (; seg < seg_end; ++seg) {
+        const int xt = (int)(seg % a.tiles_x);
+        const long r = seg / a.tiles_x;                    // (n * OD + od) * OH + oh
+        const int oh = (int)(r % a.OH);
+        const long nd = r / a.OH;
+        const int od = (int)(nd % a.OD);
+        const int n = (int)(nd / a.OD);
+        const int ow0 = 32 * xt;
+        // loads: dy chunk and the work items' dwords
+        u32x4 dv = u32x4{0u, 0u, 0u, 0u};
+        if (ow0 + dpx < a.OW) dv = *reinterpret_cast<const u32x4*>(a.dy + (r * a.OW + ow0 + dpx) * S3_CO + 8 * doct);
+        unsigned xv[S3_IPT];
+        const unsigned* rowbase = a.xq + (((long)n * a.Tp + 2 * od) * a.Hp + 2 * oh) * a.Wp + 2 * ow0;
+#pragma unroll
+        for (int i = 0; i < S3_IPT; ++i) {
+            xv[i] = 0u;
+            if (it_kb[i] >= 0 && 2 * ow0 + it_q[i] < a.Wp) {
+                const int kz = it_kb[i] / 7, ky = it_kb[i] - kz * 7;
+                xv[i] = rowbase[((long)kz * a.Hp + ky) * a.Wp + it_q[i]];
+            }
+        }
+        __syncthreads();                                   // the previous segment's fragment reads are done
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned short h = (unsigned short)((j & 1) ? (dv[j >> 1] >> 16) : (dv[j >> 1] & 0xffffu));
+            *reinterpret_cast<unsigned short*>(dyT + s3_lds(8 * doct + j, dpx)) = h;
+        }
+#pragma unroll
+        for (int i = 0; i < S3_IPT; ++i) {
+            if (it_kb[i] < 0) continue;
+            const unsigned short c0 = (unsigned short)(xv[i] & 0xffffu), c1 = (unsigned short)(xv[i] >> 16);
+            const int q = it_q[i];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kx = (q & 1) + 2 * u, ow = (q - kx) >> 1;
+                if (kx < 7 && ow >= 0 && ow < 32 && q >= kx) {
+                    const int row = it_kb[i] * 16 + 2 * kx;
+                    *reinterpret_cast<unsigned short*>(lds + s3_lds(row, ow)) = c0;
+                    *reinterpret_cast<unsigned short*>(lds + s3_lds(row + 1, ow)) = c1;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int slot = ((2 * kb + half) ^ swz) << 4;
+            u32x4 bf[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const u32x4*>(dyT + (32 * j + l31) * 64 + slot);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                if (wave + 4 * i >= 25) continue;
+                const u32x4 af = *reinterpret_cast<const u32x4*>(lds + fa[i] + slot);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf[j]),
+                                                                        acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    // partial: lane holds column l31 (co) of column tile j, rows 8 g + 4 half + e of row tile
+    float* part = a.part + (size_t)blockIdx.x * S3_ROWS * S3_CO;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        if (wave + 4 * i >= 25) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = 32 * (wave + 4 * i) + 8 * (e >> 2) + 4 * half + (e & 3);
+                part[(size_t)row * S3_CO + 32 * j + l31] = acc[i][j][e];
+            }
+    }
+}
+
+// dw [64][2][7][7][7] = sum over workgroups of part[g][kb * 16 + 2 kx + c][co], fixed order
+__global__ __launch_bounds__(256) void stem3d_wgrad_reduce_kernel(const float* __restrict__ part, int groups, float* __restrict__ dw) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S3_CO * 686) return;
+    const int co = i / 686, rem = i - co * 686, c = rem / 343, t = rem - c * 343;
+    const int kb = t / 7, kx = t - kb * 7;
+    const size_t off = (size_t)(kb * 16 + 2 * kx + c) * S3_CO + co;
+    float s = 0.f;
+    for (int g = 0; g < groups; ++g) s += part[(size_t)g * S3_ROWS * S3_CO + off];
+    dw[i] = s;
+}
+
+int s3_wg_groups(long nseg) { return (int)(nseg < 256 ? nseg : 256); }
 
 int s3_blocks(long tiles) {
     long b = (tiles + S3_WAVES - 1) / S3_WAVES;
@@ -214,6 +371,39 @@ int dmc_stem3d_bf16_fwd(const float* x, const float* w, void* workspace, void* y
     const long tiles = (long)N * a.OD * a.OH * a.tiles_x;
     stem3d_fwd_kernel<<<s3_blocks(tiles), S3_WAVES * 64, S3_WLDS, s>>>(a);
     return check_launch("stem3d_fwd");
+}
+
+// bytes of the weight gradient's workspace (padded volume + partials)
+size_t dmc_stem3d_bf16_wgrad_workspace_bytes(int N, int T, int H, int W) {
+    const long Wp = (W + 5 + 1 + 3) / 4 * 4;
+    return (size_t)N * (T + 5) * (H + 5) * Wp * 4 + (size_t)256 * S3_ROWS * S3_CO * sizeof(float) + 64;
+}
+
+// dw [64,2,7,7,7] fp32 contiguous from x [N,2,T,H,W] fp32 (rounded to bf16 as in the forward) and dy [N,OD,OH,OW,64] bf16
+// NDHWC; deterministic
+int dmc_stem3d_bf16_wgrad(const float* x, const void* dy, float* dw, void* workspace, int N, int T, int H, int W, dmc_stream_t stream) {
+    if (!x || !dy || !dw || !workspace) return fail(DMC_E_INVALID, "dmc_stem3d_bf16_wgrad: null pointer");
+    if (N <= 0 || T < 2 || H < 2 || W < 2) return fail(DMC_E_INVALID, "dmc_stem3d_bf16_wgrad: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const int Tp = T + 5, Hp = H + 5, Wp = (W + 5 + 1 + 3) / 4 * 4;
+    unsigned* xq = (unsigned*)workspace;
+    float* part = (float*)((char*)workspace + (((size_t)N * Tp * Hp * Wp * 4 + 63) / 64) * 64);
+    const long total = (long)N * Tp * Hp * Wp;
+    stem3d_prep_kernel<<<(int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256), 256, 0, s>>>(x, xq, N, T, H, W, Tp, Hp, Wp);
+    int rc = check_launch("stem3d_prep");
+    if (rc) return rc;
+    Stem3dWgArgs a;
+    a.xq = xq; a.dy = (const bf16_t*)dy; a.part = part;
+    a.N = N; a.OD = (T + 5 - 7) / 2 + 1; a.OH = (H + 5 - 7) / 2 + 1; a.OW = (W + 5 - 7) / 2 + 1;
+    a.Tp = Tp; a.Hp = Hp; a.Wp = Wp; a.tiles_x = (a.OW + 31) / 32;
+    a.nseg = (long)N * a.OD * a.OH * a.tiles_x;
+    const int groups = s3_wg_groups(a.nseg);
+    a.per_wg = (a.nseg + groups - 1) / groups;
+    const int used = (int)((a.nseg + a.per_wg - 1) / a.per_wg);
+    stem3d_wgrad_kernel<<<used, 256, 0, s>>>(a);
+    if ((rc = check_launch("stem3d_wgrad"))) return rc;
+    stem3d_wgrad_reduce_kernel<<<(S3_CO * 686 + 255) / 256, 256, 0, s>>>(part, used, dw);
+    return check_launch("stem3d_wgrad_reduce");
 }
 
 }  // extern "C"

@@ -1200,8 +1200,8 @@ def conv_bn_relu3d(x, conv, bn, relu=True):
 class _Stem3dBnRelu(torch.autograd.Function):
     """relu(BatchNorm3d(conv3d_1a_7x7(x))) of the I3D stem in a bf16 trunk (code/dmcnet_I3D/network/i3d.py:480-481,
     :390-398): forward on dmc_stem3d_bf16_fwd (statistics in its epilogue) + the fused BatchNorm3d / ReLU pass; the
-    BatchNorm / ReLU backward on bn3d_bf16.hip, the convolution's data and weight gradients on PyTorch-ROCm (MIOpen)
-    with the tensors the stock path would hand it (bf16, NCDHW, explicitly padded)."""
+    BatchNorm / ReLU backward on bn3d_bf16.hip, the weight gradient on dmc_stem3d_bf16_wgrad, the 2-channel data gradient on
+    PyTorch-ROCm (MIOpen) with the tensors the stock path would hand it (bf16, NCDHW, explicitly padded)."""
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, running_mean, running_var, eps, momentum, relu):
@@ -1226,14 +1226,14 @@ class _Stem3dBnRelu(torch.autograd.Function):
             _lib.check(lib.dmc_bn3d_bf16_fwd(_lib.ptr(y), _lib.ptr(part), nblk, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(stats),
                                              _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(out), m, 64, int(relu),
                                              float(eps), float(momentum), _stream()), "dmc_bn3d_bf16_fwd")
-        ctx.save_for_backward(xc.bfloat16(), weight, y, gamma, beta, stats)
+        ctx.save_for_backward(xc, weight, y, gamma, beta, stats)
         ctx.relu = bool(relu)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
-        xb, weight, y, gamma, beta, stats = ctx.saved_tensors
+        xc, weight, y, gamma, beta, stats = ctx.saved_tensors
         n, _, od, oh, ow = y.shape
         m = n * od * oh * ow
         dout = _as_cl3(dout)
@@ -1244,14 +1244,22 @@ class _Stem3dBnRelu(torch.autograd.Function):
             _lib.check(lib.dmc_bn3d_bf16_bwd(_lib.ptr(dout), 64, _lib.ptr(y), _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta),
                                              _lib.ptr(scratch), _lib.ptr(dy), _lib.ptr(dgamma), _lib.ptr(dbeta), m, 64,
                                              int(ctx.relu), _stream()), "dmc_bn3d_bf16_bwd")
-        t, h, w = xb.shape[2:]
-        xpad = torch.nn.functional.pad(xb, (2, 3, 2, 3, 2, 3))
-        with _span("stem3d_bwd"):
-            dxp, dw, _ = torch.ops.aten.convolution_backward(
-                dy.contiguous(), xpad, weight.detach().bfloat16(), None, (2, 2, 2), (0, 0, 0), (1, 1, 1), False, (0, 0, 0), 1,
-                (bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), False))
-        dx = dxp[:, :, 2:2 + t, 2:2 + h, 2:2 + w].float() if dxp is not None else None
-        dw = dw.to(weight.dtype) if dw is not None else None
+        t, h, w = xc.shape[2:]
+        dx = dw = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((64, 2, 7, 7, 7), dtype=torch.float32, device=y.device)
+            work = _floats(lib.dmc_stem3d_bf16_wgrad_workspace_bytes(n, t, h, w), y.device)
+            with _span("stem3d_wgrad"):
+                _lib.check(lib.dmc_stem3d_bf16_wgrad(_lib.ptr(xc), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(work), n, t, h, w, _stream()),
+                           "dmc_stem3d_bf16_wgrad")
+            dw = dw.to(weight.dtype)
+        if ctx.needs_input_grad[0]:                        # data gradient (2 channels): MIOpen, on the stock path's tensors
+            xpad = torch.nn.functional.pad(xc.bfloat16(), (2, 3, 2, 3, 2, 3))
+            with _span("stem3d_dgrad"):
+                dxp, _, _ = torch.ops.aten.convolution_backward(
+                    dy.contiguous(), xpad, weight.detach().bfloat16(), None, (2, 2, 2), (0, 0, 0), (1, 1, 1), False, (0, 0, 0), 1,
+                    (True, False, False))
+            dx = dxp[:, :, 2:2 + t, 2:2 + h, 2:2 + w].float()
         return dx, dw, dgamma, dbeta, None, None, None, None, None
 
 

@@ -412,12 +412,17 @@ int dmc_bn3d_bf16_bwd(const void* dout, long dout_ld, const void* y, const float
  * cue) and w [64,2,7,7,7] fp32 contiguous are rounded to bf16, fp32 accumulation, y [N,OD,OH,OW,64] bf16 NDHWC with
  * OD = (T + 5 - 7) / 2 + 1 (likewise OH, OW); stat_partials (NULL to skip): [dmc_stem3d_bf16_stat_blocks()][64][2]
  * floats = per-channel (sum, sum of squares) of the rounded outputs, for dmc_bn3d_bf16_fwd.  workspace:
- * dmc_stem3d_bf16_workspace_bytes().  (The stem's gradients stay on PyTorch-ROCm.)
+ * dmc_stem3d_bf16_workspace_bytes().  (The stem's data gradient stays on PyTorch-ROCm.)
  */
 size_t dmc_stem3d_bf16_workspace_bytes(int N, int T, int H, int W);
 int dmc_stem3d_bf16_stat_blocks(int N, int T, int H, int W);
 int dmc_stem3d_bf16_fwd(const float* x, const float* w, void* workspace, void* y, float* stat_partials, int N, int T, int H, int W,
                         dmc_stream_t stream);
+/* weight gradient of the same convolution: dw [64,2,7,7,7] fp32 contiguous from x (rounded to bf16 as in the forward) and
+ * dy [N,OD,OH,OW,64] bf16 NDHWC; GEMM over pixels on the bf16 matrix cores, deterministic split-K reduction; workspace:
+ * dmc_stem3d_bf16_wgrad_workspace_bytes(). */
+size_t dmc_stem3d_bf16_wgrad_workspace_bytes(int N, int T, int H, int W);
+int dmc_stem3d_bf16_wgrad(const float* x, const void* dy, float* dw, void* workspace, int N, int T, int H, int W, dmc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -238,6 +238,20 @@ def test_i3d_stem_forward_and_unit_vs_stock(shape):
     assert tuple(ref.shape) == tuple(y.shape)
     bf16_close(y, ref, "stem forward")
     g = torch.randn(n, 64, od, oh, ow, device=DEV).bfloat16()
+    # weight gradient kernel against fp64 autograd on the same bf16-rounded operands
+    wo = wt.bfloat16().double().requires_grad_(True)
+    (F.conv3d(F.pad(x.bfloat16().double(), (2, 3, 2, 3, 2, 3)), wo, None, 2, 0) * g.double()).sum().backward()
+    dw = torch.empty((64, 2, 7, 7, 7), dtype=torch.float32, device=DEV)
+    ws = torch.empty(lib.dmc_stem3d_bf16_wgrad_workspace_bytes(n, t, h, w), dtype=torch.uint8, device=DEV)
+    gcl = g.contiguous(memory_format=CL3)
+    dmcnet_amd._lib.check(lib.dmc_stem3d_bf16_wgrad(dmcnet_amd._lib.ptr(x), dmcnet_amd._lib.ptr(gcl), dmcnet_amd._lib.ptr(dw),
+                                                    dmcnet_amd._lib.ptr(ws), n, t, h, w, None), "dmc_stem3d_bf16_wgrad")
+    err = float((dw.double() - wo.grad).abs().max() / wo.grad.abs().max())
+    assert err < 2e-5, err
+    dw2 = torch.empty_like(dw)
+    dmcnet_amd._lib.check(lib.dmc_stem3d_bf16_wgrad(dmcnet_amd._lib.ptr(x), dmcnet_amd._lib.ptr(gcl), dmcnet_amd._lib.ptr(dw2),
+                                                    dmcnet_amd._lib.ptr(ws), n, t, h, w, None), "dmc_stem3d_bf16_wgrad")
+    assert torch.equal(dw, dw2)                              # deterministic
     res = {}
     for own in (True, False):
         i3d.OWN_CONV3D = own
