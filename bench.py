@@ -160,15 +160,15 @@ def classifier_conv_roofline(conv_spans, n_frames, conv_arith, hw=224):
     tot_ms = 0.0
     for name, key in (("forward", "conv_nhwc_fwd"), ("data_gradient", "conv_nhwc_dgrad"), ("weight_gradient", "conv_nhwc_wgrad")):
         if key in conv_spans:
-            ms = conv_spans[key][0] * conv_spans[key][1] / 6.0      # average call x calls per step (6 probed steps)
+            ms = conv_spans[key]                                    # median over 7 probed steps of the step's summed spans
             out[name] = {"ms_per_step": round(ms, 3), "achieved": round(flop / (ms * 1e-3) / 1e12, 1)}
             tot_ms += ms
     if tot_ms > 0:
         out["ms_per_step"] = round(tot_ms, 3)
         out["achieved"] = round(3 * flop / (tot_ms * 1e-3) / 1e12, 1)
         out["frac"] = round(out["achieved"] / out["peak"], 4)
-    out["note"] = ("HIP events around the C-ABI calls (weight split / pack launches included) in 6 steps after the timed "
-                   "region; the span names are ops.conv_nhwc_*")
+    out["note"] = ("HIP events around the C-ABI calls (weight split / pack launches included) in 7 steps after the timed "
+                   "region, median over the steps; the span names are ops.conv_nhwc_*")
     return out
 
 
@@ -367,14 +367,18 @@ def main():
     ops.PROBE = None
     conv_spans = None
     if args.own_conv and not gan and world == 1:
-        # classifier convolutions (the step's dominant kernel family): HIP-event spans around their C-ABI calls in 6
+        # classifier convolutions (the step's dominant kernel family): HIP-event spans around their C-ABI calls in 7
         # extra steps right AFTER the timed region (57 spans per step would cost the timed steps ~2 %)
-        cprobe = ops.EventProbe(("conv_nhwc_fwd", "conv_nhwc_dgrad", "conv_nhwc_wgrad"))
-        ops.PROBE = cprobe
-        for i in range(6):
+        per_step = []
+        for i in range(7):
+            cprobe = ops.EventProbe(("conv_nhwc_fwd", "conv_nhwc_dgrad", "conv_nhwc_wgrad"))
+            ops.PROBE = cprobe
             one(i)
-        conv_spans = cprobe.summary()
+            per_step.append({k: v[0] * v[1] for k, v in cprobe.summary().items()})    # ms of this step's calls
         ops.PROBE = None
+        # median over the steps (a span also contains whatever the host did between its two event records: one stalled
+        # step must not decide the figure)
+        conv_spans = {k: sorted(st[k] for st in per_step if k in st)[len(per_step) // 2] for k in per_step[0]}
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
