@@ -452,6 +452,25 @@ __global__ __launch_bounds__(256) void conv3d_pack_w_kernel(const float* __restr
     }
 }
 
+// both layouts in one launch: blockIdx.y = 0 the forward's [Cout_pad][T][Cin_p], 1 the data gradient's mirrored [Cin_pad][T][Cout_p]
+__global__ __launch_bounds__(256) void conv3d_pack_w2_kernel(const float* __restrict__ w, bf16_t* __restrict__ wf, bf16_t* __restrict__ wb,
+                                                             int Cout, int Cin, int T, long s_co, long s_ci, long s_tap) {
+    const bool bwd = blockIdx.y == 1;
+    const int rows = bwd ? Cin : Cout, cols = bwd ? Cout : Cin;
+    const int rows_pad = (rows + 127) / 128 * 128, Cp = (cols + 31) / 32 * 32;
+    const long s_row = bwd ? s_ci : s_co, s_col = bwd ? s_co : s_ci;
+    bf16_t* wp = bwd ? wb : wf;
+    const long total = (long)rows_pad * T * Cp;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % Cp);
+        const int t = (int)((i / Cp) % T);
+        const int r = (int)(i / ((long)Cp * T));
+        unsigned v = 0;
+        if (r < rows && c < cols) v = f2bf(w[r * s_row + c * s_col + (bwd ? T - 1 - t : t) * s_tap]);
+        wp[i] = (bf16_t)v;
+    }
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_c3d(const C3dArgs& a, hipStream_t s) {
     dim3 grid((unsigned)((a.M + BM - 1) / BM), (a.Cout + BN - 1) / BN);
@@ -511,6 +530,19 @@ size_t dmc_conv3d_bf16_wpack_bytes(int Cin, int Cout, int KD, int KH, int KW) {
     return 2 * (f > b ? f : b) + 16;
 }
 
+// pack the weights for the forward (wpack_f) and the data gradient (wpack_b) in one launch; each workspace has
+// dmc_conv3d_bf16_wpack_bytes() bytes.  The fwd / dgrad entry points take w == NULL to use such a workspace as it is.
+int dmc_conv3d_bf16_pack(const float* w, long w_s_co, long w_s_ci, long w_s_tap, void* wpack_f, void* wpack_b, int Cin, int Cout,
+                         int KD, int KH, int KW, dmc_stream_t stream) {
+    if (!w || !wpack_f || !wpack_b) return fail(DMC_E_INVALID, "dmc_conv3d_bf16_pack: null pointer");
+    const int T = KD * KH * KW;
+    const long tf = (long)pad_to(Cout, 128) * T * pad_to(Cin, 32), tb = (long)pad_to(Cin, 128) * T * pad_to(Cout, 32);
+    const long total = tf > tb ? tf : tb;
+    dim3 grid((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256), 2);
+    conv3d_pack_w2_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(w, (bf16_t*)wpack_f, (bf16_t*)wpack_b, Cout, Cin, T, w_s_co, w_s_ci, w_s_tap);
+    return check_launch("conv3d_pack_w2");
+}
+
 // number of [Cout][2] float partial rows the forward writes when asked for statistics
 int dmc_conv3d_bf16_stat_blocks(int N, int D, int H, int W, int Cout) {
     const long M = (long)N * D * H * W;
@@ -523,17 +555,19 @@ int dmc_conv3d_bf16_stat_blocks(int N, int D, int H, int W, int Cout) {
 int dmc_conv3d_bf16_fwd(const void* x, const float* w, long w_s_co, long w_s_ci, long w_s_tap, void* wpack, void* y,
                         float* stat_partials, int N, int D, int H, int W, int Cin, int Cout, int KD, int KH, int KW,
                         dmc_stream_t stream) {
-    if (!x || !w || !wpack || !y) return fail(DMC_E_INVALID, "dmc_conv3d_bf16_fwd: null pointer");
+    if (!x || !wpack || !y) return fail(DMC_E_INVALID, "dmc_conv3d_bf16_fwd: null pointer");
     if (!c3d_supported(N, D, H, W, Cin, Cout, KD, KH, KW))
         return fail(DMC_E_INVALID, "dmc_conv3d_bf16_fwd: unsupported shape N=%d D=%d H=%d W=%d Cin=%d Cout=%d k=%dx%dx%d",
                     N, D, H, W, Cin, Cout, KD, KH, KW);
     hipStream_t s = (hipStream_t)stream;
     const int T = KD * KH * KW, Cp = pad_to(Cin, 32), rows_pad = pad_to(Cout, 128);
     const long total = (long)rows_pad * T * Cp;
-    conv3d_pack_w_kernel<<<(int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256), 256, 0, s>>>(
-        w, (bf16_t*)wpack, Cout, rows_pad, Cin, Cp, T, w_s_co, w_s_ci, w_s_tap, 0);
-    int rc = check_launch("conv3d_pack_w");
-    if (rc) return rc;
+    int rc = DMC_OK;
+    if (w) {                                               // w == NULL: wpack already holds the packed weights (dmc_conv3d_bf16_pack)
+        conv3d_pack_w_kernel<<<(int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256), 256, 0, s>>>(
+            w, (bf16_t*)wpack, Cout, rows_pad, Cin, Cp, T, w_s_co, w_s_ci, w_s_tap, 0);
+        if ((rc = check_launch("conv3d_pack_w"))) return rc;
+    }
     C3dArgs a;
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)wpack; a.y = (bf16_t*)y; a.stat_part = stat_partials;
     a.N = N; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.Cp = Cp; a.KD = KD; a.KH = KH; a.KW = KW;
@@ -544,15 +578,17 @@ int dmc_conv3d_bf16_fwd(const void* x, const float* w, long w_s_co, long w_s_ci,
 // dx [N,D,H,W,Cin] bf16 from dy [N,D,H,W,Cout] bf16
 int dmc_conv3d_bf16_dgrad(const void* dy, const float* w, long w_s_co, long w_s_ci, long w_s_tap, void* wpack, void* dx,
                           int N, int D, int H, int W, int Cin, int Cout, int KD, int KH, int KW, dmc_stream_t stream) {
-    if (!dy || !w || !wpack || !dx) return fail(DMC_E_INVALID, "dmc_conv3d_bf16_dgrad: null pointer");
+    if (!dy || !wpack || !dx) return fail(DMC_E_INVALID, "dmc_conv3d_bf16_dgrad: null pointer");
     if (!c3d_supported(N, D, H, W, Cin, Cout, KD, KH, KW)) return fail(DMC_E_INVALID, "dmc_conv3d_bf16_dgrad: unsupported shape");
     hipStream_t s = (hipStream_t)stream;
     const int T = KD * KH * KW, Cp = pad_to(Cout, 32), rows_pad = pad_to(Cin, 128);
     const long total = (long)rows_pad * T * Cp;
-    conv3d_pack_w_kernel<<<(int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256), 256, 0, s>>>(
-        w, (bf16_t*)wpack, Cin, rows_pad, Cout, Cp, T, w_s_ci, w_s_co, w_s_tap, 1);
-    int rc = check_launch("conv3d_pack_w");
-    if (rc) return rc;
+    int rc = DMC_OK;
+    if (w) {
+        conv3d_pack_w_kernel<<<(int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256), 256, 0, s>>>(
+            w, (bf16_t*)wpack, Cin, rows_pad, Cout, Cp, T, w_s_ci, w_s_co, w_s_tap, 1);
+        if ((rc = check_launch("conv3d_pack_w"))) return rc;
+    }
     C3dArgs a;
     a.x = (const bf16_t*)dy; a.w = (const bf16_t*)wpack; a.y = (bf16_t*)dx; a.stat_part = nullptr;
     a.N = N; a.D = D; a.H = H; a.W = W; a.Cin = Cout; a.Cout = Cin; a.Cp = Cp; a.KD = KD; a.KH = KH; a.KW = KW;

@@ -1119,11 +1119,15 @@ class _ConvBnRelu3d(torch.autograd.Function):
         y = torch.empty((n, cout, d, h, w), dtype=torch.bfloat16, device=x.device, memory_format=_CL3)
         nblk = lib.dmc_conv3d_bf16_stat_blocks(n, d, h, w, cout)
         part = torch.empty((nblk, cout, 2), dtype=torch.float32, device=x.device)
-        wpack = _floats(lib.dmc_conv3d_bf16_wpack_bytes(cin, cout, kd, kh, kw), x.device)
+        nb = lib.dmc_conv3d_bf16_wpack_bytes(cin, cout, kd, kh, kw)
+        wpack, wpack_b = _floats(nb, x.device), _floats(nb, x.device)     # forward / data-gradient layouts, one pack launch
         with _span("conv3d_bf16_fwd"):
-            _lib.check(lib.dmc_conv3d_bf16_fwd(_lib.ptr(x), _lib.ptr(wc), cin * t, t, 1, _lib.ptr(wpack), _lib.ptr(y),
+            _lib.check(lib.dmc_conv3d_bf16_pack(_lib.ptr(wc), cin * t, t, 1, _lib.ptr(wpack), _lib.ptr(wpack_b), cin, cout,
+                                                kd, kh, kw, _stream()), "dmc_conv3d_bf16_pack")
+            _lib.check(lib.dmc_conv3d_bf16_fwd(_lib.ptr(x), None, cin * t, t, 1, _lib.ptr(wpack), _lib.ptr(y),
                                                _lib.ptr(part), n, d, h, w, cin, cout, kd, kh, kw, _stream()),
                        "dmc_conv3d_bf16_fwd")
+        ctx.wpack_b = wpack_b
         stats = torch.empty(2 * cout, dtype=torch.float32, device=x.device)
         out = torch.empty_like(y)
         with _span("bn3d_fwd"):
@@ -1158,9 +1162,8 @@ class _ConvBnRelu3d(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            wpack = _floats(lib.dmc_conv3d_bf16_wpack_bytes(cin, cout, kd, kh, kw), x.device)
-            with _span("conv3d_bf16_dgrad"):
-                _lib.check(lib.dmc_conv3d_bf16_dgrad(_lib.ptr(dy), _lib.ptr(wc), cin * t, t, 1, _lib.ptr(wpack),
+            with _span("conv3d_bf16_dgrad"):                # weights packed by the forward's launch
+                _lib.check(lib.dmc_conv3d_bf16_dgrad(_lib.ptr(dy), None, cin * t, t, 1, _lib.ptr(ctx.wpack_b),
                                                      _lib.ptr(dx), n, d, h, w, cin, cout, kd, kh, kw, _stream()),
                            "dmc_conv3d_bf16_dgrad")
             if not ctx.x_was_cl3:

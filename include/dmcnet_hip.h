@@ -359,10 +359,13 @@ int dmc_stem_fwd(const float* x, const float* w, long ws_co, long ws_ci, long ws
  * workgroup row, [dmc_conv3d_bf16_stat_blocks()][Cout][2] floats (for the BatchNorm3d that follows).
  * dgrad: dx = conv_transpose3d(dy, w).  wgrad: dw fp32 [Cout][Cin][KD][KH][KW] contiguous = sum over pixels
  * (1x1x1 and 3x3x3 only), deterministic split-K reduction; workspace of dmc_conv3d_bf16_wgrad_bytes().
- * wpack: workspace of dmc_conv3d_bf16_wpack_bytes() bytes.
+ * wpack: workspace of dmc_conv3d_bf16_wpack_bytes() bytes; dmc_conv3d_bf16_pack() fills the forward's and the data
+ * gradient's workspaces in one launch, and fwd / dgrad called with w == NULL use theirs as it is.
  */
 int dmc_conv3d_bf16_supported(int N, int D, int H, int W, int Cin, int Cout, int KD, int KH, int KW);
 size_t dmc_conv3d_bf16_wpack_bytes(int Cin, int Cout, int KD, int KH, int KW);
+int dmc_conv3d_bf16_pack(const float* w, long w_s_co, long w_s_ci, long w_s_tap, void* wpack_f, void* wpack_b, int Cin, int Cout,
+                         int KD, int KH, int KW, dmc_stream_t stream);
 int dmc_conv3d_bf16_stat_blocks(int N, int D, int H, int W, int Cout);
 int dmc_conv3d_bf16_fwd(const void* x, const float* w, long w_s_co, long w_s_ci, long w_s_tap, void* wpack, void* y,
                         float* stat_partials, int N, int D, int H, int W, int Cin, int Cout, int KD, int KH, int KW,
