@@ -1377,6 +1377,8 @@ constexpr int WX_FLOATS = 33 * WX_PLANE;               // 13332
 constexpr int WT_LDS = (WX_FLOATS + 63) / 64 * 64;     // 13376 floats; x2 buffers = 107,008 B
 constexpr int NT_A = 9, NT_B = 19, NT_ALL = NT_A + NT_B;   // accumulator tiles per wave
 constexpr int WPART = NT_ALL * 256;                    // floats per workgroup partial
+constexpr int NT3_A = 10, NT3_B = 21, WPART3 = (NT3_A + NT3_B) * 256;   // layout of the shared-window bf16x3 kernel (below)
+constexpr int WPART_MAX = WPART3;
 constexpr int WGRAD_MAX_GROUPS = 256;
 constexpr int BIAS_COL = 297;
 
@@ -1590,8 +1592,11 @@ __device__ __forceinline__ void dma16_s(unsigned long long sbase, unsigned voff,
 }
 // producer: stage one tile.  Lane L of instruction h (L = 64 h + lane) moves 16-byte chunk
 // (row L / 10, chunk L % 10) of an input plane; lane (row, chunk) = (lane / 8, lane % 8) of a gradient plane.
+// do_x: stage the 33 input planes; gradient planes [gp0, gp1) are staged by the caller too (the bf16x3 consumers take the
+// 30 gradient planes off the producer wave, 4-5 each: with 2.67x fewer matrix cycles the single producer had become the
+// kernel's critical path)
 __device__ __forceinline__ void wgrad_stage(const WgradArgs& a, float* buf, unsigned buf_byte, int tile, int per_frame,
-                                            size_t HW, int lane) {
+                                            size_t HW, int lane, bool do_x = true, int gp0 = 0, int gp1 = 30) {
     const int n = tile / per_frame, r0 = tile - n * per_frame;
     const int ty0 = (r0 / a.tiles_x) * PW_H, tx0 = (r0 % a.tiles_x) * WT_W;
     const int W = a.W;
@@ -1607,6 +1612,7 @@ __device__ __forceinline__ void wgrad_stage(const WgradArgs& a, float* buf, unsi
         ok0 = y0 >= 0 && y0 < a.H && x0 >= 0 && x0 < W;
         ok1 = y1 >= 0 && y1 < a.H && x1 >= 0 && x1 < W;
     }
+    if (do_x)
 #pragma unroll
     for (int plane = 0; plane < 33; ++plane) {
         const float* pb = plane < 2 ? a.mv + ((size_t)n * 2 + plane) * HW
@@ -1633,8 +1639,8 @@ __device__ __forceinline__ void wgrad_stage(const WgradArgs& a, float* buf, unsi
     const bool gok = ty0 + grow < a.H && tx0 + gch * 4 < W;
     const long gorg = ((long)ty0 * W + tx0) * 4;
     if (lane < PW_H * 8) {
-#pragma unroll
-        for (int gp = 0; gp < 30; ++gp) {
+#pragma unroll 1
+        for (int gp = gp0; gp < gp1; ++gp) {
             const float* pb = gp < NFEAT ? a.gbuf + ((size_t)n * NFEAT + gp) * HW
                                          : a.gout + ((size_t)n * 2 + (gp - NFEAT)) * HW;
             const unsigned long long sbase = (unsigned long long)pb + (unsigned long long)gorg;
@@ -1683,7 +1689,12 @@ __device__ __forceinline__ f32x4 gen_mfma_x3(const GenSplit3& a, const GenSplit3
 // LDS row), six MFMAs of 16 cycles per accumulator tile and row where the fp32 form issues eight of 32: 2.67x fewer
 // matrix cycles; the split of a fragment (44 VALU instructions) is shared by the two row tiles.  Same C layout, same
 // reductions.
-template <bool X3>
+// X3 = 2: the bf16x3 form with the three horizontal taps of a (ci, dy) pair in ONE lane: column tile tt = 3 gt + dx holds
+// columns g = 16 gt + j = 3 ci + dy; the lane reads the 10 floats x[8 kq - 1 .. 8 kq + 8] of its row once, splits them once
+// (40 VALU instructions) and forms the three 8-pixel fragments from shared packed pairs (dx = 0: P0..P3, dx = 2: P1..P4,
+// dx = 1: Q0..Q3) -- 67 VALU instructions per three column tiles where X3 = 1 spends 132.  7 x 3 = 21 column tiles for
+// the rows of layers 2-5 (+ the ones column for their bias at g = 99, dx = 0), 3 x 3 for those of layers 0 / 1.
+template <int X3>
 __global__ __launch_bounds__(512, 2) void gen_bwd_weight_pc_kernel(WgradArgs a) {
     __shared__ __attribute__((aligned(16))) float lds2[2 * PW_BUF];
     const int lane = threadIdx.x & 63;
@@ -1696,11 +1707,12 @@ __global__ __launch_bounds__(512, 2) void gen_bwd_weight_pc_kernel(WgradArgs a) 
     const int ntiles = a.N * per_frame;
     const bool producer = wave == PW_H;
 
-    f32x4 accA[NT_A], accB[NT_B];
+    constexpr int NA = X3 == 2 ? NT3_A : NT_A, NB = X3 == 2 ? NT3_B : NT_B, WP = (NA + NB) * 256;
+    f32x4 accA[NA], accB[NB];
 #pragma unroll
-    for (int t = 0; t < NT_A; ++t) accA[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NA; ++t) accA[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < NT_B; ++t) accB[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NB; ++t) accB[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     if (producer) {
         int it = 0;
@@ -1709,7 +1721,8 @@ __global__ __launch_bounds__(512, 2) void gen_bwd_weight_pc_kernel(WgradArgs a) 
         for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
             const int next = tile + (int)gridDim.x;
             if (next < ntiles)
-                wgrad_stage(a, lds2 + ((it + 1) & 1) * PW_BUF, lds0 + (unsigned)(((it + 1) & 1) * PW_BUF) * 4, next, per_frame, HW, lane);
+                wgrad_stage(a, lds2 + ((it + 1) & 1) * PW_BUF, lds0 + (unsigned)(((it + 1) & 1) * PW_BUF) * 4, next, per_frame, HW, lane,
+                            true, 0, X3 != 0 ? 0 : 30);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
     } else {
@@ -1722,6 +1735,14 @@ __global__ __launch_bounds__(512, 2) void gen_bwd_weight_pc_kernel(WgradArgs a) 
             const int ci = nn / 9, tap = nn - ci * 9;
             offB[t] = ci * PW_XPLANE + (tap / 3) * WX_PITCH + (tap % 3) + kq + WX_COL0;
         }
+        int offW[7];                                       // X3 == 2: start of this lane's 10-float window per group tile
+#pragma unroll
+        for (int gt = 0; gt < 7; ++gt) {
+            int g = 16 * gt + j;
+            g = g < 99 ? g : 98;
+            offW[gt] = (g / 3) * PW_XPLANE + (g % 3) * WX_PITCH + WX_COL0 + 8 * kq;
+        }
+        const bool ones3 = j == 3;                         // X3 == 2: g = 99 (group tile 6, column 3) is the ones column
         // A fragments: row j of M tile A = gradient plane j; of M tile B = plane 16 + j (j < 14), else zero
         const bool rowB = j < 14;
         const int offA0 = PW_X + j * PW_GPLANE + kq;
@@ -1734,7 +1755,11 @@ __global__ __launch_bounds__(512, 2) void gen_bwd_weight_pc_kernel(WgradArgs a) 
         asm volatile("s_barrier" ::: "memory");
         for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
             const float* lds = lds2 + (it & 1) * PW_BUF;
-            if constexpr (X3) {
+            if constexpr (X3 != 0) {
+                const int next = tile + (int)gridDim.x;
+                if (next < ntiles)                        // this wave's share of the next tile's gradient planes
+                    wgrad_stage(a, lds2 + ((it + 1) & 1) * PW_BUF, lds0 + (unsigned)(((it + 1) & 1) * PW_BUF) * 4, next, per_frame, HW, lane,
+                                false, (30 * wave) / PW_H, (30 * (wave + 1)) / PW_H);
                 // fragments: 8 consecutive pixels 8 kq .. 8 kq + 7 of this wave's tile row (offA / offB carry + kq: + 7 kq more)
                 const int sA = wave * WT_W + 7 * kq, sB = wave * WX_PITCH + 7 * kq;
                 float av[8];
@@ -1748,18 +1773,58 @@ __global__ __launch_bounds__(512, 2) void gen_bwd_weight_pc_kernel(WgradArgs a) 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) av[e] = rowB ? av[e] : 0.f;
                 const GenSplit3 a1s = gen_split_bf16x3(av);
+                if constexpr (X3 == 2) {
 #pragma unroll
-                for (int t = 0; t < NT_B; ++t) {
-                    float bv[8];
+                    for (int gt = 0; gt < 7; ++gt) {
+                        float wv[10];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) bv[e] = lds[offB[t] + sB + e];
-                    if (t == 18 && ones) {
+                        for (int e = 0; e < 10; ++e) wv[e] = lds[offW[gt] + wave * WX_PITCH + e];
+                        if (gt == 6 && ones3) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) bv[e] = 1.f;
+                            for (int e = 0; e < 10; ++e) wv[e] = 1.f;
+                        }
+                        unsigned u[3][10];
+#pragma unroll
+                        for (int e = 0; e < 10; ++e) {
+                            u[0][e] = __float_as_uint(wv[e]);
+                            const float r1 = wv[e] - __uint_as_float(u[0][e] & 0xffff0000u);
+                            u[1][e] = __float_as_uint(r1);
+                            u[2][e] = __float_as_uint(r1 - __uint_as_float(u[1][e] & 0xffff0000u));
+                        }
+                        unsigned P[3][5], Q[3][4];
+#pragma unroll
+                        for (int sl = 0; sl < 3; ++sl) {
+#pragma unroll
+                            for (int k = 0; k < 5; ++k) P[sl][k] = __builtin_amdgcn_perm(u[sl][2 * k + 1], u[sl][2 * k], 0x07060302u);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) Q[sl][k] = __builtin_amdgcn_perm(u[sl][2 * k + 2], u[sl][2 * k + 1], 0x07060302u);
+                        }
+#pragma unroll
+                        for (int dxi = 0; dxi < 3; ++dxi) {
+                            GenSplit3 bs;
+#pragma unroll
+                            for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) bs.s[sl][k] = dxi == 0 ? P[sl][k] : dxi == 2 ? P[sl][k + 1] : Q[sl][k];
+                            const int tt = 3 * gt + dxi;
+                            if (gt < 3) accA[tt < NA ? tt : 0] = gen_mfma_x3(a0s, bs, accA[tt < NA ? tt : 0]);
+                            accB[tt] = gen_mfma_x3(a1s, bs, accB[tt]);
+                        }
                     }
-                    const GenSplit3 bs = gen_split_bf16x3(bv);
-                    if (t < 8) accA[t] = gen_mfma_x3(a0s, bs, accA[t]);
-                    accB[t] = gen_mfma_x3(a1s, bs, accB[t]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT_B; ++t) {
+                        float bv[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) bv[e] = lds[offB[t] + sB + e];
+                        if (t == 18 && ones) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) bv[e] = 1.f;
+                        }
+                        const GenSplit3 bs = gen_split_bf16x3(bv);
+                        if (t < 8) accA[t] = gen_mfma_x3(a0s, bs, accA[t]);
+                        accB[t < NB ? t : 0] = gen_mfma_x3(a1s, bs, accB[t < NB ? t : 0]);
+                    }
                 }
             } else
 #pragma unroll
@@ -1780,6 +1845,7 @@ __global__ __launch_bounds__(512, 2) void gen_bwd_weight_pc_kernel(WgradArgs a) 
                 for (int t = 0; t < NT_B; ++t)
                     accB[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[t], accB[t], 0, 0, 0);
             }
+            if constexpr (X3 != 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's transfers have landed
             asm volatile("s_barrier" ::: "memory");        // next tile staged, this buffer may be refilled
         }
         // fold the row sums into accumulator slot 8 (N tile 18), column BIAS_COL - 288 = 9, in the MFMA
@@ -1790,7 +1856,8 @@ __global__ __launch_bounds__(512, 2) void gen_bwd_weight_pc_kernel(WgradArgs a) 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float rv = __shfl(tot, kq * 4 + q);                  // lanes 0..15 hold rows 0..15
-            accA[8][q] = ones ? rv : 0.f;
+            if constexpr (X3 == 2) accA[9][q] = ones3 ? rv : 0.f;      // slot 9, column 3
+            else accA[8][q] = ones ? rv : 0.f;
         }
     }
     // cross-wave reduction in LDS, fixed order (wave 0 stores, waves 1..6 add in turn)
@@ -1798,8 +1865,8 @@ __global__ __launch_bounds__(512, 2) void gen_bwd_weight_pc_kernel(WgradArgs a) 
     for (int w = 0; w < PW_H; ++w) {
         if (wave == w) {
 #pragma unroll
-            for (int t = 0; t < NT_ALL; ++t) {
-                const f32x4 v = t < NT_A ? accA[t < NT_A ? t : 0] : accB[t >= NT_A ? t - NT_A : 0];
+            for (int t = 0; t < NA + NB; ++t) {
+                const f32x4 v = t < NA ? accA[t < NA ? t : 0] : accB[t >= NA ? t - NA : 0];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int idx = t * 256 + (kq * 4 + q) * 16 + j;   // C row = kq*4+q, col = j
@@ -1809,27 +1876,27 @@ __global__ __launch_bounds__(512, 2) void gen_bwd_weight_pc_kernel(WgradArgs a) 
         }
         __syncthreads();
     }
-    float* part = a.partials + (size_t)blockIdx.x * WPART;
-    for (int i = threadIdx.x; i < WPART; i += 512) part[i] = lds[i];
+    float* part = a.partials + (size_t)blockIdx.x * WP;
+    for (int i = threadIdx.x; i < WP; i += 512) part[i] = lds[i];
 }
 
 // Stage 1 of the cross-workgroup reduction: partials [groups][WPART] -> [RED_CHUNKS][WPART],
 // coalesced over the WPART axis, fixed summation order.
 constexpr int RED_CHUNKS = 16;
 __global__ __launch_bounds__(256) void gen_bwd_weight_reduce1_kernel(float* __restrict__ partials,
-                                                                     int groups) {
-    const int i = blockIdx.x * 256 + threadIdx.x;          // < WPART (7168 = 28 * 256)
+                                                                     int groups, int wpart) {
+    const int i = blockIdx.x * 256 + threadIdx.x;          // < wpart (7168 = 28 * 256, or 31 * 256 for the shared-window layout)
     const int per = (groups + RED_CHUNKS - 1) / RED_CHUNKS;
     const int g0 = blockIdx.y * per, g1 = (g0 + per < groups) ? g0 + per : groups;
     float s = 0.f;
-    for (int g = g0; g < g1; ++g) s += partials[(size_t)g * WPART + i];
+    for (int g = g0; g < g1; ++g) s += partials[(size_t)g * wpart + i];
     // results are written behind the raw partials (the buffer is sized for groups + RED_CHUNKS)
-    partials[(size_t)(groups + blockIdx.y) * WPART + i] = s;
+    partials[(size_t)(groups + blockIdx.y) * wpart + i] = s;
 }
 
 // Stage 2: [RED_CHUNKS][28 tiles][16][16] -> the 12 gradient tensors in PyTorch layout
 __global__ void gen_bwd_weight_reduce_kernel(const float* __restrict__ partials, int groups,
-                                             GradPtrs G) {
+                                             GradPtrs G, int layout3) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= NPARAM) return;
     int k = 0, co, col, p = 0, tap = 0;
@@ -1844,18 +1911,23 @@ __global__ void gen_bwd_weight_reduce_kernel(const float* __restrict__ partials,
         co = i - bf_off(k);
         col = BIAS_COL;
     }
-    const int nt = col >> 4, jj = col & 15;
+    int nt = col >> 4, jj = col & 15;
     int slot, row;
+    const int na = layout3 ? NT3_A : NT_A, wpart = layout3 ? WPART3 : WPART;
+    if (layout3) {                    // shared-window layout: column tile 3 gt + dx, column g & 15 with g = 3 p + dy; bias: g = 99, dx = 0
+        const int g = col == BIAS_COL ? 99 : 3 * p + tap / 3, dxi = col == BIAS_COL ? 0 : tap % 3;
+        nt = 3 * (g >> 4) + dxi; jj = g & 15;
+    }
     if (k < 2) {                      // tile A: g0 rows 0..7, g1 rows 8..15
         row = k * 8 + co;
-        slot = nt == 18 ? 8 : nt;
+        slot = layout3 ? (col == BIAS_COL ? 9 : nt) : (nt == 18 ? 8 : nt);
     } else {                          // tile B: g2 0..5, g3 6..9, g4 10..11, g5 12..13
         row = (k == 2 ? 0 : k == 3 ? 6 : k == 4 ? 10 : 12) + co;
-        slot = NT_A + nt;
+        slot = na + nt;
     }
     const size_t off = (size_t)slot * 256 + row * 16 + jj;
     float s = 0.f;
-    for (int c = 0; c < RED_CHUNKS; ++c) s += partials[(size_t)(groups + c) * WPART + off];
+    for (int c = 0; c < RED_CHUNKS; ++c) s += partials[(size_t)(groups + c) * wpart + off];
     if (i < WF_TOTAL)
         G.w[k][(co * cin_of(k) + logical_of(k, p)) * 9 + tap] = s;
     else
@@ -1962,7 +2034,7 @@ size_t dmc_gen_tiny_saved_bytes(int N, int H, int W) {
 }
 size_t dmc_gen_tiny_gbuf_bytes(int N, int H, int W) { return dmc_gen_tiny_saved_bytes(N, H, W); }
 size_t dmc_gen_tiny_partials_bytes(int N, int H, int W) {
-    return (size_t)(wgrad_groups(N, H, W) + RED_CHUNKS) * WPART * sizeof(float);
+    return (size_t)(wgrad_groups(N, H, W) + RED_CHUNKS) * WPART_MAX * sizeof(float);
 }
 
 // flow != null: also reduce sum((out - flow)^2) into mse_part (the fused kernel's epilogue); *fused_wgs receives
@@ -2078,19 +2150,22 @@ int dmc_gen_tiny_bwd(const float* mv, const float* res, const float* const* w, c
     a.tiles_x = (W + WT_W - 1) / WT_W;
     const int groups = wgrad_groups(N, H, W);
     const int wpath = option(OPT_GEN_WGRAD_PATH);
-    if (W % 4 == 0 && (wpath == 1 || wpath == 2)) {
+    const bool layout3 = W % 4 == 0 && wpath == 3;
+    if (W % 4 == 0 && (wpath == 1 || wpath == 2 || wpath == 3)) {
         a.tiles_y = (H + PW_H - 1) / PW_H;
-        if (wpath == 2) gen_bwd_weight_pc_kernel<true><<<groups, 512, 0, s>>>(a);
-        else gen_bwd_weight_pc_kernel<false><<<groups, 512, 0, s>>>(a);
+        if (wpath == 3) gen_bwd_weight_pc_kernel<2><<<groups, 512, 0, s>>>(a);
+        else if (wpath == 2) gen_bwd_weight_pc_kernel<1><<<groups, 512, 0, s>>>(a);
+        else gen_bwd_weight_pc_kernel<0><<<groups, 512, 0, s>>>(a);
     } else {
         a.tiles_y = (H + WT_H - 1) / WT_H;
         if (W % 4 == 0) gen_bwd_weight_kernel<true><<<groups, 512, 0, s>>>(a, workspace + PACKED_TOTAL);
         else gen_bwd_weight_kernel<false><<<groups, 512, 0, s>>>(a, workspace + PACKED_TOTAL);
     }
     if ((rc = check_launch("gen_bwd_weight"))) return rc;
-    gen_bwd_weight_reduce1_kernel<<<dim3(WPART / 256, RED_CHUNKS), 256, 0, s>>>(partials, groups);
+    const int wpart = layout3 ? WPART3 : WPART;
+    gen_bwd_weight_reduce1_kernel<<<dim3(wpart / 256, RED_CHUNKS), 256, 0, s>>>(partials, groups, wpart);
     if ((rc = check_launch("gen_bwd_weight_reduce1"))) return rc;
-    gen_bwd_weight_reduce_kernel<<<(NPARAM + 127) / 128, 128, 0, s>>>(partials, groups, G);
+    gen_bwd_weight_reduce_kernel<<<(NPARAM + 127) / 128, 128, 0, s>>>(partials, groups, G, layout3 ? 1 : 0);
     return check_launch("gen_bwd_weight_reduce");
 }
 

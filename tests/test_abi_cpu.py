@@ -36,7 +36,7 @@ def test_size_queries_and_error_reporting_without_gpu():
     assert lib.dmc_version() >= 100
     assert lib.dmc_gen_tiny_workspace_bytes() == (7788 + 256) * 4
     assert lib.dmc_gen_tiny_saved_bytes(120, 224, 224) == 120 * 28 * 224 * 224 * 4
-    assert lib.dmc_gen_tiny_partials_bytes(1, 8, 32) == (1 + 16) * 28 * 256 * 4
+    assert lib.dmc_gen_tiny_partials_bytes(1, 8, 32) == (1 + 16) * 31 * 256 * 4
     # invalid arguments are rejected before any launch
     rc = lib.dmc_flow_mse_fwd(None, None, None, None, 0, None)
     assert rc == -1 and b"dmc_flow_mse_fwd" in lib.dmc_last_error()
