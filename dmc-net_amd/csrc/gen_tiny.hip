@@ -1706,6 +1706,14 @@ __global__ __launch_bounds__(512, 2) void gen_bwd_weight_pc_kernel(WgradArgs a) 
     const int per_frame = a.tiles_x * a.tiles_y;
     const int ntiles = a.N * per_frame;
     const bool producer = wave == PW_H;
+    // XCD-aware tile schedule (workgroup b runs on XCD b % 8): in round i the 32 workgroups of an XCD take 32 CONSECUTIVE
+    // tiles, so the halo columns / rows that neighbouring tiles share (a 9 x 40 patch per 7 x 32 tile, 160-byte row
+    // segments straddling 128-byte lines) hit in that XCD's L2 instead of being fetched from HBM by eight different L2s
+    const bool xcd_sched = gridDim.x % 8 == 0;
+    const int xs_per = (int)gridDim.x / 8;
+    auto tile_of = [&](int i) -> int {
+        return xcd_sched ? (i * 8 + (int)(blockIdx.x & 7)) * xs_per + (int)(blockIdx.x >> 3) : (int)blockIdx.x + i * (int)gridDim.x;
+    };
 
     constexpr int NA = X3 == 2 ? NT3_A : NT_A, NB = X3 == 2 ? NT3_B : NT_B, WP = (NA + NB) * 256;
     f32x4 accA[NA], accB[NB];
@@ -1716,10 +1724,10 @@ __global__ __launch_bounds__(512, 2) void gen_bwd_weight_pc_kernel(WgradArgs a) 
 
     if (producer) {
         int it = 0;
-        if ((int)blockIdx.x < ntiles) wgrad_stage(a, lds2, lds0, blockIdx.x, per_frame, HW, lane);
+        if (tile_of(0) < ntiles) wgrad_stage(a, lds2, lds0, tile_of(0), per_frame, HW, lane);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
-            const int next = tile + (int)gridDim.x;
+        for (int tile = tile_of(0); tile < ntiles; tile = tile_of(++it)) {
+            const int next = tile_of(it + 1);
             if (next < ntiles)
                 wgrad_stage(a, lds2 + ((it + 1) & 1) * PW_BUF, lds0 + (unsigned)(((it + 1) & 1) * PW_BUF) * 4, next, per_frame, HW, lane,
                             true, 0, X3 != 0 ? 0 : 30);
@@ -1753,10 +1761,10 @@ __global__ __launch_bounds__(512, 2) void gen_bwd_weight_pc_kernel(WgradArgs a) 
         float bias_a = 0.f;
         int it = 0;
         asm volatile("s_barrier" ::: "memory");
-        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+        for (int tile = tile_of(0); tile < ntiles; tile = tile_of(++it)) {
             const float* lds = lds2 + (it & 1) * PW_BUF;
             if constexpr (X3 != 0) {
-                const int next = tile + (int)gridDim.x;
+                const int next = tile_of(it + 1);
                 if (next < ntiles)                        // this wave's share of the next tile's gradient planes
                     wgrad_stage(a, lds2 + ((it + 1) & 1) * PW_BUF, lds0 + (unsigned)(((it + 1) & 1) * PW_BUF) * 4, next, per_frame, HW, lane,
                                 false, (30 * wave) / PW_H, (30 * (wave + 1)) / PW_H);
