@@ -9,8 +9,8 @@
 // strict `>` comparison are nn.MaxPool3d's, so ties -- frequent among rectified zeros -- resolve to the same
 // element and the gradient goes where the stock op sends it (nowhere, when a padding zero comes first).
 //
-// HBM-bound streaming kernels: a thread owns 8 channels (16 bytes) of one output pixel (forward) or one input pixel
-// (backward).  The forward stores the winning tap per output value as one byte (255 = a padding zero); the
+// HBM-bound streaming kernels: a thread owns 8 channels (16 bytes) of four consecutive output columns (forward) or four
+// consecutive input columns (backward) -- one column each in the generic kernels for strides > 2 or kernels wider than 3.  The forward stores the winning tap per output value as one byte (255 = a padding zero); the
 // backward GATHERS: every input pixel visits the <= kd kh kw windows that contain it and adds dy where the stored
 // tap is its own -- no atomics (the stock backward scatters with bf16 atomic adds: 0.7 ms per call, and rounds
 // after every add), fp32 sums rounded once, deterministic.
@@ -43,45 +43,92 @@ __device__ __forceinline__ unsigned f2bf(float v) {
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 
+constexpr int P3_OWT = 4;                                  // output columns per thread (forward) / input columns (backward)
+constexpr int P3_MAXCOL = (P3_OWT - 1) * 2 + 3;           // input columns a thread touches per (kz, ky): strides <= 2, kw <= 3
+
+// Forward.  A thread owns 8 channels of P3_OWT consecutive output columns of one (n, od, oh) row: per (kz, ky) it loads the
+// (P3_OWT - 1) sw + kw input columns those outputs share once (6 instead of 12 vectors for the 3x3x3 stride-1 pools of
+// the Inception blocks) and scans them per output in nn.MaxPool3d's order (kz, ky, kx ascending, strict >).
+template <int SW>                                          // the stride along W when it is 1 or 2 (column cache indexed at compile time); 0 = generic
 __global__ __launch_bounds__(256) void pool3d_fwd_kernel(Pool3dArgs a) {
     const int C8 = a.C >> 3;
-    const long total = (long)a.N * a.OD * a.OH * a.OW * C8;
+    const int OWG = (a.OW + P3_OWT - 1) / P3_OWT;
+    const long total = (long)a.N * a.OD * a.OH * OWG * C8;
+    constexpr bool wide = SW != 0;                         // the column cache below holds P3_MAXCOL vectors (kw <= 3)
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int c8 = (int)(i % C8);
         long p = i / C8;
-        const int ow = (int)(p % a.OW); p /= a.OW;
+        const int owg = (int)(p % OWG); p /= OWG;
         const int oh = (int)(p % a.OH); p /= a.OH;
         const int od = (int)(p % a.OD);
         const int n = (int)(p / a.OD);
-        float best[8];
-        unsigned char cd[8];
+        const int ow0 = owg * P3_OWT;
+        float best[P3_OWT][8];
+        unsigned char cd[P3_OWT][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; cd[e] = 255; }
-        int tap = 0;
+        for (int o = 0; o < P3_OWT; ++o)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { best[o][e] = -INFINITY; cd[o][e] = 255; }
+        const int ncol = wide ? (P3_OWT - 1) * SW + a.kw : 0;
         for (int kz = 0; kz < a.kd; ++kz)
-            for (int ky = 0; ky < a.kh; ++ky)
-                for (int kx = 0; kx < a.kw; ++kx, ++tap) {
-                    const int z = od * a.sd + kz, yv = oh * a.sh + ky, xv = ow * a.sw + kx;
-                    if (z >= a.PD || yv >= a.PH || xv >= a.PW) continue;        // beyond the padded extent (ceil_mode)
-                    const int iz = z - a.fd, iy = yv - a.fh, ix = xv - a.fw;
-                    const bool in = iz >= 0 && iz < a.D && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-                    u32x4 v = u32x4{0u, 0u, 0u, 0u};
-                    if (in) v = *reinterpret_cast<const u32x4*>(a.x + ((((long)n * a.D + iz) * a.H + iy) * a.W + ix) * a.C + 8 * c8);
+            for (int ky = 0; ky < a.kh; ++ky) {
+                const int z = od * a.sd + kz, yv = oh * a.sh + ky;
+                if (z >= a.PD || yv >= a.PH) continue;                             // beyond the padded extent (ceil_mode)
+                const int iz = z - a.fd, iy = yv - a.fh;
+                const bool row_in = iz >= 0 && iz < a.D && iy >= 0 && iy < a.H;
+                const bf16_t* rowp = a.x + (((long)n * a.D + (row_in ? iz : 0)) * a.H + (row_in ? iy : 0)) * a.W * a.C + 8 * c8;
+                u32x4 col[P3_MAXCOL];
+                if constexpr (wide) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float f = bf2f((e & 1) ? (v[e >> 1] >> 16) : (v[e >> 1] & 0xffffu));
-                        if (f > best[e] || f != f) { best[e] = f; cd[e] = in ? (unsigned char)tap : (unsigned char)255; }
+                    for (int q = 0; q < P3_MAXCOL; ++q) {
+                        col[q] = u32x4{0u, 0u, 0u, 0u};
+                        const int ix = ow0 * SW + q - a.fw;
+                        if (q < ncol && row_in && ix >= 0 && ix < a.W) col[q] = *reinterpret_cast<const u32x4*>(rowp + (long)ix * a.C);
                     }
                 }
-        u32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (__float_as_uint(best[2 * e]) >> 16) | (__float_as_uint(best[2 * e + 1]) & 0xffff0000u);
-        const long off = ((((long)n * a.OD + od) * a.OH + oh) * a.OW + ow) * a.C + 8 * c8;
-        *reinterpret_cast<u32x4*>(a.y + off) = o;
-        u32x2 cc;
-        cc[0] = cd[0] | (cd[1] << 8) | (cd[2] << 16) | ((unsigned)cd[3] << 24);
-        cc[1] = cd[4] | (cd[5] << 8) | (cd[6] << 16) | ((unsigned)cd[7] << 24);
-        *reinterpret_cast<u32x2*>(a.code + off) = cc;
+                for (int o = 0; o < P3_OWT; ++o) {
+                    if (ow0 + o >= a.OW) continue;
+                    auto take = [&](int kx, const u32x4& v, bool in) {
+                        const int tap = (kz * a.kh + ky) * a.kw + kx;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float f = bf2f((e & 1) ? (v[e >> 1] >> 16) : (v[e >> 1] & 0xffffu));
+                            if (f > best[o][e] || f != f) { best[o][e] = f; cd[o][e] = in ? (unsigned char)tap : (unsigned char)255; }
+                        }
+                    };
+                    if constexpr (wide) {
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const int xv = (ow0 + o) * SW + kx, ix = xv - a.fw;
+                            if (kx >= a.kw || xv >= a.PW) continue;
+                            take(kx, col[o * SW + kx], row_in && ix >= 0 && ix < a.W);
+                        }
+                    } else {
+                        for (int kx = 0; kx < a.kw; ++kx) {
+                            const int xv = (ow0 + o) * a.sw + kx, ix = xv - a.fw;
+                            if (xv >= a.PW) continue;
+                            const bool in = row_in && ix >= 0 && ix < a.W;
+                            u32x4 v = u32x4{0u, 0u, 0u, 0u};
+                            if (in) v = *reinterpret_cast<const u32x4*>(rowp + (long)ix * a.C);
+                            take(kx, v, in);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+        for (int o = 0; o < P3_OWT; ++o) {
+            if (ow0 + o >= a.OW) continue;
+            u32x4 ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[e] = (__float_as_uint(best[o][2 * e]) >> 16) | (__float_as_uint(best[o][2 * e + 1]) & 0xffff0000u);
+            const long off = ((((long)n * a.OD + od) * a.OH + oh) * a.OW + ow0 + o) * a.C + 8 * c8;
+            *reinterpret_cast<u32x4*>(a.y + off) = ov;
+            u32x2 cc;
+            cc[0] = cd[o][0] | (cd[o][1] << 8) | (cd[o][2] << 16) | ((unsigned)cd[o][3] << 24);
+            cc[1] = cd[o][4] | (cd[o][5] << 8) | (cd[o][6] << 16) | ((unsigned)cd[o][7] << 24);
+            *reinterpret_cast<u32x2*>(a.code + off) = cc;
+        }
     }
 }
 
@@ -126,6 +173,68 @@ __global__ __launch_bounds__(256) void pool3d_bwd_kernel(Pool3dArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = f2bf(s[2 * e]) | (f2bf(s[2 * e + 1]) << 16);
         *reinterpret_cast<u32x4*>(a.dx + ((((long)n * a.D + iz) * a.H + iy) * a.W + ix) * a.C + 8 * c8) = o;
+    }
+}
+
+// Backward for strides 1 / 2 along W and kw <= 3: a thread owns 8 channels of P3_OWT consecutive INPUT columns of one
+// (n, iz, iy) row; per window row pair (od, oh) it loads the (code, dy) vectors of the <= 6 window columns those inputs
+// fall into once (12 loads for four single-column threads) and adds dy where the stored tap points at each of its columns.
+template <int SW>
+__global__ __launch_bounds__(256) void pool3d_bwd_wide_kernel(Pool3dArgs a) {
+    constexpr int NWC = (P3_OWT + 1) / SW + 1;             // window columns touching P3_OWT consecutive inputs (kw <= 3): 6 / 3
+    const int C8 = a.C >> 3;
+    const int WG = (a.W + P3_OWT - 1) / P3_OWT;
+    const long total = (long)a.N * a.D * a.H * WG * C8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c8 = (int)(i % C8);
+        long p = i / C8;
+        const int wg = (int)(p % WG); p /= WG;
+        const int iy = (int)(p % a.H); p /= a.H;
+        const int iz = (int)(p % a.D);
+        const int n = (int)(p / a.D);
+        const int ix0 = wg * P3_OWT;
+        const int z = iz + a.fd, yv = iy + a.fh, xv0 = ix0 + a.fw;                // padded coordinates
+        float s[P3_OWT][8];
+#pragma unroll
+        for (int o = 0; o < P3_OWT; ++o)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[o][e] = 0.f;
+        int od_hi = z / a.sd; if (od_hi > a.OD - 1) od_hi = a.OD - 1;
+        int oh_hi = yv / a.sh; if (oh_hi > a.OH - 1) oh_hi = a.OH - 1;
+        const int ow_lo = ceil_div_floor0(xv0 - a.kw + 1, SW);
+        int ow_hi = (xv0 + P3_OWT - 1) / SW; if (ow_hi > a.OW - 1) ow_hi = a.OW - 1;
+        for (int od = ceil_div_floor0(z - a.kd + 1, a.sd); od <= od_hi; ++od)
+            for (int oh = ceil_div_floor0(yv - a.kh + 1, a.sh); oh <= oh_hi; ++oh) {
+                const unsigned tzy = (unsigned)(((z - od * a.sd) * a.kh + (yv - oh * a.sh)) * a.kw);
+                const long rowoff = (((long)n * a.OD + od) * a.OH + oh) * a.OW;
+#pragma unroll
+                for (int wc = 0; wc < NWC; ++wc) {
+                    const int ow = ow_lo + wc;
+                    if (ow > ow_hi) continue;
+                    const long off = (rowoff + ow) * a.C + 8 * c8;
+                    const u32x2 cc = *reinterpret_cast<const u32x2*>(a.code + off);
+                    const u32x4 g = *reinterpret_cast<const u32x4*>(a.y + off);
+#pragma unroll
+                    for (int o = 0; o < P3_OWT; ++o) {
+                        const int kx = xv0 + o - ow * SW;
+                        if (kx < 0 || kx >= a.kw || ix0 + o >= a.W) continue;
+                        const unsigned tap = tzy + (unsigned)kx;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const unsigned ce = (cc[e >> 2] >> (8 * (e & 3))) & 0xffu;
+                            if (ce == tap) s[o][e] += bf2f((e & 1) ? (g[e >> 1] >> 16) : (g[e >> 1] & 0xffffu));
+                        }
+                    }
+                }
+            }
+#pragma unroll
+        for (int o = 0; o < P3_OWT; ++o) {
+            if (ix0 + o >= a.W) continue;
+            u32x4 ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[e] = f2bf(s[o][2 * e]) | (f2bf(s[o][2 * e + 1]) << 16);
+            *reinterpret_cast<u32x4*>(a.dx + ((((long)n * a.D + iz) * a.H + iy) * a.W + ix0 + o) * a.C + 8 * c8) = ov;
+        }
     }
 }
 
@@ -176,7 +285,10 @@ int dmc_maxpool3d_tf_bf16_fwd(const void* x, void* y, void* code, int N, int D, 
     if (!x || !y || !code) return fail(DMC_E_INVALID, "dmc_maxpool3d_tf_bf16_fwd: null pointer");
     if (!pool_args(a, N, D, H, W, C, kd, kh, kw, sd, sh, sw)) return fail(DMC_E_INVALID, "dmc_maxpool3d_tf_bf16_fwd: unsupported shape");
     a.x = (const bf16_t*)x; a.y = (bf16_t*)y; a.code = (unsigned char*)code; a.dx = nullptr;
-    pool3d_fwd_kernel<<<grid_for((long)N * a.OD * a.OH * a.OW * (C / 8)), 256, 0, (hipStream_t)stream>>>(a);
+    const int grid = grid_for((long)N * a.OD * a.OH * ((a.OW + P3_OWT - 1) / P3_OWT) * (C / 8));
+    if (kw <= 3 && sw == 1) pool3d_fwd_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    else if (kw <= 3 && sw == 2) pool3d_fwd_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    else pool3d_fwd_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(a);
     return check_launch("pool3d_fwd");
 }
 
@@ -187,7 +299,10 @@ int dmc_maxpool3d_tf_bf16_bwd(const void* dy, const void* code, void* dx, int N,
     if (!dy || !dx || !code) return fail(DMC_E_INVALID, "dmc_maxpool3d_tf_bf16_bwd: null pointer");
     if (!pool_args(a, N, D, H, W, C, kd, kh, kw, sd, sh, sw)) return fail(DMC_E_INVALID, "dmc_maxpool3d_tf_bf16_bwd: unsupported shape");
     a.x = nullptr; a.y = (bf16_t*)const_cast<void*>(dy); a.code = (unsigned char*)const_cast<void*>(code); a.dx = (bf16_t*)dx;
-    pool3d_bwd_kernel<<<grid_for((long)N * D * H * W * (C / 8)), 256, 0, (hipStream_t)stream>>>(a);
+    const int gridw = grid_for((long)N * D * H * ((W + P3_OWT - 1) / P3_OWT) * (C / 8));
+    if (kw <= 3 && sw == 1) pool3d_bwd_wide_kernel<1><<<gridw, 256, 0, (hipStream_t)stream>>>(a);
+    else if (kw <= 3 && sw == 2) pool3d_bwd_wide_kernel<2><<<gridw, 256, 0, (hipStream_t)stream>>>(a);
+    else pool3d_bwd_kernel<<<grid_for((long)N * D * H * W * (C / 8)), 256, 0, (hipStream_t)stream>>>(a);
     return check_launch("pool3d_bwd");
 }
 

@@ -124,7 +124,10 @@ POOLS = [((1, 3, 3), (1, 2, 2), (2, 64, 4, 16, 14)),      # maxPool3d_2a / 3a
          ((3, 3, 3), (2, 2, 2), (1, 480, 6, 9, 8)),       # maxPool3d_4a, odd extents
          ((2, 2, 2), (2, 2, 2), (2, 832, 4, 7, 7)),       # maxPool3d_5a: ceil_mode windows past the edge
          ((3, 3, 3), (1, 1, 1), (1, 192, 5, 7, 6)),       # Mixed branch_3
-         ((3, 3, 3), (1, 1, 1), (2, 16, 1, 3, 2))]        # depth 1: every window mostly padding
+         ((3, 3, 3), (1, 1, 1), (2, 16, 1, 3, 2)),        # depth 1: every window mostly padding
+         ((3, 3, 3), (1, 1, 1), (1, 24, 2, 5, 11)),       # OW not a multiple of the 4 columns a thread owns
+         ((2, 4, 4), (2, 2, 2), (1, 16, 4, 10, 12)),      # kw > 3: the generic column path
+         ((1, 3, 3), (1, 3, 3), (1, 8, 2, 9, 13))]        # stride 3: generic path
 
 
 @pytest.mark.parametrize("kernel,stride,shape", POOLS)
