@@ -84,6 +84,8 @@ SIGNATURES = {
     "dmc_stem3d_bf16_fwd": (_I, [_P] * 5 + [_I] * 4 + [_P]),
     "dmc_stem3d_bf16_wgrad_workspace_bytes": (_Z, [_I] * 4),
     "dmc_stem3d_bf16_wgrad": (_I, [_P] * 4 + [_I] * 4 + [_P]),
+    "dmc_stem3d_bf16_dgrad_workspace_bytes": (_Z, []),
+    "dmc_stem3d_bf16_dgrad": (_I, [_P] * 4 + [_I] * 4 + [_P]),
     "dmc_bn3d_bf16_supported": (_I, [_L, _I]),
     "dmc_bn3d_bf16_scratch_bytes": (_Z, [_I]),
     "dmc_bn3d_bf16_fwd": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _F, _P]),

@@ -323,6 +323,104 @@ __global__ __launch_bounds__(256) void stem3d_wgrad_reduce_kernel(const float* _
     dw[i] = s;
 }
 
+// ------------------------------------------------------------------------------------------
+// Data gradient of the stem (the gradient of the 2-channel cue): per input row (n, t, h)
+//     Q[ow][(kx, c)] = sum over the (kz, ky) whose stride-2 window reaches (t, h), and over co, of dy[od][oh][ow][co] * w[co][c][kz][ky][kx]
+//     dx[t][h][w][c] = sum over kx = w (mod 2) of Q[(w + 2 - kx) / 2][(kx, c)]
+// The first line is a GEMM with M = the OW output pixels of a row, N = 14 (+ 2 zero) columns and K = 64 channels x up to 16
+// window rows -- A fragments are 16 contiguous bytes of dy (NDHWC), B fragments 16 contiguous bytes of the weights packed as
+// [kz][ky][(kx, c)][co]: no transposition anywhere, v_mfma_f32_16x16x32_bf16, 87.5 % useful columns (a per-pixel gather
+// formulation would fill 2 of 16 columns).  The second line is a 1-D fold of the row through LDS.  One wave per input row,
+// fp32 output in the cue's NCDHW layout, deterministic.
+// ------------------------------------------------------------------------------------------
+typedef float s3_f32x4 __attribute__((ext_vector_type(4)));
+
+// w fp32 [64][2][7][7][7] -> wq bf16 [49][16][64]: row (kz * 7 + ky) * 16 + 2 kx + c, 64 channels contiguous; rows 14, 15 zero
+__global__ __launch_bounds__(256) void stem3d_pack_wq_kernel(const float* __restrict__ w, bf16_t* __restrict__ wq) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S3_KB * 16 * S3_CO) return;
+    const int co = i & 63, j = (i >> 6) & 15, kb = i >> 10;
+    unsigned v = 0;
+    if (j < 14) v = f2bf(w[((co * 2 + (j & 1)) * 343) + kb * 7 + (j >> 1)]);
+    wq[i] = (bf16_t)v;
+}
+
+struct Stem3dDgArgs {
+    const bf16_t* dy;      // [N][OD][OH][OW][64]
+    const bf16_t* wq;      // [49][16][64]
+    float* dx;             // [N][2][T][H][W]
+    int N, T, H, W, OD, OH, OW;
+};
+
+constexpr int S3_DG_WAVES = 4;
+constexpr int S3_DG_MT = 8;                                // up to 128 output pixels per row
+
+__global__ __launch_bounds__(S3_DG_WAVES * 64) void stem3d_dgrad_kernel(Stem3dDgArgs a) {
+    __shared__ float qlds[S3_DG_WAVES][S3_DG_MT * 16 * 16];   // Q tile of each wave: [ow][16]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int l15 = lane & 15, kg = lane >> 4;
+    float* Q = qlds[wave];
+    const long nrows = (long)a.N * a.T * a.H;
+    const int mtiles = (a.OW + 15) / 16;
+    const long plane = (long)a.T * a.H * a.W;
+    for (long row = (long)blockIdx.x * S3_DG_WAVES + wave; row < nrows; row += (long)gridDim.x * S3_DG_WAVES) {
+        const int h = (int)(row % a.H);
+        const long nt = row / a.H;
+        const int t = (int)(nt % a.T);
+        const int n = (int)(nt / a.T);
+        s3_f32x4 acc[S3_DG_MT];
+#pragma unroll
+        for (int m = 0; m < S3_DG_MT; ++m) acc[m] = s3_f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kz = (t & 1); kz < S3_K; kz += 2) {
+            const int od = (t + 2 - kz) >> 1;
+            if (t + 2 - kz < 0 || od >= a.OD) continue;
+            for (int ky = (h & 1); ky < S3_K; ky += 2) {
+                const int oh = (h + 2 - ky) >> 1;
+                if (h + 2 - ky < 0 || oh >= a.OH) continue;
+                const bf16_t* drow = a.dy + (((long)n * a.OD + od) * a.OH + oh) * a.OW * S3_CO;
+                const bf16_t* wrow = a.wq + ((kz * S3_K + ky) * 16 + l15) * S3_CO;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const u32x4 bf = *reinterpret_cast<const u32x4*>(wrow + 32 * kb + 8 * kg);
+#pragma unroll
+                    for (int m = 0; m < S3_DG_MT; ++m) {
+                        if (m >= mtiles) continue;
+                        int ow = 16 * m + l15;
+                        ow = ow < a.OW ? ow : a.OW - 1;            // clipped rows: valid memory, their Q rows are never read
+                        const u32x4 af = *reinterpret_cast<const u32x4*>(drow + (long)ow * S3_CO + 32 * kb + 8 * kg);
+                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf), acc[m], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // C layout of 16x16: lane (column l15 = j, rows 4 kg + q = ow within the tile)
+#pragma unroll
+        for (int m = 0; m < S3_DG_MT; ++m) {
+            if (m >= mtiles) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Q[(16 * m + 4 * kg + q) * 16 + l15] = acc[m][q];
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // fold: dx[w][c] = sum_{kx = w (mod 2)} Q[(w + 2 - kx) / 2][2 kx + c]
+        float* dst = a.dx + ((long)n * 2 * a.T + t) * a.H * a.W + (long)h * a.W;
+        for (int i = lane; i < 2 * a.W; i += 64) {
+            const int c = i / a.W, w = i - c * a.W;
+            float sum = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kx = (w & 1) + 2 * u;
+                const int ow2 = w + 2 - kx;
+                if (kx < S3_K && ow2 >= 0 && (ow2 >> 1) < a.OW) sum += Q[(ow2 >> 1) * 16 + 2 * kx + c];
+            }
+            dst[c * plane + w] = sum;
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
 int s3_wg_groups(long nseg) { return (int)(nseg < 256 ? nseg : 256); }
 
 int s3_blocks(long tiles) {
@@ -404,6 +502,30 @@ int dmc_stem3d_bf16_wgrad(const float* x, const void* dy, float* dw, void* works
     if ((rc = check_launch("stem3d_wgrad"))) return rc;
     stem3d_wgrad_reduce_kernel<<<(S3_CO * 686 + 255) / 256, 256, 0, s>>>(part, used, dw);
     return check_launch("stem3d_wgrad_reduce");
+}
+
+// bytes of the data gradient's workspace (packed weights)
+size_t dmc_stem3d_bf16_dgrad_workspace_bytes(void) { return (size_t)S3_KB * 16 * S3_CO * 2 + 64; }
+
+// dx [N,2,T,H,W] fp32 (the gradient of the cue) from dy [N,OD,OH,OW,64] bf16 NDHWC and w [64,2,7,7,7] fp32 contiguous (rounded to
+// bf16); OW <= 128; deterministic
+int dmc_stem3d_bf16_dgrad(const void* dy, const float* w, float* dx, void* workspace, int N, int T, int H, int W, dmc_stream_t stream) {
+    if (!dy || !w || !dx || !workspace) return fail(DMC_E_INVALID, "dmc_stem3d_bf16_dgrad: null pointer");
+    const int OW = (W + 5 - 7) / 2 + 1;
+    if (N <= 0 || T < 2 || H < 2 || W < 2 || OW > 16 * S3_DG_MT)
+        return fail(DMC_E_INVALID, "dmc_stem3d_bf16_dgrad: unsupported shape N=%d T=%d H=%d W=%d (W <= 256)", N, T, H, W);
+    hipStream_t s = (hipStream_t)stream;
+    stem3d_pack_wq_kernel<<<(S3_KB * 16 * S3_CO + 255) / 256, 256, 0, s>>>(w, (bf16_t*)workspace);
+    int rc = check_launch("stem3d_pack_wq");
+    if (rc) return rc;
+    Stem3dDgArgs a;
+    a.dy = (const bf16_t*)dy; a.wq = (const bf16_t*)workspace; a.dx = dx;
+    a.N = N; a.T = T; a.H = H; a.W = W; a.OD = (T + 5 - 7) / 2 + 1; a.OH = (H + 5 - 7) / 2 + 1; a.OW = OW;
+    const long rows = (long)N * T * H;
+    long blocks = (rows + S3_DG_WAVES - 1) / S3_DG_WAVES;
+    if (blocks > 2048) blocks = 2048;
+    stem3d_dgrad_kernel<<<(int)blocks, S3_DG_WAVES * 64, 0, s>>>(a);
+    return check_launch("stem3d_dgrad");
 }
 
 }  // extern "C"

@@ -1204,7 +1204,7 @@ class _Stem3dBnRelu(torch.autograd.Function):
     """relu(BatchNorm3d(conv3d_1a_7x7(x))) of the I3D stem in a bf16 trunk (code/dmcnet_I3D/network/i3d.py:480-481,
     :390-398): forward on dmc_stem3d_bf16_fwd (statistics in its epilogue) + the fused BatchNorm3d / ReLU pass; the
     BatchNorm / ReLU backward on bn3d_bf16.hip, the weight gradient on dmc_stem3d_bf16_wgrad, the 2-channel data gradient on
-    PyTorch-ROCm (MIOpen) with the tensors the stock path would hand it (bf16, NCDHW, explicitly padded)."""
+    dmc_stem3d_bf16_dgrad (PyTorch-ROCm / MIOpen only for frames wider than 256)."""
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, running_mean, running_var, eps, momentum, relu):
@@ -1256,7 +1256,13 @@ class _Stem3dBnRelu(torch.autograd.Function):
                 _lib.check(lib.dmc_stem3d_bf16_wgrad(_lib.ptr(xc), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(work), n, t, h, w, _stream()),
                            "dmc_stem3d_bf16_wgrad")
             dw = dw.to(weight.dtype)
-        if ctx.needs_input_grad[0]:                        # data gradient (2 channels): MIOpen, on the stock path's tensors
+        if ctx.needs_input_grad[0] and w <= 256:           # data gradient (2 channels): row GEMM + fold on the matrix cores
+            dx = torch.empty((n, 2, t, h, w), dtype=torch.float32, device=y.device)
+            work = _floats(lib.dmc_stem3d_bf16_dgrad_workspace_bytes(), y.device)
+            with _span("stem3d_dgrad"):
+                _lib.check(lib.dmc_stem3d_bf16_dgrad(_lib.ptr(dy), _lib.ptr(weight.detach().float().contiguous()), _lib.ptr(dx),
+                                                     _lib.ptr(work), n, t, h, w, _stream()), "dmc_stem3d_bf16_dgrad")
+        elif ctx.needs_input_grad[0]:                      # wider than the kernel's row tile: MIOpen, on the stock path's tensors
             xpad = torch.nn.functional.pad(xc.bfloat16(), (2, 3, 2, 3, 2, 3))
             with _span("stem3d_dgrad"):
                 dxp, _, _ = torch.ops.aten.convolution_backward(

@@ -415,7 +415,7 @@ int dmc_bn3d_bf16_bwd(const void* dout, long dout_ld, const void* y, const float
  * cue) and w [64,2,7,7,7] fp32 contiguous are rounded to bf16, fp32 accumulation, y [N,OD,OH,OW,64] bf16 NDHWC with
  * OD = (T + 5 - 7) / 2 + 1 (likewise OH, OW); stat_partials (NULL to skip): [dmc_stem3d_bf16_stat_blocks()][64][2]
  * floats = per-channel (sum, sum of squares) of the rounded outputs, for dmc_bn3d_bf16_fwd.  workspace:
- * dmc_stem3d_bf16_workspace_bytes().  (The stem's data gradient stays on PyTorch-ROCm.)
+ * dmc_stem3d_bf16_workspace_bytes().
  */
 size_t dmc_stem3d_bf16_workspace_bytes(int N, int T, int H, int W);
 int dmc_stem3d_bf16_stat_blocks(int N, int T, int H, int W);
@@ -426,6 +426,11 @@ int dmc_stem3d_bf16_fwd(const float* x, const float* w, void* workspace, void* y
  * dmc_stem3d_bf16_wgrad_workspace_bytes(). */
 size_t dmc_stem3d_bf16_wgrad_workspace_bytes(int N, int T, int H, int W);
 int dmc_stem3d_bf16_wgrad(const float* x, const void* dy, float* dw, void* workspace, int N, int T, int H, int W, dmc_stream_t stream);
+/* data gradient of the same convolution (the gradient of the cue): dx [N,2,T,H,W] fp32 from dy [N,OD,OH,OW,64] bf16 NDHWC and
+ * w (rounded to bf16); per input row a GEMM Q[ow][(kx,c)] over (window rows, channels) on the bf16 matrix cores and a 1-D fold
+ * along x; W <= 256; deterministic; workspace: dmc_stem3d_bf16_dgrad_workspace_bytes(). */
+size_t dmc_stem3d_bf16_dgrad_workspace_bytes(void);
+int dmc_stem3d_bf16_dgrad(const void* dy, const float* w, float* dx, void* workspace, int N, int T, int H, int W, dmc_stream_t stream);
 
 #ifdef __cplusplus
 }

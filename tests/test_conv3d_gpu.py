@@ -255,6 +255,15 @@ def test_i3d_stem_forward_and_unit_vs_stock(shape):
     dmcnet_amd._lib.check(lib.dmc_stem3d_bf16_wgrad(dmcnet_amd._lib.ptr(x), dmcnet_amd._lib.ptr(gcl), dmcnet_amd._lib.ptr(dw2),
                                                     dmcnet_amd._lib.ptr(ws), n, t, h, w, None), "dmc_stem3d_bf16_wgrad")
     assert torch.equal(dw, dw2)                              # deterministic
+    # data gradient kernel against fp64 autograd (x needs no rounding here: the gradient does not depend on it)
+    xo = x.double().requires_grad_(True)
+    (F.conv3d(F.pad(xo, (2, 3, 2, 3, 2, 3)), wt.bfloat16().double(), None, 2, 0) * g.double()).sum().backward()
+    dx = torch.empty((n, 2, t, h, w), dtype=torch.float32, device=DEV)
+    wsd = torch.empty(lib.dmc_stem3d_bf16_dgrad_workspace_bytes(), dtype=torch.uint8, device=DEV)
+    dmcnet_amd._lib.check(lib.dmc_stem3d_bf16_dgrad(dmcnet_amd._lib.ptr(gcl), dmcnet_amd._lib.ptr(wt), dmcnet_amd._lib.ptr(dx),
+                                                    dmcnet_amd._lib.ptr(wsd), n, t, h, w, None), "dmc_stem3d_bf16_dgrad")
+    err = float((dx.double() - xo.grad).abs().max() / xo.grad.abs().max())
+    assert err < 2e-5, err
     res = {}
     for own in (True, False):
         i3d.OWN_CONV3D = own
