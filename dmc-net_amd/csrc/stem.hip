@@ -296,96 +296,6 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemFwdArgs a) {
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Data gradient of the same convolution (needed by the GAN variant, whose classifier loss reaches the generator):
-// per input row (n, h)
-//     Q[ox][(kx, ci)] = sum over the <= 4 kernel rows ky whose stride-2 window reaches h, and over co, of dy[oy][ox][co] * w[co][ci][ky][kx]
-//     dx[ci][h][w]    = sum over kx = w + 3 (mod 2) of Q[(w + 3 - kx) / 2][(kx, ci)]
-// The first line is an exact-fp32 GEMM on v_mfma_f32_16x16x4_f32 with M = the OW output pixels of the row, N = 14 (+ 2 zero)
-// columns, K = 64 channels x kernel rows (a per-pixel gather would fill 2 of the 16 columns); both operands are read as
-// contiguous float4 along the channels (the k order inside a group of 16 channels is permuted identically for A and B).  The
-// second line is a 1-D fold through LDS.  One wave per row; replaces the batched GEMM + col2im (0.37 ms per step pair at 120
-// frames) of the previous round.
-// ------------------------------------------------------------------------------------------
-constexpr int SD_WAVES = 4, SD_MT = 8;
-
-// w [64][2][7][7] by element strides -> wq fp32 [7 ky][16 (kx, ci)][64 co]; rows 14, 15 zero
-__global__ __launch_bounds__(256) void stem_pack_wq_kernel(const float* __restrict__ w, float* __restrict__ wq, long s_co, long s_ci,
-                                                           long s_ky, long s_kx) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 7 * 16 * 64) return;
-    const int co = i & 63, j = (i >> 6) & 15, ky = i >> 10;
-    wq[i] = j < 14 ? w[co * s_co + (j & 1) * s_ci + ky * s_ky + (j >> 1) * s_kx] : 0.f;
-}
-
-struct StemDgArgs {
-    const float* dy;       // [N][OH][OW][64]
-    const float* wq;       // [7][16][64]
-    float* dx;             // [N][2][H][W]
-    int N, H, W, OH, OW;
-};
-
-__global__ __launch_bounds__(SD_WAVES * 64) void stem_dgrad_kernel(StemDgArgs a) {
-    __shared__ float qlds[SD_WAVES][SD_MT * 16 * 16];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int l15 = lane & 15, kq = lane >> 4;
-    float* Q = qlds[wave];
-    const long nrows = (long)a.N * a.H;
-    const int mtiles = (a.OW + 15) / 16;
-    const long plane = (long)a.H * a.W;
-    for (long row = (long)blockIdx.x * SD_WAVES + wave; row < nrows; row += (long)gridDim.x * SD_WAVES) {
-        const int h = (int)(row % a.H);
-        const int n = (int)(row / a.H);
-        mfma_f32x4 acc[SD_MT];
-#pragma unroll
-        for (int m = 0; m < SD_MT; ++m) acc[m] = (mfma_f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int ky = (h + 1) & 1; ky < 7; ky += 2) {
-            const int oy = (h + 3 - ky) >> 1;
-            if (h + 3 - ky < 0 || oy >= a.OH) continue;
-            const float* drow = a.dy + ((long)n * a.OH + oy) * a.OW * S_CO;
-            const float* wrow = a.wq + (ky * 16 + l15) * S_CO;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {                      // 16 channels per s: lane kq holds co = 16 s + 4 kq + e in MFMA e
-                const float4 bv = *reinterpret_cast<const float4*>(wrow + 16 * s + 4 * kq);
-                const float b[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-                for (int m = 0; m < SD_MT; ++m) {
-                    if (m >= mtiles) continue;
-                    int ox = 16 * m + l15;
-                    ox = ox < a.OW ? ox : a.OW - 1;             // clipped rows: valid memory, never read back
-                    const float4 av = *reinterpret_cast<const float4*>(drow + (long)ox * S_CO + 16 * s + 4 * kq);
-                    const float af[4] = {av.x, av.y, av.z, av.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], b[e], acc[m], 0, 0, 0);
-                }
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < SD_MT; ++m) {
-            if (m >= mtiles) continue;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) Q[(16 * m + 4 * kq + q) * 16 + l15] = acc[m][q];
-        }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        float* dst = a.dx + (long)n * 2 * plane + (long)h * a.W;
-        for (int i = lane; i < 2 * a.W; i += 64) {
-            const int c = i / a.W, w = i - c * a.W;
-            float sum = 0.f;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int kx = ((w + 1) & 1) + 2 * u;
-                const int o2 = w + 3 - kx;
-                if (kx < 7 && o2 >= 0 && (o2 >> 1) < a.OW) sum += Q[(o2 >> 1) * 16 + 2 * kx + c];
-            }
-            dst[c * plane + w] = sum;
-        }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-}
-
 int stem_groups(int N, int H, int W) {
     const int OH = (H + 1) / 2, OW = (W + 1) / 2;
     const long tiles = (long)N * ((OH + S_TH - 1) / S_TH) * ((OW + S_TW - 1) / S_TW);
@@ -438,27 +348,6 @@ int dmc_stem_fwd(const float* x, const float* w, long ws_co, long ws_ci, long ws
     if (blocks > 512) blocks = 512;                       // two workgroups per CU, every wave walks many tiles
     stem_fwd_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(a);
     return check_launch("stem_fwd");
-}
-
-// dx [N,2,H,W] fp32 from dy [N,OH,OW,64] NHWC fp32 and w [64,2,7,7] (element strides); workspace: 7 * 16 * 64 floats
-// (dmc_stem_dgrad_workspace_bytes()); OW <= 128; exact fp32, deterministic
-size_t dmc_stem_dgrad_workspace_bytes(void) { return (size_t)7 * 16 * 64 * sizeof(float); }
-int dmc_stem_dgrad(const float* dy, const float* w, long ws_co, long ws_ci, long ws_ky, long ws_kx, float* dx, float* workspace, int N,
-                   int H, int W, dmc_stream_t stream) {
-    if (!dy || !w || !dx || !workspace) return fail(DMC_E_INVALID, "dmc_stem_dgrad: null pointer");
-    const int OW = (W + 1) / 2;
-    if (N <= 0 || H <= 0 || W <= 0 || OW > 16 * SD_MT) return fail(DMC_E_INVALID, "dmc_stem_dgrad: unsupported shape N=%d H=%d W=%d (W <= 256)", N, H, W);
-    hipStream_t s = (hipStream_t)stream;
-    stem_pack_wq_kernel<<<(7 * 16 * 64 + 255) / 256, 256, 0, s>>>(w, workspace, ws_co, ws_ci, ws_ky, ws_kx);
-    int rc = check_launch("stem_pack_wq");
-    if (rc) return rc;
-    StemDgArgs a;
-    a.dy = dy; a.wq = workspace; a.dx = dx; a.N = N; a.H = H; a.W = W; a.OH = (H + 1) / 2; a.OW = OW;
-    const long rows = (long)N * H;
-    long blocks = (rows + SD_WAVES - 1) / SD_WAVES;
-    if (blocks > 2048) blocks = 2048;
-    stem_dgrad_kernel<<<(int)blocks, SD_WAVES * 64, 0, s>>>(a);
-    return check_launch("stem_dgrad");
 }
 
 }  // extern "C"

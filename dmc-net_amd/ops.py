@@ -506,8 +506,7 @@ class _StemConv(torch.autograd.Function):
     120 frames), so
       * the weight gradient is dmc_stem_wgrad (0.24 ms, deterministic);
       * the data gradient (needed only by the GAN variant, whose classifier loss reaches the
-        generator) is dmc_stem_dgrad: per input row an exact-fp32 MFMA GEMM + a 1-D fold (a batched GEMM
-        W^T[98,64] x dy[64, OH*OW] + ``fold`` for frames wider than 256)."""
+        generator) is a batched GEMM  W^T[98,64] x dy[64, OH*OW]  followed by ``fold`` (col2im)."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -540,14 +539,7 @@ class _StemConv(torch.autograd.Function):
                                               n, h, w, _stream()), "dmc_stem_wgrad")
             if weight.is_contiguous(memory_format=torch.channels_last) and not weight.is_contiguous():
                 dw = dw.contiguous(memory_format=torch.channels_last)
-        if ctx.needs_input_grad[0] and w <= 256:
-            dx = torch.empty((n, 2, h, w), dtype=torch.float32, device=x.device)
-            work = _floats(lib.dmc_stem_dgrad_workspace_bytes(), x.device)
-            so, si, sy, sx = weight.stride()
-            with _span("stem_dgrad"):
-                _lib.check(lib.dmc_stem_dgrad(_lib.ptr(dy), _lib.ptr(weight), so, si, sy, sx, _lib.ptr(dx), _lib.ptr(work), n, h, w,
-                                              _stream()), "dmc_stem_dgrad")
-        elif ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0]:
             oh, ow = dy.shape[2], dy.shape[3]
             g = dy.permute(0, 2, 3, 1).reshape(n, oh * ow, 64)            # a view of the NHWC storage
             cols = torch.matmul(weight.reshape(64, 98).t(), g.transpose(1, 2))   # [N, 98, OH*OW]

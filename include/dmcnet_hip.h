@@ -345,12 +345,6 @@ int dmc_stem_wgrad(const float* x, const float* dy, float* dw, float* partials, 
  * channels_last: 98, 1, 14, 2).  Exact fp32 (v_mfma_f32_32x32x2_f32), any H, W. */
 int dmc_stem_fwd(const float* x, const float* w, long ws_co, long ws_ci, long ws_ky, long ws_kx, float* y, int N, int H, int W,
                  dmc_stream_t stream);
-/* data gradient of the same convolution (the GAN variant's classifier loss reaches the generator through conv1,
- * code/dmcnet_GAN/model.py:557-561): dx [N,2,H,W] fp32 from dy [N,OH,OW,64] NHWC; per input row an exact-fp32 MFMA GEMM
- * Q[ox][(kx,ci)] over (kernel rows, channels) and a 1-D fold along x; W <= 256; workspace dmc_stem_dgrad_workspace_bytes(). */
-size_t dmc_stem_dgrad_workspace_bytes(void);
-int dmc_stem_dgrad(const float* dy, const float* w, long ws_co, long ws_ci, long ws_ky, long ws_kx, float* dx, float* workspace, int N,
-                   int H, int W, dmc_stream_t stream);
 
 /* ---- I3D trunk: bf16 3-D convolutions on the matrix cores (BASELINE config 5) -------------------------
  * Replace nn.Conv3d and its autograd inside the reference's Unit3Dpy, code/dmcnet_I3D/network/i3d.py:328-403
