@@ -355,6 +355,8 @@ struct Stem3dDgArgs {
 constexpr int S3_DG_WAVES = 4;
 constexpr int S3_DG_MT = 8;                                // up to 128 output pixels per row
 
+template <int MTC>                                         // number of 16-pixel row tiles when known at compile time (the loads of a
+                                                           // k-block are then issued back to back); 0 = runtime
 __global__ __launch_bounds__(S3_DG_WAVES * 64) void stem3d_dgrad_kernel(Stem3dDgArgs a) {
     __shared__ float qlds[S3_DG_WAVES][S3_DG_MT * 16 * 16];   // Q tile of each wave: [ow][16]
     const int lane = threadIdx.x & 63;
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(S3_DG_WAVES * 64) void stem3d_dgrad_kernel(Stem3dDg
     const int l15 = lane & 15, kg = lane >> 4;
     float* Q = qlds[wave];
     const long nrows = (long)a.N * a.T * a.H;
-    const int mtiles = (a.OW + 15) / 16;
+    const int mtiles = MTC ? MTC : (a.OW + 15) / 16;
     const long plane = (long)a.T * a.H * a.W;
     for (long row = (long)blockIdx.x * S3_DG_WAVES + wave; row < nrows; row += (long)gridDim.x * S3_DG_WAVES) {
         const int h = (int)(row % a.H);
@@ -383,13 +385,18 @@ __global__ __launch_bounds__(S3_DG_WAVES * 64) void stem3d_dgrad_kernel(Stem3dDg
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
                     const u32x4 bf = *reinterpret_cast<const u32x4*>(wrow + 32 * kb + 8 * kg);
+                    u32x4 af[S3_DG_MT];
 #pragma unroll
                     for (int m = 0; m < S3_DG_MT; ++m) {
-                        if (m >= mtiles) continue;
+                        if (MTC ? m >= MTC : m >= mtiles) continue;
                         int ow = 16 * m + l15;
                         ow = ow < a.OW ? ow : a.OW - 1;            // clipped rows: valid memory, their Q rows are never read
-                        const u32x4 af = *reinterpret_cast<const u32x4*>(drow + (long)ow * S3_CO + 32 * kb + 8 * kg);
-                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf), acc[m], 0, 0, 0);
+                        af[m] = *reinterpret_cast<const u32x4*>(drow + (long)ow * S3_CO + 32 * kb + 8 * kg);
+                    }
+#pragma unroll
+                    for (int m = 0; m < S3_DG_MT; ++m) {
+                        if (MTC ? m >= MTC : m >= mtiles) continue;
+                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[m]), __builtin_bit_cast(bf16x8, bf), acc[m], 0, 0, 0);
                     }
                 }
             }
@@ -524,7 +531,10 @@ int dmc_stem3d_bf16_dgrad(const void* dy, const float* w, float* dx, void* works
     const long rows = (long)N * T * H;
     long blocks = (rows + S3_DG_WAVES - 1) / S3_DG_WAVES;
     if (blocks > 2048) blocks = 2048;
-    stem3d_dgrad_kernel<<<(int)blocks, S3_DG_WAVES * 64, 0, s>>>(a);
+    const int mt = (OW + 15) / 16;
+    if (mt == 7) stem3d_dgrad_kernel<7><<<(int)blocks, S3_DG_WAVES * 64, 0, s>>>(a);        // 224-wide frames
+    else if (mt == 8) stem3d_dgrad_kernel<8><<<(int)blocks, S3_DG_WAVES * 64, 0, s>>>(a);
+    else stem3d_dgrad_kernel<0><<<(int)blocks, S3_DG_WAVES * 64, 0, s>>>(a);
     return check_launch("stem3d_dgrad");
 }
 
