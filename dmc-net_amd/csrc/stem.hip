@@ -296,6 +296,125 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemFwdArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same forward in bf16x3 arithmetic (conv_nhwc.hip: fp32 = the exact sum of three bf16 slices; six slice products
+// per fp32 product on v_mfma_f32_32x32x16_bf16, fp32 accumulate, error <= one fp32 rounding of the product), on the
+// scheme of the I3D stem (stem3d_bf16.hip): the input is first written as three zero-padded bf16 slice volumes
+// [3][N][H+6][Wp] of (channel 0, channel 1) dwords, in which the 7 taps x 2 channels (+ 2 zero-weight slots) of a kernel
+// row for output pixel ox are 32 contiguous bytes starting at pixel 2 ox; 7 k-blocks x 6 slice products x 2 channel tiles
+// = 84 MFMAs of 32 cycles per 32-pixel tile where the fp32 form issues 98 of 64; the split weights [3][7][64][16] (43 KB)
+// sit in LDS; persistent 8-wave workgroups.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 stem_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned stem_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned stem_u32x2 __attribute__((ext_vector_type(2)));
+constexpr int SX_WLDS = 3 * 7 * S_CO * 32;                // 43,008 bytes
+
+__device__ __forceinline__ void stem_split3(float v, unsigned& s0, unsigned& s1, unsigned& s2) {
+    const unsigned u0 = __float_as_uint(v);
+    const float r1 = v - __uint_as_float(u0 & 0xffff0000u);
+    const unsigned u1 = __float_as_uint(r1);
+    const unsigned u2 = __float_as_uint(r1 - __uint_as_float(u1 & 0xffff0000u));
+    s0 = u0 >> 16; s1 = u1 >> 16; s2 = u2 >> 16;
+}
+
+// x fp32 [N][2][H][W] -> xs [3][N][Hp][Wp] dwords (slice of channel 0 | slice of channel 1 << 16), zero borders (3 in front)
+__global__ __launch_bounds__(256) void stem_prep_x3_kernel(const float* __restrict__ x, unsigned* __restrict__ xs, int N, int H, int W,
+                                                           int Hp, int Wp) {
+    const long vol = (long)N * Hp * Wp, plane = (long)H * W;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < vol; i += (long)gridDim.x * 256) {
+        const int xx = (int)(i % Wp);
+        const long r = i / Wp;
+        const int yy = (int)(r % Hp);
+        const int n = (int)(r / Hp);
+        const int h = yy - 3, w = xx - 3;
+        unsigned a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
+        if (h >= 0 && h < H && w >= 0 && w < W) {
+            const long o = (long)n * 2 * plane + (long)h * W + w;
+            stem_split3(x[o], a0, a1, a2);
+            stem_split3(x[o + plane], b0, b1, b2);
+        }
+        xs[i] = a0 | (b0 << 16); xs[vol + i] = a1 | (b1 << 16); xs[2 * vol + i] = a2 | (b2 << 16);
+    }
+}
+
+// w [64][2][7][7] by element strides -> wp3 [3][7 ky][64 co][16] bf16: slot 2 kx + ci, slots 14, 15 zero
+__global__ __launch_bounds__(256) void stem_pack_w3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, long s_co, long s_ci,
+                                                           long s_ky, long s_kx) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 7 * S_CO * 16) return;
+    const int j = i & 15, co = (i >> 4) & 63, ky = i >> 10;
+    unsigned s0 = 0, s1 = 0, s2 = 0;
+    if (j < 14) stem_split3(w[co * s_co + (j & 1) * s_ci + ky * s_ky + (j >> 1) * s_kx], s0, s1, s2);
+    wp[i] = (unsigned short)s0; wp[7 * S_CO * 16 + i] = (unsigned short)s1; wp[2 * 7 * S_CO * 16 + i] = (unsigned short)s2;
+}
+
+struct StemX3Args {
+    const unsigned* xs;    // [3][N][Hp][Wp]
+    const unsigned short* wp;   // [3][7][64][16]
+    float* y;              // [N][OH][OW][64]
+    int N, OH, OW, Hp, Wp, tiles_x;
+    long vol;              // N * Hp * Wp
+};
+
+__global__ __launch_bounds__(512) void stem_fwd_x3_kernel(StemX3Args a) {
+    extern __shared__ __attribute__((aligned(16))) char wlds3[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    for (int i = tid; i < SX_WLDS / 16; i += 512) reinterpret_cast<stem_u32x4*>(wlds3)[i] = reinterpret_cast<const stem_u32x4*>(a.wp)[i];
+    __syncthreads();
+    const long ntiles = (long)a.N * a.OH * a.tiles_x;
+    const long stride = (long)gridDim.x * 8;
+    const int woff = l31 * 32 + half * 16;
+    for (long tile = (long)blockIdx.x * 8 + wave; tile < ntiles; tile += stride) {
+        const int xt = (int)(tile % a.tiles_x);
+        const long r = tile / a.tiles_x;                    // n * OH + oy
+        const int oy = (int)(r % a.OH);
+        const int n = (int)(r / a.OH);
+        const int ox = 32 * xt + l31;
+        const int oxc = ox < a.OW ? ox : a.OW - 1;
+        const unsigned* base = a.xs + ((long)n * a.Hp + 2 * oy) * a.Wp + 2 * oxc + 4 * half;
+        stem_f32x16 acc[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
+        stem_u32x4 xb[7][3];
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+            for (int sl = 0; sl < 3; ++sl) {
+                const unsigned* p = base + sl * a.vol + (long)ky * a.Wp;
+                const stem_u32x2 lo = *reinterpret_cast<const stem_u32x2*>(p), hi = *reinterpret_cast<const stem_u32x2*>(p + 2);
+                xb[ky][sl] = stem_u32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                stem_u32x4 wf[3];
+#pragma unroll
+                for (int sl = 0; sl < 3; ++sl)
+                    wf[sl] = *reinterpret_cast<const stem_u32x4*>(wlds3 + ((sl * 7 + ky) * S_CO + 32 * ct) * 32 + woff);
+                auto mm = [&](int i, int j) {
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(stem_bf16x8, wf[i]), __builtin_bit_cast(stem_bf16x8, xb[ky][j]),
+                                                                      acc[ct], 0, 0, 0);
+                };
+                mm(0, 2); mm(2, 0); mm(1, 1); mm(0, 1); mm(1, 0); mm(0, 0);      // small terms first
+            }
+        if (ox < a.OW) {
+            float* dst = a.y + (r * a.OW + ox) * S_CO;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(dst + 32 * ct + 8 * g + 4 * half) =
+                        make_float4(acc[ct][4 * g], acc[ct][4 * g + 1], acc[ct][4 * g + 2], acc[ct][4 * g + 3]);
+        }
+    }
+}
+
 int stem_groups(int N, int H, int W) {
     const int OH = (H + 1) / 2, OW = (W + 1) / 2;
     const long tiles = (long)N * ((OH + S_TH - 1) / S_TH) * ((OW + S_TW - 1) / S_TW);
@@ -348,6 +467,35 @@ int dmc_stem_fwd(const float* x, const float* w, long ws_co, long ws_ci, long ws
     if (blocks > 512) blocks = 512;                       // two workgroups per CU, every wave walks many tiles
     stem_fwd_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(a);
     return check_launch("stem_fwd");
+}
+
+// bf16x3 form of dmc_stem_fwd (fp32-accurate; see stem_fwd_x3_kernel): workspace of dmc_stem_fwd_x3_workspace_bytes()
+size_t dmc_stem_fwd_x3_workspace_bytes(int N, int H, int W) {
+    const long Wp = (W + 8 + 3) / 4 * 4;
+    return (size_t)3 * N * (H + 6) * Wp * 4 + (size_t)3 * 7 * S_CO * 16 * 2 + 64;
+}
+int dmc_stem_fwd_x3(const float* x, const float* w, long ws_co, long ws_ci, long ws_ky, long ws_kx, void* workspace, float* y, int N,
+                    int H, int W, dmc_stream_t stream) {
+    if (!x || !w || !workspace || !y) return fail(DMC_E_INVALID, "dmc_stem_fwd_x3: null pointer");
+    if (N <= 0 || H <= 0 || W <= 0) return fail(DMC_E_INVALID, "dmc_stem_fwd_x3: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const int Hp = H + 6, Wp = (W + 8 + 3) / 4 * 4;
+    const long vol = (long)N * Hp * Wp;
+    unsigned* xs = (unsigned*)workspace;
+    unsigned short* wp = (unsigned short*)((char*)workspace + (size_t)3 * vol * 4);
+    stem_prep_x3_kernel<<<(int)((vol + 255) / 256 > 8192 ? 8192 : (vol + 255) / 256), 256, 0, s>>>(x, xs, N, H, W, Hp, Wp);
+    int rc = check_launch("stem_prep_x3");
+    if (rc) return rc;
+    stem_pack_w3_kernel<<<(7 * S_CO * 16 + 255) / 256, 256, 0, s>>>(w, wp, ws_co, ws_ci, ws_ky, ws_kx);
+    if ((rc = check_launch("stem_pack_w3"))) return rc;
+    StemX3Args a;
+    a.xs = xs; a.wp = wp; a.y = y; a.N = N; a.OH = (H + 1) / 2; a.OW = (W + 1) / 2; a.Hp = Hp; a.Wp = Wp;
+    a.tiles_x = (a.OW + 31) / 32; a.vol = vol;
+    const long tiles = (long)N * a.OH * a.tiles_x;
+    long blocks = (tiles + 7) / 8;
+    if (blocks > 512) blocks = 512;
+    stem_fwd_x3_kernel<<<(int)blocks, 512, SX_WLDS, s>>>(a);
+    return check_launch("stem_fwd_x3");
 }
 
 }  // extern "C"

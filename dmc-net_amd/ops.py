@@ -516,9 +516,15 @@ class _StemConv(torch.autograd.Function):
             y = torch.empty((n, 64, (h + 1) // 2, (w + 1) // 2), dtype=torch.float32, device=x.device,
                             memory_format=torch.channels_last)
             so, si, sy, sx = weight.stride()
+            lib = _lib.load()
             with _span("stem_fwd"):
-                _lib.check(_lib.load().dmc_stem_fwd(_lib.ptr(xc), _lib.ptr(weight), so, si, sy, sx, _lib.ptr(y), n, h, w,
-                                                    _stream()), "dmc_stem_fwd")
+                if lib.dmc_get_option(b"conv_arith") == 1:         # bf16x3 arithmetic, as the other classifier convolutions
+                    work = _floats(lib.dmc_stem_fwd_x3_workspace_bytes(n, h, w), x.device)
+                    _lib.check(lib.dmc_stem_fwd_x3(_lib.ptr(xc), _lib.ptr(weight), so, si, sy, sx, _lib.ptr(work), _lib.ptr(y),
+                                                   n, h, w, _stream()), "dmc_stem_fwd_x3")
+                else:
+                    _lib.check(lib.dmc_stem_fwd(_lib.ptr(xc), _lib.ptr(weight), so, si, sy, sx, _lib.ptr(y), n, h, w,
+                                                _stream()), "dmc_stem_fwd")
         else:
             y = torch.nn.functional.conv2d(x, weight, None, 2, 3)
         ctx.save_for_backward(xc, weight)

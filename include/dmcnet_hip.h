@@ -345,6 +345,11 @@ int dmc_stem_wgrad(const float* x, const float* dy, float* dw, float* partials, 
  * channels_last: 98, 1, 14, 2).  Exact fp32 (v_mfma_f32_32x32x2_f32), any H, W. */
 int dmc_stem_fwd(const float* x, const float* w, long ws_co, long ws_ci, long ws_ky, long ws_kx, float* y, int N, int H, int W,
                  dmc_stream_t stream);
+/* the same forward in bf16x3 arithmetic (fp32 operands as three bf16 slices, six bf16 MFMAs per product block, fp32
+ * accumulate: fp32-level error); workspace: dmc_stem_fwd_x3_workspace_bytes(N, H, W) (padded slice volumes + split weights) */
+size_t dmc_stem_fwd_x3_workspace_bytes(int N, int H, int W);
+int dmc_stem_fwd_x3(const float* x, const float* w, long ws_co, long ws_ci, long ws_ky, long ws_kx, void* workspace, float* y, int N,
+                    int H, int W, dmc_stream_t stream);
 
 /* ---- I3D trunk: bf16 3-D convolutions on the matrix cores (BASELINE config 5) -------------------------
  * Replace nn.Conv3d and its autograd inside the reference's Unit3Dpy, code/dmcnet_I3D/network/i3d.py:328-403
