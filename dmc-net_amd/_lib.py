@@ -59,6 +59,8 @@ SIGNATURES = {
     "dmc_conv_nhwc_fwd": (_I, [_P] * 7 + [_I] * 10 + [_P]),
     "dmc_conv_nhwc_stats_final": (_I, [_P, _I, _I, ctypes.c_long, _P, _P, _P, _F, _F, _P]),
     "dmc_conv_nhwc_wt_bytes": (_Z, [_I] * 4),
+    "dmc_conv_nhwc_presplit_supported": (_I, [_I, _I]),
+    "dmc_conv_nhwc_split": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dmc_conv_nhwc_dgrad": (_I, [_P] * 4 + [_I] * 9 + [_P]),
     "dmc_conv_nhwc_wgrad_bytes": (_Z, [_I] * 9),
     "dmc_conv_nhwc_wgrad": (_I, [_P] * 4 + [_I] * 9 + [_P]),

@@ -822,6 +822,30 @@ __global__ __launch_bounds__(256) void conv_split_w_kernel(const float* __restri
     }
 }
 
+// both layouts in one launch (blockIdx.y = 0: the forward's [3][Cout][KK][Cin]; 1: the data gradient's transposed [3][Cin][KK][Cout])
+__global__ __launch_bounds__(256) void conv_split_w2_kernel(const float* __restrict__ w, unsigned short* __restrict__ wf,
+                                                            unsigned short* __restrict__ wt, int Cout, int KK, int Cin) {
+    const bool transposed = blockIdx.y == 1;
+    unsigned short* ws = transposed ? wt : wf;
+    const long total = (long)Cout * KK * Cin;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        float v;
+        if (transposed) {
+            const int co = (int)(i % Cout), tap = (int)((i / Cout) % KK), ci = (int)(i / ((long)Cout * KK));
+            v = w[((long)co * KK + tap) * Cin + ci];
+        } else {
+            v = w[i];
+        }
+        const unsigned u0 = __float_as_uint(v);
+        const float r1 = v - __uint_as_float(u0 & 0xffff0000u);
+        const unsigned u1 = __float_as_uint(r1);
+        const unsigned u2 = __float_as_uint(r1 - __uint_as_float(u1 & 0xffff0000u));
+        ws[i] = (unsigned short)(u0 >> 16);
+        ws[total + i] = (unsigned short)(u1 >> 16);
+        ws[2 * total + i] = (unsigned short)(u2 >> 16);
+    }
+}
+
 // ---- data-gradient weights: wt[ci][tap][co] = w[co][tap][ci] ------------------------------------
 __global__ __launch_bounds__(256) void conv_pack_wt_kernel(const float* __restrict__ w, float* __restrict__ wt,
                                                            int Cout, int KK, int Cin) {
@@ -1831,7 +1855,7 @@ int dmc_conv_nhwc_stat_blocks(int N, int H, int W, int Cin, int Cout, int KH, in
 int dmc_conv_nhwc_fwd(const float* x, const float* w, void* wpack, const float* bias, const float* keep, float* y,
                       double* stat_partials, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                       int pad, int act, dmc_stream_t stream) {
-    if (!x || !w || !y) return fail(DMC_E_INVALID, "dmc_conv_nhwc_fwd: null pointer");
+    if (!x || !y || (!w && !wpack)) return fail(DMC_E_INVALID, "dmc_conv_nhwc_fwd: null pointer");
     ConvShape sh = {N, H, W, Cin, Cout, KH, KW, stride, pad, 0, 0};
     if (!shape_supported(sh))
         return fail(DMC_E_INVALID, "dmc_conv_nhwc_fwd: unsupported shape N=%d H=%d W=%d Cin=%d Cout=%d k=%dx%d s=%d p=%d",
@@ -1851,12 +1875,30 @@ int dmc_conv_nhwc_fwd(const float* x, const float* w, void* wpack, const float* 
     a.M = N * a.OH * a.OW;
     if (use_v3(Cin, Cout)) {
         if (!wpack) return fail(DMC_E_INVALID, "dmc_conv_nhwc_fwd: the bf16x3 arithmetic needs the weight workspace");
-        int rc = split_weights(w, wpack, Cout, a.KK, Cin, 0, (hipStream_t)stream);
-        if (rc) return rc;
+        if (w) {                                            // w == NULL: wpack already holds the slices (dmc_conv_nhwc_split)
+            int rc = split_weights(w, wpack, Cout, a.KK, Cin, 0, (hipStream_t)stream);
+            if (rc) return rc;
+        }
         a.w = reinterpret_cast<const float*>(wpack);
         return launch_conv3(a, (hipStream_t)stream);
     }
+    if (!w) return fail(DMC_E_INVALID, "dmc_conv_nhwc_fwd: pre-split weights are for the bf16x3 kernels only");
     return launch_conv(a, (hipStream_t)stream);
+}
+
+// 1 if the forward / data gradient of this channel pair run on the bf16x3 kernels (then dmc_conv_nhwc_split applies)
+int dmc_conv_nhwc_presplit_supported(int Cin, int Cout) { return use_v3(Cin, Cout) && use_v3(Cout, Cin) ? 1 : 0; }
+
+// split the weights for the forward (wpack_f) and the data gradient (wpack_t, transposed) in ONE launch; each workspace
+// has dmc_conv_nhwc_wt_bytes() bytes; dmc_conv_nhwc_fwd / _dgrad called with w == NULL then use theirs as it is
+int dmc_conv_nhwc_split(const float* w, void* wpack_f, void* wpack_t, int Cin, int Cout, int KH, int KW, dmc_stream_t stream) {
+    if (!w || !wpack_f || !wpack_t) return fail(DMC_E_INVALID, "dmc_conv_nhwc_split: null pointer");
+    if (!dmc_conv_nhwc_presplit_supported(Cin, Cout)) return fail(DMC_E_INVALID, "dmc_conv_nhwc_split: not a bf16x3 shape");
+    const long total = (long)Cout * KH * KW * Cin;
+    const long blocks = (total + 255) / 256;
+    conv_split_w2_kernel<<<dim3((unsigned)(blocks > 1024 ? 1024 : blocks), 2), 256, 0, (hipStream_t)stream>>>(
+        w, reinterpret_cast<unsigned short*>(wpack_f), reinterpret_cast<unsigned short*>(wpack_t), Cout, KH * KW, Cin);
+    return check_launch("conv_split_w2");
 }
 
 // packed-weight workspace of the forward and the data gradient: fp32 transposed weights or three bf16 slices
@@ -1865,7 +1907,7 @@ size_t dmc_conv_nhwc_wt_bytes(int Cin, int Cout, int KH, int KW) { return (size_
 // dx [N,H,W,Cin] from dy [N,OH,OW,Cout]; wt: workspace of dmc_conv_nhwc_wt_bytes() (the packed weights)
 int dmc_conv_nhwc_dgrad(const float* dy, const float* w, float* wt, float* dx, int N, int H, int W, int Cin,
                         int Cout, int KH, int KW, int stride, int pad, dmc_stream_t stream) {
-    if (!dy || !w || !wt || !dx) return fail(DMC_E_INVALID, "dmc_conv_nhwc_dgrad: null pointer");
+    if (!dy || !wt || !dx) return fail(DMC_E_INVALID, "dmc_conv_nhwc_dgrad: null pointer");
     ConvShape sh = {N, H, W, Cin, Cout, KH, KW, stride, pad, 0, 0};
     if (!shape_supported(sh)) return fail(DMC_E_INVALID, "dmc_conv_nhwc_dgrad: unsupported shape");
     hipStream_t s = (hipStream_t)stream;
@@ -1873,8 +1915,9 @@ int dmc_conv_nhwc_dgrad(const float* dy, const float* w, float* wt, float* dx, i
     const long total = (long)Cin * Cout * KK;
     const bool v3 = use_v3(Cout, Cin);                    // the GEMM contracts over Cout and produces Cin channels
     int rc;
+    if (!w && !v3) return fail(DMC_E_INVALID, "dmc_conv_nhwc_dgrad: pre-split weights are for the bf16x3 kernels only");
     if (v3) {
-        rc = split_weights(w, wt, Cout, KK, Cin, 1, s);
+        rc = w ? split_weights(w, wt, Cout, KK, Cin, 1, s) : DMC_OK;   // w == NULL: wt already holds the transposed slices
     } else {
         conv_pack_wt_kernel<<<(int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256), 256, 0, s>>>(w, wt, Cout, KK, Cin);
         rc = check_launch("conv_pack_wt");

@@ -594,7 +594,7 @@ def _conv_geom(x, weight, stride, padding):
     return n, h, w, cin, cout, kh, kw, oh, ow
 
 
-def _conv_fwd(x, weight, bias, keep, stride, padding, act, want_stats):
+def _conv_fwd(x, weight, bias, keep, stride, padding, act, want_stats, presplit=None):
     lib = _lib.load()
     n, h, w, cin, cout, kh, kw, oh, ow = _conv_geom(x, weight, stride, padding)
     y = torch.empty((n, cout, oh, ow), dtype=torch.float32, device=x.device, memory_format=_CL)
@@ -602,20 +602,20 @@ def _conv_fwd(x, weight, bias, keep, stride, padding, act, want_stats):
     if want_stats:
         nblk = lib.dmc_conv_nhwc_stat_blocks(n, h, w, cin, cout, kh, stride, padding)
         part = torch.empty((nblk, cout, 2), dtype=torch.float64, device=x.device)
-    wpack = _floats(lib.dmc_conv_nhwc_wt_bytes(cin, cout, kh, kw), x.device)
-    _lib.check(lib.dmc_conv_nhwc_fwd(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(wpack), _lib.ptr(bias), _lib.ptr(keep), _lib.ptr(y),
+    wpack = presplit if presplit is not None else _floats(lib.dmc_conv_nhwc_wt_bytes(cin, cout, kh, kw), x.device)
+    _lib.check(lib.dmc_conv_nhwc_fwd(_lib.ptr(x), None if presplit is not None else _lib.ptr(weight), _lib.ptr(wpack), _lib.ptr(bias), _lib.ptr(keep), _lib.ptr(y),
                                      _lib.ptr(part), n, h, w, cin, cout, kh, kw, stride, padding, int(act),
                                      _stream()), "dmc_conv_nhwc_fwd")
     return y, part, nblk
 
 
-def _conv_dgrad(dy, weight, x_shape, stride, padding):
+def _conv_dgrad(dy, weight, x_shape, stride, padding, presplit=None):
     lib = _lib.load()
     n, cin, h, w = x_shape
     cout, _, kh, kw = weight.shape
     dx = torch.empty((n, cin, h, w), dtype=torch.float32, device=dy.device, memory_format=_CL)
-    wt = _floats(lib.dmc_conv_nhwc_wt_bytes(cin, cout, kh, kw), dy.device)
-    _lib.check(lib.dmc_conv_nhwc_dgrad(_lib.ptr(dy), _lib.ptr(weight), _lib.ptr(wt), _lib.ptr(dx), n, h, w, cin,
+    wt = presplit if presplit is not None else _floats(lib.dmc_conv_nhwc_wt_bytes(cin, cout, kh, kw), dy.device)
+    _lib.check(lib.dmc_conv_nhwc_dgrad(_lib.ptr(dy), None if presplit is not None else _lib.ptr(weight), _lib.ptr(wt), _lib.ptr(dx), n, h, w, cin,
                                        cout, kh, kw, stride, padding, _stream()), "dmc_conv_nhwc_dgrad")
     return dx
 
@@ -688,8 +688,16 @@ class _ConvBnAct(torch.autograd.Function):
         _need_cuda(x, weight, residual, gamma, beta)
         x, wcl = _as_cl(x), _as_cl(weight)
         cout = weight.shape[0]
+        ctx.wsplit_t = None
         with _span("conv_nhwc_fwd"):
-            y, part, nblk = _conv_fwd(x, wcl, None, None, stride, padding, 0, True)
+            wf = None
+            if ctx.needs_input_grad[0] and lib.dmc_conv_nhwc_presplit_supported(weight.shape[1], cout):
+                # bf16x3 kernels: the forward's and the data gradient's weight slices from ONE launch
+                nb = lib.dmc_conv_nhwc_wt_bytes(weight.shape[1], cout, weight.shape[2], weight.shape[3])
+                wf, ctx.wsplit_t = _floats(nb, x.device), _floats(nb, x.device)
+                _lib.check(lib.dmc_conv_nhwc_split(_lib.ptr(wcl), _lib.ptr(wf), _lib.ptr(ctx.wsplit_t), weight.shape[1], cout,
+                                                   weight.shape[2], weight.shape[3], _stream()), "dmc_conv_nhwc_split")
+            y, part, nblk = _conv_fwd(x, wcl, None, None, stride, padding, 0, True, presplit=wf)
         n, _, oh, ow = y.shape
         m = n * oh * ow
         stats = _floats(lib.dmc_bn_act_stats_bytes(cout), x.device)
@@ -732,7 +740,7 @@ class _ConvBnAct(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             with _span("conv_nhwc_dgrad"):
-                dx = _conv_dgrad(dy, wcl, x.shape, stride, padding)
+                dx = _conv_dgrad(dy, wcl, x.shape, stride, padding, presplit=ctx.wsplit_t)
         if ctx.needs_input_grad[1]:
             with _span("conv_nhwc_wgrad"):
                 dw = _grad_like(_conv_wgrad(x, dy, wcl, stride, padding), weight)

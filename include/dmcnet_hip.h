@@ -286,6 +286,8 @@ int dmc_bn_relu_pool_bwd(const float* x, const float* gamma, const float* beta, 
  * wpack: workspace of dmc_conv_nhwc_wt_bytes() bytes for the weights as the kernel wants them (needed when the
  * option "conv_arith" is 1; may be NULL otherwise).
  * dgrad: dx = conv_transpose(dy, w); wt = workspace of dmc_conv_nhwc_wt_bytes().
+ * bf16x3 shapes (dmc_conv_nhwc_presplit_supported): dmc_conv_nhwc_split() fills the forward's and the data gradient's workspaces
+ * in one launch, and fwd / dgrad called with w == NULL use theirs as it is (one split launch per layer and step instead of two).
  * Arithmetic (option "conv_arith"): 0 = v_mfma_f32_32x32x2_f32 (fp32 operands, fp32 accumulate); 1 = "bf16x3" for
  * Cin % 32 == 0, Cout % 64 == 0: every fp32 operand is the exact sum of three bf16 slices, each product is formed
  * from six slice products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (the omitted three are below 2^-23 of
@@ -303,6 +305,8 @@ int dmc_conv_nhwc_stats_final(const double* partials, int nblk, int C, long coun
                               float* running_mean, float* running_var, float eps, float momentum,
                               dmc_stream_t stream);
 size_t dmc_conv_nhwc_wt_bytes(int Cin, int Cout, int KH, int KW);
+int dmc_conv_nhwc_presplit_supported(int Cin, int Cout);
+int dmc_conv_nhwc_split(const float* w, void* wpack_f, void* wpack_t, int Cin, int Cout, int KH, int KW, dmc_stream_t stream);
 int dmc_conv_nhwc_dgrad(const float* dy, const float* w, float* wt, float* dx, int N, int H, int W, int Cin,
                         int Cout, int KH, int KW, int stride, int pad, dmc_stream_t stream);
 size_t dmc_conv_nhwc_wgrad_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);

@@ -890,6 +890,30 @@ def test_conv_nhwc_fwd_dgrad_wgrad_vs_fp64(case, conv_arith):
     assert torch.equal(g1, wg.grad) and torch.equal(d1, xg.grad)
 
 
+@pytest.mark.parametrize("case", [(3, 64, 14, 14, 64, 3, 1), (2, 64, 15, 15, 128, 3, 2), (2, 128, 9, 9, 256, 1, 2)])
+def test_conv_nhwc_presplit_weights_bit_identical(case):
+    """dmc_conv_nhwc_split fills the forward's and the data gradient's bf16x3 weight slices in one launch; the
+    convolution called with w == NULL on them is bit-identical to the call that splits by itself, and the
+    fused conv + BatchNorm op (which takes that route) matches the stock modules' gradients."""
+    n, cin, h, w, cout, k, stride = case
+    pad = k // 2
+    lib = dmcnet_amd._lib.load()
+    if not lib.dmc_conv_nhwc_presplit_supported(cin, cout):
+        pytest.skip("the bf16x3 arithmetic is switched off")
+    x = rnd(211, (n, cin, h, w)).to(DEV).contiguous(memory_format=torch.channels_last)
+    wt = (rnd(212, (cout, cin, k, k)) * 0.1).to(DEV).contiguous(memory_format=torch.channels_last)
+    y0, _, _ = ops._conv_fwd(x, wt, None, None, stride, pad, 0, False)
+    go = rnd(213, tuple(y0.shape)).to(DEV).contiguous(memory_format=torch.channels_last)
+    d0 = ops._conv_dgrad(go, wt, x.shape, stride, pad)
+    nb = lib.dmc_conv_nhwc_wt_bytes(cin, cout, k, k)
+    wf, wtr = ops._floats(nb, x.device), ops._floats(nb, x.device)
+    dmcnet_amd._lib.check(lib.dmc_conv_nhwc_split(dmcnet_amd._lib.ptr(wt), dmcnet_amd._lib.ptr(wf), dmcnet_amd._lib.ptr(wtr),
+                                                  cin, cout, k, k, ops._stream()), "dmc_conv_nhwc_split")
+    y1, _, _ = ops._conv_fwd(x, wt, None, None, stride, pad, 0, False, presplit=wf)
+    d1 = ops._conv_dgrad(go, wt, x.shape, stride, pad, presplit=wtr)
+    assert torch.equal(y0, y1) and torch.equal(d0, d1)
+
+
 @pytest.mark.parametrize("first,cin,cout,stride,use_bn,hw", [(True, 2, 16, 2, False, 40), (False, 16, 16, 1, True, 20),
                                                              (False, 16, 32, 2, True, 21), (False, 64, 128, 2, True, 9),
                                                              (False, 64, 64, 1, True, 28), (False, 32, 64, 2, True, 56),
