@@ -1715,7 +1715,7 @@ __global__ __launch_bounds__(512, 2) void gen_bwd_weight_pc_kernel(WgradArgs a) 
         return xcd_sched ? (i * 8 + (int)(blockIdx.x & 7)) * xs_per + (int)(blockIdx.x >> 3) : (int)blockIdx.x + i * (int)gridDim.x;
     };
 
-    constexpr int NA = X3 == 2 ? NT3_A : NT_A, NB = X3 == 2 ? NT3_B : NT_B, WP = (NA + NB) * 256;
+    constexpr int NA = X3 >= 2 ? NT3_A : NT_A, NB = X3 >= 2 ? NT3_B : NT_B, WP = (NA + NB) * 256;
     f32x4 accA[NA], accB[NB];
 #pragma unroll
     for (int t = 0; t < NA; ++t) accA[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1781,12 +1781,28 @@ __global__ __launch_bounds__(512, 2) void gen_bwd_weight_pc_kernel(WgradArgs a) 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) av[e] = rowB ? av[e] : 0.f;
                 const GenSplit3 a1s = gen_split_bf16x3(av);
-                if constexpr (X3 == 2) {
+                if constexpr (X3 >= 2) {
 #pragma unroll
                     for (int gt = 0; gt < 7; ++gt) {
                         float wv[10];
+                        if constexpr (X3 == 3) {
+                            // the window starts at float 3 (mod 4) of its row: one 8-byte, two 16-byte, one 8-byte read.  Every
+                            // lane's address is the same mod 4 floats (rows and planes are 16-byte multiples for the LDS-DMA),
+                            // so dword reads find 8 of the 32 banks (4-way conflicts in each half-wave); the wide reads are
+                            // serviced in 16-byte slots of the 256-byte bank row: modelled 180 LDS cycles per wave and tile
+                            // where the dword reads take 640
+                            const float* wp = lds + offW[gt] + wave * WX_PITCH;
+                            typedef float f32x2 __attribute__((ext_vector_type(2)));
+                            const f32x2 e0 = *static_cast<const f32x2*>(__builtin_assume_aligned(wp - 1, 8));
+                            const f32x4 m0 = *static_cast<const f32x4*>(__builtin_assume_aligned(wp + 1, 16));
+                            const f32x4 m1 = *static_cast<const f32x4*>(__builtin_assume_aligned(wp + 5, 16));
+                            const f32x2 e9 = *static_cast<const f32x2*>(__builtin_assume_aligned(wp + 9, 8));
+                            wv[0] = e0.y; wv[1] = m0.x; wv[2] = m0.y; wv[3] = m0.z; wv[4] = m0.w;
+                            wv[5] = m1.x; wv[6] = m1.y; wv[7] = m1.z; wv[8] = m1.w; wv[9] = e9.x;
+                        } else {
 #pragma unroll
-                        for (int e = 0; e < 10; ++e) wv[e] = lds[offW[gt] + wave * WX_PITCH + e];
+                            for (int e = 0; e < 10; ++e) wv[e] = lds[offW[gt] + wave * WX_PITCH + e];
+                        }
                         if (gt == 6 && ones3) {
 #pragma unroll
                             for (int e = 0; e < 10; ++e) wv[e] = 1.f;
@@ -1864,7 +1880,7 @@ __global__ __launch_bounds__(512, 2) void gen_bwd_weight_pc_kernel(WgradArgs a) 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float rv = __shfl(tot, kq * 4 + q);                  // lanes 0..15 hold rows 0..15
-            if constexpr (X3 == 2) accA[9][q] = ones3 ? rv : 0.f;      // slot 9, column 3
+            if constexpr (X3 >= 2) accA[9][q] = ones3 ? rv : 0.f;      // slot 9, column 3
             else accA[8][q] = ones ? rv : 0.f;
         }
     }
@@ -2158,10 +2174,11 @@ int dmc_gen_tiny_bwd(const float* mv, const float* res, const float* const* w, c
     a.tiles_x = (W + WT_W - 1) / WT_W;
     const int groups = wgrad_groups(N, H, W);
     const int wpath = option(OPT_GEN_WGRAD_PATH);
-    const bool layout3 = W % 4 == 0 && wpath == 3;
-    if (W % 4 == 0 && (wpath == 1 || wpath == 2 || wpath == 3)) {
+    const bool layout3 = W % 4 == 0 && (wpath == 3 || wpath == 4);
+    if (W % 4 == 0 && wpath >= 1 && wpath <= 4) {
         a.tiles_y = (H + PW_H - 1) / PW_H;
-        if (wpath == 3) gen_bwd_weight_pc_kernel<2><<<groups, 512, 0, s>>>(a);
+        if (wpath == 4) gen_bwd_weight_pc_kernel<3><<<groups, 512, 0, s>>>(a);
+        else if (wpath == 3) gen_bwd_weight_pc_kernel<2><<<groups, 512, 0, s>>>(a);
         else if (wpath == 2) gen_bwd_weight_pc_kernel<1><<<groups, 512, 0, s>>>(a);
         else gen_bwd_weight_pc_kernel<0><<<groups, 512, 0, s>>>(a);
     } else {

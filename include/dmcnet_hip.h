@@ -45,7 +45,7 @@ const char* dmc_last_error(void);
 /* Kernel-selection options for A/B measurements (tools/, bench.py); every default is 1 = the
  * fastest measured path.  Names: "gen_layer_path" (0: VALU layer kernels instead of the matrix-core
  * ones), "gen_gather" (0: push form for the Cout-8 layers), "gen_fuse45" (0: layers 4 and 5 as two
- * launches), "gen_wgrad_path" (0: all-waves-stage weight gradient), "gen_fuse_fwd" / "gen_fuse_bwd"
+ * launches), "gen_wgrad_path" (0: all-waves-stage weight gradient; 1: fp32 producer/consumer; 2 / 3: bf16x3; 4, the default: bf16x3 with wide LDS reads), "gen_fuse_fwd" / "gen_fuse_bwd"
  * (0: the layer-by-layer forward / data-gradient launches instead of the fused groups).
  * dmc_set_option returns DMC_E_INVALID for an unknown name; dmc_get_option returns -1 for one. */
 int dmc_set_option(const char* name, int value);
