@@ -62,6 +62,7 @@ SIGNATURES = {
     "dmc_conv_nhwc_presplit_supported": (_I, [_I, _I]),
     "dmc_conv_nhwc_split": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dmc_conv_nhwc_dgrad": (_I, [_P] * 4 + [_I] * 9 + [_P]),
+    "dmc_conv_nhwc_dgrad_add": (_I, [_P] * 5 + [_I] * 9 + [_P]),
     "dmc_conv_nhwc_wgrad_bytes": (_Z, [_I] * 9),
     "dmc_conv_nhwc_wgrad": (_I, [_P] * 4 + [_I] * 9 + [_P]),
     "dmc_disc_first_supported": (_I, [_I]),

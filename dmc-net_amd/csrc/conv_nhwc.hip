@@ -42,6 +42,7 @@ struct ConvArgs {
     float* y;              // [N][OH][OW][Cout]
     const float* bias;     // [Cout] or null
     const float* keep;     // [N][Cout] or null   (Dropout2d keep mask, already divided by 1 - p)
+    const float* addend = nullptr;   // [N][OH][OW][Cout] or null: added to the result before the store (conv_tile_epilogue only)
     double* stat_part;     // [gridDim.x][Cout][2] or null
     int N, H, W, Cin, OH, OW, Cout;
     int KK;                // taps in the weight array (KH * KW): weight rows are [co][KK][Cin]
@@ -341,6 +342,10 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvArgs& a, f32x16 (&a
                 if (a.keep && mok[i]) {
                     const float4 kv = *reinterpret_cast<const float4*>(a.keep + (long)nimg[i] * a.Cout + co);
                     v[0] *= kv.x; v[1] *= kv.y; v[2] *= kv.z; v[3] *= kv.w;
+                }
+                if (a.addend && mok[i]) {
+                    const float4 av = *reinterpret_cast<const float4*>(a.addend + opix[i] * a.Cout + co);
+                    v[0] += av.x; v[1] += av.y; v[2] += av.z; v[3] += av.w;
                 }
                 if (mok[i]) {
                     *reinterpret_cast<float4*>(a.y + opix[i] * a.Cout + co) = make_float4(v[0], v[1], v[2], v[3]);
@@ -1905,8 +1910,8 @@ int dmc_conv_nhwc_split(const float* w, void* wpack_f, void* wpack_t, int Cin, i
 size_t dmc_conv_nhwc_wt_bytes(int Cin, int Cout, int KH, int KW) { return (size_t)Cin * Cout * KH * KW * 6; }
 
 // dx [N,H,W,Cin] from dy [N,OH,OW,Cout]; wt: workspace of dmc_conv_nhwc_wt_bytes() (the packed weights)
-int dmc_conv_nhwc_dgrad(const float* dy, const float* w, float* wt, float* dx, int N, int H, int W, int Cin,
-                        int Cout, int KH, int KW, int stride, int pad, dmc_stream_t stream) {
+static int conv_dgrad(const float* dy, const float* w, float* wt, const float* addend, float* dx, int N, int H, int W, int Cin,
+                      int Cout, int KH, int KW, int stride, int pad, dmc_stream_t stream) {
     if (!dy || !wt || !dx) return fail(DMC_E_INVALID, "dmc_conv_nhwc_dgrad: null pointer");
     ConvShape sh = {N, H, W, Cin, Cout, KH, KW, stride, pad, 0, 0};
     if (!shape_supported(sh)) return fail(DMC_E_INVALID, "dmc_conv_nhwc_dgrad: unsupported shape");
@@ -1925,7 +1930,7 @@ int dmc_conv_nhwc_dgrad(const float* dy, const float* w, float* wt, float* dx, i
     if (rc) return rc;
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     ConvArgs a;
-    a.x = dy; a.w = wt; a.y = dx; a.bias = nullptr; a.keep = nullptr; a.stat_part = nullptr;
+    a.x = dy; a.w = wt; a.y = dx; a.bias = nullptr; a.keep = nullptr; a.stat_part = nullptr; a.addend = addend;
     a.N = N; a.H = OH; a.W = OW; a.Cin = Cout;           // the "input" of this GEMM is dy
     a.OH = H; a.OW = W; a.Cout = Cin;                    // its "output" is dx
     a.KK = KK; a.stride = 1; a.act = 0;
@@ -1946,6 +1951,21 @@ int dmc_conv_nhwc_dgrad(const float* dy, const float* w, float* wt, float* dx, i
             if ((rc = v3 ? launch_conv3(a, s) : launch_conv(a, s))) return rc;
         }
     return DMC_OK;
+}
+
+int dmc_conv_nhwc_dgrad(const float* dy, const float* w, float* wt, float* dx, int N, int H, int W, int Cin,
+                        int Cout, int KH, int KW, int stride, int pad, dmc_stream_t stream) {
+    return conv_dgrad(dy, w, wt, nullptr, dx, N, H, W, Cin, Cout, KH, KW, stride, pad, stream);
+}
+
+// dx = data gradient + addend (same shape as dx): the residual branch's gradient of a ResNet block joins the main branch's in
+// the epilogue of the block's first convolution instead of a separate elementwise pass.  Stride 1, bf16x3 shapes
+// (dmc_conv_nhwc_presplit_supported) only.
+int dmc_conv_nhwc_dgrad_add(const float* dy, const float* w, float* wt, const float* addend, float* dx, int N, int H, int W,
+                            int Cin, int Cout, int KH, int KW, int stride, int pad, dmc_stream_t stream) {
+    if (!addend) return fail(DMC_E_INVALID, "dmc_conv_nhwc_dgrad_add: null pointer");
+    if (stride != 1 || !use_v3(Cout, Cin)) return fail(DMC_E_INVALID, "dmc_conv_nhwc_dgrad_add: stride 1 and bf16x3 shapes only");
+    return conv_dgrad(dy, w, wt, addend, dx, N, H, W, Cin, Cout, KH, KW, stride, pad, stream);
 }
 
 // BatchNorm statistics from the partials the forward wrote (nblk = dmc_conv_nhwc_stat_blocks()):

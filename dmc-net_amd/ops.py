@@ -609,12 +609,18 @@ def _conv_fwd(x, weight, bias, keep, stride, padding, act, want_stats, presplit=
     return y, part, nblk
 
 
-def _conv_dgrad(dy, weight, x_shape, stride, padding, presplit=None):
+def _conv_dgrad(dy, weight, x_shape, stride, padding, presplit=None, addend=None):
     lib = _lib.load()
     n, cin, h, w = x_shape
     cout, _, kh, kw = weight.shape
     dx = torch.empty((n, cin, h, w), dtype=torch.float32, device=dy.device, memory_format=_CL)
     wt = presplit if presplit is not None else _floats(lib.dmc_conv_nhwc_wt_bytes(cin, cout, kh, kw), dy.device)
+    if addend is not None:                      # dx = data gradient + addend, in the convolution's epilogue
+        addend = _as_cl(addend)
+        _lib.check(lib.dmc_conv_nhwc_dgrad_add(_lib.ptr(dy), None if presplit is not None else _lib.ptr(weight), _lib.ptr(wt),
+                                               _lib.ptr(addend), _lib.ptr(dx), n, h, w, cin, cout, kh, kw, stride, padding,
+                                               _stream()), "dmc_conv_nhwc_dgrad_add")
+        return dx
     _lib.check(lib.dmc_conv_nhwc_dgrad(_lib.ptr(dy), None if presplit is not None else _lib.ptr(weight), _lib.ptr(wt), _lib.ptr(dx), n, h, w, cin,
                                        cout, kh, kw, stride, padding, _stream()), "dmc_conv_nhwc_dgrad")
     return dx
@@ -674,6 +680,20 @@ def conv_nhwc(x, weight, stride=1, padding=1):
     return _ConvNHWC.apply(x, weight, int(stride), int(padding))
 
 
+class ResidualGradLink:
+    """Couples the two fused ops of an identity-shortcut residual block (torchvision BasicBlock: `out += identity`, behind
+    code/dmcnet/model.py:305): the block input feeds the first convolution AND the residual add, so autograd would sum the
+    two gradients in a separate elementwise pass over the block input (96 MB per tensor in layer1 at 120 frames).  With a link
+    the block's LAST op (the one given ``residual``) parks its residual gradient here instead of returning it, and the
+    block's FIRST op (which autograd always runs later: its output feeds the last op) adds it in the epilogue of its data-
+    gradient launch.  The sum is the same two fp32 addends; only the pass is saved."""
+    __slots__ = ("armed", "grad")
+
+    def __init__(self):
+        self.armed = False
+        self.grad = None
+
+
 class _ConvBnAct(torch.autograd.Function):
     """relu?(BatchNorm2d(conv2d(x, w)) [+ residual]) in training mode: the ResNet's conv -> bn [-> add] [-> relu]
     chains (torchvision BasicBlock / Bottleneck / downsample behind code/dmcnet/model.py:305,352) on the
@@ -683,12 +703,13 @@ class _ConvBnAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, residual, gamma, beta, running_mean, running_var, stride, padding, relu, eps,
-                momentum):
+                momentum, link=None):
         lib = _lib.load()
         _need_cuda(x, weight, residual, gamma, beta)
         x, wcl = _as_cl(x), _as_cl(weight)
         cout = weight.shape[0]
         ctx.wsplit_t = None
+        ctx.link = None
         with _span("conv_nhwc_fwd"):
             wf = None
             if ctx.needs_input_grad[0] and lib.dmc_conv_nhwc_presplit_supported(weight.shape[1], cout):
@@ -698,6 +719,12 @@ class _ConvBnAct(torch.autograd.Function):
                 _lib.check(lib.dmc_conv_nhwc_split(_lib.ptr(wcl), _lib.ptr(wf), _lib.ptr(ctx.wsplit_t), weight.shape[1], cout,
                                                    weight.shape[2], weight.shape[3], _stream()), "dmc_conv_nhwc_split")
             y, part, nblk = _conv_fwd(x, wcl, None, None, stride, padding, 0, True, presplit=wf)
+        if link is not None:
+            if residual is None:
+                if wf is not None and stride == 1:          # first op of the block: will add the parked gradient
+                    link.armed, ctx.link = True, link
+            elif link.armed and ctx.needs_input_grad[2]:    # last op of the block: will park its residual gradient
+                ctx.link = link
         n, _, oh, ow = y.shape
         m = n * oh * ow
         stats = _floats(lib.dmc_bn_act_stats_bytes(cout), x.device)
@@ -736,15 +763,21 @@ class _ConvBnAct(torch.autograd.Function):
                                           int(relu), _stream()), "dmc_bn_act_bwd")
         if want_dres and not relu:
             dres = dout
+        addend = None
+        if ctx.link is not None:
+            if has_res:
+                ctx.link.grad, dres = dres, None            # parked for the block's first op (ResidualGradLink)
+            else:
+                addend, ctx.link.grad = ctx.link.grad, None
         wcl = _as_cl(weight)
         dx = dw = None
         if ctx.needs_input_grad[0]:
             with _span("conv_nhwc_dgrad"):
-                dx = _conv_dgrad(dy, wcl, x.shape, stride, padding, presplit=ctx.wsplit_t)
+                dx = _conv_dgrad(dy, wcl, x.shape, stride, padding, presplit=ctx.wsplit_t, addend=addend)
         if ctx.needs_input_grad[1]:
             with _span("conv_nhwc_wgrad"):
                 dw = _grad_like(_conv_wgrad(x, dy, wcl, stride, padding), weight)
-        return dx, dw, dres, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, dw, dres, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 def conv_bn_act_supported(x, conv, bn):
@@ -763,8 +796,9 @@ def conv_bn_act_supported(x, conv, bn):
     return bool(_lib.load().dmc_bn_act_supported(n * oh * ow, conv.out_channels))
 
 
-def conv_bn_act(x, conv, bn, residual=None, relu=True):
-    """relu?(bn(conv(x)) [+ residual]) for a channels_last ``x`` (see conv_bn_act_supported)."""
+def conv_bn_act(x, conv, bn, residual=None, relu=True, link=None):
+    """relu?(bn(conv(x)) [+ residual]) for a channels_last ``x`` (see conv_bn_act_supported); ``link``: the
+    ResidualGradLink shared by the first and the last op of an identity-shortcut block."""
     if bn.num_batches_tracked is not None:
         if _PENDING_COUNTERS is not None:
             _PENDING_COUNTERS.append(bn.num_batches_tracked)
@@ -772,7 +806,7 @@ def conv_bn_act(x, conv, bn, residual=None, relu=True):
             bn.num_batches_tracked.add_(1)
     return _ConvBnAct.apply(x, conv.weight, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                             conv.stride[0], conv.padding[0], relu, bn.eps,
-                            bn.momentum if bn.momentum is not None else 0.1)
+                            bn.momentum if bn.momentum is not None else 0.1, link)
 
 
 class _DiscBlock(torch.autograd.Function):

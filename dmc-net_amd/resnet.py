@@ -32,12 +32,14 @@ def _bn_act(bn, x, residual=None, relu=True):
 # DMC_OWN_CONV=0 switch it off.
 import os as _os
 OWN_CONV = _os.environ.get("DMC_OWN_CONV", "1") != "0"
+# identity-shortcut blocks: residual gradient added in the first convolution's data-gradient epilogue (ops.ResidualGradLink)
+RESIDUAL_GRAD_LINK = _os.environ.get("DMC_RESIDUAL_GRAD_LINK", "1") != "0"
 
 
-def _conv_bn_act(conv, bn, x, residual=None, relu=True):
+def _conv_bn_act(conv, bn, x, residual=None, relu=True, link=None):
     """relu?(bn(conv(x)) [+ residual])"""
     if OWN_CONV and x.is_cuda and ops.conv_bn_act_supported(x, conv, bn):
-        return ops.conv_bn_act(x, conv, bn, residual, relu)
+        return ops.conv_bn_act(x, conv, bn, residual, relu, link)
     return _bn_act(bn, conv(x), residual, relu)
 
 
@@ -75,15 +77,18 @@ class ResidualUnit(nn.Module):
         self.out_channels = cout
 
     def forward(self, x):
+        link = None
         if self.downsample is None:
             shortcut = x
+            # identity shortcut: x feeds conv1 and the add; the two gradients are summed in conv1's data-gradient epilogue
+            link = ops.ResidualGradLink() if RESIDUAL_GRAD_LINK and x.requires_grad else None
         else:
             shortcut = _conv_bn_act(self.downsample[0], self.downsample[1], x, relu=False)
-        y = _conv_bn_act(self.conv1, self.bn1, x)
+        y = _conv_bn_act(self.conv1, self.bn1, x, link=link)
         if self.kind == "basic":
-            return _conv_bn_act(self.conv2, self.bn2, y, residual=shortcut)
+            return _conv_bn_act(self.conv2, self.bn2, y, residual=shortcut, link=link)
         y = _conv_bn_act(self.conv2, self.bn2, y)
-        return _conv_bn_act(self.conv3, self.bn3, y, residual=shortcut)
+        return _conv_bn_act(self.conv3, self.bn3, y, residual=shortcut, link=link)
 
 
 class ResNet(nn.Module):

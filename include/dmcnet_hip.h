@@ -309,6 +309,10 @@ int dmc_conv_nhwc_presplit_supported(int Cin, int Cout);
 int dmc_conv_nhwc_split(const float* w, void* wpack_f, void* wpack_t, int Cin, int Cout, int KH, int KW, dmc_stream_t stream);
 int dmc_conv_nhwc_dgrad(const float* dy, const float* w, float* wt, float* dx, int N, int H, int W, int Cin,
                         int Cout, int KH, int KW, int stride, int pad, dmc_stream_t stream);
+/* dx = data gradient + addend (the residual branch's gradient of a torchvision BasicBlock, resnet.py BasicBlock.forward:
+ * `out += identity`), added in the convolution's epilogue; stride 1 and dmc_conv_nhwc_presplit_supported shapes only. */
+int dmc_conv_nhwc_dgrad_add(const float* dy, const float* w, float* wt, const float* addend, float* dx, int N, int H, int W,
+                            int Cin, int Cout, int KH, int KW, int stride, int pad, dmc_stream_t stream);
 size_t dmc_conv_nhwc_wgrad_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 int dmc_conv_nhwc_wgrad(const float* x, const float* dy, float* dw, float* workspace, int N, int H, int W,
                         int Cin, int Cout, int KH, int KW, int stride, int pad, dmc_stream_t stream);

@@ -914,6 +914,44 @@ def test_conv_nhwc_presplit_weights_bit_identical(case):
     assert torch.equal(y0, y1) and torch.equal(d0, d1)
 
 
+@pytest.mark.parametrize("kind,cin,planes,hw", [("basic", 64, 64, 14), ("basic", 128, 128, 9), ("bottleneck", 256, 64, 8)])
+def test_residual_grad_link_bit_identical(kind, cin, planes, hw, monkeypatch):
+    """Identity-shortcut blocks (torchvision BasicBlock / Bottleneck, `out += identity`): the residual branch's gradient joins
+    the main branch's in the epilogue of the first convolution's data-gradient launch (ops.ResidualGradLink,
+    dmc_conv_nhwc_dgrad_add) instead of autograd's separate add -- same two fp32 addends, so every gradient is bit-identical
+    to the unlinked run, and both match the stock modules in fp64."""
+    from dmcnet_amd import resnet
+    if not dmcnet_amd._lib.load().dmc_conv_nhwc_presplit_supported(cin, planes):
+        pytest.skip("the bf16x3 arithmetic is switched off")
+    monkeypatch.setattr(resnet, "OWN_CONV", True)
+    torch.manual_seed(5)
+    unit = resnet.ResidualUnit(kind, cin, planes, 1).to(DEV).train()
+    assert unit.downsample is None
+    x0 = rnd(221, (6, cin, hw, hw)).to(DEV).contiguous(memory_format=torch.channels_last)
+    go = rnd(222, (6, cin, hw, hw)).to(DEV).contiguous(memory_format=torch.channels_last)
+    state = {k: v.clone() for k, v in unit.state_dict().items()}
+    res = {}
+    for linked in (True, False):
+        monkeypatch.setattr(resnet, "RESIDUAL_GRAD_LINK", linked)
+        unit.load_state_dict(state)
+        unit.zero_grad(set_to_none=True)
+        x = (x0 * 1.0).requires_grad_(True)          # a non-leaf producer, as the block input is in the trunk
+        x.retain_grad()
+        (unit(x) * go).sum().backward()
+        res[linked] = [x.grad.clone()] + [p.grad.clone() for p in unit.parameters()]
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
+    # the unlinked run against the stock modules in fp64
+    monkeypatch.setattr(resnet, "OWN_CONV", False)
+    ref = resnet.ResidualUnit(kind, cin, planes, 1).double().train()
+    ref.load_state_dict({k: v.cpu().double() if v.is_floating_point() else v.cpu() for k, v in state.items()})
+    xr = x0.cpu().double().requires_grad_(True)
+    (ref(xr) * go.cpu().double()).sum().backward()
+    assert rel_err(res[True][0], xr.grad) < 2e-5
+    for a, p in zip(res[True][1:], ref.parameters()):
+        assert rel_err(a, p.grad) < 2e-4
+
+
 @pytest.mark.parametrize("first,cin,cout,stride,use_bn,hw", [(True, 2, 16, 2, False, 40), (False, 16, 16, 1, True, 20),
                                                              (False, 16, 32, 2, True, 21), (False, 64, 128, 2, True, 9),
                                                              (False, 64, 64, 1, True, 28), (False, 32, 64, 2, True, 56),
