@@ -603,7 +603,8 @@ def _conv_fwd(x, weight, bias, keep, stride, padding, act, want_stats, presplit=
         nblk = lib.dmc_conv_nhwc_stat_blocks(n, h, w, cin, cout, kh, stride, padding)
         part = torch.empty((nblk, cout, 2), dtype=torch.float64, device=x.device)
     wpack = presplit if presplit is not None else _floats(lib.dmc_conv_nhwc_wt_bytes(cin, cout, kh, kw), x.device)
-    _lib.check(lib.dmc_conv_nhwc_fwd(_lib.ptr(x), None if presplit is not None else _lib.ptr(weight), _lib.ptr(wpack), _lib.ptr(bias), _lib.ptr(keep), _lib.ptr(y),
+    wptr = None if presplit is not None else _lib.ptr(weight)      # NULL: wpack already holds the slices
+    _lib.check(lib.dmc_conv_nhwc_fwd(_lib.ptr(x), wptr, _lib.ptr(wpack), _lib.ptr(bias), _lib.ptr(keep), _lib.ptr(y),
                                      _lib.ptr(part), n, h, w, cin, cout, kh, kw, stride, padding, int(act),
                                      _stream()), "dmc_conv_nhwc_fwd")
     return y, part, nblk
@@ -615,13 +616,13 @@ def _conv_dgrad(dy, weight, x_shape, stride, padding, presplit=None, addend=None
     cout, _, kh, kw = weight.shape
     dx = torch.empty((n, cin, h, w), dtype=torch.float32, device=dy.device, memory_format=_CL)
     wt = presplit if presplit is not None else _floats(lib.dmc_conv_nhwc_wt_bytes(cin, cout, kh, kw), dy.device)
+    wptr = None if presplit is not None else _lib.ptr(weight)      # NULL: wt already holds the transposed slices
     if addend is not None:                      # dx = data gradient + addend, in the convolution's epilogue
         addend = _as_cl(addend)
-        _lib.check(lib.dmc_conv_nhwc_dgrad_add(_lib.ptr(dy), None if presplit is not None else _lib.ptr(weight), _lib.ptr(wt),
-                                               _lib.ptr(addend), _lib.ptr(dx), n, h, w, cin, cout, kh, kw, stride, padding,
-                                               _stream()), "dmc_conv_nhwc_dgrad_add")
+        _lib.check(lib.dmc_conv_nhwc_dgrad_add(_lib.ptr(dy), wptr, _lib.ptr(wt), _lib.ptr(addend), _lib.ptr(dx), n, h, w,
+                                               cin, cout, kh, kw, stride, padding, _stream()), "dmc_conv_nhwc_dgrad_add")
         return dx
-    _lib.check(lib.dmc_conv_nhwc_dgrad(_lib.ptr(dy), None if presplit is not None else _lib.ptr(weight), _lib.ptr(wt), _lib.ptr(dx), n, h, w, cin,
+    _lib.check(lib.dmc_conv_nhwc_dgrad(_lib.ptr(dy), wptr, _lib.ptr(wt), _lib.ptr(dx), n, h, w, cin,
                                        cout, kh, kw, stride, padding, _stream()), "dmc_conv_nhwc_dgrad")
     return dx
 
