@@ -116,3 +116,47 @@ def test_i3d_3d_ops_host_side_without_gpu():
         ops.conv3d_bf16(x, torch.zeros(8, 16, 3, 3, 3))
     unit = i3d.Unit3Dpy(16, 8, (3, 3, 3))
     assert unit(torch.zeros(1, 16, 2, 4, 4)).shape == (1, 8, 2, 4, 4)                                # stock path on the CPU
+
+
+def test_classifier_conv_entry_points_host_side_without_gpu():
+    """Host-only parts of the round-2 classifier convolution entry points: which channel pairs take the bf16x3
+    kernels (and therefore the one-launch weight split, dmc_conv_nhwc_split), the option that switches the arithmetic,
+    and argument validation of the split and of the data gradient with the residual addend -- all of which return
+    before any launch; the identity-shortcut blocks of resnet.py (torchvision BasicBlock / Bottleneck behind
+    code/dmcnet/model.py:305) run on the stock ops on the CPU with the residual-gradient link switched on or off."""
+    from dmcnet_amd import resnet
+    lib = _lib.load()
+    assert lib.dmc_get_option(b"conv_arith") == 1 and lib.dmc_get_option(b"gen_wgrad_path") == 4
+    for cin, cout, want in [(64, 64, 1), (64, 128, 1), (512, 512, 1), (256, 64, 1), (3, 64, 0), (16, 32, 0), (96, 64, 0)]:
+        assert lib.dmc_conv_nhwc_presplit_supported(cin, cout) == want, (cin, cout)
+    _lib.check(lib.dmc_set_option(b"conv_arith", 0), "dmc_set_option")
+    try:
+        assert lib.dmc_conv_nhwc_presplit_supported(64, 64) == 0                     # fp32-MFMA arithmetic: no slices
+    finally:
+        _lib.check(lib.dmc_set_option(b"conv_arith", 1), "dmc_set_option")
+    assert lib.dmc_conv_nhwc_wt_bytes(64, 128, 3, 3) == 3 * 2 * 64 * 128 * 9         # three bf16 slices
+    assert lib.dmc_conv_nhwc_split(None, None, None, 64, 64, 3, 3, None) == -1
+    assert b"dmc_conv_nhwc_split" in lib.dmc_last_error()
+    dummy = torch.zeros(16)
+    p = _lib.ptr(dummy)
+    assert lib.dmc_conv_nhwc_split(p, p, p, 16, 32, 3, 3, None) == -1                # not a bf16x3 shape
+    assert lib.dmc_conv_nhwc_dgrad_add(p, p, p, None, p, 1, 8, 8, 64, 64, 3, 3, 1, 1, None) == -1     # no addend
+    assert lib.dmc_conv_nhwc_dgrad_add(p, p, p, p, p, 1, 8, 8, 64, 64, 3, 3, 2, 1, None) == -1        # stride 2
+    assert b"stride 1" in lib.dmc_last_error()
+    assert lib.dmc_conv_nhwc_dgrad_add(p, p, p, p, p, 1, 8, 8, 16, 32, 3, 3, 1, 1, None) == -1        # not a bf16x3 shape
+    torch.manual_seed(0)
+    unit = resnet.ResidualUnit("basic", 16, 16, 1).train()
+    x0 = torch.randn(2, 16, 6, 6)
+    grads = []
+    for linked in (True, False):
+        old = resnet.RESIDUAL_GRAD_LINK
+        resnet.RESIDUAL_GRAD_LINK = linked
+        try:
+            unit.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            unit(x).square().sum().backward()
+            grads.append([x.grad.clone()] + [q.grad.clone() for q in unit.parameters()])
+        finally:
+            resnet.RESIDUAL_GRAD_LINK = old
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
