@@ -98,8 +98,10 @@ def test_dmcnet_step_full_batch_vs_oracle(num_class):
             worst = max(worst, e_hip)
             assert e_hip <= max(4 * e_ref, 1e-4), (k, e_hip, e_ref)
         print("classifier gradients at B=40: worst HIP-vs-fp64 error %.1e" % worst)
-    # generator: 5 % of its Adam step; classifier: 25 % (its gradients carry the ~1e-3 fp32 error of the
-    # BatchNorm chain, which Adam(eps=1e-3) maps to up to ~lr/4eps times that in the update)
+    # generator: 5 % of its Adam step.  Classifier: 25 % -- a SMOKE bound only (it catches a missing or doubled
+    # update, not a gradient error): the classifier's gradients carry the ~1e-3 fp32 error of the BatchNorm chain,
+    # which Adam(eps=1e-3) maps to up to ~lr/4eps times that in the update.  The real check of the classifier's
+    # gradients is the fp64-anchored criterion above.
     _check_post_step(m, o, [k for k in WATCH if k.startswith("gen_flow_model")], 0.05)
     _check_post_step(m, o, [k for k in WATCH if not k.startswith("gen_flow_model")] +
                      ["base_model.conv1.weight", "base_model.layer4.1.conv2.weight"], 0.25)
@@ -199,6 +201,7 @@ def test_two_ranks_on_one_gpu_match_single_process_shards(tmp_path, phase):
     r0, r1 = _run_two_ranks(tmp_path, phase)
     gan = phase == "gan"
     from tests.two_rank_worker import build, shard_batches, run_phases
+    from dmcnet_amd import resnet
     expected = {}
     for rank in range(2):
         m = build(gan).to(DEV).train()
@@ -217,14 +220,19 @@ def test_two_ranks_on_one_gpu_match_single_process_shards(tmp_path, phase):
             mean_local = (r0["local"][tag][k].double() + r1["local"][tag][k].double()) / 2
             scale = float(mean_local.abs().max()) + 1e-30
             assert float((g0.double() - mean_local).abs().max()) <= 1e-6 * scale, (tag, k)
-            # (2) against the two shards evaluated one after the other in THIS process.  The dmcnet step's
-            #     generator gradients come from the MSE graph alone: deterministic HIP kernels -> equal to
-            #     rounding.  Everything that passes the classifier / discriminator goes through MIOpen,
-            #     which may choose another algorithm in another process; the BatchNorm backward chain (batch
-            #     statistics over 6 frames here, 294 values per channel in layer4) amplifies that
-            #     reordering to percents of the largest entry -- a sanity bound only.
+            # (2) against the two shards evaluated one after the other in THIS process.  Every kernel on the
+            #     default path (own convolutions, DMC_OWN_CONV=1) has a fixed reduction order, so another
+            #     process computes the same per-shard gradients; what is left is the fp32 rounding of the
+            #     exchange's mean against the float64 mean taken here (<= 1 ulp of the largest entry) -> 1e-5,
+            #     2e-6 for the generator's short MSE graph.  Only the stock path (DMC_OWN_CONV=0) goes through
+            #     MIOpen, which may choose another algorithm in another process; there the BatchNorm backward
+            #     chain (batch statistics over 6 frames, 294 values per channel in layer4) amplifies the
+            #     reordering to percents of the largest entry and the bar is a sanity bound only.
             err = float((g0.double() - ge).abs().max()) / (float(ge.abs().max()) + 1e-30)
-            bar = 2e-6 if (tag == "step" and k.startswith("gen_flow_model")) else 0.25
+            if tag == "step" and k.startswith("gen_flow_model"):
+                bar = 2e-6
+            else:
+                bar = 1e-5 if resnet.OWN_CONV else 0.25
             assert err < bar, (tag, k, err)
         assert set(r0["grads"][tag]) == set(expected[tag]), tag       # same set of parameters received a gradient
     # which buckets travelled
