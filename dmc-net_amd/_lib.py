@@ -65,6 +65,21 @@ SIGNATURES = {
     "dmc_conv_nhwc_dgrad_add": (_I, [_P] * 5 + [_I] * 9 + [_P]),
     "dmc_conv_nhwc_wgrad_bytes": (_Z, [_I] * 9),
     "dmc_conv_nhwc_wgrad": (_I, [_P] * 4 + [_I] * 9 + [_P]),
+    "dmc_x3s_slices_bytes": (_Z, [_L, _I]),
+    "dmc_x3s_split": (_I, [_P, _P, _L, _I, _P]),
+    "dmc_x3s_merge": (_I, [_P, _P, _L, _I, _P]),
+    "dmc_x3s_wpack_bytes": (_Z, [_I, _I]),
+    "dmc_x3s_pack_weights": (_I, [_P, _P, _P, _I, _I, _P]),
+    "dmc_x3s_conv_supported": (_I, [_I] * 5),
+    "dmc_x3s_conv_stat_blocks": (_I, [_I] * 4),
+    "dmc_x3s_conv_fwd": (_I, [_P] * 4 + [_I] * 5 + [_P]),
+    "dmc_x3s_conv_dgrad": (_I, [_P] * 4 + [_I] * 5 + [_P]),
+    "dmc_x3s_conv_wgrad_supported": (_I, [_I] * 5),
+    "dmc_x3s_conv_wgrad_bytes": (_Z, [_I] * 5),
+    "dmc_x3s_conv_wgrad": (_I, [_P] * 4 + [_I] * 5 + [_P]),
+    "dmc_bn_apply_act_x3s": (_I, [_P] * 8 + [_I, _I, _I, _P]),
+    "dmc_bn_act_bwd_x3s": (_I, [_P] * 13 + [_I, _I, _I, _P]),
+    "dmc_bn_relu_pool_fwd_x3s": (_I, [_P] * 9 + [_I, _I, _I, _I, _I, _F, _F, _P]),
     "dmc_disc_first_supported": (_I, [_I]),
     "dmc_disc_first_fwd": (_I, [_P] * 5 + [_I] * 5 + [_P]),
     "dmc_disc_first_dgrad": (_I, [_P] * 3 + [_I] * 4 + [_P]),

@@ -463,6 +463,124 @@ int stream_blocks(size_t total) {
     return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
+
+// ---- variants that write bf16x3 slice tensors (dmc_common.h; consumed by conv_x3s.hip) -------------------------
+// Eight channels per thread (two float4 in, one 16-byte store per slice).  The forward writes the normalised
+// activation as fp32 (y, nullable) and / or as slices (ys, nullable): the next convolution reads the slices, only a
+// residual add / pooling / the classifier head need fp32.  The backward writes the convolution's output gradient the
+// same way (dx / dxs): its only readers are that convolution's data- and weight-gradient kernels.
+__device__ __forceinline__ void load8(const float* p, size_t i8, float (&v)[8]) {
+    const float4 a = reinterpret_cast<const float4*>(p)[2 * i8], b = reinterpret_cast<const float4*>(p)[2 * i8 + 1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void store8(float* p, size_t i8, const float (&v)[8]) {
+    reinterpret_cast<float4*>(p)[2 * i8] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4*>(p)[2 * i8 + 1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+__global__ __launch_bounds__(256) void bn_apply_fwd_x3s_kernel(BnArgs a, unsigned short* __restrict__ ys) {
+    const int c8 = a.C >> 3;
+    const size_t total = (size_t)a.M * c8;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+        const int tx = (int)(o & (size_t)(c8 - 1));     // c8 is a power of two
+        const size_t m = o / c8;
+        float mean[8], istd[8], g[8], b[8], x[8], v[8];
+        load8(a.stats, tx, mean); load8(a.stats + a.C, tx, istd); load8(a.gamma, tx, g); load8(a.beta, tx, b);
+        load8(a.x, o, x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaf((x[e] - mean[e]) * istd[e], g[e], b[e]);
+        if (a.res) {
+            float rr[8];
+            load8(a.res, o, rr);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rr[e];
+        }
+        if (a.relu) {
+            if (a.mask) {
+                unsigned mb = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) mb |= (v[e] > 0.f ? 1u : 0u) << e;
+                reinterpret_cast<unsigned short*>(a.mask)[o] = (unsigned short)((mb & 15u) | ((mb >> 4) << 8));   // one byte per float4
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (a.y) store8(a.y, o, v);
+        if (ys) x3s_store8(ys, v, (size_t)a.M, a.C >> 4, m, tx);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_bwd_x3s_kernel(BnArgs a, const float* __restrict__ dgamma,
+                                                               const float* __restrict__ dbeta, float inv_count,
+                                                               unsigned short* __restrict__ dxs) {
+    const int c8 = a.C >> 3;
+    const size_t total = (size_t)a.M * c8;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+        const int tx = (int)(o & (size_t)(c8 - 1));
+        const size_t m = o / c8;
+        float mean[8], istd[8], g[8], b[8], dg[8], db[8], x[8], d[8], xh[8], r[8];
+        load8(a.stats, tx, mean); load8(a.stats + a.C, tx, istd); load8(a.gamma, tx, g); load8(a.beta, tx, b);
+        load8(dgamma, tx, dg); load8(dbeta, tx, db);
+        load8(a.x, o, x); load8(a.dy, o, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xh[e] = (x[e] - mean[e]) * istd[e];
+        if (a.relu && a.mask) {
+            const unsigned mw = reinterpret_cast<const unsigned short*>(a.mask)[o];
+            const unsigned mb = (mw & 15u) | ((mw >> 8) << 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[e] = ((mb >> e) & 1u) ? d[e] : 0.f;
+        } else if (a.relu) {
+            float rr[8];
+            if (a.res) load8(a.res, o, rr);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = fmaf(xh[e], g[e], b[e]);
+                if (a.res) v += rr[e];
+                d[e] = v > 0.f ? d[e] : 0.f;
+            }
+        }
+        if (a.dres) store8(a.dres, o, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = g[e] * istd[e] * (d[e] - db[e] * inv_count - xh[e] * dg[e] * inv_count);
+        if (a.dx) store8(a.dx, o, r);
+        if (dxs) x3s_store8(dxs, r, (size_t)a.M, a.C >> 4, m, tx);
+    }
+}
+
+// pool_fwd_kernel with eight channels per thread, pooled map as fp32 (nullable) and / or slices
+__global__ __launch_bounds__(256) void pool_fwd_x3s_kernel(PoolArgs a, unsigned short* __restrict__ ys) {
+    const int c8 = a.C >> 3;
+    const size_t total = (size_t)a.N * a.PH * a.PW * c8;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+        const int tx = (int)(o & (size_t)(c8 - 1));
+        size_t r = o / c8;
+        const size_t mp = r;
+        const int px = (int)(r % a.PW); r /= a.PW;
+        const int py = (int)(r % a.PH);
+        const int n = (int)(r / a.PH);
+        float mean[8], istd[8], g[8], b[8], mx[8];
+        load8(a.stats, tx, mean); load8(a.stats + a.C, tx, istd); load8(a.gamma, tx, g); load8(a.beta, tx, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx[e] = 0.f;              // relu(.) >= 0 and the window centre is always inside
+        float xv[9][8];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {                          // clamped coordinates repeat a value of the same window
+            int iy = 2 * py + k / 3 - 1, ix = 2 * px + k % 3 - 1;
+            iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
+            ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
+            load8(a.x, ((size_t)(n * a.H + iy) * a.W + ix) * c8 + tx, xv[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mx[e] = fmaxf(mx[e], fmaxf(fmaf((xv[k][e] - mean[e]) * istd[e], g[e], b[e]), 0.f));
+        if (a.ypool) store8(a.ypool, o, mx);
+        if (ys) x3s_store8(ys, mx, (size_t)a.N * a.PH * a.PW, a.C >> 4, mp, tx);
+    }
+}
+
+bool shape_ok8(int M, int C) { return shape_ok(M, C) && C % 16 == 0 && C >= 16; }
+
 }  // namespace
 
 extern "C" {
@@ -629,6 +747,62 @@ int dmc_channel_sum_nhwc(const float* g, void* scratch_, float* out, int M, int 
     if (rc) return rc;
     channel_sum_final_kernel<<<(C + 7) / 8, 256, 0, s>>>(static_cast<const double*>(scratch_), out, C, split);
     return check_launch("channel_sum_final");
+}
+
+/* dmc_bn_apply_act_nhwc with slice output: y (fp32, nullable) and / or ys (bf16x3 slice tensor of the same values,
+ * nullable; dmc_x3s_slices_bytes(M, C)); C % 16 == 0. */
+int dmc_bn_apply_act_x3s(const float* x, const float* residual, const float* gamma, const float* beta, const float* stats,
+                         float* y, void* ys, unsigned char* relu_mask, int M, int C, int relu, dmc_stream_t stream) {
+    if (!x || !gamma || !beta || !stats || (!y && !ys)) return fail(DMC_E_INVALID, "dmc_bn_apply_act_x3s: null pointer");
+    if (!shape_ok8(M, C)) return fail(DMC_E_INVALID, "dmc_bn_apply_act_x3s: unsupported shape M=%d C=%d", M, C);
+    BnArgs a = {x, residual, gamma, beta, stats, nullptr, y, nullptr, nullptr, M, C, relu, relu_mask};
+    bn_apply_fwd_x3s_kernel<<<stream_blocks((size_t)M * (C / 8)), 256, 0, (hipStream_t)stream>>>(a, static_cast<unsigned short*>(ys));
+    return check_launch("bn_apply_act_x3s");
+}
+
+/* dmc_bn_act_bwd with the BatchNorm input gradient as fp32 (dx, nullable) and / or as a slice tensor (dxs, nullable). */
+int dmc_bn_act_bwd_x3s(const float* x, const float* residual, const float* gamma, const float* beta, const float* stats,
+                       void* scratch_, const float* dy, float* dx, void* dxs, float* dresidual, float* dgamma, float* dbeta,
+                       const unsigned char* relu_mask, int M, int C, int relu, dmc_stream_t stream) {
+    if (!x || !gamma || !beta || !stats || !scratch_ || !dy || (!dx && !dxs) || !dgamma || !dbeta)
+        return fail(DMC_E_INVALID, "dmc_bn_act_bwd_x3s: null pointer");
+    if (!shape_ok8(M, C)) return fail(DMC_E_INVALID, "dmc_bn_act_bwd_x3s: unsupported shape M=%d C=%d", M, C);
+    hipStream_t s = (hipStream_t)stream;
+    BnArgs a = {x, residual, gamma, beta, stats, dy, nullptr, dx, dresidual, M, C, relu, const_cast<unsigned char*>(relu_mask)};
+    double* scratch = static_cast<double*>(scratch_);
+    int rc;
+    const int split = split_of(M);
+    bn_partial_kernel<1><<<split, 256, 0, s>>>(a, scratch);
+    if ((rc = check_launch("bn_bwd_partial"))) return rc;
+    bn_bwd_final_kernel<<<(C + 7) / 8, 256, 0, s>>>(scratch, dgamma, dbeta, C, split);
+    if ((rc = check_launch("bn_bwd_final"))) return rc;
+    bn_apply_bwd_x3s_kernel<<<stream_blocks((size_t)M * (C / 8)), 256, 0, s>>>(a, dgamma, dbeta, 1.f / (float)M, static_cast<unsigned short*>(dxs));
+    return check_launch("bn_apply_bwd_x3s");
+}
+
+/* dmc_bn_relu_pool_fwd with the pooled map as fp32 (y_pool, nullable) and / or as a slice tensor (ys, nullable). */
+int dmc_bn_relu_pool_fwd_x3s(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                             float* y_pool, void* ys, float* stats, void* scratch_, int N, int H, int W, int C, int training,
+                             float eps, float momentum, dmc_stream_t stream) {
+    if (!x || !gamma || !beta || !running_mean || !running_var || (!y_pool && !ys) || !stats || (training && !scratch_))
+        return fail(DMC_E_INVALID, "dmc_bn_relu_pool_fwd_x3s: null pointer");
+    if (!dmc_bn_relu_pool_supported(N, H, W, C) || C % 16 != 0)
+        return fail(DMC_E_INVALID, "dmc_bn_relu_pool_fwd_x3s: unsupported shape N=%d H=%d W=%d C=%d", N, H, W, C);
+    hipStream_t s = (hipStream_t)stream;
+    const int M = N * H * W;
+    BnArgs a = {x, nullptr, gamma, beta, stats, nullptr, nullptr, nullptr, nullptr, M, C, 1, nullptr};
+    double* scratch = static_cast<double*>(scratch_);
+    int rc;
+    const int split = split_of(M);
+    if (training) {
+        bn_partial_kernel<0><<<split, 256, 0, s>>>(a, scratch);
+        if ((rc = check_launch("bn_partial"))) return rc;
+    }
+    bn_stats_final_kernel<<<(C + 7) / 8, 256, 0, s>>>(scratch, stats, running_mean, running_var, C, (long)M, training, eps, momentum, split);
+    if ((rc = check_launch("bn_stats_final"))) return rc;
+    PoolArgs p = {x, gamma, beta, stats, nullptr, y_pool, nullptr, N, H, W, C, (H - 1) / 2 + 1, (W - 1) / 2 + 1};
+    pool_fwd_x3s_kernel<<<stream_blocks((size_t)N * p.PH * p.PW * (C / 8)), 256, 0, s>>>(p, static_cast<unsigned short*>(ys));
+    return check_launch("pool_fwd_x3s");
 }
 
 }  // extern "C"

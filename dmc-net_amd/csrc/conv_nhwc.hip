@@ -1729,7 +1729,7 @@ int v3_choice(int cout, long M) {
     const int cfg = option(OPT_CONV_CFG);                  // measurement switch: 0 = automatic, 1 + configuration otherwise
     if (cfg >= 1 && cfg <= 13) {
         const int c = cfg - 1;
-        if ((c == 1 || c == 5) || (c == 3 ? cout % 256 == 0 : cout % 128 == 0)) return c;
+        if (c != 10 && ((c == 1 || c == 5) || (c == 3 ? cout % 256 == 0 : cout % 128 == 0))) return c;   // 10 (384 x 128) spilled: removed
     }
     const long need = 512;
     if (cout % 128 == 0 && ((M + 255) / 256) * (cout / 128) >= need) return 0;
@@ -1786,7 +1786,6 @@ int launch_conv3(ConvArgs a, hipStream_t s) {
         case 7: return launch_cfg3<64, 128, 2, 1>(a, s);
         case 8: return launch_cfg3<256, 128, 4, 1>(a, s);
         case 9: return launch_cfg3<128, 128, 2, 1>(a, s);
-        case 10: return launch_cfg3<384, 128, 4, 2>(a, s);
         case 11: return launch_cfg3<192, 128, 2, 2>(a, s);
         case 12: return launch_cfg3<96, 128, 3, 1>(a, s);
         default: return launch_cfg3<128, 64, 4, 1>(a, s);

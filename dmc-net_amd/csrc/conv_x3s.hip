@@ -1,0 +1,781 @@
+// 3x3 / stride-1 NHWC convolutions in bf16x3 arithmetic on PRE-SPLIT operands (gfx950).
+//
+// Fourth generation of the classifier's convolution path (torchvision BasicBlock 3x3 convolutions behind
+// code/dmcnet/model.py:305, run at :352; the same arithmetic as conv3_kernel in conv_nhwc.hip: an fp32 value is the
+// exact sum of three bf16 slices, a product is formed from six of the nine slice products, fp32 accumulate).
+// What changed: the PRODUCER of an activation (BatchNorm apply / pooling / the BatchNorm backward) writes the three
+// slices, so the convolutions neither read fp32 fragments nor split them -- the main loop is ds_read_b128 + MFMA only.
+//
+// Activation slices ("x3s" tensor):  bf16 [3 slices][C / 16 chunks][M pixels][16 channels]   (6 bytes per value)
+//   -- chunk-planar: one (slice, chunk) plane is a dense array of 32-byte pixel rows, so a run of consecutive pixels is
+//   one contiguous run of memory whatever the channel count (LDS-DMA transfers of 32 pixels x 32 B = 1 KB, no partial
+//   cache lines).
+//
+// Forward / data gradient = direct convolution from an LDS-resident PATCH:
+//   a workgroup owns BM consecutive output pixels x 64 output channels.  Per 16-channel chunk it stages, ONCE, the input
+//   patch that those pixels' 3x3 windows touch -- the image rows of the tile plus a halo row above and below, W + 2
+//   columns, zero rows/columns where the window leaves the image (written by the hardware range check of
+//   buffer_load ... lds: no zero source, no select) -- and all nine taps read their B fragments from it at shifted
+//   addresses.  Against the per-tap tiles of conv3_kernel this is 5x less L2 -> LDS traffic and 3x fewer transfers per
+//   MFMA.  The weights of a step (one tap row x 16 channels x 3 slices x 64 channels = 18 KB) are packed by
+//   x3s_pack_w_kernel in exactly the LDS image the fragments are read from, so their transfers are linear copies.
+//   Steps (chunk, tap row) are double-buffered: the transfers of step s + 1 (its weights and a third of the next chunk's
+//   patch) are issued at the top of step s and waited for at its end -- one barrier per 36 MFMAs per wave.
+//   LDS rows are 32 bytes (16 channels); the 16-byte half h of row r lives in half h ^ ((r >> 3) & 1), which makes a
+//   ds_read_b128 of any 32 consecutive rows conflict-free at every tap shift (applied to the transfer's source address,
+//   the LDS image stays lane-linear).
+//   Data gradient = the same kernel on the dy slices with the weights packed transposed and the taps mirrored.
+#include "dmc_common.h"
+#include <type_traits>
+
+using namespace dmc;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) char* lds_cptr;
+
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// fp32 -> three bf16 slices (truncation split: s0 = upper 16 bits, s1 = upper 16 bits of the exact remainder, s2 = the rest)
+__device__ __forceinline__ void split3(float v, unsigned& u0, unsigned& u1, unsigned& u2) {
+    u0 = __float_as_uint(v);
+    const float r1 = v - __uint_as_float(u0 & 0xffff0000u);
+    u1 = __float_as_uint(r1);
+    u2 = __float_as_uint(r1 - __uint_as_float(u1 & 0xffff0000u));
+}
+__device__ __forceinline__ unsigned pack_hi(unsigned hi_of_second, unsigned hi_of_first) {   // (upper half of b, upper half of a)
+    return __builtin_amdgcn_perm(hi_of_second, hi_of_first, 0x07060302u);
+}
+
+constexpr unsigned OOB = 0x80000000u;          // a transfer offset beyond num_records: the lane's 16 bytes arrive as zeros
+
+// 16 bytes per lane global -> LDS through a buffer descriptor (range-checked: offsets >= num_records write zeros).
+// LDS destination = lds_byte_addr + 16 * lane.  srd / soff / lds_byte_addr must be wave-uniform; the s_nops cover the
+// M0 -> LDS-DMA wait state and an SGPR written by v_readfirstlane just in front of the statement.
+__device__ __forceinline__ void dma_buf16(const u32x4& srd, unsigned voff, unsigned soff, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
+                 :: "v"(voff), "s"(srd), "s"(lds_byte_addr), "s"(soff) : "memory");
+}
+__device__ __forceinline__ u32x4 make_srd(const void* base) {
+    const unsigned long long b = (unsigned long long)base;
+    u32x4 srd;
+    srd[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
+    srd[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu);
+    srd[2] = 0x7fffffffu;
+    srd[3] = 0x00020000u;
+    return srd;
+}
+
+// ---- producers of the slice tensors ------------------------------------------------------------------
+// x [M][C] fp32 (channels_last memory) -> xs [3][C/16][M][16] bf16.  One thread = 8 channels of one pixel.
+__global__ __launch_bounds__(256) void x3s_split_kernel(const float* __restrict__ x, unsigned short* __restrict__ xs, long M, int C) {
+    const int c8 = C >> 3;
+    const long total = M * c8;
+    const int nchunk = C >> 4;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
+        const long m = o / c8;
+        const int g = (int)(o - m * c8);                       // 8-channel group
+        const float4 a = reinterpret_cast<const float4*>(x)[2 * o], b = reinterpret_cast<const float4*>(x)[2 * o + 1];
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        x3s_store8(xs, v, (size_t)M, nchunk, (size_t)m, g);
+    }
+}
+
+// xs -> x (exact: s0 + s1 + s2 reproduces the fp32 value bit for bit); tests and fallbacks
+__global__ __launch_bounds__(256) void x3s_merge_kernel(const unsigned short* __restrict__ xs, float* __restrict__ x, long M, int C) {
+    const long total = M * C;
+    const size_t plane = (size_t)M * 16;
+    const int nchunk = C >> 4;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
+        const long m = o / C;
+        const int c = (int)(o - m * C);
+        const size_t w = ((size_t)(c >> 4) * M + m) * 16 + (c & 15);
+        const float a = __uint_as_float((unsigned)xs[w] << 16);
+        const float b = __uint_as_float((unsigned)xs[(size_t)nchunk * plane + w] << 16);
+        const float d = __uint_as_float((unsigned)xs[(size_t)2 * nchunk * plane + w] << 16);
+        x[o] = (a + b) + d;
+    }
+}
+
+// ---- weights: w [R][9][K'] fp32 OHWI -> the LDS image of every step ----------------------------------------
+// GEMM rows r (output channels of the launch) x k (its input channels):
+//   forward:        r = co, k = ci, element = w[co][tap][ci]
+//   data gradient:  r = ci, k = co, element = w[co][8 - tap][ci]          (mirrored taps)
+// packed [r / 64][k / 16][tap row 3][tap 3][slice 3][r % 64][16], the 8-channel half of a row swapped when
+// ((r % 64) >> 3) & 1 (the LDS bank swizzle of the fragment reads).  blockIdx.y selects the direction.
+__global__ __launch_bounds__(256) void x3s_pack_w_kernel(const float* __restrict__ w, unsigned short* __restrict__ wf,
+                                                         unsigned short* __restrict__ wt, int Cout, int Cin) {
+    const bool transposed = blockIdx.y == 1;
+    unsigned short* dst = transposed ? wt : wf;
+    if (!dst) return;
+    const int R = transposed ? Cin : Cout, K = transposed ? Cout : Cin;
+    const int nchunk = K >> 4;
+    const long total = (long)R * 9 * K;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        // destination-major enumeration: i = ((((rt * nchunk + ch) * 9 + tap) * 3 [slice below]) ...) -- enumerate (rt, ch, tap, rl, kk)
+        long t = i;
+        const int kk = (int)(t & 15); t >>= 4;
+        const int rl = (int)(t & 63); t >>= 6;
+        const int tap = (int)(t % 9); t /= 9;
+        const int ch = (int)(t % nchunk);
+        const int rt = (int)(t / nchunk);
+        const int r = rt * 64 + rl, k = ch * 16 + kk;
+        const float v = transposed ? w[((long)k * 9 + (8 - tap)) * Cin + r] : w[((long)r * 9 + tap) * Cin + k];
+        unsigned u0, u1, u2;
+        split3(v, u0, u1, u2);
+        const size_t base = ((((size_t)(rt * nchunk + ch) * 9 + tap) * 3) * 64 + rl) * 16 + (kk ^ (((rl >> 3) & 1) << 3));
+        dst[base] = (unsigned short)(u0 >> 16);
+        dst[base + 64 * 16] = (unsigned short)(u1 >> 16);
+        dst[base + 2 * 64 * 16] = (unsigned short)(u2 >> 16);
+    }
+}
+
+// ---- forward / data gradient ---------------------------------------------------------------------------
+struct X3Args {
+    const void* xs;        // activation slices [3][K/16][M][16]
+    const void* wp;        // packed weights (this direction)
+    float* y;              // [M][R] fp32
+    const float* addend;   // [M][R] or null: added before the store
+    double* stat_part;     // [gridDim.x][R][2] or null
+    int N, H, W, K, R;     // K input channels, R output channels of this launch
+    int M;                 // N * H * W
+    unsigned plane_bytes;  // M * 32
+    int ablate;            // measurement only (option conv_ablate): 16 = no wait for transfers, 32 = no statistics, 64 = no transfers,
+                           // 128 = no output stores, 256 = no main loop (results wrong / missing)
+};
+
+// WM waves along pixels x WN along channels; a wave owns TM x TN tiles of 32 pixels x 32 channels.
+// BN = 32 TN WN must be 64 (the packed weight image); PPMAX = patch pixels the LDS is laid out for.
+template <int WM, int WN, int TM, int TN, int PPMAX>
+__global__ __launch_bounds__(WM * WN * 64) void x3s_conv_kernel(X3Args a) {
+    constexpr int NW = WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN;
+    static_assert(BN == 64, "packed weight image is 64 rows wide");
+    static_assert(PPMAX % 32 == 0, "patch transfers move 32 pixel rows");
+    constexpr int PSL = PPMAX * 32;                        // bytes of one slice of a patch buffer
+    constexpr int PB = 3 * PSL;                            // one patch buffer
+    constexpr int WB = 3 * 3 * BN * 32;                    // one weight buffer: tap row x 3 slices x 64 rows x 32 B
+    constexpr int WOFF = 2 * PB;
+    constexpr int NDW = (PPMAX / 32 + NW - 1) / NW;        // patch transfers per wave and slice
+    constexpr int NEW = WB / 1024;                         // weight transfers per step (18)
+    extern __shared__ __attribute__((aligned(1024))) char lds_x3[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const unsigned lds0 = lds_addr_of(lds_x3);
+
+    // ---- patch geometry (wave-uniform) ----
+    const int HW = a.H * a.W, PW = a.W + 2, HP = a.H + 2;
+    const int m0 = blockIdx.x * BM;
+    const int mlast = (m0 + BM < a.M ? m0 + BM : a.M) - 1;
+    const int n0 = m0 / HW, y0 = (m0 - n0 * HW) / a.W;
+    const int n1 = mlast / HW, y1 = (mlast - n1 * HW) / a.W;
+    const int g0m1 = n0 * HP + y0;                         // padded global row of the patch's first row
+    const int NR = n1 * HP + y1 + 1 - g0m1 + 2;
+    const int PP = NR * PW;
+    const int ND = (PP + 31) >> 5;                         // transfers per slice
+
+    // ---- this lane's patch transfers: instruction d = wave + NW k moves patch rows 32 d .. 32 d + 31 ----
+    unsigned pvoff[NDW];
+#pragma unroll
+    for (int k = 0; k < NDW; ++k) {
+        const int pr = 32 * (wave + NW * k) + (lane >> 1), h = lane & 1;
+        pvoff[k] = OOB;
+        if (pr < PP) {
+            const int prow = pr / PW, col = pr - prow * PW;
+            const int g = g0m1 + prow;
+            const int n = g / HP, yy = g - n * HP - 1, xx = col - 1;
+            if (n < a.N && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
+                pvoff[k] = (unsigned)((n * a.H + yy) * a.W + xx) * 32u + (unsigned)((h ^ ((pr >> 3) & 1)) << 4);
+        }
+    }
+    // ---- fragment addresses: B operand (activations) per tile and tap; A operand (weights) per lane ----
+    int xaddr[TM][9];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int m = m0 + (wm * TM + i) * 32 + l31;
+        if (m > mlast) m = mlast;                          // rows beyond M: a valid address, result not stored
+        const int n = m / HW, rem = m - n * HW, yy = rem / a.W, xx = rem - yy * a.W;
+        const int pp = (n * HP + yy + 1 - g0m1) * PW + xx + 1;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int row = pp + (t / 3 - 1) * PW + (t % 3 - 1);
+            xaddr[i][t] = row * 32 + ((khalf ^ ((row >> 3) & 1)) << 4);
+        }
+    }
+    const int waddr = (wn * TN * 32 + l31) * 32 + ((khalf ^ ((l31 >> 3) & 1)) << 4);
+
+    const u32x4 srd_x = make_srd(a.xs);
+    const int nchunk = a.K >> 4, S = 3 * nchunk;
+    const u32x4 srd_w = make_srd(reinterpret_cast<const char*>(a.wp) + (size_t)blockIdx.y * S * WB);
+    const unsigned lane16 = (unsigned)lane * 16u;
+
+    auto issue_weights = [&](int step, int wbuf) {          // step's weight image -> weight buffer wbuf
+#pragma unroll
+        for (int k = 0; k < (NEW + NW - 1) / NW; ++k) {
+            const int e = wave + NW * k;
+            if (NEW % NW == 0 || e < NEW)
+                dma_buf16(srd_w, lane16, (unsigned)(step * WB + e * 1024), lds0 + WOFF + wbuf * WB + e * 1024);
+        }
+    };
+    auto issue_patch = [&](int chunk, int slice, int pbuf) { // one slice of chunk's patch -> patch buffer pbuf
+        const unsigned soff = (unsigned)(slice * nchunk + chunk) * a.plane_bytes;
+#pragma unroll
+        for (int k = 0; k < NDW; ++k) {
+            const int d = wave + NW * k;
+            if (d < ND) dma_buf16(srd_x, pvoff[k], soff, lds0 + pbuf * PB + slice * PSL + d * 1024);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    lds_cptr const L = (lds_cptr)lds_x3;
+    struct Frag { u32x4 X[TM][3], W[TN][3]; };              // one tap's operands: 3 (TM + TN) reads, 6 TM TN MFMAs
+    auto load_frags = [&](auto pbufc, auto wbufc, auto tc, Frag& f) {
+        constexpr int pbuf = decltype(pbufc)::value, wbuf = decltype(wbufc)::value, t = decltype(tc)::value;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                f.W[j][s] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(
+                    L + waddr + (WOFF + wbuf * WB + (((t % 3) * 3 + s) * BN + 32 * j) * 32));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                f.X[i][s] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(L + xaddr[i][t] + (pbuf * PB + s * PSL));
+        }
+    };
+    auto mfma_frags = [&](const Frag& f) {                  // slice products (weight, input): (0,2) (0,1) (0,0) (1,1) (1,0) (2,0)
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+            constexpr int WS[6] = {0, 0, 0, 1, 1, 2}, XS[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(f.W[j][WS[p]], f.X[i][XS[p]], acc[i][j]);
+        }
+    };
+    constexpr int NRD = 3 * (TM + TN), NMF = 6 * TM * TN;
+    auto interleave = [&]() {                                // one fragment read behind each of the first NRD MFMAs
+#pragma unroll
+        for (int k = 0; k < NRD; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
+    };
+    const bool dma_on = !(a.ablate & 64);
+    // One step = tap row q of chunk c (operands in patch buffer pbuf / weight buffer wbuf).  On entry FA holds the
+    // fragments of its first tap.  The loop is software-pipelined over taps -- tap t + 1's fragments are read behind tap
+    // t's MFMAs -- and the step's barrier stands in front of its LAST tap's MFMAs: by then every fragment of the step is
+    // in registers (its buffers are dead: the transfers of step s + 2 go into them), and the next step's first fragments
+    // are read behind that last tap's MFMAs, so nobody waits for LDS after the barrier.
+    auto step = [&](auto pbufc, auto wbufc, auto qc, Frag& FA, Frag& FB, int c) {
+        constexpr int pbuf = decltype(pbufc)::value, wbuf = decltype(wbufc)::value, q = decltype(qc)::value;
+        using NP = std::integral_constant<int, q == 2 ? (pbuf ^ 1) : pbuf>;     // next step's buffers and first tap
+        using NWB = std::integral_constant<int, wbuf ^ 1>;
+        using NT = std::integral_constant<int, q == 2 ? 0 : 3 * (q + 1)>;
+        const int s = 3 * c + q;
+        load_frags(pbufc, wbufc, std::integral_constant<int, 3 * q + 1>{}, FB);
+        mfma_frags(FA);
+        interleave();
+        load_frags(pbufc, wbufc, std::integral_constant<int, 3 * q + 2>{}, FA);
+        mfma_frags(FB);
+        interleave();
+        if (a.ablate & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's transfers for step s + 1 have landed
+        __builtin_amdgcn_s_barrier();                                  // ... everyone's; step s's buffers are dead
+        if (dma_on) {
+            if (s + 2 < S) issue_weights(s + 2, wbuf);
+            if (q == 2) { if (c + 2 < nchunk) issue_patch(c + 2, 0, pbuf); }
+            else if (c + 1 < nchunk) issue_patch(c + 1, q + 1, pbuf ^ 1);
+        }
+        if (s + 1 < S) load_frags(NP{}, NWB{}, NT{}, FB);
+        mfma_frags(FA);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using Q0 = std::integral_constant<int, 0>;
+    using Q1 = std::integral_constant<int, 1>;
+    using Q2 = std::integral_constant<int, 2>;
+
+    issue_weights(0, 0);
+    issue_patch(0, 0, 0); issue_patch(0, 1, 0); issue_patch(0, 2, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (dma_on) {
+        if (S > 1) issue_weights(1, 1);
+        if (nchunk > 1) issue_patch(1, 0, 1);
+    }
+    Frag F0, F1;
+    load_frags(I0{}, I0{}, Q0{}, F0);
+    // chunk pairs (K % 32 == 0): patch buffers 0, 1; weight buffers alternate per step: 0 1 0 | 1 0 1
+#pragma unroll 1
+    for (int c = 0; c < ((a.ablate & 256) ? 0 : nchunk); c += 2) {
+        step(I0{}, I0{}, Q0{}, F0, F1, c);
+        step(I0{}, I1{}, Q1{}, F1, F0, c);
+        step(I0{}, I0{}, Q2{}, F0, F1, c);
+        step(I1{}, I1{}, Q0{}, F1, F0, c + 1);
+        step(I1{}, I0{}, Q1{}, F0, F1, c + 1);
+        step(I1{}, I1{}, Q2{}, F1, F0, c + 1);
+    }
+
+    // ---- epilogue ----
+    // lane holds pixel l31 of tile i, channels 32 j + 8 g + 4 khalf + e in acc[i][j][4 g + e].  The wave writes its tile
+    // as fp32 [32 TM pixels][64 channels] into its own piece of the (dead) operand LDS, rows padded to 272 B, and reads it
+    // back (i) row-major, 16 bytes per lane: the global stores are whole 256-byte pixel rows, 1 KB contiguous per
+    // instruction (+ the optional addend, read the same way); (ii) column-wise, lane = channel: the BatchNorm sums of the
+    // tile in fp64, fixed order.  (Statistics are those of the convolution result; the forward passes no addend.)
+    static_assert(WN == 1 && TN == 2, "epilogue: a wave owns all 64 channels of its pixels");
+    constexpr int EP = 272, ETILE = 32 * TM * EP;
+    char* etile = lds_x3 + wave * ETILE;
+    const int mw0 = m0 + wm * TM * 32;                            // first pixel of this wave
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const bool ok = mw0 + 32 * i + l31 <= mlast;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(etile + (32 * i + l31) * EP + (32 * j + 8 * g + 4 * khalf) * 4) = v;
+            }
+    }
+    const int rbase = blockIdx.y * BN;
+    if (!(a.ablate & 128)) {
+#pragma unroll
+        for (int it = 0; it < 8 * TM; ++it) {
+            const int prow = 4 * it + (lane >> 4);
+            const int m = mw0 + prow;
+            float4 v = *reinterpret_cast<const float4*>(etile + prow * EP + (lane & 15) * 16);
+            if (m <= mlast) {
+                const size_t o = (size_t)m * a.R + rbase + (lane & 15) * 4;
+                if (a.addend) {
+                    const float4 av = *reinterpret_cast<const float4*>(a.addend + o);
+                    v.x += av.x; v.y += av.y; v.z += av.z; v.w += av.w;
+                }
+                *reinterpret_cast<float4*>(a.y + o) = v;
+            }
+        }
+    }
+    if (a.stat_part) {
+        double* red = reinterpret_cast<double*>(lds_x3 + NW * ETILE);   // [WM][64][2]
+        double d1 = 0.0, d2 = 0.0;
+#pragma unroll 8
+        for (int p = 0; p < 32 * TM; ++p) {
+            const double v = (double)*reinterpret_cast<const float*>(etile + p * EP + lane * 4);
+            d1 += v;
+            d2 += v * v;
+        }
+        red[(wm * 64 + lane) * 2 + 0] = d1;
+        red[(wm * 64 + lane) * 2 + 1] = d2;
+        __syncthreads();
+        for (int c = tid; c < BN; c += NW * 64) {
+            double e1 = 0.0, e2 = 0.0;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { e1 += red[(w * 64 + c) * 2 + 0]; e2 += red[(w * 64 + c) * 2 + 1]; }
+            double* dst = a.stat_part + ((size_t)blockIdx.x * a.R + rbase + c) * 2;
+            dst[0] = e1; dst[1] = e2;
+        }
+    }
+}
+
+// patch pixels the tiles of BM consecutive output pixels need at most: rows spanned + halo + the zero rows between images
+int patch_pixels_max(int N, int H, int W, int BM) {
+    const long M = (long)N * H * W;
+    const int HW = H * W, HP = H + 2;
+    int worst = 0;
+    // tile starts repeat with period lcm(BM, HW) pixels; scanning one period (at most HW tiles) is exact
+    long tiles = (M + BM - 1) / BM;
+    if (tiles > HW) tiles = HW;
+    for (long t = 0; t < tiles; ++t) {
+        const long m0 = t * BM, ml = (m0 + BM < M ? m0 + BM : M) - 1;
+        const int n0 = (int)(m0 / HW), y0 = (int)((m0 - (long)n0 * HW) / W);
+        const int n1 = (int)(ml / HW), y1 = (int)((ml - (long)n1 * HW) / W);
+        const int NR = n1 * HP + y1 + 1 - (n0 * HP + y0) + 2;
+        if (NR * (W + 2) > worst) worst = NR * (W + 2);
+    }
+    return worst;
+}
+
+struct X3Cfg { int id, BM, PPMAX, threads; };
+// configurations: 0 = 256 pixels, 8 waves (one tile of 32 x 64 each), 1 = 128 pixels, 4 waves, 2 = 64 pixels, 2 waves
+constexpr X3Cfg X3CFGS[] = {{0, 256, 608, 512}, {1, 128, 320, 256}, {2, 64, 192, 128}};
+
+bool x3s_shape_ok(int N, int H, int W, int K, int R) {
+    if (N <= 0 || H <= 0 || W <= 0 || K % 32 != 0 || R % 64 != 0 || K <= 0 || R <= 0) return false;
+    const long M = (long)N * H * W;
+    return M * (K > R ? K : R) * 6 < (1L << 31);             // every slice tensor stays below the descriptor's 2 GB
+}
+
+int x3s_choose(int N, int H, int W, int R) {
+    const long M = (long)N * H * W;
+    const int forced = option(OPT_CONV_CFG);                 // measurement switch: 101 + configuration
+    if (forced >= 101 && forced <= 103 && patch_pixels_max(N, H, W, X3CFGS[forced - 101].BM) <= X3CFGS[forced - 101].PPMAX) return forced - 101;
+    // the largest tile that still gives the 256 CUs two workgroups each; else the smallest one whose patch fits
+    int fallback = -1;
+    for (const X3Cfg& c : X3CFGS) {
+        if (patch_pixels_max(N, H, W, c.BM) > c.PPMAX) continue;
+        const long wgs = ((M + c.BM - 1) / c.BM) * (R / 64);
+        if (wgs >= 512) return c.id;
+        fallback = c.id;
+    }
+    return fallback;
+}
+
+template <int WM, int TM, int PPMAX>
+int launch_x3s(const X3Args& a, hipStream_t s) {
+    constexpr int BM = 32 * TM * WM;
+    constexpr size_t op_bytes = 2 * 3 * PPMAX * 32 + 2 * 3 * 3 * 64 * 32, ep_bytes = (size_t)BM * 272 + WM * 64 * 16;
+    constexpr size_t lds_bytes = op_bytes > ep_bytes ? op_bytes : ep_bytes;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&x3s_conv_kernel<WM, 1, TM, 2, PPMAX>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (attr != hipSuccess) return fail(DMC_E_LAUNCH, "x3s_conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
+    dim3 grid((a.M + BM - 1) / BM, a.R / 64);
+    x3s_conv_kernel<WM, 1, TM, 2, PPMAX><<<grid, WM * 64, lds_bytes, s>>>(a);
+    return check_launch("x3s_conv");
+}
+
+int run_x3s(const void* xs, const void* wp, const float* addend, float* y, double* stat_part, int N, int H, int W, int K, int R,
+            hipStream_t s) {
+    if (!xs || !wp || !y) return fail(DMC_E_INVALID, "x3s_conv: null pointer");
+    if (!x3s_shape_ok(N, H, W, K, R)) return fail(DMC_E_INVALID, "x3s_conv: unsupported shape N=%d H=%d W=%d K=%d R=%d", N, H, W, K, R);
+    const int cfg = x3s_choose(N, H, W, R);
+    X3Args a;
+    a.xs = xs; a.wp = wp; a.y = y; a.addend = addend; a.stat_part = stat_part;
+    a.N = N; a.H = H; a.W = W; a.K = K; a.R = R; a.M = N * H * W;
+    a.plane_bytes = (unsigned)a.M * 32u;
+    a.ablate = option(OPT_CONV_ABLATE);
+    if (a.ablate & 32) a.stat_part = nullptr;
+    switch (cfg) {
+        case 0: return launch_x3s<8, 1, 608>(a, s);
+        case 1: return launch_x3s<4, 1, 320>(a, s);
+        case 2: return launch_x3s<2, 1, 192>(a, s);
+        default: return fail(DMC_E_INVALID, "x3s_conv: the patch of a %d x %d image does not fit the LDS", H, W);
+    }
+}
+
+// ---- weight gradient ------------------------------------------------------------------------------------
+// dw[co][tap][ci] = sum over pixels of dy[p][co] * x[p + tap][ci]: a GEMM over PIXELS, while both slice tensors are
+// channel-contiguous.  ds_read_b64_tr_b16 does the transposition on the way out of LDS: a 16-lane group hands in the
+// addresses of a [4 pixels][16 channels] block (lane L: pixel L / 4, channels 4 (L % 4) ..) and lane i receives channel i
+// of the four pixels -- two such reads are the eight consecutive k-values (pixels) of one MFMA operand row (channel).
+// In a chunk plane four consecutive pixels are 128 contiguous bytes and the two groups of a half-wave read planes whose
+// strides are = 128 (mod 256) bytes: conflict-free, no swizzle, at every tap shift.
+//   workgroup = 64 co x 64 ci block of dw, all nine taps, a run of steps; 12 waves = 4 quarters (32 co x 32 ci) x 3 tap
+//   rows, three per SIMD; 3 x 16 accumulators per wave, kept for the whole run.
+//   The pixel space is walked in PADDED image rows (every image has a zero row above and below, H + 2 rows): step s
+//   covers padded rows [R s, R s + R) -- its dy tile [R x W pixel slots][64 co] (pad rows arrive as zeros: range check)
+//   and the R + 2 input rows around it, which live in a RING of input rows in LDS ([ring row][W + 2 pixels][64 ci]): each
+//   step only transfers the R rows that entered the window, 3x less staging than a patch per step, and image borders
+//   need no special case.  Transfers of step s + 1 are issued at the top of step s (dy double-buffered), one barrier per
+//   step.  Partials [group][Cout][9][Cin] are summed in group order by x3s_wgrad_reduce_kernel: deterministic.
+struct X3WgArgs {
+    const void* xs;        // [3][Cin/16][M][16]
+    const void* dys;       // [3][Cout/16][M][16]
+    float* part;           // [groups][Cout][9][Cin]
+    int N, H, Cin, Cout;
+    unsigned plane_bytes;  // M * 32
+    int steps, per_group, tiles_ci;
+};
+
+template <int W_, int R>
+struct WgGeom {
+    static constexpr int PW = W_ + 2;
+    // ring = NGRP groups of R rows.  A step reads its own group and the last / first row of its neighbours: groups s - 1,
+    // s, s + 1 resident, s + 2 arriving (4 groups); when a group is a whole padded image (R = H + 2) the neighbours are only
+    // touched by pad-row pixel slots, whose dy is zero: 2 groups, one arriving.
+    static constexpr int NGRP = R >= W_ + 2 ? 2 : 4, LA = NGRP / 2;
+    static constexpr int NRING = NGRP * R;
+    static constexpr int XPX = NRING * PW;                             // ring pixels
+    static constexpr int XPL = ((XPX + 3) / 8) * 8 + 4;                // plane stride in pixels: = 4 (mod 8) -> 128 (mod 256) bytes
+    static constexpr int NPX = R * W_;                                 // pixel slots per step
+    static constexpr int NKB = (NPX + 15) / 16;
+    static constexpr int DYP = NKB * 16;
+    static constexpr int DYT = ((DYP + 31) / 32) * 32;                 // transfers move 32 pixel rows
+    static constexpr int DYPL = ((DYT + 3) / 8) * 8 + 4;
+    static constexpr int XI = (R * PW + 31) / 32;                      // transfers per plane and step: input rows / dy tile
+    static constexpr int DI = DYT / 32;
+    static constexpr int XBYTES = 12 * XPL * 32, DYBYTES = 12 * DYPL * 32;
+    static constexpr int LDS = XBYTES + 2 * DYBYTES;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void tr_read2(lds_cptr p0, lds_cptr p1, u32x4& f) {   // eight k-values = two transposed reads
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+    f[0] = ua[0]; f[1] = ua[1]; f[2] = ub[0]; f[3] = ub[1];
+}
+
+template <int W_, int R>
+__global__ __launch_bounds__(768) void x3s_wgrad_kernel(X3WgArgs a) {
+    using G = WgGeom<W_, R>;
+    constexpr int PW = G::PW, NRING = G::NRING, XPL = G::XPL, DYPL = G::DYPL, NKB = G::NKB;
+    extern __shared__ __attribute__((aligned(1024))) char lds_wg[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, khalf = lane >> 5, L = lane & 15, grp = (lane >> 4) & 1;
+    const int quarter = wave & 3, trow = wave >> 2;
+    const int wi = quarter & 1, wj = quarter >> 1;
+    const int tci = blockIdx.x % a.tiles_ci, tco = blockIdx.x / a.tiles_ci;
+    const unsigned lds0 = lds_addr_of(lds_wg);
+    const int HP = a.H + 2;
+    const int s_begin = blockIdx.y * a.per_group;
+    const int s_end = s_begin + a.per_group < a.steps ? s_begin + a.per_group : a.steps;
+    const u32x4 srd_x = make_srd(a.xs), srd_d = make_srd(a.dys);
+    // this wave's plane of both tiles: slice = wave / 4, chunk = wave % 4
+    const unsigned soff_x = (unsigned)((wave >> 2) * (a.Cin >> 4) + tci * 4 + (wave & 3)) * a.plane_bytes;
+    const unsigned soff_d = (unsigned)((wave >> 2) * (a.Cout >> 4) + tco * 4 + (wave & 3)) * a.plane_bytes;
+    const unsigned xplane = lds0 + (unsigned)wave * XPL * 32, dplane = lds0 + G::XBYTES + (unsigned)wave * DYPL * 32;
+    const int lpx = lane >> 1;
+    const unsigned lhalf = (unsigned)(lane & 1) << 4;
+
+    // global byte offset of pixel (padded row g, column x) in a plane, or OOB
+    auto pix_off = [&](int g, int x) -> unsigned {
+        const int n = g / HP, y = g - n * HP - 1;
+        return (g >= 0 && n < a.N && y >= 0 && y < a.H && x >= 0 && x < W_) ? (unsigned)((n * a.H + y) * W_ + x) * 32u + lhalf : OOB;
+    };
+    // input rows of group q (padded rows [R q, R q + R)) -> ring slots R (q mod NGRP) ..
+    auto issue_x = [&](int q) {
+        const int slot0 = (((q % G::NGRP) + G::NGRP) % G::NGRP) * R;
+#pragma unroll
+        for (int i = 0; i < G::XI; ++i) {
+            const int px = 32 * i + lpx;                            // pixel of the R x PW range
+            const int r = px / PW, col = px - r * PW;
+            if (px < R * PW) dma_buf16(srd_x, pix_off(R * q + r, col - 1), soff_x, xplane + (unsigned)(slot0 * PW + 32 * i) * 32u);
+        }
+    };
+    // dy tile of step s: pixel slot p = r W + x of padded rows R s + r
+    auto issue_dy = [&](int s, int buf) {
+#pragma unroll
+        for (int i = 0; i < G::DI; ++i) {
+            const int p = 32 * i + lpx;
+            const int r = p / W_, x = p - r * W_;
+            dma_buf16(srd_d, p < G::NPX ? pix_off(R * s + r, x) : OOB, soff_d, dplane + (unsigned)buf * G::DYBYTES + (unsigned)(32 * i) * 32u);
+        }
+    };
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    if (s_begin < s_end) {
+        // every ring row the first step can touch holds zeros or data (never uninitialised LDS: 0 x NaN pattern = NaN)
+#pragma unroll
+        for (int q = -1; q < G::LA; ++q) issue_x(s_begin + q);
+        issue_dy(s_begin, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    lds_cptr const LB = (lds_cptr)lds_wg;
+#pragma unroll 1
+    for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        issue_x(s + G::LA);                                          // the group entering the window
+        if (s + 1 < s_end) issue_dy(s + 1, buf ^ 1);
+        // fragment addresses of this step.  Unit (kb, u) of this lane: pixel slot P = 16 kb + 8 khalf + 4 u + L / 4
+        const int dchunk = (2 * wi + grp) * DYPL * 32 + buf * G::DYBYTES + G::XBYTES + (L & 3) * 8;
+        const int xchunk = (2 * wj + grp) * XPL * 32 + (L & 3) * 8;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            int dyo[2], xo[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                int P = 16 * kb + 8 * khalf + 4 * u + (L >> 2);
+                dyo[u] = dchunk + P * 32;
+                if (P >= G::NPX) P = G::NPX - 1;                     // beyond the tile: dy is zero there, any valid input address
+                const int r = P / W_, x = P - r * W_;
+                const int slot = (((R * s + r + trow - 1) % NRING) + NRING) % NRING;   // input row of this wave's tap row
+                xo[u] = xchunk + (slot * PW + x) * 32;               // + tap column dx * 32 below
+            }
+            u32x4 A[3], B[3][3];
+#pragma unroll
+            for (int sl = 0; sl < 3; ++sl) {
+                tr_read2(LB + dyo[0] + sl * 4 * DYPL * 32, LB + dyo[1] + sl * 4 * DYPL * 32, A[sl]);
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    tr_read2(LB + xo[0] + (sl * 4 * XPL + t) * 32, LB + xo[1] + (sl * 4 * XPL + t) * 32, B[t][sl]);
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                acc[t] = mfma_bf16(A[0], B[t][2], acc[t]);
+                acc[t] = mfma_bf16(A[2], B[t][0], acc[t]);
+                acc[t] = mfma_bf16(A[1], B[t][1], acc[t]);
+                acc[t] = mfma_bf16(A[0], B[t][1], acc[t]);
+                acc[t] = mfma_bf16(A[1], B[t][0], acc[t]);
+                acc[t] = mfma_bf16(A[0], B[t][0], acc[t]);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    float* out = a.part + (size_t)blockIdx.y * a.Cout * 9 * a.Cin;
+    const int ci = tci * 64 + 32 * wj + l31;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = tco * 64 + 32 * wi + 8 * (e >> 2) + 4 * khalf + (e & 3);
+            out[((size_t)co * 9 + 3 * trow + t) * a.Cin + ci] = acc[t][e];
+        }
+}
+
+// dw = sum over groups of the partials, fixed order (16 group lanes x 16 float4 columns per workgroup)
+__global__ __launch_bounds__(256) void x3s_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int ngroup, long numel) {
+    __shared__ float4 red[16][17];
+    const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    for (long i0 = (long)blockIdx.x * 64; i0 < numel; i0 += (long)gridDim.x * 64) {
+        const long i = i0 + 4 * o;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < numel)
+            for (int k = sl; k < ngroup; k += 16) {
+                const float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * numel + i);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        red[sl][o] = s;
+        __syncthreads();
+        if (sl == 0 && i < numel) {
+            float4 t = red[0][o];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) { const float4 v = red[k][o]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+            *reinterpret_cast<float4*>(dw + i) = t;
+        }
+        __syncthreads();
+    }
+}
+
+struct X3WgPlan { int R, steps, tiles, groups, per_group; };
+bool x3s_wgrad_plan(int N, int H, int W, int Cin, int Cout, X3WgPlan& p) {
+    p.R = W == 56 ? 1 : W == 28 ? 2 : W == 14 ? 4 : W == 7 ? 9 : 0;
+    if (!p.R || (H + 2) % p.R != 0 || (W == 7 && H != 7) || Cin % 64 != 0 || Cout % 64 != 0) return false;
+    p.steps = N * (H + 2) / p.R;
+    p.tiles = (Cout / 64) * (Cin / 64);
+    int groups = 256 / p.tiles;
+    if (groups < 1) groups = 1;
+    if (groups > p.steps) groups = p.steps;
+    p.per_group = (p.steps + groups - 1) / groups;
+    p.groups = (p.steps + p.per_group - 1) / p.per_group;
+    return true;
+}
+
+template <int W_, int R>
+int launch_x3s_wgrad(const X3WgPlan& p, X3WgArgs a, float* dw, hipStream_t s) {
+    using G = WgGeom<W_, R>;
+    static_assert(G::LDS <= 160 * 1024, "weight-gradient tiles exceed the LDS");
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&x3s_wgrad_kernel<W_, R>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    if (attr != hipSuccess) return fail(DMC_E_LAUNCH, "x3s_wgrad: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
+    x3s_wgrad_kernel<W_, R><<<dim3(p.tiles, p.groups), 768, G::LDS, s>>>(a);
+    int rc = check_launch("x3s_wgrad");
+    if (rc || p.groups == 1) return rc;
+    const long numel = (long)a.Cout * 9 * a.Cin;
+    const long blocks = (numel + 63) / 64;
+    x3s_wgrad_reduce_kernel<<<(int)(blocks > 4096 ? 4096 : blocks), 256, 0, s>>>(a.part, dw, p.groups, numel);
+    return check_launch("x3s_wgrad_reduce");
+}
+
+int stream_blocks(long total) {
+    long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dmc_x3s_slices_bytes(long M, int C) { return (size_t)M * (size_t)C * 6; }
+
+int dmc_x3s_split(const float* x, void* xs, long M, int C, dmc_stream_t stream) {
+    if (!x || !xs || M <= 0 || C <= 0 || C % 16 != 0) return fail(DMC_E_INVALID, "dmc_x3s_split: bad argument");
+    x3s_split_kernel<<<stream_blocks(M * (C / 8)), 256, 0, (hipStream_t)stream>>>(x, static_cast<unsigned short*>(xs), M, C);
+    return check_launch("x3s_split");
+}
+
+int dmc_x3s_merge(const void* xs, float* x, long M, int C, dmc_stream_t stream) {
+    if (!x || !xs || M <= 0 || C <= 0 || C % 16 != 0) return fail(DMC_E_INVALID, "dmc_x3s_merge: bad argument");
+    x3s_merge_kernel<<<stream_blocks(M * C), 256, 0, (hipStream_t)stream>>>(static_cast<const unsigned short*>(xs), x, M, C);
+    return check_launch("x3s_merge");
+}
+
+size_t dmc_x3s_wpack_bytes(int Cin, int Cout) { return (size_t)Cin * (size_t)Cout * 9 * 6; }
+
+int dmc_x3s_pack_weights(const float* w, void* wpack_f, void* wpack_t, int Cin, int Cout, dmc_stream_t stream) {
+    if (!w || (!wpack_f && !wpack_t) || Cin % 64 != 0 || Cout % 64 != 0 || Cin <= 0 || Cout <= 0)
+        return fail(DMC_E_INVALID, "dmc_x3s_pack_weights: bad argument");
+    const long total = (long)Cin * Cout * 9;
+    x3s_pack_w_kernel<<<dim3(stream_blocks(total) > 1024 ? 1024 : stream_blocks(total), 2), 256, 0, (hipStream_t)stream>>>(
+        w, static_cast<unsigned short*>(wpack_f), static_cast<unsigned short*>(wpack_t), Cout, Cin);
+    return check_launch("x3s_pack_w");
+}
+
+int dmc_x3s_conv_supported(int N, int H, int W, int Cin, int Cout) {
+    return Cin % 64 == 0 && Cout % 64 == 0 && x3s_shape_ok(N, H, W, Cin, Cout) && x3s_shape_ok(N, H, W, Cout, Cin) &&
+           x3s_choose(N, H, W, Cout) >= 0 && x3s_choose(N, H, W, Cin) >= 0 ? 1 : 0;
+}
+
+int dmc_x3s_conv_stat_blocks(int N, int H, int W, int Cout) {
+    const int cfg = x3s_choose(N, H, W, Cout);
+    if (cfg < 0) return 0;
+    const long M = (long)N * H * W;
+    return (int)((M + X3CFGS[cfg].BM - 1) / X3CFGS[cfg].BM);
+}
+
+int dmc_x3s_conv_fwd(const void* xs, const void* wpack_f, float* y, double* stat_partials, int N, int H, int W, int Cin, int Cout,
+                     dmc_stream_t stream) {
+    return run_x3s(xs, wpack_f, nullptr, y, stat_partials, N, H, W, Cin, Cout, (hipStream_t)stream);
+}
+
+int dmc_x3s_conv_dgrad(const void* dys, const void* wpack_t, const float* addend, float* dx, int N, int H, int W, int Cin, int Cout,
+                       dmc_stream_t stream) {
+    return run_x3s(dys, wpack_t, addend, dx, nullptr, N, H, W, Cout, Cin, (hipStream_t)stream);
+}
+
+int dmc_x3s_conv_wgrad_supported(int N, int H, int W, int Cin, int Cout) {
+    X3WgPlan p;
+    return x3s_wgrad_plan(N, H, W, Cin, Cout, p) && x3s_shape_ok(N, H, W, Cin, Cout) && x3s_shape_ok(N, H, W, Cout, Cin) ? 1 : 0;
+}
+
+size_t dmc_x3s_conv_wgrad_bytes(int N, int H, int W, int Cin, int Cout) {
+    X3WgPlan p;
+    if (!x3s_wgrad_plan(N, H, W, Cin, Cout, p) || p.groups <= 1) return 0;
+    return (size_t)p.groups * Cout * 9 * Cin * sizeof(float);
+}
+
+int dmc_x3s_conv_wgrad(const void* xs, const void* dys, float* dw, float* workspace, int N, int H, int W, int Cin, int Cout,
+                       dmc_stream_t stream) {
+    X3WgPlan p;
+    if (!xs || !dys || !dw) return fail(DMC_E_INVALID, "dmc_x3s_conv_wgrad: null pointer");
+    if (!dmc_x3s_conv_wgrad_supported(N, H, W, Cin, Cout) || !x3s_wgrad_plan(N, H, W, Cin, Cout, p))
+        return fail(DMC_E_INVALID, "dmc_x3s_conv_wgrad: unsupported shape N=%d H=%d W=%d Cin=%d Cout=%d", N, H, W, Cin, Cout);
+    if (p.groups > 1 && !workspace) return fail(DMC_E_INVALID, "dmc_x3s_conv_wgrad: workspace required");
+    X3WgArgs a;
+    a.xs = xs; a.dys = dys; a.part = p.groups > 1 ? workspace : dw;
+    a.N = N; a.H = H; a.Cin = Cin; a.Cout = Cout;
+    a.plane_bytes = (unsigned)((long)N * H * W) * 32u;
+    a.steps = p.steps; a.per_group = p.per_group; a.tiles_ci = Cin / 64;
+    hipStream_t s = (hipStream_t)stream;
+    switch (W) {
+        case 56: return launch_x3s_wgrad<56, 1>(p, a, dw, s);
+        case 28: return launch_x3s_wgrad<28, 2>(p, a, dw, s);
+        case 14: return launch_x3s_wgrad<14, 4>(p, a, dw, s);
+        default: return launch_x3s_wgrad<7, 9>(p, a, dw, s);
+    }
+}
+
+}  // extern "C"

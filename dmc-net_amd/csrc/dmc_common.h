@@ -112,3 +112,34 @@ __device__ __forceinline__ void lds_dma16(unsigned long long sbase, unsigned vof
                  :: "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)) : "memory");
 }
 }  // namespace dmc
+
+// ---- bf16x3 slice tensors (conv_x3s.hip and their producers in bn_act.hip) -------------------------------
+// An fp32 value is the exact sum of three bf16 values: s0 = its upper 16 bits, s1 = the upper 16 bits of the exact
+// remainder, s2 = the second remainder.  A slice tensor of a [M][C] fp32 activation is bf16 [3][C / 16][M][16].
+namespace dmc {
+typedef unsigned x3s_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void x3s_split3(float v, unsigned& u0, unsigned& u1, unsigned& u2) {
+    u0 = __float_as_uint(v);
+    const float r1 = v - __uint_as_float(u0 & 0xffff0000u);
+    u1 = __float_as_uint(r1);
+    u2 = __float_as_uint(r1 - __uint_as_float(u1 & 0xffff0000u));
+}
+// the three slices of 8 consecutive channels (8 g .. 8 g + 7) of pixel m -> xs
+__device__ __forceinline__ void x3s_store8(unsigned short* __restrict__ xs, const float (&v)[8], size_t M, int nchunk, size_t m, int g) {
+    unsigned u0[8], u1[8], u2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x3s_split3(v[e], u0[e], u1[e], u2[e]);
+    x3s_u32x4 s0, s1, s2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        s0[e] = __builtin_amdgcn_perm(u0[2 * e + 1], u0[2 * e], 0x07060302u);
+        s1[e] = __builtin_amdgcn_perm(u1[2 * e + 1], u1[2 * e], 0x07060302u);
+        s2[e] = __builtin_amdgcn_perm(u2[2 * e + 1], u2[2 * e], 0x07060302u);
+    }
+    const size_t plane = M * 16;
+    const size_t w = ((size_t)(g >> 1) * M + m) * 16 + (size_t)(g & 1) * 8;
+    *reinterpret_cast<x3s_u32x4*>(xs + w) = s0;
+    *reinterpret_cast<x3s_u32x4*>(xs + (size_t)nchunk * plane + w) = s1;
+    *reinterpret_cast<x3s_u32x4*>(xs + (size_t)2 * nchunk * plane + w) = s2;
+}
+}  // namespace dmc

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void stem3d_wgrad_kernel(Stem3dWgArgs a) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    int fa[7], fb[2][2];
+    int fa[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) fa[i] = (32 * (wave + 4 * i) + l31) * 64;       // row of tile wave + 4 i (tile 28 does not exist: i = 6 only for wave 0)
     const int swz = (l31 >> 2) & 3;

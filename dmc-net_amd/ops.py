@@ -434,7 +434,7 @@ class _BnReluPool(torch.autograd.Function):
     code/dmcnet/model.py:305,352) on a channels_last ``x``; the rectified tensor is never stored."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, eps, momentum):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, eps, momentum, want_slices=False):
         lib = _lib.load()
         _need_cuda(x, gamma, beta)
         n, c, h, w = x.shape
@@ -443,18 +443,29 @@ class _BnReluPool(torch.autograd.Function):
                         memory_format=torch.channels_last)
         stats = _floats(lib.dmc_bn_act_stats_bytes(c), x.device)
         scratch = _floats(lib.dmc_bn_act_scratch_bytes(c), x.device) if training else None
+        ys = None
         with _span("bn_relu_pool_fwd"):
-            _lib.check(lib.dmc_bn_relu_pool_fwd(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta),
-                                                _lib.ptr(running_mean), _lib.ptr(running_var),
-                                                _lib.ptr(y), _lib.ptr(stats), _lib.ptr(scratch), n, h, w, c, int(training),
-                                                float(eps), float(momentum), _stream()),
-                       "dmc_bn_relu_pool_fwd")
+            if want_slices and c % 16 == 0:     # the pooled map also as a bf16x3 slice tensor (layer1's first convolution)
+                ys = torch.empty(lib.dmc_x3s_slices_bytes(n * ph * pw, c), dtype=torch.uint8, device=x.device)
+                _lib.check(lib.dmc_bn_relu_pool_fwd_x3s(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean),
+                                                        _lib.ptr(running_var), _lib.ptr(y), _lib.ptr(ys), _lib.ptr(stats),
+                                                        _lib.ptr(scratch), n, h, w, c, int(training), float(eps),
+                                                        float(momentum), _stream()), "dmc_bn_relu_pool_fwd_x3s")
+            else:
+                _lib.check(lib.dmc_bn_relu_pool_fwd(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta),
+                                                    _lib.ptr(running_mean), _lib.ptr(running_var),
+                                                    _lib.ptr(y), _lib.ptr(stats), _lib.ptr(scratch), n, h, w, c, int(training),
+                                                    float(eps), float(momentum), _stream()),
+                           "dmc_bn_relu_pool_fwd")
         ctx.save_for_backward(x, gamma, beta, stats)
         ctx.training = bool(training)
-        return y
+        if ys is None:
+            ys = torch.empty(0, dtype=torch.uint8, device=x.device)
+        ctx.mark_non_differentiable(ys)
+        return y, ys
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dys):
         lib = _lib.load()
         x, gamma, beta, stats = ctx.saved_tensors
         if not ctx.training:
@@ -470,7 +481,7 @@ class _BnReluPool(torch.autograd.Function):
                                                 _lib.ptr(stats), _lib.ptr(scratch), _lib.ptr(dy), _lib.ptr(dx),
                                                 _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(codes),
                                                 n, h, w, c, _stream()), "dmc_bn_relu_pool_bwd")
-        return dx, dgamma, dbeta, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
 def bn_relu_pool_supported(x):
@@ -483,16 +494,21 @@ def bn_relu_pool_supported(x):
     return bool(_lib.load().dmc_bn_relu_pool_supported(n, h, w, c))
 
 
-def bn_relu_pool(x, bn):
-    """maxpool(3, 2, 1)(relu(bn(x))) for a channels_last ``x`` and an ``nn.BatchNorm2d`` ``bn``."""
+def bn_relu_pool(x, bn, want_slices=False):
+    """maxpool(3, 2, 1)(relu(bn(x))) for a channels_last ``x`` and an ``nn.BatchNorm2d`` ``bn``; ``want_slices``: the
+    pooled map's bf16x3 slice tensor is attached to the result (x3s_of) for a pre-split convolution."""
     training = bn.training
     if training and bn.num_batches_tracked is not None:
         if _PENDING_COUNTERS is not None:
             _PENDING_COUNTERS.append(bn.num_batches_tracked)
         else:
             bn.num_batches_tracked.add_(1)
-    return _BnReluPool.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps,
-                             bn.momentum if bn.momentum is not None else 0.1)
+    y, ys = _BnReluPool.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps,
+                              bn.momentum if bn.momentum is not None else 0.1, bool(want_slices))
+    if ys.numel():
+        y._dmc_x3s = ys
+        y._dmc_f32 = True
+    return y
 
 
 #: True (default): conv1's forward on dmc_stem_fwd (exact fp32 MFMA, no LDS); False = F.conv2d (MIOpen)
@@ -681,6 +697,104 @@ def conv_nhwc(x, weight, stride=1, padding=1):
     return _ConvNHWC.apply(x, weight, int(stride), int(padding))
 
 
+
+# ------------------------------------------------------------------ pre-split bf16x3 operands (conv_x3s.hip)
+#: True (default): stride-1 3x3 convolutions of the fused conv -> bn op run on conv_x3s.hip -- both operands arrive as
+#: bf16x3 slice tensors written by the PRODUCER of the activation (BatchNorm apply / stem pool / BatchNorm backward), the
+#: convolution's main loop is LDS reads + MFMAs only.  DMC_X3S=0: the in-loop-split kernels of conv_nhwc.hip.
+X3S = __import__("os").environ.get("DMC_X3S", "1") != "0"
+
+
+def x3s_of(t):
+    """The slice tensor attached to activation ``t`` by its producer (or None)."""
+    return getattr(t, "_dmc_x3s", None)
+
+
+def f32_valid(t):
+    """False when ``t``'s fp32 memory was not written (its producer emitted slices only)."""
+    return getattr(t, "_dmc_f32", True)
+
+
+def _attach_x3s(t, xs, has_f32=True):
+    t._dmc_x3s = xs
+    t._dmc_f32 = has_f32
+    return t
+
+
+def _x3s_buffer(m, c, device):
+    return torch.empty(_lib.load().dmc_x3s_slices_bytes(m, c), dtype=torch.uint8, device=device)
+
+
+def x3s_split(x):
+    """Slice tensor of a channels_last fp32 activation (the stand-alone producer: tests, inputs nobody split)."""
+    n, c, h, w = x.shape
+    xs = _x3s_buffer(n * h * w, c, x.device)
+    _lib.check(_lib.load().dmc_x3s_split(_lib.ptr(x), _lib.ptr(xs), n * h * w, c, _stream()), "dmc_x3s_split")
+    return xs
+
+
+def x3s_merge(xs, shape):
+    """fp32 channels_last tensor of ``shape`` from its slice tensor (exact: the three slices sum to the value)."""
+    n, c, h, w = shape
+    x = torch.empty(shape, dtype=torch.float32, device=xs.device, memory_format=torch.channels_last)
+    _lib.check(_lib.load().dmc_x3s_merge(_lib.ptr(xs), _lib.ptr(x), n * h * w, c, _stream()), "dmc_x3s_merge")
+    return x
+
+
+def x3s_pack_weights(weight, forward=True, transposed=True):
+    """(wpack_f, wpack_t) of a channels_last [Cout, Cin, 3, 3] weight for dmc_x3s_conv_fwd / dmc_x3s_conv_dgrad."""
+    lib = _lib.load()
+    cout, cin = weight.shape[0], weight.shape[1]
+    nb = lib.dmc_x3s_wpack_bytes(cin, cout)
+    wf = torch.empty(nb, dtype=torch.uint8, device=weight.device) if forward else None
+    wt = torch.empty(nb, dtype=torch.uint8, device=weight.device) if transposed else None
+    _lib.check(lib.dmc_x3s_pack_weights(_lib.ptr(_as_cl(weight)), _lib.ptr(wf), _lib.ptr(wt), cin, cout, _stream()),
+               "dmc_x3s_pack_weights")
+    return wf, wt
+
+
+def x3s_conv_fwd(xs, wpack_f, n, h, w, cin, cout, want_stats=False):
+    """conv3x3 (stride 1, padding 1) of the activation whose slice tensor is ``xs`` -> (y fp32 channels_last, statistics
+    partials [blocks, Cout, 2] float64 or None)."""
+    lib = _lib.load()
+    y = torch.empty((n, cout, h, w), dtype=torch.float32, device=xs.device, memory_format=torch.channels_last)
+    part = None
+    if want_stats:
+        part = torch.empty((lib.dmc_x3s_conv_stat_blocks(n, h, w, cout), cout, 2), dtype=torch.float64, device=xs.device)
+    _lib.check(lib.dmc_x3s_conv_fwd(_lib.ptr(xs), _lib.ptr(wpack_f), _lib.ptr(y), _lib.ptr(part), n, h, w, cin, cout, _stream()),
+               "dmc_x3s_conv_fwd")
+    return y, part
+
+
+def x3s_conv_dgrad(dys, wpack_t, n, h, w, cin, cout, addend=None):
+    dx = torch.empty((n, cin, h, w), dtype=torch.float32, device=dys.device, memory_format=torch.channels_last)
+    _lib.check(_lib.load().dmc_x3s_conv_dgrad(_lib.ptr(dys), _lib.ptr(wpack_t), _lib.ptr(addend), _lib.ptr(dx), n, h, w, cin, cout,
+                                              _stream()), "dmc_x3s_conv_dgrad")
+    return dx
+
+
+def x3s_conv_wgrad(xs, dys, n, h, w, cin, cout):
+    lib = _lib.load()
+    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=xs.device, memory_format=torch.channels_last)
+    work = _floats(lib.dmc_x3s_conv_wgrad_bytes(n, h, w, cin, cout), xs.device)
+    _lib.check(lib.dmc_x3s_conv_wgrad(_lib.ptr(xs), _lib.ptr(dys), _lib.ptr(dw), _lib.ptr(work), n, h, w, cin, cout, _stream()),
+               "dmc_x3s_conv_wgrad")
+    return dw
+
+
+def x3s_usable(n, h, w, conv):
+    """True if ``conv`` on an [n, Cin, h, w] activation takes the pre-split path (3x3, stride 1, padding 1, no bias)."""
+    if not X3S or conv.kernel_size != (3, 3) or conv.stride != (1, 1) or conv.padding != (1, 1) or conv.bias is not None:
+        return False
+    if conv.dilation != (1, 1) or conv.groups != 1:
+        return False
+    lib = _lib.load()
+    if lib.dmc_get_option(b"conv_arith") != 1 or lib.dmc_get_option(b"conv_path") != 1:
+        return False
+    cin, cout = conv.in_channels, conv.out_channels
+    return bool(lib.dmc_x3s_conv_supported(n, h, w, cin, cout)) and bool(lib.dmc_x3s_conv_wgrad_supported(n, h, w, cin, cout))
+
+
 class ResidualGradLink:
     """Couples the two fused ops of an identity-shortcut residual block (torchvision BasicBlock: `out += identity`, behind
     code/dmcnet/model.py:305): the block input feeds the first convolution AND the residual add, so autograd would sum the
@@ -700,68 +814,116 @@ class _ConvBnAct(torch.autograd.Function):
     chains (torchvision BasicBlock / Bottleneck / downsample behind code/dmcnet/model.py:305,352) on the
     matrix-core NHWC kernels.  The convolution's epilogue reduces the batch statistics (no separate pass
     over its output), one streaming pass normalises / adds / rectifies; the backward runs the BatchNorm
-    backward (two passes) and feeds the data- and weight-gradient kernels (deterministic)."""
+    backward (two passes) and feeds the data- and weight-gradient kernels (deterministic).
+
+    ``xs``: the slice tensor of ``x`` (or None); ``mode`` bit 0: write the fp32 result, bit 1: write its slice tensor
+    (returned second, non-differentiable), bit 2: take the pre-split convolution path (conv_x3s.hip)."""
 
     @staticmethod
     def forward(ctx, x, weight, residual, gamma, beta, running_mean, running_var, stride, padding, relu, eps,
-                momentum, link=None):
+                momentum, link=None, xs=None, mode=1):
         lib = _lib.load()
         _need_cuda(x, weight, residual, gamma, beta)
-        x, wcl = _as_cl(x), _as_cl(weight)
-        cout = weight.shape[0]
+        want_f32, want_xs, use_x3s = bool(mode & 1), bool(mode & 2), bool(mode & 4)
+        wcl = _as_cl(weight)
+        cout, cin = weight.shape[0], weight.shape[1]
+        n, _, h, w = x.shape
         ctx.wsplit_t = None
         ctx.link = None
-        with _span("conv_nhwc_fwd"):
-            wf = None
-            if ctx.needs_input_grad[0] and lib.dmc_conv_nhwc_presplit_supported(weight.shape[1], cout):
-                # bf16x3 kernels: the forward's and the data gradient's weight slices from ONE launch
-                nb = lib.dmc_conv_nhwc_wt_bytes(weight.shape[1], cout, weight.shape[2], weight.shape[3])
-                wf, ctx.wsplit_t = _floats(nb, x.device), _floats(nb, x.device)
-                _lib.check(lib.dmc_conv_nhwc_split(_lib.ptr(wcl), _lib.ptr(wf), _lib.ptr(ctx.wsplit_t), weight.shape[1], cout,
-                                                   weight.shape[2], weight.shape[3], _stream()), "dmc_conv_nhwc_split")
-            y, part, nblk = _conv_fwd(x, wcl, None, None, stride, padding, 0, True, presplit=wf)
+        if use_x3s:
+            if xs is None:
+                xs = x3s_split(_as_cl(x))
+            with _span("conv_nhwc_fwd"):
+                nb = lib.dmc_x3s_wpack_bytes(cin, cout)
+                wf = torch.empty(nb, dtype=torch.uint8, device=x.device)
+                ctx.wsplit_t = torch.empty(nb, dtype=torch.uint8, device=x.device) if ctx.needs_input_grad[0] else None
+                _lib.check(lib.dmc_x3s_pack_weights(_lib.ptr(wcl), _lib.ptr(wf), _lib.ptr(ctx.wsplit_t), cin, cout, _stream()),
+                           "dmc_x3s_pack_weights")
+                y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device, memory_format=_CL)
+                nblk = lib.dmc_x3s_conv_stat_blocks(n, h, w, cout)
+                part = torch.empty((nblk, cout, 2), dtype=torch.float64, device=x.device)
+                _lib.check(lib.dmc_x3s_conv_fwd(_lib.ptr(xs), _lib.ptr(wf), _lib.ptr(y), _lib.ptr(part), n, h, w, cin, cout,
+                                                _stream()), "dmc_x3s_conv_fwd")
+            wf_ok = True
+        else:
+            if not f32_valid(x):
+                raise RuntimeError("conv_bn_act: the input's fp32 memory was not written by its producer (slices only)")
+            x = _as_cl(x)
+            with _span("conv_nhwc_fwd"):
+                wf = None
+                if ctx.needs_input_grad[0] and lib.dmc_conv_nhwc_presplit_supported(cin, cout):
+                    # bf16x3 kernels: the forward's and the data gradient's weight slices from ONE launch
+                    nb = lib.dmc_conv_nhwc_wt_bytes(cin, cout, weight.shape[2], weight.shape[3])
+                    wf, ctx.wsplit_t = _floats(nb, x.device), _floats(nb, x.device)
+                    _lib.check(lib.dmc_conv_nhwc_split(_lib.ptr(wcl), _lib.ptr(wf), _lib.ptr(ctx.wsplit_t), cin, cout,
+                                                       weight.shape[2], weight.shape[3], _stream()), "dmc_conv_nhwc_split")
+                y, part, nblk = _conv_fwd(x, wcl, None, None, stride, padding, 0, True, presplit=wf)
+            wf_ok = wf is not None
         if link is not None:
             if residual is None:
-                if wf is not None and stride == 1:          # first op of the block: will add the parked gradient
+                if wf_ok and stride == 1:                   # first op of the block: will add the parked gradient
                     link.armed, ctx.link = True, link
             elif link.armed and ctx.needs_input_grad[2]:    # last op of the block: will park its residual gradient
                 ctx.link = link
         n, _, oh, ow = y.shape
         m = n * oh * ow
         stats = _floats(lib.dmc_bn_act_stats_bytes(cout), x.device)
-        out = torch.empty_like(y)
+        out = torch.empty_like(y)                           # not written when the consumer reads slices only
+        out_xs = _x3s_buffer(m, cout, x.device) if want_xs else None
         mask = None
-        if relu and residual is not None:
+        if residual is not None:
+            if not f32_valid(residual):
+                raise RuntimeError("conv_bn_act: the residual's fp32 memory was not written by its producer")
             residual = _as_cl(residual)
-            mask = torch.empty(m * (cout // 4), dtype=torch.uint8, device=x.device)
+            if relu:
+                mask = torch.empty(m * (cout // 4), dtype=torch.uint8, device=x.device)
         with _span("bn_apply_fwd"):
             _lib.check(lib.dmc_conv_nhwc_stats_final(_lib.ptr(part), nblk, cout, m, _lib.ptr(stats),
                                                      _lib.ptr(running_mean), _lib.ptr(running_var), float(eps),
                                                      float(momentum), _stream()), "dmc_conv_nhwc_stats_final")
-            _lib.check(lib.dmc_bn_apply_act_nhwc(_lib.ptr(y), _lib.ptr(residual), _lib.ptr(gamma), _lib.ptr(beta),
-                                                 _lib.ptr(stats), _lib.ptr(out), _lib.ptr(mask), m, cout, int(relu),
-                                                 _stream()), "dmc_bn_apply_act_nhwc")
-        ctx.save_for_backward(x, weight, y, gamma, beta, stats, mask)
-        ctx.cfg = (int(stride), int(padding), bool(relu), residual is not None)
-        return out
+            if want_xs or not want_f32:
+                _lib.check(lib.dmc_bn_apply_act_x3s(_lib.ptr(y), _lib.ptr(residual), _lib.ptr(gamma), _lib.ptr(beta),
+                                                    _lib.ptr(stats), _lib.ptr(out) if want_f32 else None, _lib.ptr(out_xs),
+                                                    _lib.ptr(mask), m, cout, int(relu), _stream()), "dmc_bn_apply_act_x3s")
+            else:
+                _lib.check(lib.dmc_bn_apply_act_nhwc(_lib.ptr(y), _lib.ptr(residual), _lib.ptr(gamma), _lib.ptr(beta),
+                                                     _lib.ptr(stats), _lib.ptr(out), _lib.ptr(mask), m, cout, int(relu),
+                                                     _stream()), "dmc_bn_apply_act_nhwc")
+        # the pre-split path keeps the input's slices for its weight gradient, not the fp32 input
+        ctx.save_for_backward(xs if use_x3s else x, weight, y, gamma, beta, stats, mask)
+        ctx.cfg = (int(stride), int(padding), bool(relu), residual is not None, use_x3s, tuple(x.shape))
+        if out_xs is None:
+            out_xs = torch.empty(0, dtype=torch.uint8, device=x.device)
+        ctx.mark_non_differentiable(out_xs)
+        return out, out_xs
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _dxs):
         lib = _lib.load()
         x, weight, y, gamma, beta, stats, mask = ctx.saved_tensors
-        stride, padding, relu, has_res = ctx.cfg
+        stride, padding, relu, has_res, use_x3s, x_shape = ctx.cfg
         n, cout, oh, ow = y.shape
+        m = n * oh * ow
+        cin = weight.shape[1]
         dout = _as_cl(dout)
-        dy = torch.empty_like(y)
         want_dres = has_res and ctx.needs_input_grad[2]
         dres = torch.empty_like(y) if (want_dres and relu) else None
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         scratch = _floats(lib.dmc_bn_act_scratch_bytes(cout), y.device)
+        dy = dys = None
         with _span("bn_act_bwd"):
-            _lib.check(lib.dmc_bn_act_bwd(_lib.ptr(y), None, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(stats),
-                                          _lib.ptr(scratch), _lib.ptr(dout), _lib.ptr(dy), _lib.ptr(dres),
-                                          _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(mask), n * oh * ow, cout,
-                                          int(relu), _stream()), "dmc_bn_act_bwd")
+            if use_x3s:                                     # the convolution's output gradient: slices only
+                dys = _x3s_buffer(m, cout, y.device)
+                _lib.check(lib.dmc_bn_act_bwd_x3s(_lib.ptr(y), None, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(stats),
+                                                  _lib.ptr(scratch), _lib.ptr(dout), None, _lib.ptr(dys), _lib.ptr(dres),
+                                                  _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(mask), m, cout,
+                                                  int(relu), _stream()), "dmc_bn_act_bwd_x3s")
+            else:
+                dy = torch.empty_like(y)
+                _lib.check(lib.dmc_bn_act_bwd(_lib.ptr(y), None, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(stats),
+                                              _lib.ptr(scratch), _lib.ptr(dout), _lib.ptr(dy), _lib.ptr(dres),
+                                              _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(mask), m, cout,
+                                              int(relu), _stream()), "dmc_bn_act_bwd")
         if want_dres and not relu:
             dres = dout
         addend = None
@@ -772,18 +934,37 @@ class _ConvBnAct(torch.autograd.Function):
                 addend, ctx.link.grad = ctx.link.grad, None
         wcl = _as_cl(weight)
         dx = dw = None
-        if ctx.needs_input_grad[0]:
-            with _span("conv_nhwc_dgrad"):
-                dx = _conv_dgrad(dy, wcl, x.shape, stride, padding, presplit=ctx.wsplit_t, addend=addend)
-        if ctx.needs_input_grad[1]:
-            with _span("conv_nhwc_wgrad"):
-                dw = _grad_like(_conv_wgrad(x, dy, wcl, stride, padding), weight)
-        return dx, dw, dres, dgamma, dbeta, None, None, None, None, None, None, None, None
+        if use_x3s:
+            nn_, _, h, w = x_shape
+            if ctx.needs_input_grad[0]:
+                with _span("conv_nhwc_dgrad"):
+                    dx = torch.empty(x_shape, dtype=torch.float32, device=y.device, memory_format=_CL)
+                    if addend is not None:
+                        addend = _as_cl(addend)
+                    _lib.check(lib.dmc_x3s_conv_dgrad(_lib.ptr(dys), _lib.ptr(ctx.wsplit_t), _lib.ptr(addend), _lib.ptr(dx),
+                                                      nn_, h, w, cin, cout, _stream()), "dmc_x3s_conv_dgrad")
+            if ctx.needs_input_grad[1]:
+                with _span("conv_nhwc_wgrad"):
+                    dwc = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=y.device, memory_format=_CL)
+                    work = _floats(lib.dmc_x3s_conv_wgrad_bytes(nn_, h, w, cin, cout), y.device)
+                    _lib.check(lib.dmc_x3s_conv_wgrad(_lib.ptr(x), _lib.ptr(dys), _lib.ptr(dwc), _lib.ptr(work), nn_, h, w, cin,
+                                                      cout, _stream()), "dmc_x3s_conv_wgrad")
+                    dw = _grad_like(dwc, weight)
+        else:
+            if ctx.needs_input_grad[0]:
+                with _span("conv_nhwc_dgrad"):
+                    dx = _conv_dgrad(dy, wcl, x.shape, stride, padding, presplit=ctx.wsplit_t, addend=addend)
+            if ctx.needs_input_grad[1]:
+                with _span("conv_nhwc_wgrad"):
+                    dw = _grad_like(_conv_wgrad(x, dy, wcl, stride, padding), weight)
+        return dx, dw, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
 def conv_bn_act_supported(x, conv, bn):
     """True if conv -> bn [-> add] [-> relu] can run as the fused NHWC training op."""
     if not (torch.is_grad_enabled() and bn.training and bn.track_running_stats and bn.affine):
+        return False
+    if bn.momentum is None:                       # cumulative moving average: the stock module handles it
         return False
     if conv.bias is not None or conv.dilation != (1, 1) or conv.groups != 1 or conv.padding_mode != "zeros":
         return False
@@ -797,17 +978,28 @@ def conv_bn_act_supported(x, conv, bn):
     return bool(_lib.load().dmc_bn_act_supported(n * oh * ow, conv.out_channels))
 
 
-def conv_bn_act(x, conv, bn, residual=None, relu=True, link=None):
+def conv_bn_act(x, conv, bn, residual=None, relu=True, link=None, want_f32=True, want_slices=False):
     """relu?(bn(conv(x)) [+ residual]) for a channels_last ``x`` (see conv_bn_act_supported); ``link``: the
-    ResidualGradLink shared by the first and the last op of an identity-shortcut block."""
+    ResidualGradLink shared by the first and the last op of an identity-shortcut block.  ``want_slices``: also write
+    the result's bf16x3 slice tensor (attached to the returned tensor, see x3s_of) for a pre-split consumer;
+    ``want_f32=False``: ONLY the slices -- the returned tensor's fp32 memory is then not written (f32_valid)."""
     if bn.num_batches_tracked is not None:
         if _PENDING_COUNTERS is not None:
             _PENDING_COUNTERS.append(bn.num_batches_tracked)
         else:
             bn.num_batches_tracked.add_(1)
-    return _ConvBnAct.apply(x, conv.weight, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                            conv.stride[0], conv.padding[0], relu, bn.eps,
-                            bn.momentum if bn.momentum is not None else 0.1, link)
+    if not want_f32 and not want_slices:
+        want_f32 = True
+    n, _, h, w = x.shape
+    use_x3s = x3s_usable(n, h, w, conv)
+    mode = int(want_f32) | (int(want_slices) << 1) | (int(use_x3s) << 2)
+    out, out_xs = _ConvBnAct.apply(x, conv.weight, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                   conv.stride[0], conv.padding[0], relu, bn.eps,
+                                   bn.momentum if bn.momentum is not None else 0.1, link,
+                                   x3s_of(x) if use_x3s else None, mode)
+    if want_slices:
+        _attach_x3s(out, out_xs, want_f32)
+    return out
 
 
 class _DiscBlock(torch.autograd.Function):

@@ -36,10 +36,17 @@ OWN_CONV = _os.environ.get("DMC_OWN_CONV", "1") != "0"
 RESIDUAL_GRAD_LINK = _os.environ.get("DMC_RESIDUAL_GRAD_LINK", "1") != "0"
 
 
-def _conv_bn_act(conv, bn, x, residual=None, relu=True, link=None):
-    """relu?(bn(conv(x)) [+ residual])"""
+def _conv_bn_act(conv, bn, x, residual=None, relu=True, link=None, next_conv=None, only_consumer=False):
+    """relu?(bn(conv(x)) [+ residual]).  ``next_conv``: a convolution that reads the result -- when it takes the
+    pre-split bf16x3 path (ops.x3s_usable) the result's slice tensor is written alongside; ``only_consumer``: nothing
+    else reads the result, so its fp32 form is not written at all."""
     if OWN_CONV and x.is_cuda and ops.conv_bn_act_supported(x, conv, bn):
-        return ops.conv_bn_act(x, conv, bn, residual, relu, link)
+        slices = False
+        if next_conv is not None:
+            n, _, h, w = x.shape
+            k, s_, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+            slices = ops.x3s_usable(n, (h + 2 * p - k) // s_ + 1, (w + 2 * p - k) // s_ + 1, next_conv)
+        return ops.conv_bn_act(x, conv, bn, residual, relu, link, want_f32=not (slices and only_consumer), want_slices=slices)
     return _bn_act(bn, conv(x), residual, relu)
 
 
@@ -75,6 +82,7 @@ class ResidualUnit(nn.Module):
         if stride != 1 or cin != cout:
             self.downsample = nn.Sequential(_conv(cin, cout, 1, stride), nn.BatchNorm2d(cout))
         self.out_channels = cout
+        self.next_conv = [None]      # the next unit's first convolution (set by ResNet; in a list: not a sub-module)
 
     def forward(self, x):
         link = None
@@ -84,11 +92,12 @@ class ResidualUnit(nn.Module):
             link = ops.ResidualGradLink() if RESIDUAL_GRAD_LINK and x.requires_grad else None
         else:
             shortcut = _conv_bn_act(self.downsample[0], self.downsample[1], x, relu=False)
-        y = _conv_bn_act(self.conv1, self.bn1, x, link=link)
+        # conv1's result is read by conv2 alone: slices only when conv2 takes the pre-split path
+        y = _conv_bn_act(self.conv1, self.bn1, x, link=link, next_conv=self.conv2, only_consumer=True)
         if self.kind == "basic":
-            return _conv_bn_act(self.conv2, self.bn2, y, residual=shortcut, link=link)
-        y = _conv_bn_act(self.conv2, self.bn2, y)
-        return _conv_bn_act(self.conv3, self.bn3, y, residual=shortcut, link=link)
+            return _conv_bn_act(self.conv2, self.bn2, y, residual=shortcut, link=link, next_conv=self.next_conv[0])
+        y = _conv_bn_act(self.conv2, self.bn2, y, next_conv=self.conv3, only_consumer=True)
+        return _conv_bn_act(self.conv3, self.bn3, y, residual=shortcut, link=link, next_conv=self.next_conv[0])
 
 
 class ResNet(nn.Module):
@@ -106,6 +115,9 @@ class ResNet(nn.Module):
                 width = unit.out_channels
                 units.append(unit)
             setattr(self, "layer%d" % (stage + 1), nn.Sequential(*units))
+        chain = [u for st in (self.layer1, self.layer2, self.layer3, self.layer4) for u in st]
+        for u, nxt in zip(chain, chain[1:]):
+            u.next_conv[0] = nxt.conv1
         self.avgpool = nn.AvgPool2d(7, stride=1)
         self.fc = nn.Linear(width, num_classes)
 
@@ -124,7 +136,10 @@ class ResNet(nn.Module):
         if (x.is_cuda and bn.track_running_stats and (bn.training or not torch.is_grad_enabled())
                 and mp.kernel_size == 3 and mp.stride == 2 and mp.padding == 1 and mp.dilation == 1
                 and not mp.ceil_mode and not mp.return_indices and ops.bn_relu_pool_supported(x)):
-            return ops.bn_relu_pool(x, bn)
+            n, _, h, w = x.shape
+            first = self.layer1[0].conv1
+            return ops.bn_relu_pool(x, bn, want_slices=OWN_CONV and torch.is_grad_enabled() and bn.training and
+                                    ops.x3s_usable(n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, first))
         return mp(_bn_act(bn, x))
 
     def forward(self, x):

@@ -317,6 +317,54 @@ size_t dmc_conv_nhwc_wgrad_bytes(int N, int H, int W, int Cin, int Cout, int KH,
 int dmc_conv_nhwc_wgrad(const float* x, const float* dy, float* dw, float* workspace, int N, int H, int W,
                         int Cin, int Cout, int KH, int KW, int stride, int pad, dmc_stream_t stream);
 
+/* ---- 3x3 / stride-1 convolutions on PRE-SPLIT bf16x3 operands (conv_x3s.hip) ---------------------------------
+ * Replaces: the stride-1 3x3 convolutions of the ResNet-18 classifier (torchvision BasicBlock behind
+ *           code/dmcnet/model.py:305, run at :352) and their autograd, in the same bf16x3 arithmetic as
+ *           dmc_conv_nhwc_* (fp32 products from three bf16 slices per operand), with the split moved to the PRODUCER of
+ *           each activation: every operand arrives as a "slice tensor"
+ *               bf16 [3 slices][C / 16][M pixels][16 channels]        (dmc_x3s_slices_bytes(M, C) = 6 M C bytes)
+ *           whose three slices sum to the fp32 value exactly.  dmc_x3s_split / dmc_x3s_merge convert from / to the
+ *           fp32 [M][C] (channels_last) tensor; the BatchNorm kernels below write slice tensors directly.
+ * Weights: dmc_x3s_pack_weights() packs w [Cout][3][3][Cin] (channels_last memory of the PyTorch weight) once per step
+ *           into the forward's and / or the data gradient's image (dmc_x3s_wpack_bytes() each; either may be NULL).
+ * fwd:     y [M][Cout] fp32 = conv3x3(x, w), padding 1, stride 1; stat_partials (nullable) receives the per-channel
+ *           (sum, sum of squares) of y per workgroup row, [dmc_x3s_conv_stat_blocks()][Cout][2] doubles, for
+ *           dmc_conv_nhwc_stats_final().
+ * dgrad:   dx [M][Cin] fp32 = conv_transpose(dy, w) [+ addend, nullable: the residual branch's gradient].
+ * Cin % 64 == 0, Cout % 64 == 0; dmc_x3s_conv_supported() says whether a shape is handled.  Deterministic. */
+size_t dmc_x3s_slices_bytes(long M, int C);
+int dmc_x3s_split(const float* x, void* xs, long M, int C, dmc_stream_t stream);
+int dmc_x3s_merge(const void* xs, float* x, long M, int C, dmc_stream_t stream);
+size_t dmc_x3s_wpack_bytes(int Cin, int Cout);
+int dmc_x3s_pack_weights(const float* w, void* wpack_f, void* wpack_t, int Cin, int Cout, dmc_stream_t stream);
+int dmc_x3s_conv_supported(int N, int H, int W, int Cin, int Cout);
+int dmc_x3s_conv_stat_blocks(int N, int H, int W, int Cout);
+int dmc_x3s_conv_fwd(const void* xs, const void* wpack_f, float* y, double* stat_partials, int N, int H, int W, int Cin,
+                     int Cout, dmc_stream_t stream);
+int dmc_x3s_conv_dgrad(const void* dys, const void* wpack_t, const float* addend, float* dx, int N, int H, int W, int Cin,
+                       int Cout, dmc_stream_t stream);
+/* wgrad: dw [Cout][3][3][Cin] fp32 (channels_last memory of the PyTorch gradient) from the slice tensors of x and dy;
+ * workspace of dmc_x3s_conv_wgrad_bytes() (per-workgroup-row partials, summed in fixed order).  W in {56, 28, 14, 7}. */
+int dmc_x3s_conv_wgrad_supported(int N, int H, int W, int Cin, int Cout);
+size_t dmc_x3s_conv_wgrad_bytes(int N, int H, int W, int Cin, int Cout);
+int dmc_x3s_conv_wgrad(const void* xs, const void* dys, float* dw, float* workspace, int N, int H, int W, int Cin, int Cout,
+                       dmc_stream_t stream);
+
+/* Producers of slice tensors (bn_act.hip): the BatchNorm kernels above with the result written as fp32 (nullable) and / or
+ * as a bf16x3 slice tensor (nullable), C % 16 == 0 -- the forward's activation for the next convolution
+ * (dmc_bn_apply_act_nhwc / dmc_bn_relu_pool_fwd semantics), the backward's convolution-output gradient (dmc_bn_act_bwd
+ * semantics) for that convolution's dmc_x3s_conv_dgrad / dmc_x3s_conv_wgrad. */
+int dmc_bn_apply_act_x3s(const float* x, const float* residual, const float* gamma, const float* beta, const float* stats,
+                         float* y, void* ys, unsigned char* relu_mask, int M, int C, int relu, dmc_stream_t stream);
+int dmc_bn_act_bwd_x3s(const float* x, const float* residual, const float* gamma, const float* beta, const float* stats,
+                       void* scratch, const float* dy, float* dx, void* dxs, float* dresidual, float* dgamma, float* dbeta,
+                       const unsigned char* relu_mask, int M, int C, int relu, dmc_stream_t stream);
+int dmc_bn_relu_pool_fwd_x3s(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                             float* y_pool, void* ys, float* stats, void* scratch, int N, int H, int W, int C, int training,
+                             float eps, float momentum, dmc_stream_t stream);
+
+
+
 /* ---- first discriminator block: Conv2d(2, Cout, 3, stride 2, padding 1) on the NCHW cue ------------
  * Replaces the convolution (+ LeakyReLU(0.2) + Dropout2d keep mask) of `discriminator_block(ch_in, 16,
  * bn=False)`, code/dmcnet_GAN/model.py:254-265 as used at :287,:308,:334,:371,:400, and its autograd.

@@ -1,0 +1,234 @@
+"""GPU tests of the pre-split bf16x3 convolution path (dmc-net_amd/csrc/conv_x3s.hip and its producers in bn_act.hip),
+through the C ABI: slice tensors, the 3x3 / stride-1 convolution and both gradients against an fp64 evaluation of
+F.conv2d (the arithmetic of the torchvision BasicBlock convolutions behind code/dmcnet/model.py:305,352), the slice-writing
+BatchNorm / pool kernels bit for bit against their fp32 forms, and the fused conv -> bn op in this mode against the stock
+modules.  Bars: 1e-5 relative on convolution results (fp32-accurate products, as the in-loop-split kernels), bit equality
+wherever the same fp32 arithmetic is only stored differently."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import dmcnet_amd
+from dmcnet_amd import ops, resnet
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+CL = torch.channels_last
+
+
+def rnd(seed, shape):
+    return torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32))
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def test_split_merge_round_trip_is_exact():
+    """s0 + s1 + s2 reproduces every finite fp32 value exactly (normal, tiny, huge, exact bf16 values); the only bit pattern
+    that changes is -0.0, which comes back as +0.0 (its remainder slices are +0)."""
+    rs = np.random.RandomState(3)
+    v = rs.standard_normal((3, 64, 9, 7)).astype(np.float32)
+    v *= np.exp(rs.uniform(-40, 40, v.shape)).astype(np.float32)
+    v.flat[:8] = [0.0, -0.0, 1.0, -1.5, 3.0e38, -3.0e38, 1.0e-30, 2.0 ** -100]
+    x = torch.from_numpy(v).to(DEV).contiguous(memory_format=CL)
+    xs = ops.x3s_split(x)
+    back = ops.x3s_merge(xs, tuple(x.shape))
+    assert torch.equal(back, x)
+    nz = x != 0
+    assert torch.equal(back.view(torch.int32)[nz], x.view(torch.int32)[nz])
+    assert xs.numel() == x.numel() * 6
+
+
+X3S_CASES = [
+    (2, 64, 56, 56, 64),         # layer1: 256-pixel tiles, tiles crossing image rows
+    (3, 128, 28, 28, 128),       # layer2
+    (2, 256, 14, 14, 256),       # layer3
+    (5, 512, 7, 7, 512),         # layer4: whole padded images per weight-gradient step
+    (3, 64, 28, 28, 128),        # Cin != Cout
+    (1, 128, 14, 14, 64),
+    (7, 64, 7, 7, 64),           # tiles spanning several images
+    (2, 64, 10, 14, 64),         # H != W
+    (2, 128, 30, 28, 64),
+    (37, 64, 14, 14, 64),        # enough pixels for the 256-pixel configuration on 14 x 14 images
+]
+
+
+@pytest.mark.parametrize("case", X3S_CASES)
+def test_x3s_conv_fwd_dgrad_wgrad_vs_fp64(case):
+    n, cin, h, w, cout = case
+    lib = dmcnet_amd._lib.load()
+    assert lib.dmc_x3s_conv_supported(n, h, w, cin, cout) and lib.dmc_x3s_conv_wgrad_supported(n, h, w, cin, cout)
+    x, wt = rnd(301, (n, cin, h, w)), rnd(302, (cout, cin, 3, 3)) * 0.1
+    xo, wo = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    yo = F.conv2d(xo, wo, None, 1, 1)
+    go = rnd(303, tuple(yo.shape))
+    (yo * go.double()).sum().backward()
+    xg = x.to(DEV).contiguous(memory_format=CL)
+    wg = wt.to(DEV).contiguous(memory_format=CL)
+    gg = go.to(DEV).contiguous(memory_format=CL)
+    xs, dys = ops.x3s_split(xg), ops.x3s_split(gg)
+    wf, wtr = ops.x3s_pack_weights(wg)
+    y, part = ops.x3s_conv_fwd(xs, wf, n, h, w, cin, cout, want_stats=True)
+    dx = ops.x3s_conv_dgrad(dys, wtr, n, h, w, cin, cout)
+    dw = ops.x3s_conv_wgrad(xs, dys, n, h, w, cin, cout)
+    assert rel_err(y, yo) < 1e-5
+    assert rel_err(dx, xo.grad) < 1e-5
+    assert rel_err(dw, wo.grad) < 1e-5
+    assert y.is_contiguous(memory_format=CL) and dw.is_contiguous(memory_format=CL)
+    # BatchNorm partials of the forward's epilogue = the sums of the STORED outputs
+    s = part.sum(0).cpu()
+    yd = y.double().permute(1, 0, 2, 3).reshape(cout, -1).cpu()
+    assert float((s[:, 0] - yd.sum(1)).abs().max()) <= 1e-9 * float(yd.abs().sum(1).max())
+    assert float((s[:, 1] - (yd * yd).sum(1)).abs().max()) <= 1e-9 * float((yd * yd).sum(1).max())
+    # the addend of the data gradient (the residual branch's gradient) is added exactly once, in fp32
+    add = rnd(304, (n, cin, h, w)).to(DEV).contiguous(memory_format=CL)
+    assert torch.equal(ops.x3s_conv_dgrad(dys, wtr, n, h, w, cin, cout, addend=add), dx + add)
+    # deterministic
+    y2, part2 = ops.x3s_conv_fwd(xs, wf, n, h, w, cin, cout, want_stats=True)
+    assert torch.equal(y, y2) and torch.equal(part, part2)
+    assert torch.equal(dx, ops.x3s_conv_dgrad(dys, wtr, n, h, w, cin, cout))
+    assert torch.equal(dw, ops.x3s_conv_wgrad(xs, dys, n, h, w, cin, cout))
+
+
+def test_x3s_conv_unsupported_shapes_are_refused():
+    lib = dmcnet_amd._lib.load()
+    assert not lib.dmc_x3s_conv_supported(2, 14, 14, 48, 64)          # Cin % 64
+    assert not lib.dmc_x3s_conv_wgrad_supported(2, 13, 13, 64, 64)    # width without a weight-gradient configuration
+    xs = torch.zeros(16, dtype=torch.uint8, device=DEV)
+    y = torch.zeros(16, device=DEV)
+    assert lib.dmc_x3s_conv_fwd(dmcnet_amd._lib.ptr(xs), dmcnet_amd._lib.ptr(xs), dmcnet_amd._lib.ptr(y), None, 2, 14, 14, 48, 64,
+                                None) != 0
+
+
+@pytest.mark.parametrize("m,c,relu,res", [(3 * 28 * 28, 128, 1, 1), (2 * 56 * 56, 64, 1, 0), (5 * 7 * 7, 512, 0, 1), (977, 64, 0, 0)])
+def test_bn_producers_bit_identical_to_fp32_forms(m, c, relu, res):
+    """dmc_bn_apply_act_x3s / dmc_bn_act_bwd_x3s: fp32 outputs, ReLU mask, dgamma / dbeta bit-identical to
+    dmc_bn_apply_act_nhwc / dmc_bn_act_bwd, and the slice tensors are exactly the split of those fp32 outputs."""
+    L, lib = dmcnet_amd._lib, dmcnet_amd._lib.load()
+    st = ops._stream()
+    x = rnd(311, (m, c)).to(DEV)
+    r = rnd(312, (m, c)).to(DEV) if res else None
+    gamma, beta = (rnd(313, (c,)) * 0.5 + 1).to(DEV), rnd(314, (c,)).to(DEV)
+    stats = torch.cat([rnd(315, (c,)) * 0.1, rnd(316, (c,)).abs() + 0.5]).to(DEV)
+    mask_a = torch.zeros(m * c // 4, dtype=torch.uint8, device=DEV) if (relu and res) else None
+    mask_b = torch.zeros(m * c // 4, dtype=torch.uint8, device=DEV) if (relu and res) else None
+    ya, yb = torch.empty_like(x), torch.empty_like(x)
+    ys = torch.empty(lib.dmc_x3s_slices_bytes(m, c), dtype=torch.uint8, device=DEV)
+    L.check(lib.dmc_bn_apply_act_nhwc(L.ptr(x), L.ptr(r), L.ptr(gamma), L.ptr(beta), L.ptr(stats), L.ptr(ya), L.ptr(mask_a),
+                                      m, c, relu, st), "a")
+    L.check(lib.dmc_bn_apply_act_x3s(L.ptr(x), L.ptr(r), L.ptr(gamma), L.ptr(beta), L.ptr(stats), L.ptr(yb), L.ptr(ys),
+                                     L.ptr(mask_b), m, c, relu, st), "b")
+    assert torch.equal(ya, yb)
+    if mask_a is not None:
+        assert torch.equal(mask_a, mask_b)
+    ref = torch.empty_like(ys)
+    L.check(lib.dmc_x3s_split(L.ptr(ya), L.ptr(ref), m, c, st), "split")
+    assert torch.equal(ys, ref)
+    # slices only (no fp32 output)
+    ys2 = torch.empty_like(ys)
+    L.check(lib.dmc_bn_apply_act_x3s(L.ptr(x), L.ptr(r), L.ptr(gamma), L.ptr(beta), L.ptr(stats), None, L.ptr(ys2),
+                                     L.ptr(mask_b), m, c, relu, st), "c")
+    assert torch.equal(ys, ys2)
+    # backward
+    dout = rnd(317, (m, c)).to(DEV)
+    scratch = ops._floats(lib.dmc_bn_act_scratch_bytes(c), DEV)
+    outs = []
+    for form in (0, 1):
+        dx, dres = torch.empty_like(x), (torch.empty_like(x) if (res and relu) else None)
+        dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+        dxs = torch.empty_like(ys)
+        rr = r if (relu and mask_a is None) else None
+        if form == 0:
+            L.check(lib.dmc_bn_act_bwd(L.ptr(x), L.ptr(rr), L.ptr(gamma), L.ptr(beta), L.ptr(stats), L.ptr(scratch), L.ptr(dout),
+                                       L.ptr(dx), L.ptr(dres), L.ptr(dg), L.ptr(db), L.ptr(mask_a), m, c, relu, st), "d")
+            L.check(lib.dmc_x3s_split(L.ptr(dx), L.ptr(dxs), m, c, st), "split")
+        else:
+            L.check(lib.dmc_bn_act_bwd_x3s(L.ptr(x), L.ptr(rr), L.ptr(gamma), L.ptr(beta), L.ptr(stats), L.ptr(scratch), L.ptr(dout),
+                                           L.ptr(dx), L.ptr(dxs), L.ptr(dres), L.ptr(dg), L.ptr(db), L.ptr(mask_a), m, c, relu, st), "e")
+        outs.append((dx, dres, dg, db, dxs))
+    for a, b in zip(*outs):
+        assert (a is None and b is None) or torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 112, 112), (2, 64, 17, 23), (2, 128, 8, 8)])
+def test_pool_slices_match_fp32_form(shape):
+    n, c, h, w = shape
+    x = rnd(321, shape).to(DEV).contiguous(memory_format=CL)
+    bn = torch.nn.BatchNorm2d(c).to(DEV).train()
+    bn2 = torch.nn.BatchNorm2d(c).to(DEV).train()
+    y0 = ops.bn_relu_pool(x, bn)
+    y1 = ops.bn_relu_pool(x, bn2, want_slices=True)
+    assert torch.equal(y0, y1) and ops.x3s_of(y0) is None
+    assert torch.equal(ops.x3s_of(y1), ops.x3s_split(y1))
+    assert torch.equal(bn.running_var, bn2.running_var)
+
+
+@pytest.mark.parametrize("cin,planes,hw,n,seed", [(64, 64, 14, 6, 331), (128, 128, 28, 3, 338), (64, 64, 56, 2, 342), (512, 512, 7, 5, 339)])
+def test_basic_block_presplit_vs_in_loop_split_and_stock(cin, planes, hw, n, seed, monkeypatch):
+    """An identity-shortcut BasicBlock in training mode: (a) pre-split path (conv1 reads the input's slices, writes ONLY
+    slices for conv2; both convolutions, their gradients and the residual link on conv_x3s.hip), (b) the in-loop-split kernels,
+    (c) the stock modules in fp64.  (a) and (b) use the same bf16x3 products in a different summation order: both within
+    the usual bars of (c), BatchNorm statistics included.  The input seeds are chosen so that no ReLU pre-activation of the
+    block lies within fp32 rounding of zero (asserted below on the fp64 evaluation): a branch that flips with the
+    summation order moves a whole channel's dbeta by one pixel's gradient, in ANY fp32 implementation."""
+    monkeypatch.setattr(resnet, "OWN_CONV", True)
+    torch.manual_seed(7)
+    unit = resnet.ResidualUnit("basic", cin, planes, 1).to(DEV).train()
+    state = {k: v.clone() for k, v in unit.state_dict().items()}
+    x0 = rnd(seed, (n, cin, hw, hw)).to(DEV).contiguous(memory_format=CL)
+    go = rnd(332, (n, cin, hw, hw)).to(DEV).contiguous(memory_format=CL)
+    res = {}
+    for mode in (True, False):
+        monkeypatch.setattr(ops, "X3S", mode)
+        unit.load_state_dict(state)
+        unit.zero_grad(set_to_none=True)
+        x = (x0 * 1.0).requires_grad_(True)
+        x.retain_grad()
+        if mode:
+            assert ops.x3s_usable(n, hw, hw, unit.conv1) and ops.x3s_usable(n, hw, hw, unit.conv2)
+            ops._attach_x3s(x, ops.x3s_split(x.detach()))
+        out = unit(x)
+        (out * go).sum().backward()
+        res[mode] = [out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in unit.parameters()] + \
+                    [unit.bn1.running_var.clone(), unit.bn2.running_mean.clone()]
+    monkeypatch.setattr(resnet, "OWN_CONV", False)
+    ref = resnet.ResidualUnit("basic", cin, planes, 1).double().train()
+    ref.load_state_dict({k: v.cpu().double() if v.is_floating_point() else v.cpu() for k, v in state.items()})
+    xr = x0.cpu().double().requires_grad_(True)
+    with torch.no_grad():                          # conditioning of the test data: ReLU margins of the fp64 evaluation
+        refc = resnet.ResidualUnit("basic", cin, planes, 1).double().train()
+        refc.load_state_dict(ref.state_dict())
+        p1 = refc.bn1(refc.conv1(xr))
+        p2 = refc.bn2(refc.conv2(torch.relu(p1))) + xr
+        assert float(p1.abs().min()) > 4e-6 and float(p2.abs().min()) > 4e-6, "pick another input seed"
+    outr = ref(xr)
+    (outr * go.cpu().double()).sum().backward()
+    want = [outr, xr.grad] + [p.grad for p in ref.parameters()] + [ref.bn1.running_var, ref.bn2.running_mean]
+    for mode in (True, False):
+        assert rel_err(res[mode][0], want[0]) < 1e-5
+        assert rel_err(res[mode][1], want[1]) < 2e-5
+        for a, b in zip(res[mode][2:], want[2:]):
+            assert rel_err(a, b) < 2e-4
+    for a, b in zip(res[True], res[False]):
+        assert rel_err(a, b) < 2e-4
+
+
+def test_fp32_memory_of_a_slices_only_result_is_guarded(monkeypatch):
+    """conv_bn_act(want_f32=False) does not write the fp32 result: a consumer that needs it must fail loudly."""
+    monkeypatch.setattr(resnet, "OWN_CONV", True)
+    torch.manual_seed(9)
+    conv = torch.nn.Conv2d(64, 64, 3, 1, 1, bias=False).to(DEV).to(memory_format=CL)
+    bn = torch.nn.BatchNorm2d(64).to(DEV).train()
+    x = rnd(341, (2, 64, 14, 14)).to(DEV).contiguous(memory_format=CL).requires_grad_(True)
+    y = ops.conv_bn_act(x, conv, bn, want_f32=False, want_slices=True)
+    assert not ops.f32_valid(y) and ops.x3s_of(y) is not None
+    conv1x1 = torch.nn.Conv2d(64, 64, 1, 1, 0, bias=False).to(DEV).to(memory_format=CL)
+    with pytest.raises(RuntimeError):
+        ops.conv_bn_act(y, conv1x1, bn)
+    z = ops.conv_bn_act(y, conv, bn)                 # a pre-split consumer is fine
+    full = ops.conv_bn_act(x, conv, bn, want_f32=True, want_slices=True)
+    assert torch.equal(ops.x3s_of(full), ops.x3s_of(y)) and torch.equal(ops.x3s_merge(ops.x3s_of(y), tuple(y.shape)), full)
+    assert torch.isfinite(z).all()
