@@ -424,17 +424,23 @@ int x3s_choose(int N, int H, int W, int R) {
     const long M = (long)N * H * W;
     const int forced = option(OPT_CONV_CFG);                 // measurement switch: 101 + configuration
     if (forced >= 101 && forced <= 103 && patch_pixels_max(N, H, W, X3CFGS[forced - 101].BM) <= X3CFGS[forced - 101].PPMAX) return forced - 101;
-    // the largest tile that still gives the 256 CUs two workgroups each; else the smallest one whose patch fits
+    // the largest tile whose workgroups still cover most of the 256 CUs (measured, 120 frames: 8-wave workgroups of 256
+    // pixels win down to layer4's 184 workgroups -- 160-187 TFLOP/s against 123-133 with 64-pixel tiles); else the
+    // smallest tile whose patch fits
     int fallback = -1;
     for (const X3Cfg& c : X3CFGS) {
         if (patch_pixels_max(N, H, W, c.BM) > c.PPMAX) continue;
         const long wgs = ((M + c.BM - 1) / c.BM) * (R / 64);
-        if (wgs >= 512) return c.id;
+        if (wgs >= 160) return c.id;
         fallback = c.id;
     }
     return fallback;
 }
 
+// Measured and not kept (profiles/r3_x3s_persistent_ab.txt): a persistent form -- one workgroup per CU walking tiles, the
+// transfer pipeline running across tiles (no tile starts by waiting for HBM), transfers issued by half of the waves at a
+// time.  Correct, but 3-6 % SLOWER on every layer (layer1 forward 0.150 vs 0.141 ms): two tile geometries and the
+// cross-tile cases cost 108 spilled SGPRs and 250 wave-uniform branches in the step bodies, more than the hidden prologue.
 template <int WM, int TM, int PPMAX>
 int launch_x3s(const X3Args& a, hipStream_t s) {
     constexpr int BM = 32 * TM * WM;

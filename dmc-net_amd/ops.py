@@ -437,6 +437,7 @@ class _BnReluPool(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, eps, momentum, want_slices=False):
         lib = _lib.load()
         _need_cuda(x, gamma, beta)
+        ctx.set_materialize_grads(False)
         n, c, h, w = x.shape
         ph, pw = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         y = torch.empty((n, c, ph, pw), dtype=x.dtype, device=x.device,
@@ -468,6 +469,8 @@ class _BnReluPool(torch.autograd.Function):
     def backward(ctx, dy, _dys):
         lib = _lib.load()
         x, gamma, beta, stats = ctx.saved_tensors
+        if dy is None:
+            return (None,) * 9
         if not ctx.training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not implemented")
         n, c, h, w = x.shape
@@ -824,6 +827,7 @@ class _ConvBnAct(torch.autograd.Function):
                 momentum, link=None, xs=None, mode=1):
         lib = _lib.load()
         _need_cuda(x, weight, residual, gamma, beta)
+        ctx.set_materialize_grads(False)    # else autograd zero-fills a gradient for the slice output every backward
         want_f32, want_xs, use_x3s = bool(mode & 1), bool(mode & 2), bool(mode & 4)
         wcl = _as_cl(weight)
         cout, cin = weight.shape[0], weight.shape[1]
@@ -901,6 +905,8 @@ class _ConvBnAct(torch.autograd.Function):
     def backward(ctx, dout, _dxs):
         lib = _lib.load()
         x, weight, y, gamma, beta, stats, mask = ctx.saved_tensors
+        if dout is None:                    # the result did not reach the loss
+            return (None,) * 15
         stride, padding, relu, has_res, use_x3s, x_shape = ctx.cfg
         n, cout, oh, ow = y.shape
         m = n * oh * ow
