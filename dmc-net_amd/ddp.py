@@ -24,6 +24,8 @@ reduced), a set that produced no gradient costs nothing, and ``finish()`` only w
 xGMI is point to point, so a ring all-reduce is bound by one link (~153 GB/s): the 44.8 MB of
 ResNet-18 gradients cost ~0.5 ms; a few large buckets in reverse execution order are enough.
 """
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -84,6 +86,12 @@ class GradBucketReducer(object):
         #: what the last begin()..finish() reduced: [(set name, bucket index, bytes, where)] with
         #: where = "hook" (launched from backward) or "finish" (a partially filled bucket)
         self.last_reduced = []
+        #: exposed communication: time spent in finish() waiting for exchanges launched from the hooks (device time
+        #: from HIP events on the compute stream when the buckets live on the GPU, host time otherwise)
+        self.time_waits = False
+        self._wait_events = []
+        self._wait_host_s = 0.0
+        self._finished_steps = 0
         if self.world > 1 and broadcast_from is not None:
             for p in self.params:
                 dist.broadcast(p.data, src=broadcast_from, group=group)
@@ -163,11 +171,48 @@ class GradBucketReducer(object):
                     if p not in self._seen:
                         flat[off:off + n].zero_()
                 self._launch(b, "finish")
+        timed = self.time_waits and bool(self._works)
+        on_gpu = timed and self.buckets[0][0].is_cuda
+        if on_gpu:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        t0 = time.perf_counter()
         for b, work in self._works:
             work.wait()
             if not self._use_avg:
                 self.buckets[b][0].div_(self.world)
+        if on_gpu:
+            e1.record()
+            self._wait_events.append((e0, e1))
+        if timed:
+            self._wait_host_s += time.perf_counter() - t0
+        if self.time_waits:
+            self._finished_steps += 1
         self._works = []
+
+    def comm_summary(self, reset=True):
+        """What a multi-GPU run should look at first: the communicator this reducer really uses (backend, world size),
+        the bucket plan, what the LAST step exchanged per parameter set, and the exposed communication per step (the wait
+        in finish(); everything else overlapped the backward pass) accumulated since ``time_waits`` was set."""
+        exposed_ms = None
+        steps = self._finished_steps
+        if self._wait_events:
+            torch.cuda.synchronize()
+            exposed_ms = sum(a.elapsed_time(b) for a, b in self._wait_events)
+        out = {
+            "backend": dist.get_backend(self.group) if dist.is_initialized() else None,
+            "world_size": self.world,
+            "buckets": [{"set": name, "bytes": flat.numel() * flat.element_size()} for (flat, _), name in zip(self.buckets, self.bucket_set)],
+            "reduce_op": "avg" if self._use_avg else "sum, then / world",
+            "last_step_bytes_by_set": self.reduced_bytes(by_set=True),
+            "last_step_launched_from": sorted(set(w for _, _, _, w in self.last_reduced)),
+            "timed_steps": steps,
+            "exposed_wait_ms_per_step": None if (exposed_ms is None or not steps) else round(exposed_ms / steps, 4),
+            "exposed_wait_host_ms_per_step": round(1e3 * self._wait_host_s / steps, 4) if steps else None,
+        }
+        if reset:
+            self._wait_events, self._wait_host_s, self._finished_steps = [], 0.0, 0
+        return out
 
     def reduced_bytes(self, by_set=False):
         """Bytes all-reduced by the last step (optionally per parameter set)."""

@@ -12,6 +12,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: BASELINE-size cases that take tens of seconds on the GPU (still part of -m gpu)")
 
 
 @pytest.fixture(scope="session")

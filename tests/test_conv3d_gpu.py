@@ -284,22 +284,25 @@ def test_i3d_stem_forward_and_unit_vs_stock(shape):
         assert err < tol, (name, err)
 
 
-def test_i3d_trunk_end_to_end_own_vs_stock_bf16():
-    """The whole I3D trunk (stem, 57 conv -> BatchNorm3d -> ReLU units, 13 pools, head) under bf16 autocast on a 16-frame
-    224x224 cue: this package's 3-D kernels and the stock PyTorch-ROCm bf16 ops, from the same weights, are both compared
-    with the fp32 trunk (no autocast).  bf16 gradients of a random-init network decorrelate with depth (ReLU / max-pool
-    routing and BatchNorm cancellation amplify 8-bit rounding: the stock bf16 path itself reaches only cos ~0.4 against
-    fp32 at the stem), so the bar is relative: per watched tensor, the own path must be as close to the fp32 gradients as
-    the stock bf16 path is (cosine similarity, 0.15 slack: the stock path itself varies from run to run through its atomic pool backward); logits cos > 0.99; running statistics to 1e-2."""
+@pytest.mark.parametrize("clips,frames", [(2, 16), pytest.param(3, 64, marks=pytest.mark.slow)])
+def test_i3d_trunk_end_to_end_own_vs_stock_bf16(clips, frames):
+    """The whole I3D trunk (stem, 57 conv -> BatchNorm3d -> ReLU units, 13 pools, head) under bf16 autocast on a 224x224 cue
+    -- 2 clips x 16 frames, and config 5's real micro-step, 3 clips x 64 frames (code/dmcnet_I3D train.sh) --: this
+    package's 3-D kernels and the stock PyTorch-ROCm bf16 ops, from the same weights, are both compared with the fp32 trunk
+    (no autocast).  bf16 gradients of a random-init network decorrelate with depth (ReLU / max-pool routing and BatchNorm
+    cancellation amplify 8-bit rounding: the stock bf16 path itself reaches only cos ~0.4 against fp32 at the stem), so the
+    bar is relative: per watched tensor, the own path (deterministic) must be as close to the fp32 gradients as the stock
+    bf16 path is ON AVERAGE over three stock runs (its pool backward scatters with atomics and varies from run to run), with
+    0.08 slack (measured gaps: -0.004 .. +0.059, the largest on a BatchNorm3d weight deep in the trunk), and never below an absolute floor; logits cos > 0.99; running statistics to 1e-2."""
     import copy
     torch.manual_seed(21)
     net = i3d.I3D(51, modality="flow").to(DEV).train()
     net.trunk_dtype = torch.bfloat16
-    ref = copy.deepcopy(net)
+    stocks = [copy.deepcopy(net) for _ in range(3)]
     ref32 = copy.deepcopy(net)
     ref32.trunk_dtype = None
-    x = torch.randn(2, 2, 16, 224, 224, device=DEV)
-    tgt = torch.tensor([3, 40], device=DEV)
+    x = torch.randn(clips, 2, frames, 224, 224, device=DEV)
+    tgt = torch.tensor([3, 40, 17][:clips], device=DEV)
 
     def run(model, own):
         i3d.OWN_CONV3D = own
@@ -310,20 +313,24 @@ def test_i3d_trunk_end_to_end_own_vs_stock_bf16():
             i3d.OWN_CONV3D = True
         return out.detach().float()
 
-    lo, ls, l32 = run(net, True), run(ref, False), run(ref32, False)
+    lo, l32 = run(net, True), run(ref32, False)
+    ls = [run(m, False) for m in stocks]
 
     def cos(a, b):
         a, b = a.flatten().double(), b.flatten().double()
         return float((a * b).sum() / (a.norm() * b.norm()).clamp_min(1e-30))
 
-    assert cos(lo, l32) > 0.99 and cos(ls, l32) > 0.99, (cos(lo, l32), cos(ls, l32))
-    pn, pr, p32 = dict(net.named_parameters()), dict(ref.named_parameters()), dict(ref32.named_parameters())
+    assert cos(lo, l32) > 0.99 and min(cos(l, l32) for l in ls) > 0.99, (cos(lo, l32), [cos(l, l32) for l in ls])
+    pn, p32 = dict(net.named_parameters()), dict(ref32.named_parameters())
+    prs = [dict(m.named_parameters()) for m in stocks]
     for k in ("conv3d_1a_7x7.conv3d.weight", "conv3d_2c_3x3.conv3d.weight", "mixed_3b.branch_1.1.conv3d.weight",
               "mixed_4c.branch_2.1.batch3d.weight", "mixed_4f.branch_0.conv3d.weight", "mixed_5c.branch_3.1.conv3d.weight",
               "classifier.weight"):
-        c_own, c_stock = cos(pn[k].grad, p32[k].grad), cos(pr[k].grad, p32[k].grad)
-        print("  grad cos vs fp32  %-42s own %.4f  stock bf16 %.4f  (own vs stock %.4f)" % (k, c_own, c_stock, cos(pn[k].grad, pr[k].grad)))
-        assert c_own > c_stock - 0.15, (k, c_own, c_stock)
+        c_own = cos(pn[k].grad, p32[k].grad)
+        c_stock = sum(cos(pr[k].grad, p32[k].grad) for pr in prs) / len(prs)
+        print("  grad cos vs fp32  %-42s own %.4f  stock bf16 (mean of 3) %.4f" % (k, c_own, c_stock))
+        assert c_own > c_stock - 0.08, (k, c_own, c_stock)
+        assert c_own > 0.25, (k, c_own)                      # recorded values: 0.43 (stem) .. 0.99 (head)
     bn, b32 = dict(net.named_buffers()), dict(ref32.named_buffers())
     for k in ("conv3d_2c_3x3.batch3d.running_var", "mixed_4d.branch_1.1.batch3d.running_mean", "mixed_5c.branch_0.batch3d.running_var"):
         assert float((bn[k] - b32[k]).abs().max() / b32[k].abs().max().clamp_min(1e-6)) < 1e-2, k

@@ -107,12 +107,14 @@ def test_dmcnet_step_full_batch_vs_oracle(num_class):
                      ["base_model.conv1.weight", "base_model.layer4.1.conv2.weight"], 0.25)
 
 
-def test_gan_step_pair_full_batch_vs_oracle():
-    """Config 3 at B=40: a D step (240 frames through Discriminator3, classifier + discriminator
-    step) followed by a G step (generator steps), Dropout2d masks forced to the oracle's."""
-    o, m = _pair(51, True, 143)
-    b0 = O.synthetic_batch(seed=144, batch=40, num_segments=3, num_class=51)
-    b1 = O.synthetic_batch(seed=145, batch=40, num_segments=3, num_class=51)
+@pytest.mark.parametrize("num_class", [51, 101])
+def test_gan_step_pair_full_batch_vs_oracle(num_class):
+    """Config 3 at B=40 (C=51) and config 4's per-rank workload (dmcnet_GAN on UCF-101, C=101,
+    code/dmcnet_GAN/train.py:43-44,261-371): a D step (240 frames through Discriminator3, classifier +
+    discriminator step) followed by a G step (generator steps), Dropout2d masks forced to the oracle's."""
+    o, m = _pair(num_class, True, 143)
+    b0 = O.synthetic_batch(seed=144, batch=40, num_segments=3, num_class=num_class)
+    b1 = O.synthetic_batch(seed=145, batch=40, num_segments=3, num_class=num_class)
     md = O.seeded_dropout_masks(146, o.discriminator, 240)
     mg = O.seeded_dropout_masks(147, o.discriminator, 120)
     oopts = O.make_optimizers(o, lr_d_mult=HP["lr_d_mult"], **OPT)
@@ -139,6 +141,40 @@ def test_gan_step_pair_full_batch_vs_oracle():
             # MIOpen 0.23, fp32 MFMA 0.30, bf16x3 0.28) -- a property of the comparison, not of the kernels.  The
             # generator's optimizer has not stepped yet, so no optimizer state is lost.
             m.load_state_dict(o.state_dict())
+
+
+@pytest.mark.parametrize("gan", [False, True])
+def test_full_batch_step_is_bitwise_deterministic(gan):
+    """Two B=40 steps from the same state on the same batch (a D step + a G step for the GAN variant): every kernel of
+    the default path has a fixed reduction order (no atomics; the convolutions, BatchNorm sums, weight gradients and
+    the generator reduce partials in a fixed order), so losses, logits, the generated flow and EVERY parameter and
+    BatchNorm buffer after the optimizer steps are bit-identical."""
+    from dmcnet_amd import resnet
+    if not resnet.OWN_CONV:
+        pytest.skip("MIOpen's split-K weight gradients use atomics")
+    runs = []
+    for _ in range(2):
+        _, m = _pair(51, gan, 151)
+        batches = [O.synthetic_batch(seed=152 + i, batch=40, num_segments=3, num_class=51, flow_ds_factor=0 if gan else 16)
+                   for i in range(2 if gan else 1)]
+        outs = []
+        if gan:
+            step = T.GanTrainStep(m, 3, HP["lr_cls"], HP["lr_adv_g"], HP["lr_adv_d"], HP["lr_mse"],
+                                  lr_d_mult=HP["lr_d_mult"], **OPT)
+            for i, b in enumerate(batches):
+                m.discriminator.forced_masks = O.seeded_dropout_masks(160 + i, m.discriminator, 240 if i == 0 else 120)
+                outs.append(step.step(tuple(t.to(DEV) for t in b), i))
+        else:
+            step = T.DmcnetTrainStep(m, 3, HP["lr_cls"], HP["lr_mse"], **OPT)
+            outs.append(step.step(tuple(t.to(DEV) for t in batches[0])))
+        runs.append((outs, {k: v.detach().clone() for k, v in m.state_dict().items()}))
+    (oa, sa), (ob, sb) = runs
+    for ra, rb in zip(oa, ob):
+        for k in ra:
+            if torch.is_tensor(ra[k]):
+                assert torch.equal(ra[k], rb[k]), k
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
 
 
 @pytest.mark.parametrize("weights", ["generic"])

@@ -150,6 +150,7 @@ def _ddp_worker(rank, world, port, out_dir):
     net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.ReLU(), torch.nn.Linear(8, 4),
                               torch.nn.ReLU(), torch.nn.Linear(4, 3))
     red = ddp.GradBucketReducer(list(net.parameters()), bucket_bytes=128)    # several buckets
+    red.time_waits = True
     torch.manual_seed(7)
     x, t = torch.randn(8, 6), torch.randint(0, 3, (8,))
     shard = slice(rank * 4, rank * 4 + 4)
@@ -167,7 +168,8 @@ def _ddp_worker(rank, world, port, out_dir):
     red.finish()
     torch.save({"params": [p.detach().clone() for p in net.parameters()],
                 "grads": [None if p.grad is None else p.grad.clone() for p in net.parameters()],
-                "x": x, "t": t, "nbuckets": len(red.buckets)}, os.path.join(out_dir, "r%d.pt" % rank))
+                "x": x, "t": t, "nbuckets": len(red.buckets), "comm": red.comm_summary()},
+               os.path.join(out_dir, "r%d.pt" % rank))
     dist.destroy_process_group()
 
 
@@ -176,6 +178,17 @@ def test_grad_bucket_reducer_two_ranks_gloo(tmp_path):
     mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = (torch.load(os.path.join(tmp_path, "r%d.pt" % r)) for r in (0, 1))
     assert r0["nbuckets"] > 1
+    # the "comm" object of bench.py --gpus N (the first thing to read after a multi-GPU run): schema and plausibility
+    c = r0["comm"]
+    assert set(c) >= {"backend", "world_size", "buckets", "reduce_op", "last_step_bytes_by_set", "last_step_launched_from",
+                      "timed_steps", "exposed_wait_ms_per_step", "exposed_wait_host_ms_per_step"}
+    assert c["backend"] == "gloo" and c["world_size"] == 2 and c["timed_steps"] == 2
+    assert len(c["buckets"]) == r0["nbuckets"] and all(b["set"] == "all" and b["bytes"] > 0 for b in c["buckets"])
+    # the second step froze one weight: its bucket travels whole (completed with zeros in finish())
+    assert sum(g.numel() * 4 for g in r0["grads"] if g is not None) <= sum(c["last_step_bytes_by_set"].values()) \
+        <= sum(b["bytes"] for b in c["buckets"])
+    assert "finish" in c["last_step_launched_from"]
+    assert c["exposed_wait_ms_per_step"] is None and c["exposed_wait_host_ms_per_step"] >= 0.0   # CPU buckets: host time only
     for a, b in zip(r0["params"], r1["params"]):
         assert torch.equal(a, b)                      # broadcast from rank 0
     for a, b in zip(r0["grads"], r1["grads"]):
