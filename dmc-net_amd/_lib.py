@@ -77,6 +77,9 @@ SIGNATURES = {
     "dmc_x3s_conv_wgrad_supported": (_I, [_I] * 5),
     "dmc_x3s_conv_wgrad_bytes": (_Z, [_I] * 5),
     "dmc_x3s_conv_wgrad": (_I, [_P] * 4 + [_I] * 5 + [_P]),
+    "dmc_x3s_conv_dgrad_s2_supported": (_I, [_I] * 5),
+    "dmc_x3s_pack_weights_s2": (_I, [_P, _P, _I, _I, _P]),
+    "dmc_x3s_conv_dgrad_s2": (_I, [_P] * 3 + [_I] * 5 + [_P]),
     "dmc_bn_apply_act_x3s": (_I, [_P] * 8 + [_I, _I, _I, _P]),
     "dmc_bn_act_bwd_x3s": (_I, [_P] * 13 + [_I, _I, _I, _P]),
     "dmc_bn_relu_pool_fwd_x3s": (_I, [_P] * 9 + [_I, _I, _I, _I, _I, _F, _F, _P]),

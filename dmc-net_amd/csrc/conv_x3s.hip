@@ -109,8 +109,8 @@ __global__ __launch_bounds__(256) void x3s_merge_kernel(const unsigned short* __
 // packed [r / 64][k / 16][tap row 3][tap 3][slice 3][r % 64][16], the 8-channel half of a row swapped when
 // ((r % 64) >> 3) & 1 (the LDS bank swizzle of the fragment reads).  blockIdx.y selects the direction.
 __global__ __launch_bounds__(256) void x3s_pack_w_kernel(const float* __restrict__ w, unsigned short* __restrict__ wf,
-                                                         unsigned short* __restrict__ wt, int Cout, int Cin) {
-    const bool transposed = blockIdx.y == 1;
+                                                         unsigned short* __restrict__ wt, int Cout, int Cin, int mirror) {
+    const bool transposed = blockIdx.y == 1;                  // mirror = 0: the stride-2 data gradient's image (taps as they are)
     unsigned short* dst = transposed ? wt : wf;
     if (!dst) return;
     const int R = transposed ? Cin : Cout, K = transposed ? Cout : Cin;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void x3s_pack_w_kernel(const float* __restrict
         const int ch = (int)(t % nchunk);
         const int rt = (int)(t / nchunk);
         const int r = rt * 64 + rl, k = ch * 16 + kk;
-        const float v = transposed ? w[((long)k * 9 + (8 - tap)) * Cin + r] : w[((long)r * 9 + tap) * Cin + k];
+        const float v = transposed ? w[((long)k * 9 + (mirror ? 8 - tap : tap)) * Cin + r] : w[((long)r * 9 + tap) * Cin + k];
         unsigned u0, u1, u2;
         split3(v, u0, u1, u2);
         const size_t base = ((((size_t)(rt * nchunk + ch) * 9 + tap) * 3) * 64 + rl) * 16 + (kk ^ (((rl >> 3) & 1) << 3));
@@ -151,7 +151,15 @@ struct X3Args {
 
 // WM waves along pixels x WN along channels; a wave owns TM x TN tiles of 32 pixels x 32 channels.
 // BN = 32 TN WN must be 64 (the packed weight image); PPMAX = patch pixels the LDS is laid out for.
-template <int WM, int WN, int TM, int TN, int PPMAX>
+// STAG: the transfers are issued by HALF of the waves at a time, one behind each pair of MFMAs: waves 0 .. NW/2-1 (one per
+// SIMD) issue the patch transfers in the tap behind the step's barrier, waves NW/2 .. (their SIMD partners) the next step's
+// weights one tap later -- a SIMD always has one wave whose MFMA stream is not interrupted by transfer issue.
+// CLS = 4: the data gradient of a STRIDE-2 3x3 convolution (padding 1, even input size) in one launch.  The launch's
+// pixels are the positions (a, b) of dy; input pixel (2a + py, 2b + px) of parity class (py, px) receives only the taps
+// with ty = 1 (py = 0) or ty in {0, 2} (py = 1), likewise in x: 1 + 2 + 2 + 4 = 9 (tap, class) pairs, every tap feeds
+// exactly one class's accumulators, reading dy at offset (+1 for t = 0, else 0) -- the same step structure, four accumulator
+// sets, no multiply on structural zeros (the in-loop-split path issued four small launches per convolution).
+template <int WM, int WN, int TM, int TN, int PPMAX, bool STAG = false, int CLS = 1>
 __global__ __launch_bounds__(WM * WN * 64) void x3s_conv_kernel(X3Args a) {
     constexpr int NW = WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN;
     static_assert(BN == 64, "packed weight image is 64 rows wide");
@@ -160,8 +168,11 @@ __global__ __launch_bounds__(WM * WN * 64) void x3s_conv_kernel(X3Args a) {
     constexpr int PB = 3 * PSL;                            // one patch buffer
     constexpr int WB = 3 * 3 * BN * 32;                    // one weight buffer: tap row x 3 slices x 64 rows x 32 B
     constexpr int WOFF = 2 * PB;
-    constexpr int NDW = (PPMAX / 32 + NW - 1) / NW;        // patch transfers per wave and slice
+    static_assert(!STAG || NW >= 4, "two transfer groups need four waves");
+    constexpr int NA = STAG ? NW / 2 : NW, NB = NW - (STAG ? NA : 0);   // waves issuing patch / weight transfers
+    constexpr int NDW = (PPMAX / 32 + NA - 1) / NA;        // patch transfers per issuing wave and slice
     constexpr int NEW = WB / 1024;                         // weight transfers per step (18)
+    constexpr int NEWW = (NEW + NB - 1) / NB;
     extern __shared__ __attribute__((aligned(1024))) char lds_x3[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -185,7 +196,7 @@ __global__ __launch_bounds__(WM * WN * 64) void x3s_conv_kernel(X3Args a) {
     unsigned pvoff[NDW];
 #pragma unroll
     for (int k = 0; k < NDW; ++k) {
-        const int pr = 32 * (wave + NW * k) + (lane >> 1), h = lane & 1;
+        const int pr = 32 * (wave + NA * k) + (lane >> 1), h = lane & 1;
         pvoff[k] = OOB;
         if (pr < PP) {
             const int prow = pr / PW, col = pr - prow * PW;
@@ -205,7 +216,7 @@ __global__ __launch_bounds__(WM * WN * 64) void x3s_conv_kernel(X3Args a) {
         const int pp = (n * HP + yy + 1 - g0m1) * PW + xx + 1;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const int row = pp + (t / 3 - 1) * PW + (t % 3 - 1);
+            const int row = CLS == 4 ? pp + (t / 3 == 0 ? PW : 0) + (t % 3 == 0 ? 1 : 0) : pp + (t / 3 - 1) * PW + (t % 3 - 1);
             xaddr[i][t] = row * 32 + ((khalf ^ ((row >> 3) & 1)) << 4);
         }
     }
@@ -216,30 +227,38 @@ __global__ __launch_bounds__(WM * WN * 64) void x3s_conv_kernel(X3Args a) {
     const u32x4 srd_w = make_srd(reinterpret_cast<const char*>(a.wp) + (size_t)blockIdx.y * S * WB);
     const unsigned lane16 = (unsigned)lane * 16u;
 
-    auto issue_weights = [&](int step, int wbuf) {          // step's weight image -> weight buffer wbuf
+    const bool grp_a = wave < NA, grp_b = !STAG || wave >= NA;
+    const int wb = STAG ? wave - NA : wave;
+    auto dma_weight = [&](int step, int wbuf, int k) {      // transfer k of this wave for step's weight image
+        const int e = wb + NB * k;
+        if (e < NEW) dma_buf16(srd_w, lane16, (unsigned)(step * WB + e * 1024), lds0 + WOFF + wbuf * WB + e * 1024);
+    };
+    auto dma_patch = [&](int chunk, int slice, int pbuf, int k) {   // transfer k of this wave for one slice of chunk's patch
+        const int d = wave + NA * k;
+        if (d < ND) dma_buf16(srd_x, pvoff[k], (unsigned)(slice * nchunk + chunk) * a.plane_bytes, lds0 + pbuf * PB + slice * PSL + d * 1024);
+    };
+    auto issue_weights = [&](int step, int wbuf) {
+        if (grp_b) {
 #pragma unroll
-        for (int k = 0; k < (NEW + NW - 1) / NW; ++k) {
-            const int e = wave + NW * k;
-            if (NEW % NW == 0 || e < NEW)
-                dma_buf16(srd_w, lane16, (unsigned)(step * WB + e * 1024), lds0 + WOFF + wbuf * WB + e * 1024);
+            for (int k = 0; k < NEWW; ++k) dma_weight(step, wbuf, k);
         }
     };
-    auto issue_patch = [&](int chunk, int slice, int pbuf) { // one slice of chunk's patch -> patch buffer pbuf
-        const unsigned soff = (unsigned)(slice * nchunk + chunk) * a.plane_bytes;
+    auto issue_patch = [&](int chunk, int slice, int pbuf) {
+        if (grp_a) {
 #pragma unroll
-        for (int k = 0; k < NDW; ++k) {
-            const int d = wave + NW * k;
-            if (d < ND) dma_buf16(srd_x, pvoff[k], soff, lds0 + pbuf * PB + slice * PSL + d * 1024);
+            for (int k = 0; k < NDW; ++k) dma_patch(chunk, slice, pbuf, k);
         }
     };
 
-    f32x16 acc[TM][TN];
+    f32x16 acc[CLS][TM][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int cl = 0; cl < CLS; ++cl)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[cl][i][j][e] = 0.f;
 
     lds_cptr const L = (lds_cptr)lds_x3;
     struct Frag { u32x4 X[TM][3], W[TN][3]; };              // one tap's operands: 3 (TM + TN) reads, 6 TM TN MFMAs
@@ -256,16 +275,22 @@ __global__ __launch_bounds__(WM * WN * 64) void x3s_conv_kernel(X3Args a) {
                 f.X[i][s] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(L + xaddr[i][t] + (pbuf * PB + s * PSL));
         }
     };
-    auto mfma_frags = [&](const Frag& f) {                  // slice products (weight, input): (0,2) (0,1) (0,0) (1,1) (1,0) (2,0)
+    // slice products (weight, input): (0,2) (0,1) (0,0) (1,1) (1,0) (2,0); `between(p)` runs behind product p
+    // (tc = the tap: its parity class selects the accumulator set when CLS = 4)
+    auto mfma_frags = [&](const Frag& f, auto tc, auto&& between) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int cl = CLS == 4 ? (t / 3 != 1) * 2 + (t % 3 != 1) : 0;
 #pragma unroll
         for (int p = 0; p < 6; ++p) {
             constexpr int WS[6] = {0, 0, 0, 1, 1, 2}, XS[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(f.W[j][WS[p]], f.X[i][XS[p]], acc[i][j]);
+                for (int j = 0; j < TN; ++j) acc[cl][i][j] = mfma_bf16(f.W[j][WS[p]], f.X[i][XS[p]], acc[cl][i][j]);
+            between(p);
         }
     };
+    auto nothing = [](int) {};
     constexpr int NRD = 3 * (TM + TN), NMF = 6 * TM * TN;
     auto interleave = [&]() {                                // one fragment read behind each of the first NRD MFMAs
 #pragma unroll
@@ -286,23 +311,48 @@ __global__ __launch_bounds__(WM * WN * 64) void x3s_conv_kernel(X3Args a) {
         using NP = std::integral_constant<int, q == 2 ? (pbuf ^ 1) : pbuf>;     // next step's buffers and first tap
         using NWB = std::integral_constant<int, wbuf ^ 1>;
         using NT = std::integral_constant<int, q == 2 ? 0 : 3 * (q + 1)>;
+        using T0 = std::integral_constant<int, 3 * q>;
+        using T1 = std::integral_constant<int, 3 * q + 1>;
+        using T2 = std::integral_constant<int, 3 * q + 2>;
         const int s = 3 * c + q;
         load_frags(pbufc, wbufc, std::integral_constant<int, 3 * q + 1>{}, FB);
-        mfma_frags(FA);
-        interleave();
+        if constexpr (STAG) {       // group B: the next step's weights (their buffer was released by the previous step's barrier)
+            const bool go = grp_b && dma_on && s + 1 < S;
+            mfma_frags(FA, T0{}, [&](int p) {
+                if (go) {
+#pragma unroll
+                    for (int k = p; k < NEWW; k += 6) dma_weight(s + 1, wbuf ^ 1, k);
+                }
+            });
+        } else {
+            mfma_frags(FA, T0{}, nothing);
+            interleave();
+        }
         load_frags(pbufc, wbufc, std::integral_constant<int, 3 * q + 2>{}, FA);
-        mfma_frags(FB);
+        mfma_frags(FB, T1{}, nothing);
         interleave();
         if (a.ablate & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's transfers for step s + 1 have landed
         __builtin_amdgcn_s_barrier();                                  // ... everyone's; step s's buffers are dead
-        if (dma_on) {
-            if (s + 2 < S) issue_weights(s + 2, wbuf);
-            if (q == 2) { if (c + 2 < nchunk) issue_patch(c + 2, 0, pbuf); }
-            else if (c + 1 < nchunk) issue_patch(c + 1, q + 1, pbuf ^ 1);
+        // the patch slice whose buffer the barrier released: q = 0, 1: slice q + 1 of chunk c + 1; q = 2: slice 0 of chunk c + 2
+        const int vc = q == 2 ? c + 2 : c + 1;
+        if constexpr (STAG) {
+            if (s + 1 < S) load_frags(NP{}, NWB{}, NT{}, FB);
+            const bool go = grp_a && dma_on && vc < nchunk;
+            mfma_frags(FA, T2{}, [&](int p) {
+                if (go) {
+#pragma unroll
+                    for (int k = p; k < NDW; k += 6) dma_patch(vc, q == 2 ? 0 : q + 1, q == 2 ? pbuf : (pbuf ^ 1), k);
+                }
+            });
+        } else {
+            if (dma_on) {
+                if (s + 2 < S) issue_weights(s + 2, wbuf);
+                if (vc < nchunk) issue_patch(vc, q == 2 ? 0 : q + 1, q == 2 ? pbuf : (pbuf ^ 1));
+            }
+            if (s + 1 < S) load_frags(NP{}, NWB{}, NT{}, FB);
+            mfma_frags(FA, T2{}, nothing);
         }
-        if (s + 1 < S) load_frags(NP{}, NWB{}, NT{}, FB);
-        mfma_frags(FA);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -315,7 +365,7 @@ __global__ __launch_bounds__(WM * WN * 64) void x3s_conv_kernel(X3Args a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (dma_on) {
-        if (S > 1) issue_weights(1, 1);
+        if (!STAG && S > 1) issue_weights(1, 1);           // STAG: step 0's first tap issues them
         if (nchunk > 1) issue_patch(1, 0, 1);
     }
     Frag F0, F1;
@@ -341,36 +391,44 @@ __global__ __launch_bounds__(WM * WN * 64) void x3s_conv_kernel(X3Args a) {
     constexpr int EP = 272, ETILE = 32 * TM * EP;
     char* etile = lds_x3 + wave * ETILE;
     const int mw0 = m0 + wm * TM * 32;                            // first pixel of this wave
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const bool ok = mw0 + 32 * i + l31 <= mlast;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(etile + (32 * i + l31) * EP + (32 * j + 8 * g + 4 * khalf) * 4) = v;
-            }
-    }
     const int rbase = blockIdx.y * BN;
-    if (!(a.ablate & 128)) {
 #pragma unroll
-        for (int it = 0; it < 8 * TM; ++it) {
-            const int prow = 4 * it + (lane >> 4);
-            const int m = mw0 + prow;
-            float4 v = *reinterpret_cast<const float4*>(etile + prow * EP + (lane & 15) * 16);
-            if (m <= mlast) {
-                const size_t o = (size_t)m * a.R + rbase + (lane & 15) * 4;
-                if (a.addend) {
-                    const float4 av = *reinterpret_cast<const float4*>(a.addend + o);
-                    v.x += av.x; v.y += av.y; v.z += av.z; v.w += av.w;
+    for (int cl = 0; cl < CLS; ++cl) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const bool ok = mw0 + 32 * i + l31 <= mlast;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 v = make_float4(acc[cl][i][j][4 * g], acc[cl][i][j][4 * g + 1], acc[cl][i][j][4 * g + 2], acc[cl][i][j][4 * g + 3]);
+                    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(etile + (32 * i + l31) * EP + (32 * j + 8 * g + 4 * khalf) * 4) = v;
                 }
-                *reinterpret_cast<float4*>(a.y + o) = v;
+        }
+        if (!(a.ablate & 128)) {
+#pragma unroll
+            for (int it = 0; it < 8 * TM; ++it) {
+                const int prow = 4 * it + (lane >> 4);
+                const int m = mw0 + prow;
+                float4 v = *reinterpret_cast<const float4*>(etile + prow * EP + (lane & 15) * 16);
+                if (m <= mlast) {
+                    size_t opix = (size_t)m;
+                    if (CLS == 4) {                               // position (n, ya, xb) of dy -> input pixel (2 ya + py, 2 xb + px)
+                        const int n = m / HW, rem = m - n * HW, ya = rem / a.W, xb = rem - ya * a.W;
+                        opix = ((size_t)n * (2 * a.H) + 2 * ya + (cl >> 1)) * (2 * a.W) + 2 * xb + (cl & 1);
+                    }
+                    const size_t o = opix * a.R + rbase + (lane & 15) * 4;
+                    if (a.addend) {
+                        const float4 av = *reinterpret_cast<const float4*>(a.addend + o);
+                        v.x += av.x; v.y += av.y; v.z += av.z; v.w += av.w;
+                    }
+                    *reinterpret_cast<float4*>(a.y + o) = v;
+                }
             }
         }
     }
-    if (a.stat_part) {
+    if (CLS == 1 && a.stat_part) {
         double* red = reinterpret_cast<double*>(lds_x3 + NW * ETILE);   // [WM][64][2]
         double d1 = 0.0, d2 = 0.0;
 #pragma unroll 8
@@ -446,10 +504,19 @@ int launch_x3s(const X3Args& a, hipStream_t s) {
     constexpr int BM = 32 * TM * WM;
     constexpr size_t op_bytes = 2 * 3 * PPMAX * 32 + 2 * 3 * 3 * 64 * 32, ep_bytes = (size_t)BM * 272 + WM * 64 * 16;
     constexpr size_t lds_bytes = op_bytes > ep_bytes ? op_bytes : ep_bytes;
+    dim3 grid((a.M + BM - 1) / BM, a.R / 64);
+    if constexpr (WM >= 4) {
+        if (!(option(OPT_CONV_ABLATE) & 512)) {               // 512: measurement, every wave issues its share behind the barrier
+            static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&x3s_conv_kernel<WM, 1, TM, 2, PPMAX, true>),
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (attr2 != hipSuccess) return fail(DMC_E_LAUNCH, "x3s_conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr2));
+            x3s_conv_kernel<WM, 1, TM, 2, PPMAX, true><<<grid, WM * 64, lds_bytes, s>>>(a);
+            return check_launch("x3s_conv");
+        }
+    }
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&x3s_conv_kernel<WM, 1, TM, 2, PPMAX>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (attr != hipSuccess) return fail(DMC_E_LAUNCH, "x3s_conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
-    dim3 grid((a.M + BM - 1) / BM, a.R / 64);
     x3s_conv_kernel<WM, 1, TM, 2, PPMAX><<<grid, WM * 64, lds_bytes, s>>>(a);
     return check_launch("x3s_conv");
 }
@@ -726,7 +793,7 @@ int dmc_x3s_pack_weights(const float* w, void* wpack_f, void* wpack_t, int Cin, 
         return fail(DMC_E_INVALID, "dmc_x3s_pack_weights: bad argument");
     const long total = (long)Cin * Cout * 9;
     x3s_pack_w_kernel<<<dim3(stream_blocks(total) > 1024 ? 1024 : stream_blocks(total), 2), 256, 0, (hipStream_t)stream>>>(
-        w, static_cast<unsigned short*>(wpack_f), static_cast<unsigned short*>(wpack_t), Cout, Cin);
+        w, static_cast<unsigned short*>(wpack_f), static_cast<unsigned short*>(wpack_t), Cout, Cin, 1);
     return check_launch("x3s_pack_w");
 }
 
@@ -782,6 +849,42 @@ int dmc_x3s_conv_wgrad(const void* xs, const void* dys, float* dw, float* worksp
         case 14: return launch_x3s_wgrad<14, 4>(p, a, dw, s);
         default: return launch_x3s_wgrad<7, 9>(p, a, dw, s);
     }
+}
+
+/* Data gradient of a 3x3 / stride-2 / padding-1 convolution on pre-split operands, ONE launch (the four input-parity
+ * classes keep their own accumulators): dys = slice tensor of dy [N][OH][OW][Cout], dx [N][2 OH][2 OW][Cin] fp32;
+ * wpack_t2 from dmc_x3s_pack_weights_s2 (dmc_x3s_wpack_bytes).  Even input sizes only (H = 2 OH, W = 2 OW). */
+int dmc_x3s_conv_dgrad_s2_supported(int N, int OH, int OW, int Cin, int Cout) {
+    return Cin % 64 == 0 && Cout % 64 == 0 && x3s_shape_ok(N, OH, OW, Cout, Cin) && (long)N * OH * OW * 4 * Cin * 4 < (1L << 40) &&
+           patch_pixels_max(N, OH, OW, 128) <= 320 ? 1 : 0;
+}
+
+int dmc_x3s_pack_weights_s2(const float* w, void* wpack_t2, int Cin, int Cout, dmc_stream_t stream) {
+    if (!w || !wpack_t2 || Cin % 64 != 0 || Cout % 64 != 0 || Cin <= 0 || Cout <= 0)
+        return fail(DMC_E_INVALID, "dmc_x3s_pack_weights_s2: bad argument");
+    const long total = (long)Cin * Cout * 9;
+    x3s_pack_w_kernel<<<dim3(stream_blocks(total) > 1024 ? 1024 : stream_blocks(total), 2), 256, 0, (hipStream_t)stream>>>(
+        w, nullptr, static_cast<unsigned short*>(wpack_t2), Cout, Cin, 0);
+    return check_launch("x3s_pack_w_s2");
+}
+
+int dmc_x3s_conv_dgrad_s2(const void* dys, const void* wpack_t2, float* dx, int N, int OH, int OW, int Cin, int Cout,
+                          dmc_stream_t stream) {
+    if (!dys || !wpack_t2 || !dx) return fail(DMC_E_INVALID, "dmc_x3s_conv_dgrad_s2: null pointer");
+    if (!dmc_x3s_conv_dgrad_s2_supported(N, OH, OW, Cin, Cout))
+        return fail(DMC_E_INVALID, "dmc_x3s_conv_dgrad_s2: unsupported shape N=%d OH=%d OW=%d Cin=%d Cout=%d", N, OH, OW, Cin, Cout);
+    X3Args a;
+    a.xs = dys; a.wp = wpack_t2; a.y = dx; a.addend = nullptr; a.stat_part = nullptr;
+    a.N = N; a.H = OH; a.W = OW; a.K = Cout; a.R = Cin; a.M = N * OH * OW;
+    a.plane_bytes = (unsigned)a.M * 32u;
+    a.ablate = option(OPT_CONV_ABLATE);
+    constexpr size_t lds_bytes = 2 * 3 * 320 * 32 + 2 * 3 * 3 * 64 * 32;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&x3s_conv_kernel<4, 1, 1, 2, 320, true, 4>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (attr != hipSuccess) return fail(DMC_E_LAUNCH, "x3s_conv_dgrad_s2: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
+    dim3 grid((a.M + 127) / 128, Cin / 64);
+    x3s_conv_kernel<4, 1, 1, 2, 320, true, 4><<<grid, 256, lds_bytes, (hipStream_t)stream>>>(a);
+    return check_launch("x3s_conv_dgrad_s2");
 }
 
 }  // extern "C"

@@ -833,6 +833,7 @@ class _ConvBnAct(torch.autograd.Function):
         cout, cin = weight.shape[0], weight.shape[1]
         n, _, h, w = x.shape
         ctx.wsplit_t = None
+        ctx.wsplit_t2 = None
         ctx.link = None
         if use_x3s:
             if xs is None:
@@ -862,6 +863,14 @@ class _ConvBnAct(torch.autograd.Function):
                     _lib.check(lib.dmc_conv_nhwc_split(_lib.ptr(wcl), _lib.ptr(wf), _lib.ptr(ctx.wsplit_t), cin, cout,
                                                        weight.shape[2], weight.shape[3], _stream()), "dmc_conv_nhwc_split")
                 y, part, nblk = _conv_fwd(x, wcl, None, None, stride, padding, 0, True, presplit=wf)
+                # 3x3 / stride 2 (layerN.0.conv1): the data gradient in ONE pre-split launch instead of four parity-class launches
+                ctx.wsplit_t2 = None
+                if (X3S and ctx.needs_input_grad[0] and stride == 2 and padding == 1 and tuple(weight.shape[2:]) == (3, 3)
+                        and h == 2 * y.shape[2] and w == 2 * y.shape[3] and lib.dmc_get_option(b"conv_arith") == 1
+                        and lib.dmc_x3s_conv_dgrad_s2_supported(n, y.shape[2], y.shape[3], cin, cout)):
+                    ctx.wsplit_t2 = torch.empty(lib.dmc_x3s_wpack_bytes(cin, cout), dtype=torch.uint8, device=x.device)
+                    _lib.check(lib.dmc_x3s_pack_weights_s2(_lib.ptr(wcl), _lib.ptr(ctx.wsplit_t2), cin, cout, _stream()),
+                               "dmc_x3s_pack_weights_s2")
             wf_ok = wf is not None
         if link is not None:
             if residual is None:
@@ -924,6 +933,13 @@ class _ConvBnAct(torch.autograd.Function):
                                                   _lib.ptr(scratch), _lib.ptr(dout), None, _lib.ptr(dys), _lib.ptr(dres),
                                                   _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(mask), m, cout,
                                                   int(relu), _stream()), "dmc_bn_act_bwd_x3s")
+            elif ctx.wsplit_t2 is not None and ctx.needs_input_grad[0]:   # fp32 for the weight gradient, slices for the data gradient
+                dy = torch.empty_like(y)
+                dys = _x3s_buffer(m, cout, y.device)
+                _lib.check(lib.dmc_bn_act_bwd_x3s(_lib.ptr(y), None, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(stats),
+                                                  _lib.ptr(scratch), _lib.ptr(dout), _lib.ptr(dy), _lib.ptr(dys), _lib.ptr(dres),
+                                                  _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(mask), m, cout,
+                                                  int(relu), _stream()), "dmc_bn_act_bwd_x3s")
             else:
                 dy = torch.empty_like(y)
                 _lib.check(lib.dmc_bn_act_bwd(_lib.ptr(y), None, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(stats),
@@ -959,7 +975,12 @@ class _ConvBnAct(torch.autograd.Function):
         else:
             if ctx.needs_input_grad[0]:
                 with _span("conv_nhwc_dgrad"):
-                    dx = _conv_dgrad(dy, wcl, x.shape, stride, padding, presplit=ctx.wsplit_t, addend=addend)
+                    if dys is not None:
+                        dx = torch.empty(x_shape, dtype=torch.float32, device=y.device, memory_format=_CL)
+                        _lib.check(lib.dmc_x3s_conv_dgrad_s2(_lib.ptr(dys), _lib.ptr(ctx.wsplit_t2), _lib.ptr(dx), n, oh, ow, cin,
+                                                             cout, _stream()), "dmc_x3s_conv_dgrad_s2")
+                    else:
+                        dx = _conv_dgrad(dy, wcl, x.shape, stride, padding, presplit=ctx.wsplit_t, addend=addend)
             if ctx.needs_input_grad[1]:
                 with _span("conv_nhwc_wgrad"):
                     dw = _grad_like(_conv_wgrad(x, dy, wcl, stride, padding), weight)

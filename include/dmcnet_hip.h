@@ -349,6 +349,14 @@ int dmc_x3s_conv_wgrad_supported(int N, int H, int W, int Cin, int Cout);
 size_t dmc_x3s_conv_wgrad_bytes(int N, int H, int W, int Cin, int Cout);
 int dmc_x3s_conv_wgrad(const void* xs, const void* dys, float* dw, float* workspace, int N, int H, int W, int Cin, int Cout,
                        dmc_stream_t stream);
+/* Stride-2 3x3 data gradient on pre-split operands in ONE launch (four input-parity classes, nine (tap, class) pairs):
+ * dys = slice tensor of dy [N][OH][OW][Cout]; dx [N][2 OH][2 OW][Cin] fp32; weights from dmc_x3s_pack_weights_s2
+ * (dmc_x3s_wpack_bytes()).  Replaces the stride-2 convolutions' backward of torchvision's BasicBlock (layerN.0.conv1). */
+int dmc_x3s_conv_dgrad_s2_supported(int N, int OH, int OW, int Cin, int Cout);
+int dmc_x3s_pack_weights_s2(const float* w, void* wpack_t2, int Cin, int Cout, dmc_stream_t stream);
+int dmc_x3s_conv_dgrad_s2(const void* dys, const void* wpack_t2, float* dx, int N, int OH, int OW, int Cin, int Cout,
+                          dmc_stream_t stream);
+
 
 /* Producers of slice tensors (bn_act.hip): the BatchNorm kernels above with the result written as fp32 (nullable) and / or
  * as a bf16x3 slice tensor (nullable), C % 16 == 0 -- the forward's activation for the next convolution

@@ -232,3 +232,45 @@ def test_fp32_memory_of_a_slices_only_result_is_guarded(monkeypatch):
     full = ops.conv_bn_act(x, conv, bn, want_f32=True, want_slices=True)
     assert torch.equal(ops.x3s_of(full), ops.x3s_of(y)) and torch.equal(ops.x3s_merge(ops.x3s_of(y), tuple(y.shape)), full)
     assert torch.isfinite(z).all()
+
+
+@pytest.mark.parametrize("cin,cout,hw,n,seed", [(64, 128, 56, 2, 351), (128, 256, 28, 3, 357), (256, 512, 14, 5, 351)])
+def test_stride2_unit_data_gradient_in_one_presplit_launch(cin, cout, hw, n, seed, monkeypatch):
+    """layerN.0.conv1 (3x3, stride 2) -> bn -> relu: with DMC_X3S the data gradient is ONE dmc_x3s_conv_dgrad_s2 launch on
+    the slices of dy (four input-parity classes, nine (tap, class) pairs) instead of four parity-class launches; forward and
+    weight gradient stay on the in-loop-split kernels.  Both modes against the stock modules in fp64 (input seeds without
+    ReLU near-ties, asserted)."""
+    monkeypatch.setattr(resnet, "OWN_CONV", True)
+    torch.manual_seed(11)
+    conv = torch.nn.Conv2d(cin, cout, 3, 2, 1, bias=False)
+    bn = torch.nn.BatchNorm2d(cout)
+    state = ({k: v.clone() for k, v in conv.state_dict().items()}, {k: v.clone() for k, v in bn.state_dict().items()})
+    x0 = rnd(seed, (n, cin, hw, hw))
+    go = rnd(361, (n, cout, hw // 2, hw // 2))
+    cd, bd = torch.nn.Conv2d(cin, cout, 3, 2, 1, bias=False).double(), torch.nn.BatchNorm2d(cout).double().train()
+    cd.load_state_dict({k: v.double() for k, v in state[0].items()})
+    xr = x0.double().requires_grad_(True)
+    pre = bd(cd(xr))
+    assert float(pre.detach().abs().min()) > 4e-6, "pick another input seed"
+    (torch.relu(pre) * go.double()).sum().backward()
+    lib = dmcnet_amd._lib.load()
+    assert lib.dmc_x3s_conv_dgrad_s2_supported(n, hw // 2, hw // 2, cin, cout)
+    res = {}
+    for mode in (True, False):
+        monkeypatch.setattr(ops, "X3S", mode)
+        cm = torch.nn.Conv2d(cin, cout, 3, 2, 1, bias=False).to(DEV).to(memory_format=CL)
+        bm = torch.nn.BatchNorm2d(cout).to(DEV).train()
+        cm.load_state_dict(state[0]); bm.load_state_dict(state[1])
+        x = (x0.to(DEV).contiguous(memory_format=CL) * 1.0).requires_grad_(True)
+        x.retain_grad()
+        assert ops.conv_bn_act_supported(x, cm, bm)
+        out = ops.conv_bn_act(x, cm, bm)
+        (out * go.to(DEV)).sum().backward()
+        res[mode] = (out.detach(), x.grad, cm.weight.grad, bm.weight.grad, bm.bias.grad)
+    for mode in (True, False):
+        assert rel_err(res[mode][0], torch.relu(pre)) < 1e-5
+        assert rel_err(res[mode][1], xr.grad) < 2e-5
+        assert rel_err(res[mode][2], cd.weight.grad) < 2e-5
+        assert rel_err(res[mode][3], bd.weight.grad) < 2e-4 and rel_err(res[mode][4], bd.bias.grad) < 2e-4
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][2], res[False][2])   # same forward / weight-gradient kernels
+    assert not torch.equal(res[True][1], res[False][1])          # the data gradient really took the other kernel

@@ -171,5 +171,41 @@ int main(int argc, char** argv) {
         printf("wgrad : x3s %.3f ms (%.1f TF)  conv3 %.3f ms (%.1f TF)\n", t4, gf / t4, t3, gf / t3);
     }
 #endif
+    if (what & 8) {   // stride-2 data gradient: here N H W are the dy dims (OH, OW); dx is [N][2H][2W][Cin]
+        if (!dmc_x3s_conv_dgrad_s2_supported(N, H, W, Cin, Cout)) { printf("dgrad_s2: shape not supported\n"); return 0; }
+        const long M2 = M * 4;
+        float *dx2, *dx3; void* wt2;
+        CK(hipMalloc(&dx2, M2 * Cin * 4)); CK(hipMalloc(&dx3, M2 * Cin * 4)); CK(hipMalloc(&wt2, dmc_x3s_wpack_bytes(Cin, Cout)));
+        DK(dmc_x3s_pack_weights_s2(w, wt2, Cin, Cout, 0));
+        DK(dmc_x3s_conv_dgrad_s2(dys, wt2, dx2, N, H, W, Cin, Cout, 0));
+        DK(dmc_conv_nhwc_dgrad(dy, nullptr, (float*)w3t, dx3, N, 2 * H, 2 * W, Cin, Cout, 3, 3, 2, 1, 0));
+        std::vector<float> h2(M2 * Cin), h3(M2 * Cin);
+        CK(hipMemcpy(h2.data(), dx2, M2 * Cin * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(h3.data(), dx3, M2 * Cin * 4, hipMemcpyDeviceToHost));
+        double ymax = 0, e4 = 0, e3 = 0;
+        const int H2 = 2 * H, W2 = 2 * W;
+        for (int t = 0; t < 4000; ++t) {
+            const long m = (t < 128 ? t : t < 256 ? M2 - 1 - (t - 128) : (long)(((unsigned long long)rand() * 2654435761ull) % M2));
+            const int ci = rand() % Cin;
+            const int n = (int)(m / (H2 * W2)), iy = (int)(m % (H2 * W2)) / W2, ix = (int)(m % W2);
+            double r = 0;
+            for (int ty = 0; ty < 3; ++ty) for (int tx = 0; tx < 3; ++tx) {
+                const int ny = iy + 1 - ty, nx = ix + 1 - tx;
+                if (ny < 0 || nx < 0 || (ny & 1) || (nx & 1)) continue;
+                const int oy = ny / 2, ox = nx / 2;
+                if (oy >= H || ox >= W) continue;
+                const float* dp = &hdy[(((long)n * H + oy) * W + ox) * Cout];
+                for (int c = 0; c < Cout; ++c) r += (double)dp[c] * hw[((size_t)c * 9 + ty * 3 + tx) * Cin + ci];
+            }
+            ymax = fmax(ymax, fabs(r));
+            e4 = fmax(e4, fabs(r - h2[m * Cin + ci]));
+            e3 = fmax(e3, fabs(r - h3[m * Cin + ci]));
+        }
+        printf("dgrad2: max|dx| %.3f  err vs fp64: x3s %.3e  conv3 %.3e (rel %.2e / %.2e)\n", ymax, e4, e3, e4 / ymax, e3 / ymax);
+        const double gf2 = gf;   // 2 * M(dy) * Cout * Cin * 9
+        const float t4 = time_ms([&] { DK(dmc_x3s_conv_dgrad_s2(dys, wt2, dx2, N, H, W, Cin, Cout, 0)); }, iters);
+        const float t3 = time_ms([&] { DK(dmc_conv_nhwc_dgrad(dy, nullptr, (float*)w3t, dx3, N, 2 * H, 2 * W, Cin, Cout, 3, 3, 2, 1, 0)); }, iters);
+        printf("dgrad2: x3s %.3f ms (%.1f TF)  conv3 %.3f ms (%.1f TF)\n", t4, gf2 / t4, t3, gf2 / t3);
+    }
     return 0;
 }
