@@ -56,6 +56,7 @@ def train_epoch(loader, stepper, epoch, device="cuda:0", freeze=False, print_fre
 
 
 @torch.no_grad()
+@torch.no_grad()
 def validate(loader, model, num_segments, lr_cls, lr_mse, device="cuda:0", log=print, loss_mse="MSELoss",
              prep=None):
     """``validate()``: eval mode, CE on the segment consensus + flow MSE, Prec@1/5; returns the

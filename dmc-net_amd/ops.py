@@ -1005,6 +1005,61 @@ def conv_bn_act_supported(x, conv, bn):
     return bool(_lib.load().dmc_bn_act_supported(n * oh * ow, conv.out_channels))
 
 
+def conv_bn_eval_supported(x, conv, bn):
+    """True if conv -> bn(running statistics) [-> add] [-> relu] can run forward-only on this package's kernels
+    (evaluation / validation: code/dmcnet/test.py:139-198, validate() of code/dmcnet/train.py)."""
+    if torch.is_grad_enabled() or bn.training or not bn.track_running_stats or not bn.affine:
+        return False
+    if conv.bias is not None or conv.dilation != (1, 1) or conv.groups != 1 or conv.padding_mode != "zeros":
+        return False
+    if conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1]:
+        return False
+    if not _is_cl(x) or not conv_nhwc_supported(x, conv.weight, conv.stride[0], conv.padding[0]):
+        return False
+    n, _, h, w = x.shape
+    k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+    oh, ow = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    return bool(_lib.load().dmc_bn_act_supported(n * oh * ow, conv.out_channels)) and conv.out_channels % 16 == 0
+
+
+def conv_bn_act_eval(x, conv, bn, residual=None, relu=True, want_f32=True, want_slices=False):
+    """Forward-only relu?(bn(conv(x)) [+ residual]) with the BatchNorm's RUNNING statistics (eval mode, no autograd): the
+    same convolution kernels as the training op (pre-split path for stride-1 3x3), no statistics epilogue, and the
+    normalisation as one streaming pass with (mean, 1 / sqrt(var + eps)) taken from the module's buffers."""
+    lib = _lib.load()
+    _need_cuda(x, conv.weight, residual)
+    n, cin, h, w = x.shape
+    cout = conv.out_channels
+    wcl = _as_cl(conv.weight.detach())
+    stride, padding = conv.stride[0], conv.padding[0]
+    if x3s_usable(n, h, w, conv):
+        xs = x3s_of(x)
+        if xs is None:
+            xs = x3s_split(_as_cl(x))
+        wf, _ = x3s_pack_weights(wcl, forward=True, transposed=False)
+        y, _ = x3s_conv_fwd(xs, wf, n, h, w, cin, cout)
+    else:
+        if not f32_valid(x):
+            raise RuntimeError("conv_bn_act_eval: the input's fp32 memory was not written by its producer (slices only)")
+        y, _, _ = _conv_fwd(_as_cl(x), wcl, None, None, stride, padding, 0, False)
+    m = y.shape[0] * y.shape[2] * y.shape[3]
+    stats = torch.cat([bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)]).contiguous()
+    if not want_f32 and not want_slices:
+        want_f32 = True
+    out = torch.empty_like(y)
+    out_xs = _x3s_buffer(m, cout, x.device) if want_slices else None
+    if residual is not None:
+        if not f32_valid(residual):
+            raise RuntimeError("conv_bn_act_eval: the residual's fp32 memory was not written by its producer")
+        residual = _as_cl(residual)
+    _lib.check(lib.dmc_bn_apply_act_x3s(_lib.ptr(y), _lib.ptr(residual), _lib.ptr(bn.weight), _lib.ptr(bn.bias), _lib.ptr(stats),
+                                        _lib.ptr(out) if want_f32 else None, _lib.ptr(out_xs), None, m, cout, int(relu),
+                                        _stream()), "dmc_bn_apply_act_x3s")
+    if want_slices:
+        _attach_x3s(out, out_xs, want_f32)
+    return out
+
+
 def conv_bn_act(x, conv, bn, residual=None, relu=True, link=None, want_f32=True, want_slices=False):
     """relu?(bn(conv(x)) [+ residual]) for a channels_last ``x`` (see conv_bn_act_supported); ``link``: the
     ResidualGradLink shared by the first and the last op of an identity-shortcut block.  ``want_slices``: also write

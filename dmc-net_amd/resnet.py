@@ -40,13 +40,19 @@ def _conv_bn_act(conv, bn, x, residual=None, relu=True, link=None, next_conv=Non
     """relu?(bn(conv(x)) [+ residual]).  ``next_conv``: a convolution that reads the result -- when it takes the
     pre-split bf16x3 path (ops.x3s_usable) the result's slice tensor is written alongside; ``only_consumer``: nothing
     else reads the result, so its fp32 form is not written at all."""
-    if OWN_CONV and x.is_cuda and ops.conv_bn_act_supported(x, conv, bn):
+    train_op = OWN_CONV and x.is_cuda and ops.conv_bn_act_supported(x, conv, bn)
+    eval_op = OWN_CONV and x.is_cuda and not train_op and ops.conv_bn_eval_supported(x, conv, bn)
+    if train_op or eval_op:
         slices = False
         if next_conv is not None:
             n, _, h, w = x.shape
             k, s_, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
             slices = ops.x3s_usable(n, (h + 2 * p - k) // s_ + 1, (w + 2 * p - k) // s_ + 1, next_conv)
+        if eval_op:     # evaluation / validation: running statistics, forward only, the same convolution kernels
+            return ops.conv_bn_act_eval(x, conv, bn, residual, relu, want_f32=not (slices and only_consumer), want_slices=slices)
         return ops.conv_bn_act(x, conv, bn, residual, relu, link, want_f32=not (slices and only_consumer), want_slices=slices)
+    if not ops.f32_valid(x):
+        raise RuntimeError("the activation's fp32 memory was not written (slices only) but the stock path needs it")
     return _bn_act(bn, conv(x), residual, relu)
 
 
@@ -125,8 +131,9 @@ class ResNet(nn.Module):
         # 2-channel flow input: own gradients for conv1 (MIOpen's degenerate with 2 input channels)
         c = self.conv1
         if (c.in_channels == 2 and c.bias is None and c.stride == (2, 2) and c.padding == (3, 3)
-                and c.dilation == (1, 1) and c.groups == 1 and torch.is_grad_enabled()
-                and (c.weight.requires_grad or x.requires_grad) and ops.stem_conv_supported(x, c.weight)):
+                and c.dilation == (1, 1) and c.groups == 1
+                and (not torch.is_grad_enabled() or c.weight.requires_grad or x.requires_grad)
+                and ops.stem_conv_supported(x, c.weight)):
             return ops.stem_conv(x, c.weight)
         return c(x)
 
@@ -138,7 +145,7 @@ class ResNet(nn.Module):
                 and not mp.ceil_mode and not mp.return_indices and ops.bn_relu_pool_supported(x)):
             n, _, h, w = x.shape
             first = self.layer1[0].conv1
-            return ops.bn_relu_pool(x, bn, want_slices=OWN_CONV and torch.is_grad_enabled() and bn.training and
+            return ops.bn_relu_pool(x, bn, want_slices=OWN_CONV and (bn.training or not torch.is_grad_enabled()) and
                                     ops.x3s_usable(n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, first))
         return mp(_bn_act(bn, x))
 

@@ -637,6 +637,28 @@ def test_eval_path_25_segments_vs_oracle():
     assert len(out) == 1 and out[0][1] == 7 and acc in (0.0, 100.0)
 
 
+def test_eval_and_validate_run_no_stock_convolution(monkeypatch):
+    """Forward-only paths (evaluate.forward_video = code/dmcnet/test.py:139-198, driver.validate = validate() of
+    code/dmcnet/train.py): every convolution of the classifier runs on this package's kernels with the BatchNorm's running
+    statistics -- nn.Conv2d's stock forward (MIOpen) is never entered -- and the scores equal the oracle's."""
+    from dmcnet_amd import driver, evaluate, resnet
+    if not resnet.OWN_CONV:
+        pytest.skip("stock convolutions requested")
+    o, m = _product(False, 63)
+    o.eval(); m.eval()
+    flow, mv, res, tgt = O.synthetic_batch(seed=64, batch=2, num_segments=25, num_class=51)
+    calls = []
+    orig = torch.nn.Conv2d._conv_forward
+    monkeypatch.setattr(torch.nn.Conv2d, "_conv_forward", lambda self, x, w, b: (calls.append(tuple(w.shape)), orig(self, x, w, b))[1])
+    got = evaluate.forward_video(m, mv.to(DEV), res.to(DEV), 25, 1)
+    val = driver.validate([(flow, mv, res, tgt)], m, 25, 1.0, 10.0, DEV, log=None)
+    assert calls == [], calls
+    with torch.no_grad():
+        ref = o(mv, res)[0].view(2, 25, 51).mean(1).numpy()
+    assert rel_err(torch.from_numpy(got), ref) < 1e-4
+    assert np.isfinite(val["loss"]) and 0.0 <= val["top1"] <= 100.0
+
+
 @pytest.mark.parametrize("size,factor", [(224, 0), (224, 16), (50, 16), (37, 0)])
 def test_prepare_inputs_bit_exact(size, factor):
     """GPU input preparation == the reference dataset's tensors, bit for bit, incl. the flip."""
