@@ -182,7 +182,12 @@ __global__ __launch_bounds__(WM * WN * 64) void x3s_conv_kernel(X3Args a) {
     const unsigned lds0 = lds_addr_of(lds_x3);
 
     // ---- patch geometry (wave-uniform) ----
-    const int HW = a.H * a.W, PW = a.W + 2, HP = a.H + 2;
+    // patch rows have NO halo columns (pitch W): the 32 pixels of an MFMA tile are then 32 consecutive 32-byte LDS rows, the
+    // pattern the half-swap swizzle makes conflict-free (with W + 2 columns every image-row end shifted the later lanes by
+    // two rows: 13 % of the LDS cycles were bank conflicts at W = 56, 37 % at W = 7).  A tap that leaves the image sideways
+    // reads the patch's last row instead, which is kept zero.
+    const int HW = a.H * a.W, PW = a.W, HP = a.H + 2;
+    constexpr int ZROW = PPMAX - 1;
     const int m0 = blockIdx.x * BM;
     const int mlast = (m0 + BM < a.M ? m0 + BM : a.M) - 1;
     const int n0 = m0 / HW, y0 = (m0 - n0 * HW) / a.W;
@@ -201,8 +206,8 @@ __global__ __launch_bounds__(WM * WN * 64) void x3s_conv_kernel(X3Args a) {
         if (pr < PP) {
             const int prow = pr / PW, col = pr - prow * PW;
             const int g = g0m1 + prow;
-            const int n = g / HP, yy = g - n * HP - 1, xx = col - 1;
-            if (n < a.N && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
+            const int n = g / HP, yy = g - n * HP - 1, xx = col;
+            if (n < a.N && yy >= 0 && yy < a.H)
                 pvoff[k] = (unsigned)((n * a.H + yy) * a.W + xx) * 32u + (unsigned)((h ^ ((pr >> 3) & 1)) << 4);
         }
     }
@@ -213,10 +218,11 @@ __global__ __launch_bounds__(WM * WN * 64) void x3s_conv_kernel(X3Args a) {
         int m = m0 + (wm * TM + i) * 32 + l31;
         if (m > mlast) m = mlast;                          // rows beyond M: a valid address, result not stored
         const int n = m / HW, rem = m - n * HW, yy = rem / a.W, xx = rem - yy * a.W;
-        const int pp = (n * HP + yy + 1 - g0m1) * PW + xx + 1;
+        const int pp = (n * HP + yy + 1 - g0m1) * PW + xx;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const int row = CLS == 4 ? pp + (t / 3 == 0 ? PW : 0) + (t % 3 == 0 ? 1 : 0) : pp + (t / 3 - 1) * PW + (t % 3 - 1);
+            const int dx = CLS == 4 ? (t % 3 == 0 ? 1 : 0) : t % 3 - 1, dy = CLS == 4 ? (t / 3 == 0 ? 1 : 0) : t / 3 - 1;
+            const int row = (xx + dx >= 0 && xx + dx < a.W) ? pp + dy * PW + dx : ZROW;
             xaddr[i][t] = row * 32 + ((khalf ^ ((row >> 3) & 1)) << 4);
         }
     }
@@ -360,6 +366,8 @@ __global__ __launch_bounds__(WM * WN * 64) void x3s_conv_kernel(X3Args a) {
     using Q1 = std::integral_constant<int, 1>;
     using Q2 = std::integral_constant<int, 2>;
 
+    if (tid < 12)                                          // the zero row of the 2 x 3 slice regions (never a transfer target that carries data)
+        *reinterpret_cast<float4*>(lds_x3 + (tid >> 1) * PSL + ZROW * 32 + (tid & 1) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
     issue_weights(0, 0);
     issue_patch(0, 0, 0); issue_patch(0, 1, 0); issue_patch(0, 2, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -463,7 +471,7 @@ int patch_pixels_max(int N, int H, int W, int BM) {
         const int n0 = (int)(m0 / HW), y0 = (int)((m0 - (long)n0 * HW) / W);
         const int n1 = (int)(ml / HW), y1 = (int)((ml - (long)n1 * HW) / W);
         const int NR = n1 * HP + y1 + 1 - (n0 * HP + y0) + 2;
-        if (NR * (W + 2) > worst) worst = NR * (W + 2);
+        if (NR * W + 1 > worst) worst = NR * W + 1;              // rows of W pixels (no halo columns) + the zero row
     }
     return worst;
 }
