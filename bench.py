@@ -428,10 +428,13 @@ def main():
                                    ", batch %d clips/GPU, random-init weights" % args.batch,
                        "global_batch": world * args.batch, "num_class": args.num_class,
                        "parallelism": "dp%d" % world, "final_loss": round(loss, 6),
-                       "classifier_convs": ("libdmcnet_hip conv_nhwc, " + ("bf16x3 arithmetic (fp32 tensors; every fp32 "
+                       "classifier_convs": ("libdmcnet_hip conv_x3s (3x3 stride 1: operands pre-split into bf16x3 slice tensors by "
+                                            "their producers; stride-2 data gradient likewise) + conv_nhwc (stride-2 / 1x1), "
+                                            if (args.conv_arith and ops.X3S) else "libdmcnet_hip conv_nhwc, ") +
+                                           ("bf16x3 arithmetic (fp32 values; every fp32 "
                                             "product formed from three bf16 slices by six bf16 MFMAs, fp32 accumulate: "
                                             "error vs fp64 <= the fp32 MFMA's, tools/conv_x3_check.py)"
-                                            if args.conv_arith else "fp32 MFMA")) if args.own_conv
+                                            if args.conv_arith else "fp32 MFMA") if args.own_conv
                                            else "PyTorch-ROCm (MIOpen fp32, NHWC, solver search)"},
             "roofline": {
                 "kernel": "dmc_gen_tiny_fwd (EstimatorDenseNetTiny forward, %d frames)" % n_frames,

@@ -18,9 +18,10 @@
  *     (code/dmcnet/model.py:187-194: layer k sees [y_{k-1}, ..., y_0, mv(2), residual(3)]);
  *   - return value: DMC_OK (0) or a negative DMC_E_* code; dmc_last_error() gives the text
  *     (thread-local);
- *   - no global mutable state apart from the kernel-selection options of dmc_set_option() (A/B
- *     measurement knobs, relaxed atomics, defaults = fastest path); the library never reads the
- *     environment: safe from several host threads on distinct streams.
+ *   - the ONLY process-wide state is the table of kernel-selection options behind dmc_set_option() (A/B
+ *     measurement knobs, relaxed atomics, defaults = fastest path; an operator reads them at each of its
+ *     entry points, so do not change them while another thread is between two calls of one operator); the
+ *     library never reads the environment; otherwise safe from several host threads on distinct streams.
  */
 #ifndef DMCNET_HIP_H
 #define DMCNET_HIP_H

@@ -38,9 +38,12 @@ int main(int argc, char** argv) {
     if (getenv("CFG")) DK(dmc_set_option("conv_cfg", atoi(getenv("CFG"))));
     srand(7);
     std::vector<float> hx(M * Cin), hw((size_t)Cout * 9 * Cin), hdy(M * Cout);
-    for (auto& v : hx) v = frand();
-    for (auto& v : hw) v = frand() * 0.1f;
-    for (auto& v : hdy) v = frand();
+    // FILL=0: all-zero operands (same instruction stream, minimal switching power: shows how much of the gap to the
+    // peak is the chip's power limit on random data -- results are then trivially zero)
+    const int fill = getenv("FILL") ? atoi(getenv("FILL")) : 1;
+    for (auto& v : hx) v = fill ? frand() : 0.f;
+    for (auto& v : hw) v = fill ? frand() * 0.1f : 0.f;
+    for (auto& v : hdy) v = fill ? frand() : 0.f;
     float *x, *w, *y, *dy, *dx, *y3, *dw, *dw3, *wsp;
     void *xs, *dys, *wf, *wt, *w3f, *w3t;
     double* part;
