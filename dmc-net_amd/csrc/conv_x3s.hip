@@ -478,7 +478,7 @@ int patch_pixels_max(int N, int H, int W, int BM) {
 
 struct X3Cfg { int id, BM, PPMAX, threads; };
 // configurations: 0 = 256 pixels, 8 waves (one tile of 32 x 64 each), 1 = 128 pixels, 4 waves, 2 = 64 pixels, 2 waves
-constexpr X3Cfg X3CFGS[] = {{0, 256, 608, 512}, {1, 128, 320, 256}, {2, 64, 192, 128}};
+constexpr X3Cfg X3CFGS[] = {{0, 256, 608, 512}, {1, 128, 320, 256}, {2, 64, 192, 128}, {3, 256, 608, 256}};   // 3 (measurement): 4 waves of 64 x 64
 
 bool x3s_shape_ok(int N, int H, int W, int K, int R) {
     if (N <= 0 || H <= 0 || W <= 0 || K % 32 != 0 || R % 64 != 0 || K <= 0 || R <= 0) return false;
@@ -489,13 +489,13 @@ bool x3s_shape_ok(int N, int H, int W, int K, int R) {
 int x3s_choose(int N, int H, int W, int R) {
     const long M = (long)N * H * W;
     const int forced = option(OPT_CONV_CFG);                 // measurement switch: 101 + configuration
-    if (forced >= 101 && forced <= 103 && patch_pixels_max(N, H, W, X3CFGS[forced - 101].BM) <= X3CFGS[forced - 101].PPMAX) return forced - 101;
+    if (forced >= 101 && forced <= 104 && patch_pixels_max(N, H, W, X3CFGS[forced - 101].BM) <= X3CFGS[forced - 101].PPMAX) return forced - 101;
     // the largest tile whose workgroups still cover most of the 256 CUs (measured, 120 frames: 8-wave workgroups of 256
     // pixels win down to layer4's 184 workgroups -- 160-187 TFLOP/s against 123-133 with 64-pixel tiles); else the
     // smallest tile whose patch fits
     int fallback = -1;
     for (const X3Cfg& c : X3CFGS) {
-        if (patch_pixels_max(N, H, W, c.BM) > c.PPMAX) continue;
+        if (c.id > 2 || patch_pixels_max(N, H, W, c.BM) > c.PPMAX) continue;
         const long wgs = ((M + c.BM - 1) / c.BM) * (R / 64);
         if (wgs >= 160) return c.id;
         fallback = c.id;
@@ -544,6 +544,7 @@ int run_x3s(const void* xs, const void* wp, const float* addend, float* y, doubl
         case 0: return launch_x3s<8, 1, 608>(a, s);
         case 1: return launch_x3s<4, 1, 320>(a, s);
         case 2: return launch_x3s<2, 1, 192>(a, s);
+        case 3: return launch_x3s<4, 2, 608>(a, s);
         default: return fail(DMC_E_INVALID, "x3s_conv: the patch of a %d x %d image does not fit the LDS", H, W);
     }
 }

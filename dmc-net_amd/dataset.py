@@ -282,6 +282,8 @@ class DevicePrep(object):
         b, s = frames.shape[:2]
         fr = ops.u8_frames_buffer((b * s,) + tuple(frames.shape[2:]), self.device)
         fr.copy_(frames.flatten(0, 1), non_blocking=True)
+        if not boxes.is_cuda:        # host plans: refuse boxes that leave the frame (the kernel cannot truncate like numpy slicing)
+            ops.check_geometry_plans(boxes, int(frames.shape[2]), int(frames.shape[3]), int(out[0]), int(out[1]))
         bx = boxes.to(self.device, non_blocking=True).repeat_interleave(s, 0)
         fl = flips.to(self.device, non_blocking=True).repeat_interleave(s, 0)
         flow, mv, res = ops.prepare_inputs(fr, fl, self.flow_ds_factor, boxes=bx, out_size=out)

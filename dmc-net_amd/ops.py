@@ -1236,6 +1236,19 @@ def u8_frames_buffer(shape, device):
     return torch.empty(n + 16, dtype=torch.uint8, device=device)[:n].view(tuple(shape))
 
 
+def check_geometry_plans(boxes, h0, w0, oh, ow):
+    """Raise ValueError unless every plan (y0, x0, h, w, rh, rw, cy, cx) crops inside the H0 x W0 frame, resizes to a
+    positive size and takes its OH x OW output window inside the resized box."""
+    b = boxes.to(torch.int64)
+    y0, x0, h, w, rh, rw, cy, cx = (b[:, i] for i in range(8))
+    ok = (y0 >= 0) & (x0 >= 0) & (h > 0) & (w > 0) & (y0 + h <= h0) & (x0 + w <= w0) & (rh > 0) & (rw > 0) & \
+         (cy >= 0) & (cx >= 0) & (cy + oh <= rh) & (cx + ow <= rw)
+    if not bool(ok.all()):
+        bad = int((~ok).nonzero()[0])
+        raise ValueError("geometry plan %d = %s leaves the %d x %d frame or its resized box (output %d x %d)"
+                         % (bad, [int(v) for v in boxes[bad]], h0, w0, oh, ow))
+
+
 def prepare_inputs(frames_u8, flip=None, flow_ds_factor=0, boxes=None, out_size=None):
     """uint8 [N,H0,W0,7] HWC frames (+ optional [N] flip flags, [N,8] int32 geometry plans
     (y0,x0,h,w,rh,rw,cy,cx -- see transforms.geometry_plan) and an output size) on the GPU ->
@@ -1262,9 +1275,14 @@ def prepare_inputs(frames_u8, flip=None, flow_ds_factor=0, boxes=None, out_size=
     if flip is not None:
         flip = flip.to(dev, torch.uint8).contiguous()
     if boxes is not None:
-        boxes = boxes.to(dev, torch.int32).contiguous()
         if tuple(boxes.shape) != (n, 8):
             raise ValueError("boxes must be [N,8] (y0, x0, h, w, rh, rw, cy, cx)")
+        if not boxes.is_cuda:
+            # the kernel indexes the frames with these numbers and cannot truncate the way numpy slicing does: a plan that
+            # leaves the frame or the resized box is refused while it is still a host tensor (plans already on the device
+            # are the caller's responsibility: checking them would cost a synchronisation per batch)
+            check_geometry_plans(boxes, h0, w0, oh, ow)
+        boxes = boxes.to(dev, torch.int32).contiguous()
     elif (oh, ow) != (h0, w0):
         boxes = torch.tensor([[0, 0, h0, w0, oh, ow, 0, 0]] * n, dtype=torch.int32, device=dev)
     flow = torch.empty((n, 2, oh, ow), dtype=torch.float32, device=dev)

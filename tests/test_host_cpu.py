@@ -598,3 +598,18 @@ def test_i3d_trainer_two_ranks_gloo_equals_full_micro_batches(golden, tmp_path):
     np.testing.assert_allclose(r0["params"], tiny_i3d.snapshot(net), rtol=2e-4, atol=2e-6)
     names = [[n for n, _ in e] for e in r0["log"]]
     assert names[0] == [] and names[1] == ["optimizer", "optimizer_3"] and names[2] == [] and names[3] == ["optimizer_mse"]
+
+
+def test_geometry_plans_are_validated_on_the_host():
+    """ops.check_geometry_plans (used by prepare_inputs / DevicePrep for host-side plans): a box that leaves the frame, a
+    non-positive size or an output window outside the resized box raises instead of reaching the kernel."""
+    from dmcnet_amd import ops
+    good = torch.tensor([[16, 58, 224, 224, 224, 224, 0, 0], [0, 0, 256, 340, 256, 340, 16, 58]], dtype=torch.int32)
+    ops.check_geometry_plans(good, 256, 340, 224, 224)
+    for bad in ([40, 58, 224, 224, 224, 224, 0, 0],          # y0 + h > H0
+                [0, 200, 224, 224, 224, 224, 0, 0],          # x0 + w > W0
+                [0, 0, 224, 224, 200, 224, 0, 0],            # output taller than the resized box
+                [0, 0, 224, 224, 224, 224, 0, 8],            # window leaves the resized box
+                [-1, 0, 224, 224, 224, 224, 0, 0], [0, 0, 0, 224, 224, 224, 0, 0]):
+        with pytest.raises(ValueError):
+            ops.check_geometry_plans(torch.tensor([good[0].tolist(), bad], dtype=torch.int32), 256, 340, 224, 224)
