@@ -82,6 +82,8 @@ SIGNATURES = {
     "dmc_x3s_conv_dgrad_s2": (_I, [_P] * 3 + [_I] * 5 + [_P]),
     "dmc_bn_apply_act_x3s": (_I, [_P] * 8 + [_I, _I, _I, _P]),
     "dmc_bn_act_bwd_x3s": (_I, [_P] * 13 + [_I, _I, _I, _P]),
+    "dmc_x3s_conv_dgrad_bnb": (_I, [_P] * 9 + [_I] + [_P] * 3 + [_I] * 5 + [_P]),
+    "dmc_bn_act_bwd_x3s_apply": (_I, [_P] * 12 + [_I, _I, _I, _P]),
     "dmc_bn_relu_pool_fwd_x3s": (_I, [_P] * 9 + [_I, _I, _I, _I, _I, _F, _F, _P]),
     "dmc_disc_first_supported": (_I, [_I]),
     "dmc_disc_first_fwd": (_I, [_P] * 5 + [_I] * 5 + [_P]),

@@ -805,4 +805,17 @@ int dmc_bn_relu_pool_fwd_x3s(const float* x, const float* gamma, const float* be
     return check_launch("pool_fwd_x3s");
 }
 
+/* Second half of dmc_bn_act_bwd_x3s alone: dgamma / dbeta are INPUTS (reduced by the launch that produced dy,
+ * dmc_x3s_conv_dgrad_bnb); one streaming pass writes dx (fp32, nullable) / dxs (slices, nullable) / dresidual. */
+int dmc_bn_act_bwd_x3s_apply(const float* x, const float* residual, const float* gamma, const float* beta, const float* stats,
+                             const float* dy, float* dx, void* dxs, float* dresidual, const float* dgamma, const float* dbeta,
+                             const unsigned char* relu_mask, int M, int C, int relu, dmc_stream_t stream) {
+    if (!x || !gamma || !beta || !stats || !dy || (!dx && !dxs) || !dgamma || !dbeta)
+        return fail(DMC_E_INVALID, "dmc_bn_act_bwd_x3s_apply: null pointer");
+    if (!shape_ok8(M, C)) return fail(DMC_E_INVALID, "dmc_bn_act_bwd_x3s_apply: unsupported shape M=%d C=%d", M, C);
+    BnArgs a = {x, residual, gamma, beta, stats, dy, nullptr, dx, dresidual, M, C, relu, const_cast<unsigned char*>(relu_mask)};
+    bn_apply_bwd_x3s_kernel<<<stream_blocks((size_t)M * (C / 8)), 256, 0, (hipStream_t)stream>>>(a, dgamma, dbeta, 1.f / (float)M, static_cast<unsigned short*>(dxs));
+    return check_launch("bn_apply_bwd_x3s");
+}
+
 }  // extern "C"

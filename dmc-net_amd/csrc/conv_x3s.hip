@@ -145,6 +145,15 @@ struct X3Args {
     int N, H, W, K, R;     // K input channels, R output channels of this launch
     int M;                 // N * H * W
     unsigned plane_bytes;  // M * 32
+    // data gradient only: BatchNorm-backward sums of the UPSTREAM unit (the one whose output gradient this launch writes):
+    // per channel sum(d) and sum(d * xhat), d = dx [* relu'], from the tile in LDS -- that unit's bn_partial pass disappears
+    const float* bnb_y = nullptr;        // its convolution output [M][R]
+    const float* bnb_stats = nullptr;    // mean[R], invstd[R]
+    const float* bnb_gamma = nullptr;
+    const float* bnb_beta = nullptr;
+    const unsigned char* bnb_mask = nullptr;   // ReLU sign bits (4 per float4) or null: recomputed
+    int bnb_relu = 0;
+    double* bnb_part = nullptr;          // [gridDim.x][R][2]
     int ablate;            // measurement only (option conv_ablate): 16 = no wait for transfers, 32 = no statistics, 64 = no transfers,
                            // 128 = no output stores, 256 = no main loop (results wrong / missing)
 };
@@ -432,8 +441,56 @@ __global__ __launch_bounds__(WM * WN * 64) void x3s_conv_kernel(X3Args a) {
                         v.x += av.x; v.y += av.y; v.z += av.z; v.w += av.w;
                     }
                     *reinterpret_cast<float4*>(a.y + o) = v;
+                    if (CLS == 1 && a.bnb_part) {
+                        // upstream BatchNorm sums: this lane's four channels of the pixel, read like the addend (coalesced,
+                        // all iterations' loads in flight together): d = dx [* relu'] and xhat go back to LDS for the column sums
+                        const int c4 = rbase + (lane & 15) * 4;
+                        const float4 yv = *reinterpret_cast<const float4*>(a.bnb_y + o);
+                        const float4 mean = *reinterpret_cast<const float4*>(a.bnb_stats + c4);
+                        const float4 istd = *reinterpret_cast<const float4*>(a.bnb_stats + a.R + c4);
+                        const float4 xh = make_float4((yv.x - mean.x) * istd.x, (yv.y - mean.y) * istd.y, (yv.z - mean.z) * istd.z, (yv.w - mean.w) * istd.w);
+                        if (a.bnb_relu) {
+                            unsigned mb;
+                            if (a.bnb_mask) {
+                                mb = a.bnb_mask[o >> 2];
+                            } else {
+                                const float4 g = *reinterpret_cast<const float4*>(a.bnb_gamma + c4), b = *reinterpret_cast<const float4*>(a.bnb_beta + c4);
+                                mb = (fmaf(xh.x, g.x, b.x) > 0.f ? 1u : 0u) | (fmaf(xh.y, g.y, b.y) > 0.f ? 2u : 0u) |
+                                     (fmaf(xh.z, g.z, b.z) > 0.f ? 4u : 0u) | (fmaf(xh.w, g.w, b.w) > 0.f ? 8u : 0u);
+                            }
+                            v.x = (mb & 1) ? v.x : 0.f; v.y = (mb & 2) ? v.y : 0.f; v.z = (mb & 4) ? v.z : 0.f; v.w = (mb & 8) ? v.w : 0.f;
+                        }
+                        *reinterpret_cast<float4*>(etile + prow * EP + (lane & 15) * 16) = v;
+                        *reinterpret_cast<float4*>(etile + NW * ETILE + 8192 + prow * EP + (lane & 15) * 16) = xh;
+                    }
+                } else if (CLS == 1 && a.bnb_part) {                // pixels beyond M: no contribution
+                    *reinterpret_cast<float4*>(etile + prow * EP + (lane & 15) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(etile + NW * ETILE + 8192 + prow * EP + (lane & 15) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
+        }
+    }
+    if (CLS == 1 && a.bnb_part) {
+        // lane = channel: column sums of d and d * xhat over the wave's pixels, fp64, fixed order
+        double* red = reinterpret_cast<double*>(lds_x3 + NW * ETILE);   // [WM][64][2]
+        const char* xtile = etile + NW * ETILE + 8192;                  // this wave's xhat tile (behind all d tiles and `red`)
+        double d1 = 0.0, d2 = 0.0;
+#pragma unroll 8
+        for (int p = 0; p < 32 * TM; ++p) {
+            const double d = (double)*reinterpret_cast<const float*>(etile + p * EP + lane * 4);
+            const double xh = (double)*reinterpret_cast<const float*>(xtile + p * EP + lane * 4);
+            d1 += d;
+            d2 += d * xh;
+        }
+        red[(wm * 64 + lane) * 2 + 0] = d1;
+        red[(wm * 64 + lane) * 2 + 1] = d2;
+        __syncthreads();
+        for (int cc = tid; cc < BN; cc += NW * 64) {
+            double e1 = 0.0, e2 = 0.0;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { e1 += red[(w * 64 + cc) * 2 + 0]; e2 += red[(w * 64 + cc) * 2 + 1]; }
+            double* dst = a.bnb_part + ((size_t)blockIdx.x * a.R + rbase + cc) * 2;
+            dst[0] = e1; dst[1] = e2;
         }
     }
     if (CLS == 1 && a.stat_part) {
@@ -510,7 +567,7 @@ int x3s_choose(int N, int H, int W, int R) {
 template <int WM, int TM, int PPMAX>
 int launch_x3s(const X3Args& a, hipStream_t s) {
     constexpr int BM = 32 * TM * WM;
-    constexpr size_t op_bytes = 2 * 3 * PPMAX * 32 + 2 * 3 * 3 * 64 * 32, ep_bytes = (size_t)BM * 272 + WM * 64 * 16;
+    constexpr size_t op_bytes = 2 * 3 * PPMAX * 32 + 2 * 3 * 3 * 64 * 32, ep_bytes = 2 * (size_t)BM * 272 + 8192;   // d tiles, sums, xhat tiles
     constexpr size_t lds_bytes = op_bytes > ep_bytes ? op_bytes : ep_bytes;
     dim3 grid((a.M + BM - 1) / BM, a.R / 64);
     if constexpr (WM >= 4) {
@@ -529,8 +586,10 @@ int launch_x3s(const X3Args& a, hipStream_t s) {
     return check_launch("x3s_conv");
 }
 
+struct X3Bnb { const float *y, *stats, *gamma, *beta; const unsigned char* mask; int relu; double* part; };
+
 int run_x3s(const void* xs, const void* wp, const float* addend, float* y, double* stat_part, int N, int H, int W, int K, int R,
-            hipStream_t s) {
+            hipStream_t s, const X3Bnb* bnb = nullptr) {
     if (!xs || !wp || !y) return fail(DMC_E_INVALID, "x3s_conv: null pointer");
     if (!x3s_shape_ok(N, H, W, K, R)) return fail(DMC_E_INVALID, "x3s_conv: unsupported shape N=%d H=%d W=%d K=%d R=%d", N, H, W, K, R);
     const int cfg = x3s_choose(N, H, W, R);
@@ -538,6 +597,10 @@ int run_x3s(const void* xs, const void* wp, const float* addend, float* y, doubl
     a.xs = xs; a.wp = wp; a.y = y; a.addend = addend; a.stat_part = stat_part;
     a.N = N; a.H = H; a.W = W; a.K = K; a.R = R; a.M = N * H * W;
     a.plane_bytes = (unsigned)a.M * 32u;
+    if (bnb) {
+        a.bnb_y = bnb->y; a.bnb_stats = bnb->stats; a.bnb_gamma = bnb->gamma; a.bnb_beta = bnb->beta; a.bnb_mask = bnb->mask;
+        a.bnb_relu = bnb->relu; a.bnb_part = bnb->part;
+    }
     a.ablate = option(OPT_CONV_ABLATE);
     if (a.ablate & 32) a.stat_part = nullptr;
     switch (cfg) {
@@ -772,6 +835,26 @@ int launch_x3s_wgrad(const X3WgPlan& p, X3WgArgs a, float* dw, hipStream_t s) {
     return check_launch("x3s_wgrad_reduce");
 }
 
+// dgamma / dbeta of the upstream BatchNorm from the data gradient's per-workgroup sums (fixed order, one workgroup per channel)
+__global__ __launch_bounds__(256) void x3s_bnb_final_kernel(const double* __restrict__ part, int nblk, int C,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double red[2][4];
+    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double s = 0.0, ss = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 256) {
+        const double2 v = *reinterpret_cast<const double2*>(part + ((size_t)b * C + c) * 2);
+        s += v.x;
+        ss += v.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o, 64); ss += __shfl_down(ss, o, 64); }
+    if (lane == 0) { red[0][wave] = s; red[1][wave] = ss; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    dbeta[c] = (float)(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    dgamma[c] = (float)(red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+}
+
 int stream_blocks(long total) {
     long b = (total + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -894,6 +977,23 @@ int dmc_x3s_conv_dgrad_s2(const void* dys, const void* wpack_t2, float* dx, int 
     dim3 grid((a.M + 127) / 128, Cin / 64);
     x3s_conv_kernel<4, 1, 1, 2, 320, true, 4><<<grid, 256, lds_bytes, (hipStream_t)stream>>>(a);
     return check_launch("x3s_conv_dgrad_s2");
+}
+
+/* dmc_x3s_conv_dgrad that ALSO reduces the BatchNorm-backward sums of the unit whose output gradient it writes (dx is that
+ * unit's dout): bn_y / bn_stats / bn_gamma / bn_beta / bn_relu_mask (nullable) / bn_relu describe that unit's BatchNorm
+ * [+ ReLU]; partials = dmc_x3s_conv_stat_blocks(N, H, W, Cin) x Cin x 2 doubles of workspace; dgamma / dbeta [Cin] receive
+ * sum(d * xhat) / sum(d) with d = dx [zeroed where the ReLU was off] -- what dmc_bn_act_bwd's first pass computes. */
+int dmc_x3s_conv_dgrad_bnb(const void* dys, const void* wpack_t, const float* addend, float* dx, const float* bn_y,
+                           const float* bn_stats, const float* bn_gamma, const float* bn_beta, const unsigned char* bn_relu_mask,
+                           int bn_relu, double* partials, float* dgamma, float* dbeta, int N, int H, int W, int Cin, int Cout,
+                           dmc_stream_t stream) {
+    if (!bn_y || !bn_stats || !bn_gamma || !bn_beta || !partials || !dgamma || !dbeta)
+        return fail(DMC_E_INVALID, "dmc_x3s_conv_dgrad_bnb: null pointer");
+    X3Bnb b = {bn_y, bn_stats, bn_gamma, bn_beta, bn_relu_mask, bn_relu, partials};
+    int rc = run_x3s(dys, wpack_t, addend, dx, nullptr, N, H, W, Cout, Cin, (hipStream_t)stream, &b);
+    if (rc) return rc;
+    x3s_bnb_final_kernel<<<Cin, 256, 0, (hipStream_t)stream>>>(partials, dmc_x3s_conv_stat_blocks(N, H, W, Cin), Cin, dgamma, dbeta);
+    return check_launch("x3s_bnb_final");
 }
 
 }  // extern "C"

@@ -706,6 +706,10 @@ def conv_nhwc(x, weight, stride=1, padding=1):
 #: bf16x3 slice tensors written by the PRODUCER of the activation (BatchNorm apply / stem pool / BatchNorm backward), the
 #: convolution's main loop is LDS reads + MFMAs only.  DMC_X3S=0: the in-loop-split kernels of conv_nhwc.hip.
 X3S = __import__("os").environ.get("DMC_X3S", "1") != "0"
+#: DMC_BN_BWD_LINK=1: a pre-split data gradient also reduces the BatchNorm-backward sums of the unit it feeds (BnBwdLink).
+#: Off by default: measured neutral (13.28 vs 13.27 ms per step, two A/B pairs on one box) -- the 0.33 ms of bn_partial
+#: launches it removes come back as un-overlapped epilogue time of the data-gradient kernels.
+BN_BWD_LINK = __import__("os").environ.get("DMC_BN_BWD_LINK", "0") == "1"
 
 
 def x3s_of(t):
@@ -812,6 +816,21 @@ class ResidualGradLink:
         self.grad = None
 
 
+class BnBwdLink:
+    """Couples a fused conv -> bn op U with the ONE pre-split convolution V that reads its result: V's data-gradient launch
+    writes U's output gradient, so it also reduces U's BatchNorm-backward sums (dbeta, dgamma) from the tile it holds in LDS
+    (dmc_x3s_conv_dgrad_bnb) and U's backward skips its reduction pass (bn_partial: a read of dout and y).  ``kind``:
+    "inner" = U's result feeds V alone (conv1 -> conv2 of a block); "block" = U closes a block whose output feeds an
+    identity-shortcut block -- V's launch is then U's complete output gradient only when it also adds the residual branch's
+    gradient (ResidualGradLink), which V checks at backward time.  Unused links cost nothing: U falls back to its own pass."""
+    __slots__ = ("kind", "y", "stats", "gamma", "beta", "mask", "relu", "dgamma", "dbeta", "ready")
+
+    def __init__(self, kind):
+        self.kind, self.ready = kind, False
+        self.y = self.stats = self.gamma = self.beta = self.mask = self.dgamma = self.dbeta = None
+        self.relu = False
+
+
 class _ConvBnAct(torch.autograd.Function):
     """relu?(BatchNorm2d(conv2d(x, w)) [+ residual]) in training mode: the ResNet's conv -> bn [-> add] [-> relu]
     chains (torchvision BasicBlock / Bottleneck / downsample behind code/dmcnet/model.py:305,352) on the
@@ -824,10 +843,11 @@ class _ConvBnAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, residual, gamma, beta, running_mean, running_var, stride, padding, relu, eps,
-                momentum, link=None, xs=None, mode=1):
+                momentum, link=None, xs=None, mode=1, bn_out=None, bn_in=None):
         lib = _lib.load()
         _need_cuda(x, weight, residual, gamma, beta)
-        ctx.set_materialize_grads(False)    # else autograd zero-fills a gradient for the slice output every backward
+        ctx.set_materialize_grads(False)
+        ctx.bn_out, ctx.bn_in = bn_out, None    # else autograd zero-fills a gradient for the slice output every backward
         want_f32, want_xs, use_x3s = bool(mode & 1), bool(mode & 2), bool(mode & 4)
         wcl = _as_cl(weight)
         cout, cin = weight.shape[0], weight.shape[1]
@@ -850,6 +870,8 @@ class _ConvBnAct(torch.autograd.Function):
                 _lib.check(lib.dmc_x3s_conv_fwd(_lib.ptr(xs), _lib.ptr(wf), _lib.ptr(y), _lib.ptr(part), n, h, w, cin, cout,
                                                 _stream()), "dmc_x3s_conv_fwd")
             wf_ok = True
+            if bn_in is not None and stride == 1 and ctx.needs_input_grad[0]:
+                ctx.bn_in = bn_in                           # this op's data gradient is the producer's output gradient
         else:
             if not f32_valid(x):
                 raise RuntimeError("conv_bn_act: the input's fp32 memory was not written by its producer (slices only)")
@@ -902,6 +924,8 @@ class _ConvBnAct(torch.autograd.Function):
                 _lib.check(lib.dmc_bn_apply_act_nhwc(_lib.ptr(y), _lib.ptr(residual), _lib.ptr(gamma), _lib.ptr(beta),
                                                      _lib.ptr(stats), _lib.ptr(out), _lib.ptr(mask), m, cout, int(relu),
                                                      _stream()), "dmc_bn_apply_act_nhwc")
+        if bn_out is not None:                              # what the consumer's data gradient needs for this op's BatchNorm sums
+            bn_out.y, bn_out.stats, bn_out.gamma, bn_out.beta, bn_out.mask, bn_out.relu = y, stats, gamma, beta, mask, bool(relu)
         # the pre-split path keeps the input's slices for its weight gradient, not the fp32 input
         ctx.save_for_backward(xs if use_x3s else x, weight, y, gamma, beta, stats, mask)
         ctx.cfg = (int(stride), int(padding), bool(relu), residual is not None, use_x3s, tuple(x.shape))
@@ -915,7 +939,7 @@ class _ConvBnAct(torch.autograd.Function):
         lib = _lib.load()
         x, weight, y, gamma, beta, stats, mask = ctx.saved_tensors
         if dout is None:                    # the result did not reach the loss
-            return (None,) * 15
+            return (None,) * 17
         stride, padding, relu, has_res, use_x3s, x_shape = ctx.cfg
         n, cout, oh, ow = y.shape
         m = n * oh * ow
@@ -926,8 +950,20 @@ class _ConvBnAct(torch.autograd.Function):
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         scratch = _floats(lib.dmc_bn_act_scratch_bytes(cout), y.device)
         dy = dys = None
+        pre = ctx.bn_out is not None and ctx.bn_out.ready   # the consumer's data gradient already reduced dgamma / dbeta
         with _span("bn_act_bwd"):
-            if use_x3s:                                     # the convolution's output gradient: slices only
+            if pre:
+                dgamma, dbeta = ctx.bn_out.dgamma, ctx.bn_out.dbeta
+                s2 = ctx.wsplit_t2 is not None and ctx.needs_input_grad[0]
+                if use_x3s or s2:
+                    dys = _x3s_buffer(m, cout, y.device)
+                if not use_x3s:
+                    dy = torch.empty_like(y)
+                _lib.check(lib.dmc_bn_act_bwd_x3s_apply(_lib.ptr(y), None, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(stats),
+                                                        _lib.ptr(dout), _lib.ptr(dy), _lib.ptr(dys), _lib.ptr(dres),
+                                                        _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(mask), m, cout,
+                                                        int(relu), _stream()), "dmc_bn_act_bwd_x3s_apply")
+            elif use_x3s:                                   # the convolution's output gradient: slices only
                 dys = _x3s_buffer(m, cout, y.device)
                 _lib.check(lib.dmc_bn_act_bwd_x3s(_lib.ptr(y), None, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(stats),
                                                   _lib.ptr(scratch), _lib.ptr(dout), None, _lib.ptr(dys), _lib.ptr(dres),
@@ -963,8 +999,21 @@ class _ConvBnAct(torch.autograd.Function):
                     dx = torch.empty(x_shape, dtype=torch.float32, device=y.device, memory_format=_CL)
                     if addend is not None:
                         addend = _as_cl(addend)
-                    _lib.check(lib.dmc_x3s_conv_dgrad(_lib.ptr(dys), _lib.ptr(ctx.wsplit_t), _lib.ptr(addend), _lib.ptr(dx),
-                                                      nn_, h, w, cin, cout, _stream()), "dmc_x3s_conv_dgrad")
+                    bl = ctx.bn_in
+                    if bl is not None and bl.y is not None and (bl.kind == "inner" or addend is not None):
+                        # dx is the producer's COMPLETE output gradient: reduce its BatchNorm sums in this launch's epilogue
+                        nblk = lib.dmc_x3s_conv_stat_blocks(nn_, h, w, cin)
+                        part = torch.empty((nblk, cin, 2), dtype=torch.float64, device=y.device)
+                        bl.dgamma, bl.dbeta = torch.empty_like(bl.gamma), torch.empty_like(bl.gamma)
+                        _lib.check(lib.dmc_x3s_conv_dgrad_bnb(_lib.ptr(dys), _lib.ptr(ctx.wsplit_t), _lib.ptr(addend), _lib.ptr(dx),
+                                                              _lib.ptr(bl.y), _lib.ptr(bl.stats), _lib.ptr(bl.gamma), _lib.ptr(bl.beta),
+                                                              _lib.ptr(bl.mask), int(bl.relu), _lib.ptr(part), _lib.ptr(bl.dgamma),
+                                                              _lib.ptr(bl.dbeta), nn_, h, w, cin, cout, _stream()),
+                                   "dmc_x3s_conv_dgrad_bnb")
+                        bl.ready = True
+                    else:
+                        _lib.check(lib.dmc_x3s_conv_dgrad(_lib.ptr(dys), _lib.ptr(ctx.wsplit_t), _lib.ptr(addend), _lib.ptr(dx),
+                                                          nn_, h, w, cin, cout, _stream()), "dmc_x3s_conv_dgrad")
             if ctx.needs_input_grad[1]:
                 with _span("conv_nhwc_wgrad"):
                     dwc = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=y.device, memory_format=_CL)
@@ -984,7 +1033,7 @@ class _ConvBnAct(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 with _span("conv_nhwc_wgrad"):
                     dw = _grad_like(_conv_wgrad(x, dy, wcl, stride, padding), weight)
-        return dx, dw, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def conv_bn_act_supported(x, conv, bn):
@@ -1060,11 +1109,13 @@ def conv_bn_act_eval(x, conv, bn, residual=None, relu=True, want_f32=True, want_
     return out
 
 
-def conv_bn_act(x, conv, bn, residual=None, relu=True, link=None, want_f32=True, want_slices=False):
+def conv_bn_act(x, conv, bn, residual=None, relu=True, link=None, want_f32=True, want_slices=False, bn_link=None):
     """relu?(bn(conv(x)) [+ residual]) for a channels_last ``x`` (see conv_bn_act_supported); ``link``: the
     ResidualGradLink shared by the first and the last op of an identity-shortcut block.  ``want_slices``: also write
     the result's bf16x3 slice tensor (attached to the returned tensor, see x3s_of) for a pre-split consumer;
-    ``want_f32=False``: ONLY the slices -- the returned tensor's fp32 memory is then not written (f32_valid)."""
+    ``want_f32=False``: ONLY the slices -- the returned tensor's fp32 memory is then not written (f32_valid).
+    ``bn_link``: "inner" / "block" -- the result has ONE pre-split consumer (see BnBwdLink); the link travels on the
+    returned tensor and that consumer picks it up from its input."""
     if bn.num_batches_tracked is not None:
         if _PENDING_COUNTERS is not None:
             _PENDING_COUNTERS.append(bn.num_batches_tracked)
@@ -1075,12 +1126,16 @@ def conv_bn_act(x, conv, bn, residual=None, relu=True, link=None, want_f32=True,
     n, _, h, w = x.shape
     use_x3s = x3s_usable(n, h, w, conv)
     mode = int(want_f32) | (int(want_slices) << 1) | (int(use_x3s) << 2)
+    bn_out = BnBwdLink(bn_link) if (bn_link and BN_BWD_LINK and want_slices) else None
+    bn_in = getattr(x, "_dmc_bnlink", None) if use_x3s else None
     out, out_xs = _ConvBnAct.apply(x, conv.weight, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                    conv.stride[0], conv.padding[0], relu, bn.eps,
                                    bn.momentum if bn.momentum is not None else 0.1, link,
-                                   x3s_of(x) if use_x3s else None, mode)
+                                   x3s_of(x) if use_x3s else None, mode, bn_out, bn_in)
     if want_slices:
         _attach_x3s(out, out_xs, want_f32)
+    if bn_out is not None:
+        out._dmc_bnlink = bn_out
     return out
 
 

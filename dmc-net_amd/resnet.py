@@ -36,7 +36,7 @@ OWN_CONV = _os.environ.get("DMC_OWN_CONV", "1") != "0"
 RESIDUAL_GRAD_LINK = _os.environ.get("DMC_RESIDUAL_GRAD_LINK", "1") != "0"
 
 
-def _conv_bn_act(conv, bn, x, residual=None, relu=True, link=None, next_conv=None, only_consumer=False):
+def _conv_bn_act(conv, bn, x, residual=None, relu=True, link=None, next_conv=None, only_consumer=False, bn_link=None):
     """relu?(bn(conv(x)) [+ residual]).  ``next_conv``: a convolution that reads the result -- when it takes the
     pre-split bf16x3 path (ops.x3s_usable) the result's slice tensor is written alongside; ``only_consumer``: nothing
     else reads the result, so its fp32 form is not written at all."""
@@ -50,7 +50,8 @@ def _conv_bn_act(conv, bn, x, residual=None, relu=True, link=None, next_conv=Non
             slices = ops.x3s_usable(n, (h + 2 * p - k) // s_ + 1, (w + 2 * p - k) // s_ + 1, next_conv)
         if eval_op:     # evaluation / validation: running statistics, forward only, the same convolution kernels
             return ops.conv_bn_act_eval(x, conv, bn, residual, relu, want_f32=not (slices and only_consumer), want_slices=slices)
-        return ops.conv_bn_act(x, conv, bn, residual, relu, link, want_f32=not (slices and only_consumer), want_slices=slices)
+        return ops.conv_bn_act(x, conv, bn, residual, relu, link, want_f32=not (slices and only_consumer), want_slices=slices,
+                               bn_link=bn_link if slices else None)
     if not ops.f32_valid(x):
         raise RuntimeError("the activation's fp32 memory was not written (slices only) but the stock path needs it")
     return _bn_act(bn, conv(x), residual, relu)
@@ -89,6 +90,7 @@ class ResidualUnit(nn.Module):
             self.downsample = nn.Sequential(_conv(cin, cout, 1, stride), nn.BatchNorm2d(cout))
         self.out_channels = cout
         self.next_conv = [None]      # the next unit's first convolution (set by ResNet; in a list: not a sub-module)
+        self.next_identity = [False] # ... and whether that unit has an identity shortcut
 
     def forward(self, x):
         link = None
@@ -99,9 +101,12 @@ class ResidualUnit(nn.Module):
         else:
             shortcut = _conv_bn_act(self.downsample[0], self.downsample[1], x, relu=False)
         # conv1's result is read by conv2 alone: slices only when conv2 takes the pre-split path
-        y = _conv_bn_act(self.conv1, self.bn1, x, link=link, next_conv=self.conv2, only_consumer=True)
+        # (bn_link: conv2's data gradient is conv1-unit's whole output gradient; the block's output gradient is the next
+        # block's conv1 data gradient + its residual gradient when that block has an identity shortcut -- ops.BnBwdLink)
+        y = _conv_bn_act(self.conv1, self.bn1, x, link=link, next_conv=self.conv2, only_consumer=True, bn_link="inner")
         if self.kind == "basic":
-            return _conv_bn_act(self.conv2, self.bn2, y, residual=shortcut, link=link, next_conv=self.next_conv[0])
+            return _conv_bn_act(self.conv2, self.bn2, y, residual=shortcut, link=link, next_conv=self.next_conv[0],
+                                bn_link="block" if (self.next_identity[0] and RESIDUAL_GRAD_LINK) else None)
         y = _conv_bn_act(self.conv2, self.bn2, y, next_conv=self.conv3, only_consumer=True)
         return _conv_bn_act(self.conv3, self.bn3, y, residual=shortcut, link=link, next_conv=self.next_conv[0])
 
@@ -124,6 +129,7 @@ class ResNet(nn.Module):
         chain = [u for st in (self.layer1, self.layer2, self.layer3, self.layer4) for u in st]
         for u, nxt in zip(chain, chain[1:]):
             u.next_conv[0] = nxt.conv1
+            u.next_identity[0] = nxt.downsample is None
         self.avgpool = nn.AvgPool2d(7, stride=1)
         self.fc = nn.Linear(width, num_classes)
 

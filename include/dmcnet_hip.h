@@ -371,6 +371,18 @@ int dmc_bn_act_bwd_x3s(const float* x, const float* residual, const float* gamma
 int dmc_bn_relu_pool_fwd_x3s(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                              float* y_pool, void* ys, float* stats, void* scratch, int N, int H, int W, int C, int training,
                              float eps, float momentum, dmc_stream_t stream);
+/* BatchNorm-backward sums from the data gradient's epilogue: dmc_x3s_conv_dgrad_bnb = dmc_x3s_conv_dgrad that also
+ * reduces, for the unit whose output gradient it writes (dx), dbeta = sum(d) and dgamma = sum(d * xhat) (d = dx, zeroed
+ * where that unit's ReLU was off; partials: dmc_x3s_conv_stat_blocks(N, H, W, Cin) x Cin x 2 doubles);
+ * dmc_bn_act_bwd_x3s_apply = the second half of dmc_bn_act_bwd_x3s with those sums as inputs (no reduction pass). */
+int dmc_x3s_conv_dgrad_bnb(const void* dys, const void* wpack_t, const float* addend, float* dx, const float* bn_y,
+                           const float* bn_stats, const float* bn_gamma, const float* bn_beta, const unsigned char* bn_relu_mask,
+                           int bn_relu, double* partials, float* dgamma, float* dbeta, int N, int H, int W, int Cin, int Cout,
+                           dmc_stream_t stream);
+int dmc_bn_act_bwd_x3s_apply(const float* x, const float* residual, const float* gamma, const float* beta, const float* stats,
+                             const float* dy, float* dx, void* dxs, float* dresidual, const float* dgamma, const float* dbeta,
+                             const unsigned char* relu_mask, int M, int C, int relu, dmc_stream_t stream);
+
 
 
 

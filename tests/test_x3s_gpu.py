@@ -274,3 +274,40 @@ def test_stride2_unit_data_gradient_in_one_presplit_launch(cin, cout, hw, n, see
         assert rel_err(res[mode][3], bd.weight.grad) < 2e-4 and rel_err(res[mode][4], bd.bias.grad) < 2e-4
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][2], res[False][2])   # same forward / weight-gradient kernels
     assert not torch.equal(res[True][1], res[False][1])          # the data gradient really took the other kernel
+
+
+def test_bn_backward_sums_from_the_data_gradient_epilogue(monkeypatch):
+    """ops.BnBwdLink: in layer1 (two identity-shortcut BasicBlocks) the BatchNorm-backward sums of three of the four
+    conv -> bn units come out of the epilogue of the data-gradient launch that writes their output gradient
+    (dmc_x3s_conv_dgrad_bnb: conv1 -> conv2 inside a block, and the first block's output through the second block's
+    conv1 + residual-gradient addend); the last unit has no pre-split consumer and keeps its own reduction pass.  Same
+    arithmetic in another summation order: every gradient within 1e-5 of the unlinked run."""
+    monkeypatch.setattr(resnet, "OWN_CONV", True)
+    torch.manual_seed(13)
+    net = resnet.ResNet("basic", (2, 2, 2, 2)).to(DEV).train()
+    layer = net.layer1
+    state = {k: v.clone() for k, v in layer.state_dict().items()}
+    x0 = rnd(371, (4, 64, 56, 56)).to(DEV).contiguous(memory_format=CL)
+    go = rnd(372, (4, 64, 56, 56)).to(DEV).contiguous(memory_format=CL)
+    links = []
+    orig_init = ops.BnBwdLink.__init__
+    monkeypatch.setattr(ops.BnBwdLink, "__init__", lambda self, kind: (orig_init(self, kind), links.append(self))[0])
+    res = {}
+    for linked in (True, False):
+        monkeypatch.setattr(ops, "BN_BWD_LINK", linked)
+        layer.load_state_dict(state)
+        layer.zero_grad(set_to_none=True)
+        links.clear()
+        x = (x0 * 1.0).requires_grad_(True)
+        x.retain_grad()
+        ops._attach_x3s(x, ops.x3s_split(x.detach()))
+        # the last unit of the stage normally feeds layer2's stride-2 convolution: no pre-split consumer here either
+        (layer(x) * go).sum().backward()
+        res[linked] = [x.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+        if linked:
+            assert [(l.kind, l.ready) for l in links] == [("inner", True), ("block", True), ("inner", True)], \
+                [(l.kind, l.ready) for l in links]
+        else:
+            assert links == []
+    for a, b in zip(res[True], res[False]):
+        assert rel_err(a, b) < 1e-5
