@@ -85,6 +85,8 @@ SIGNATURES = {
     "dmc_x3s_conv_dgrad_bnb": (_I, [_P] * 9 + [_I] + [_P] * 3 + [_I] * 5 + [_P]),
     "dmc_bn_act_bwd_x3s_apply": (_I, [_P] * 12 + [_I, _I, _I, _P]),
     "dmc_bn_relu_pool_fwd_x3s": (_I, [_P] * 9 + [_I, _I, _I, _I, _I, _F, _F, _P]),
+    "dmc_bn_relu_pool_fwd_arg": (_I, [_P] * 11 + [_I, _I, _I, _I, _I, _F, _F, _P]),
+    "dmc_bn_relu_pool_bwd_arg": (_I, [_P] * 11 + [_I, _I, _I, _I, _P]),
     "dmc_disc_first_supported": (_I, [_I]),
     "dmc_disc_first_fwd": (_I, [_P] * 5 + [_I] * 5 + [_P]),
     "dmc_disc_first_dgrad": (_I, [_P] * 3 + [_I] * 4 + [_P]),

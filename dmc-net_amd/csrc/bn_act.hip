@@ -548,7 +548,13 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_x3s_kernel(BnArgs a, const f
 }
 
 // pool_fwd_kernel with eight channels per thread, pooled map as fp32 (nullable) and / or slices
-__global__ __launch_bounds__(256) void pool_fwd_x3s_kernel(PoolArgs a, unsigned short* __restrict__ ys) {
+// codes / xmax (both or neither, nullable): the arg-max record for the streaming backward (dmc_bn_relu_pool_bwd_arg) --
+// codes = the window position 0..8 of each channel's maximum under PyTorch's rule (row-major scan of the in-bounds
+// positions, strictly greater wins), one byte per channel, the layout pool_bwd_kernel<2> reads; xmax = the RAW input at
+// that position [N][PH][PW][C], from which the backward's first pass forms xhat and the ReLU derivative without
+// touching the 4x larger input again.
+__global__ __launch_bounds__(256) void pool_fwd_x3s_kernel(PoolArgs a, unsigned short* __restrict__ ys, unsigned* __restrict__ codes,
+                                                           float* __restrict__ xmax) {
     const int c8 = a.C >> 3;
     const size_t total = (size_t)a.N * a.PH * a.PW * c8;
     for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
@@ -560,8 +566,6 @@ __global__ __launch_bounds__(256) void pool_fwd_x3s_kernel(PoolArgs a, unsigned 
         const int n = (int)(r / a.PH);
         float mean[8], istd[8], g[8], b[8], mx[8];
         load8(a.stats, tx, mean); load8(a.stats + a.C, tx, istd); load8(a.gamma, tx, g); load8(a.beta, tx, b);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) mx[e] = 0.f;              // relu(.) >= 0 and the window centre is always inside
         float xv[9][8];
 #pragma unroll
         for (int k = 0; k < 9; ++k) {                          // clamped coordinates repeat a value of the same window
@@ -570,10 +574,35 @@ __global__ __launch_bounds__(256) void pool_fwd_x3s_kernel(PoolArgs a, unsigned 
             ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
             load8(a.x, ((size_t)(n * a.H + iy) * a.W + ix) * c8 + tx, xv[k]);
         }
+        if (codes) {
+            float bx[8];
+            unsigned ck[8];
 #pragma unroll
-        for (int k = 0; k < 9; ++k)
+            for (int e = 0; e < 8; ++e) { mx[e] = -INFINITY; bx[e] = 0.f; ck[e] = 0; }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) mx[e] = fmaxf(mx[e], fmaxf(fmaf((xv[k][e] - mean[e]) * istd[e], g[e], b[e]), 0.f));
+            for (int k = 0; k < 9; ++k) {
+                const int iy = 2 * py + k / 3 - 1, ix = 2 * px + k % 3 - 1;
+                const bool in = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = fmaxf(fmaf((xv[k][e] - mean[e]) * istd[e], g[e], b[e]), 0.f);
+                    const bool take = in && v > mx[e];
+                    mx[e] = take ? v : mx[e];
+                    bx[e] = take ? xv[k][e] : bx[e];
+                    ck[e] = take ? (unsigned)k : ck[e];
+                }
+            }
+            reinterpret_cast<uint2*>(codes)[o] = make_uint2(ck[0] | (ck[1] << 8) | (ck[2] << 16) | (ck[3] << 24),
+                                                            ck[4] | (ck[5] << 8) | (ck[6] << 16) | (ck[7] << 24));
+            store8(xmax, o, bx);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mx[e] = 0.f;          // relu(.) >= 0 and the window centre is always inside
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) mx[e] = fmaxf(mx[e], fmaxf(fmaf((xv[k][e] - mean[e]) * istd[e], g[e], b[e]), 0.f));
+        }
         if (a.ypool) store8(a.ypool, o, mx);
         if (ys) x3s_store8(ys, mx, (size_t)a.N * a.PH * a.PW, a.C >> 4, mp, tx);
     }
@@ -781,11 +810,12 @@ int dmc_bn_act_bwd_x3s(const float* x, const float* residual, const float* gamma
 }
 
 /* dmc_bn_relu_pool_fwd with the pooled map as fp32 (y_pool, nullable) and / or as a slice tensor (ys, nullable). */
-int dmc_bn_relu_pool_fwd_x3s(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                             float* y_pool, void* ys, float* stats, void* scratch_, int N, int H, int W, int C, int training,
-                             float eps, float momentum, dmc_stream_t stream) {
+int dmc_bn_relu_pool_fwd_arg(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                             float* y_pool, void* ys, void* codes, float* xmax, float* stats, void* scratch_, int N, int H, int W,
+                             int C, int training, float eps, float momentum, dmc_stream_t stream) {
     if (!x || !gamma || !beta || !running_mean || !running_var || (!y_pool && !ys) || !stats || (training && !scratch_))
         return fail(DMC_E_INVALID, "dmc_bn_relu_pool_fwd_x3s: null pointer");
+    if ((codes == nullptr) != (xmax == nullptr)) return fail(DMC_E_INVALID, "dmc_bn_relu_pool_fwd_arg: codes and xmax go together");
     if (!dmc_bn_relu_pool_supported(N, H, W, C) || C % 16 != 0)
         return fail(DMC_E_INVALID, "dmc_bn_relu_pool_fwd_x3s: unsupported shape N=%d H=%d W=%d C=%d", N, H, W, C);
     hipStream_t s = (hipStream_t)stream;
@@ -801,8 +831,45 @@ int dmc_bn_relu_pool_fwd_x3s(const float* x, const float* gamma, const float* be
     bn_stats_final_kernel<<<(C + 7) / 8, 256, 0, s>>>(scratch, stats, running_mean, running_var, C, (long)M, training, eps, momentum, split);
     if ((rc = check_launch("bn_stats_final"))) return rc;
     PoolArgs p = {x, gamma, beta, stats, nullptr, y_pool, nullptr, N, H, W, C, (H - 1) / 2 + 1, (W - 1) / 2 + 1};
-    pool_fwd_x3s_kernel<<<stream_blocks((size_t)N * p.PH * p.PW * (C / 8)), 256, 0, s>>>(p, static_cast<unsigned short*>(ys));
+    pool_fwd_x3s_kernel<<<stream_blocks((size_t)N * p.PH * p.PW * (C / 8)), 256, 0, s>>>(p, static_cast<unsigned short*>(ys),
+                                                                                         static_cast<unsigned*>(codes), xmax);
     return check_launch("pool_fwd_x3s");
+}
+
+int dmc_bn_relu_pool_fwd_x3s(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                             float* y_pool, void* ys, float* stats, void* scratch_, int N, int H, int W, int C, int training,
+                             float eps, float momentum, dmc_stream_t stream) {
+    return dmc_bn_relu_pool_fwd_arg(x, gamma, beta, running_mean, running_var, y_pool, ys, nullptr, nullptr, stats, scratch_, N, H, W, C,
+                                    training, eps, momentum, stream);
+}
+
+/* Backward of dmc_bn_relu_pool_fwd_arg from its arg-max record: the BatchNorm-backward sums come from ONE streaming pass
+ * over the pooled-size tensors (d_pool, xmax) -- sum(dz) and sum(dz * xhat) over input pixels = the same sums over the
+ * windows, each window's gradient counted at its arg-max -- instead of a pass over the 4x larger input with window
+ * gathers (0.225 -> 0.05 ms at 120 x 112 x 112 x 64); the second pass routes d_pool through `codes` and writes dx. */
+int dmc_bn_relu_pool_bwd_arg(const float* x, const float* gamma, const float* beta, const float* stats, void* scratch_,
+                             const float* d_pool, const void* codes, const float* xmax, float* dx, float* dgamma, float* dbeta,
+                             int N, int H, int W, int C, dmc_stream_t stream) {
+    if (!x || !gamma || !beta || !stats || !scratch_ || !d_pool || !codes || !xmax || !dx || !dgamma || !dbeta)
+        return fail(DMC_E_INVALID, "dmc_bn_relu_pool_bwd_arg: null pointer");
+    if (!dmc_bn_relu_pool_supported(N, H, W, C) || C % 16 != 0)
+        return fail(DMC_E_INVALID, "dmc_bn_relu_pool_bwd_arg: unsupported shape N=%d H=%d W=%d C=%d", N, H, W, C);
+    hipStream_t s = (hipStream_t)stream;
+    PoolArgs p = {x, gamma, beta, stats, d_pool, nullptr, dx, N, H, W, C, (H - 1) / 2 + 1, (W - 1) / 2 + 1};
+    double* scratch = static_cast<double*>(scratch_);
+    const int MP = N * p.PH * p.PW;
+    BnArgs a = {xmax, nullptr, gamma, beta, stats, d_pool, nullptr, nullptr, nullptr, MP, C, 1, nullptr};
+    const int split = split_of(MP);
+    int rc;
+    bn_partial_kernel<1><<<split, 256, 0, s>>>(a, scratch);
+    if ((rc = check_launch("pool_bwd_sums"))) return rc;
+    bn_bwd_final_kernel<<<(C + 7) / 8, 256, 0, s>>>(scratch, dgamma, dbeta, C, split);
+    if ((rc = check_launch("bn_bwd_final"))) return rc;
+    const long tiles = (long)N * ((p.PH + PT - 1) / PT) * ((p.PW + PT - 1) / PT);
+    const long blocks = tiles * 4 > 8192 ? 8192 : tiles * 4;
+    pool_bwd_kernel<2><<<(int)blocks, 256, 0, s>>>(p, nullptr, dgamma, dbeta, 1.f / (float)((long)N * H * W),
+                                                   const_cast<unsigned*>(static_cast<const unsigned*>(codes)));
+    return check_launch("pool_bwd_apply");
 }
 
 /* Second half of dmc_bn_act_bwd_x3s alone: dgamma / dbeta are INPUTS (reduced by the launch that produced dy,

@@ -429,6 +429,12 @@ def bn_act(x, bn, residual=None, relu=True):
                         training, bn.eps, bn.momentum if bn.momentum is not None else 0.1)
 
 
+#: True (default): the stem tail's forward records each pooling window's arg-max (position + raw input value, +120 MB at
+#: 120 frames) and the backward's BatchNorm sums stream over that record (dmc_bn_relu_pool_bwd_arg); DMC_POOL_ARGMAX=0:
+#: the backward recomputes the arg-max from the input (dmc_bn_relu_pool_bwd)
+POOL_ARGMAX = __import__("os").environ.get("DMC_POOL_ARGMAX", "1") != "0"
+
+
 class _BnReluPool(torch.autograd.Function):
     """maxpool3x3s2p1(relu(bn(x))) of the ResNet stem (torchvision's bn1 / relu / maxpool behind
     code/dmcnet/model.py:305,352) on a channels_last ``x``; the rectified tensor is never stored."""
@@ -444,21 +450,29 @@ class _BnReluPool(torch.autograd.Function):
                         memory_format=torch.channels_last)
         stats = _floats(lib.dmc_bn_act_stats_bytes(c), x.device)
         scratch = _floats(lib.dmc_bn_act_scratch_bytes(c), x.device) if training else None
-        ys = None
+        ys = codes = xmax = None
         with _span("bn_relu_pool_fwd"):
             if want_slices and c % 16 == 0:     # the pooled map also as a bf16x3 slice tensor (layer1's first convolution)
                 ys = torch.empty(lib.dmc_x3s_slices_bytes(n * ph * pw, c), dtype=torch.uint8, device=x.device)
-                _lib.check(lib.dmc_bn_relu_pool_fwd_x3s(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean),
-                                                        _lib.ptr(running_var), _lib.ptr(y), _lib.ptr(ys), _lib.ptr(stats),
-                                                        _lib.ptr(scratch), n, h, w, c, int(training), float(eps),
-                                                        float(momentum), _stream()), "dmc_bn_relu_pool_fwd_x3s")
+                if training and POOL_ARGMAX and any(ctx.needs_input_grad[:3]):
+                    # arg-max record for the backward: its BatchNorm sums then stream over pooled-size tensors
+                    codes = _floats(lib.dmc_bn_relu_pool_codes_bytes(n, h, w, c), x.device)
+                    xmax = torch.empty_like(y)
+                _lib.check(lib.dmc_bn_relu_pool_fwd_arg(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean),
+                                                        _lib.ptr(running_var), _lib.ptr(y), _lib.ptr(ys), _lib.ptr(codes),
+                                                        _lib.ptr(xmax), _lib.ptr(stats), _lib.ptr(scratch), n, h, w, c,
+                                                        int(training), float(eps), float(momentum), _stream()),
+                           "dmc_bn_relu_pool_fwd_arg")
             else:
                 _lib.check(lib.dmc_bn_relu_pool_fwd(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta),
                                                     _lib.ptr(running_mean), _lib.ptr(running_var),
                                                     _lib.ptr(y), _lib.ptr(stats), _lib.ptr(scratch), n, h, w, c, int(training),
                                                     float(eps), float(momentum), _stream()),
                            "dmc_bn_relu_pool_fwd")
-        ctx.save_for_backward(x, gamma, beta, stats)
+        if codes is not None:
+            ctx.save_for_backward(x, gamma, beta, stats, codes, xmax)
+        else:
+            ctx.save_for_backward(x, gamma, beta, stats)
         ctx.training = bool(training)
         if ys is None:
             ys = torch.empty(0, dtype=torch.uint8, device=x.device)
@@ -468,7 +482,7 @@ class _BnReluPool(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dys):
         lib = _lib.load()
-        x, gamma, beta, stats = ctx.saved_tensors
+        x, gamma, beta, stats = ctx.saved_tensors[:4]
         if dy is None:
             return (None,) * 9
         if not ctx.training:
@@ -477,13 +491,20 @@ class _BnReluPool(torch.autograd.Function):
         dy = dy.contiguous(memory_format=torch.channels_last)
         dx = torch.empty_like(x)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
-        codes = _floats(lib.dmc_bn_relu_pool_codes_bytes(n, h, w, c), x.device)
         scratch = _floats(lib.dmc_bn_act_scratch_bytes(c), x.device)
         with _span("bn_relu_pool_bwd"):
-            _lib.check(lib.dmc_bn_relu_pool_bwd(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta),
-                                                _lib.ptr(stats), _lib.ptr(scratch), _lib.ptr(dy), _lib.ptr(dx),
-                                                _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(codes),
-                                                n, h, w, c, _stream()), "dmc_bn_relu_pool_bwd")
+            if len(ctx.saved_tensors) == 6:
+                codes, xmax = ctx.saved_tensors[4:]
+                _lib.check(lib.dmc_bn_relu_pool_bwd_arg(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(stats),
+                                                        _lib.ptr(scratch), _lib.ptr(dy), _lib.ptr(codes), _lib.ptr(xmax),
+                                                        _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta), n, h, w, c, _stream()),
+                           "dmc_bn_relu_pool_bwd_arg")
+            else:
+                codes = _floats(lib.dmc_bn_relu_pool_codes_bytes(n, h, w, c), x.device)
+                _lib.check(lib.dmc_bn_relu_pool_bwd(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta),
+                                                    _lib.ptr(stats), _lib.ptr(scratch), _lib.ptr(dy), _lib.ptr(dx),
+                                                    _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(codes),
+                                                    n, h, w, c, _stream()), "dmc_bn_relu_pool_bwd")
         return dx, dgamma, dbeta, None, None, None, None, None, None
 
 

@@ -371,6 +371,18 @@ int dmc_bn_act_bwd_x3s(const float* x, const float* residual, const float* gamma
 int dmc_bn_relu_pool_fwd_x3s(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                              float* y_pool, void* ys, float* stats, void* scratch, int N, int H, int W, int C, int training,
                              float eps, float momentum, dmc_stream_t stream);
+/* The stem tail with an arg-max record (replaces torchvision's bn1 / relu / maxpool behind
+ * /root/reference/code/dmcnet/model.py:305, as dmc_bn_relu_pool_fwd does): dmc_bn_relu_pool_fwd_arg =
+ * dmc_bn_relu_pool_fwd_x3s that also writes, when `codes` / `xmax` are given (both or neither), each window's arg-max
+ * position per channel (codes: dmc_bn_relu_pool_codes_bytes) and the raw input there (xmax: fp32 [N][PH][PW][C]);
+ * dmc_bn_relu_pool_bwd_arg = dmc_bn_relu_pool_bwd from that record: its BatchNorm-backward sums stream over the
+ * pooled-size (d_pool, xmax) pair instead of gathering over the 4x larger input.  Same dx / dgamma / dbeta semantics. */
+int dmc_bn_relu_pool_fwd_arg(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                             float* y_pool, void* ys, void* codes, float* xmax, float* stats, void* scratch, int N, int H, int W,
+                             int C, int training, float eps, float momentum, dmc_stream_t stream);
+int dmc_bn_relu_pool_bwd_arg(const float* x, const float* gamma, const float* beta, const float* stats, void* scratch,
+                             const float* d_pool, const void* codes, const float* xmax, float* dx, float* dgamma, float* dbeta,
+                             int N, int H, int W, int C, dmc_stream_t stream);
 /* BatchNorm-backward sums from the data gradient's epilogue: dmc_x3s_conv_dgrad_bnb = dmc_x3s_conv_dgrad that also
  * reduces, for the unit whose output gradient it writes (dx), dbeta = sum(d) and dgamma = sum(d * xhat) (d = dx, zeroed
  * where that unit's ReLU was off; partials: dmc_x3s_conv_stat_blocks(N, H, W, Cin) x Cin x 2 doubles);

@@ -166,6 +166,53 @@ def test_pool_slices_match_fp32_form(shape):
     assert torch.equal(bn.running_var, bn2.running_var)
 
 
+@pytest.mark.parametrize("shape", [(3, 64, 112, 112), (2, 64, 17, 23), (2, 128, 8, 8), (1, 64, 1, 5), (2, 64, 30, 31)])
+def test_pool_argmax_record_backward(shape, monkeypatch):
+    """The stem tail with the arg-max record (forward writes each window's arg-max position and the raw input there;
+    the backward's BatchNorm sums stream over that pooled-size record, dmc_bn_relu_pool_bwd_arg) against the stock
+    modules and against the recomputing backward (dmc_bn_relu_pool_bwd); quantised inputs: exact ties inside windows
+    pin PyTorch's arg-max rule in the FORWARD's scan."""
+    n, c, h, w = shape
+    x = torch.round(rnd(81, shape) * 4) / 4
+    go = rnd(82, (n, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1))
+    bn_o = torch.nn.BatchNorm2d(c)
+    with torch.no_grad():
+        bn_o.weight.copy_(rnd(83, (c,)) * 0.5 + 1.0)       # both signs of gamma: the maximum of relu(bn(x)) is not the maximum of x
+        bn_o.weight[::3] *= -1
+        bn_o.bias.copy_(rnd(84, (c,)) * 0.3)
+    mp = torch.nn.MaxPool2d(3, 2, 1)
+    xo = x.clone().double().requires_grad_(True)
+    bn_d = torch.nn.BatchNorm2d(c).double()
+    bn_d.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn_o.state_dict().items()})
+    yo = mp(torch.relu(bn_d(xo)))
+    (yo * go.double()).sum().backward()
+    res = {}
+    for rec in (True, False):
+        monkeypatch.setattr(ops, "POOL_ARGMAX", rec)
+        bn_m = torch.nn.BatchNorm2d(c)
+        bn_m.load_state_dict(bn_o.state_dict())
+        bn_m.to(DEV)
+        xg = x.to(DEV).contiguous(memory_format=CL).requires_grad_(True)
+        y = ops.bn_relu_pool(xg, bn_m, want_slices=True)
+        (y * go.to(DEV)).sum().backward()
+        res[rec] = (y.detach(), xg.grad, bn_m.weight.grad, bn_m.bias.grad)
+        assert rel_err(y, yo.float()) < 1e-5
+        assert rel_err(xg.grad, xo.grad.float()) < 1e-4
+        assert rel_err(bn_m.weight.grad, bn_d.weight.grad.float()) < 1e-4
+        assert rel_err(bn_m.bias.grad, bn_d.bias.grad.float()) < 1e-4
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b in zip(res[True][1:], res[False][1:]):      # same arg-max, same sums up to the summation order
+        assert rel_err(a, b) < 1e-5
+    # deterministic
+    monkeypatch.setattr(ops, "POOL_ARGMAX", True)
+    bn_m = torch.nn.BatchNorm2d(c)
+    bn_m.load_state_dict(bn_o.state_dict())
+    bn_m.to(DEV)
+    xg = x.to(DEV).contiguous(memory_format=CL).requires_grad_(True)
+    (ops.bn_relu_pool(xg, bn_m, want_slices=True) * go.to(DEV)).sum().backward()
+    assert torch.equal(xg.grad, res[True][1]) and torch.equal(bn_m.weight.grad, res[True][2])
+
+
 @pytest.mark.parametrize("cin,planes,hw,n,seed", [(64, 64, 14, 6, 331), (128, 128, 28, 3, 338), (64, 64, 56, 2, 342), (512, 512, 7, 5, 339)])
 def test_basic_block_presplit_vs_in_loop_split_and_stock(cin, planes, hw, n, seed, monkeypatch):
     """An identity-shortcut BasicBlock in training mode: (a) pre-split path (conv1 reads the input's slices, writes ONLY
