@@ -85,7 +85,7 @@ SIGNATURES = {
     "dmc_x3s_conv_dgrad_bnb": (_I, [_P] * 9 + [_I] + [_P] * 3 + [_I] * 5 + [_P]),
     "dmc_bn_act_bwd_x3s_apply": (_I, [_P] * 12 + [_I, _I, _I, _P]),
     "dmc_bn_relu_pool_fwd_x3s": (_I, [_P] * 9 + [_I, _I, _I, _I, _I, _F, _F, _P]),
-    "dmc_bn_relu_pool_fwd_arg": (_I, [_P] * 11 + [_I, _I, _I, _I, _I, _F, _F, _P]),
+    "dmc_bn_relu_pool_fwd_arg": (_I, [_P] * 11 + [_I, _I, _I, _I, _I, _I, _F, _F, _P]),
     "dmc_bn_relu_pool_bwd_arg": (_I, [_P] * 11 + [_I, _I, _I, _I, _P]),
     "dmc_disc_first_supported": (_I, [_I]),
     "dmc_disc_first_fwd": (_I, [_P] * 5 + [_I] * 5 + [_P]),
@@ -98,6 +98,8 @@ SIGNATURES = {
     "dmc_stem_fwd": (_I, [_P, _P, _L, _L, _L, _L, _P, _I, _I, _I, _P]),
     "dmc_stem_fwd_x3_workspace_bytes": (_Z, [_I, _I, _I]),
     "dmc_stem_fwd_x3": (_I, [_P, _P, _L, _L, _L, _L, _P, _P, _I, _I, _I, _P]),
+    "dmc_stem_fwd_x3_stat_blocks": (_I, [_I, _I, _I]),
+    "dmc_stem_fwd_x3_stats": (_I, [_P, _P, _L, _L, _L, _L, _P, _P, _P, _I, _I, _I, _P]),
     "dmc_conv3d_bf16_supported": (_I, [_I] * 9),
     "dmc_conv3d_bf16_wpack_bytes": (_Z, [_I] * 5),
     "dmc_conv3d_bf16_pack": (_I, [_P, _L, _L, _L, _P, _P] + [_I] * 5 + [_P]),

@@ -17,7 +17,7 @@ using namespace dmc;
 
 namespace {
 
-constexpr int MAX_SPLIT = 1024;   // row-splits of the per-channel reductions (scratch is sized for this)
+constexpr int MAX_SPLIT = BN_MAX_SPLIT;   // row-splits of the per-channel reductions (scratch is sized for this)
 
 struct BnArgs {
     const float* x;
@@ -452,10 +452,12 @@ bool shape_ok(int M, int C) {
     return M > 0 && C > 0 && C % 4 == 0 && cq <= 256 && 256 % cq == 0;
 }
 
-// enough row-splits to fill the chip (>= 64 rows each), at most MAX_SPLIT
-int split_of(int M) {
-    int sp = M / 64;
-    return sp < 1 ? 1 : (sp > MAX_SPLIT ? MAX_SPLIT : sp);
+// row-splits of a per-channel reduction: a workgroup covers 1024 / C rows per iteration; at most ~8 iterations per thread
+// (two batches of four independent loads) as long as MAX_SPLIT allows -- the small late-stage maps (5,880 rows x 512
+// channels) were latency-bound at 64 rows per workgroup: 91 workgroups, 32 dependent iterations each, 15 us for 24 MB
+int split_of(int M, int C) {
+    long sp = (long)M * C / 8192;
+    return sp < 1 ? 1 : (sp > MAX_SPLIT ? MAX_SPLIT : (int)sp);
 }
 
 int stream_blocks(size_t total) {
@@ -630,7 +632,7 @@ int dmc_bn_act_fwd(const float* x, const float* residual, const float* gamma, co
     BnArgs a = {x, residual, gamma, beta, stats, nullptr, y, nullptr, nullptr, M, C, relu, relu_mask};
     double* scratch = static_cast<double*>(scratch_);
     int rc;
-    const int split = split_of(M);
+    const int split = split_of(M, C);
     if (training) {
         bn_partial_kernel<0><<<split, 256, 0, s>>>(a, scratch);
         if ((rc = check_launch("bn_partial"))) return rc;
@@ -654,7 +656,7 @@ int dmc_bn_act_bwd(const float* x, const float* residual, const float* gamma, co
                 const_cast<unsigned char*>(relu_mask)};
     double* scratch = static_cast<double*>(scratch_);
     int rc;
-    const int split = split_of(M);
+    const int split = split_of(M, C);
     bn_partial_kernel<1><<<split, 256, 0, s>>>(a, scratch);
     if ((rc = check_launch("bn_bwd_partial"))) return rc;
     bn_bwd_final_kernel<<<(C + 7) / 8, 256, 0, s>>>(scratch, dgamma, dbeta, C, split);
@@ -679,7 +681,7 @@ int dmc_bn_relu_pool_fwd(const float* x, const float* gamma, const float* beta, 
     BnArgs a = {x, nullptr, gamma, beta, stats, nullptr, nullptr, nullptr, nullptr, M, C, 1, nullptr};
     double* scratch = static_cast<double*>(scratch_);
     int rc;
-    const int split = split_of(M);
+    const int split = split_of(M, C);
     if (training) {
         bn_partial_kernel<0><<<split, 256, 0, s>>>(a, scratch);
         if ((rc = check_launch("bn_partial"))) return rc;
@@ -755,7 +757,7 @@ int dmc_bn_bwd_act_nhwc(const float* z, const float* gamma, const float* beta, c
     BnArgs a = {z, nullptr, gamma, beta, stats, dy, nullptr, dpre, nullptr, M, C, 0, nullptr, keep, hw, slope};
     double* scratch = static_cast<double*>(scratch_);
     int rc;
-    const int split = split_of(M);
+    const int split = split_of(M, C);
     bn_partial_kernel<1><<<split, 256, 0, s>>>(a, scratch);
     if ((rc = check_launch("bn_bwd_partial"))) return rc;
     bn_bwd_final_kernel<<<(C + 7) / 8, 256, 0, s>>>(scratch, dgamma, dbeta, C, split);
@@ -770,7 +772,7 @@ int dmc_channel_sum_nhwc(const float* g, void* scratch_, float* out, int M, int 
     if (!shape_ok(M, C)) return fail(DMC_E_INVALID, "dmc_channel_sum_nhwc: unsupported shape M=%d C=%d", M, C);
     hipStream_t s = (hipStream_t)stream;
     BnArgs a = {g, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, M, C, 0, nullptr};
-    const int split = split_of(M);
+    const int split = split_of(M, C);
     bn_partial_kernel<0><<<split, 256, 0, s>>>(a, static_cast<double*>(scratch_));
     int rc = check_launch("channel_sum_partial");
     if (rc) return rc;
@@ -800,7 +802,7 @@ int dmc_bn_act_bwd_x3s(const float* x, const float* residual, const float* gamma
     BnArgs a = {x, residual, gamma, beta, stats, dy, nullptr, dx, dresidual, M, C, relu, const_cast<unsigned char*>(relu_mask)};
     double* scratch = static_cast<double*>(scratch_);
     int rc;
-    const int split = split_of(M);
+    const int split = split_of(M, C);
     bn_partial_kernel<1><<<split, 256, 0, s>>>(a, scratch);
     if ((rc = check_launch("bn_bwd_partial"))) return rc;
     bn_bwd_final_kernel<<<(C + 7) / 8, 256, 0, s>>>(scratch, dgamma, dbeta, C, split);
@@ -811,10 +813,11 @@ int dmc_bn_act_bwd_x3s(const float* x, const float* residual, const float* gamma
 
 /* dmc_bn_relu_pool_fwd with the pooled map as fp32 (y_pool, nullable) and / or as a slice tensor (ys, nullable). */
 int dmc_bn_relu_pool_fwd_arg(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                             float* y_pool, void* ys, void* codes, float* xmax, float* stats, void* scratch_, int N, int H, int W,
-                             int C, int training, float eps, float momentum, dmc_stream_t stream) {
+                             float* y_pool, void* ys, void* codes, float* xmax, float* stats, void* scratch_, int stat_split,
+                             int N, int H, int W, int C, int training, float eps, float momentum, dmc_stream_t stream) {
     if (!x || !gamma || !beta || !running_mean || !running_var || (!y_pool && !ys) || !stats || (training && !scratch_))
         return fail(DMC_E_INVALID, "dmc_bn_relu_pool_fwd_x3s: null pointer");
+    if (stat_split < 0 || stat_split > MAX_SPLIT) return fail(DMC_E_INVALID, "dmc_bn_relu_pool_fwd_arg: bad stat_split %d", stat_split);
     if ((codes == nullptr) != (xmax == nullptr)) return fail(DMC_E_INVALID, "dmc_bn_relu_pool_fwd_arg: codes and xmax go together");
     if (!dmc_bn_relu_pool_supported(N, H, W, C) || C % 16 != 0)
         return fail(DMC_E_INVALID, "dmc_bn_relu_pool_fwd_x3s: unsupported shape N=%d H=%d W=%d C=%d", N, H, W, C);
@@ -823,8 +826,9 @@ int dmc_bn_relu_pool_fwd_arg(const float* x, const float* gamma, const float* be
     BnArgs a = {x, nullptr, gamma, beta, stats, nullptr, nullptr, nullptr, nullptr, M, C, 1, nullptr};
     double* scratch = static_cast<double*>(scratch_);
     int rc;
-    const int split = split_of(M);
-    if (training) {
+    // stat_split > 0: the producer of x (dmc_stem_fwd_x3_stats) left that many partial sums per channel in scratch
+    const int split = stat_split > 0 ? stat_split : split_of(M, C);
+    if (training && stat_split == 0) {
         bn_partial_kernel<0><<<split, 256, 0, s>>>(a, scratch);
         if ((rc = check_launch("bn_partial"))) return rc;
     }
@@ -839,7 +843,7 @@ int dmc_bn_relu_pool_fwd_arg(const float* x, const float* gamma, const float* be
 int dmc_bn_relu_pool_fwd_x3s(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                              float* y_pool, void* ys, float* stats, void* scratch_, int N, int H, int W, int C, int training,
                              float eps, float momentum, dmc_stream_t stream) {
-    return dmc_bn_relu_pool_fwd_arg(x, gamma, beta, running_mean, running_var, y_pool, ys, nullptr, nullptr, stats, scratch_, N, H, W, C,
+    return dmc_bn_relu_pool_fwd_arg(x, gamma, beta, running_mean, running_var, y_pool, ys, nullptr, nullptr, stats, scratch_, 0, N, H, W, C,
                                     training, eps, momentum, stream);
 }
 
@@ -859,7 +863,7 @@ int dmc_bn_relu_pool_bwd_arg(const float* x, const float* gamma, const float* be
     double* scratch = static_cast<double*>(scratch_);
     const int MP = N * p.PH * p.PW;
     BnArgs a = {xmax, nullptr, gamma, beta, stats, d_pool, nullptr, nullptr, nullptr, MP, C, 1, nullptr};
-    const int split = split_of(MP);
+    const int split = split_of(MP, C);
     int rc;
     bn_partial_kernel<1><<<split, 256, 0, s>>>(a, scratch);
     if ((rc = check_launch("pool_bwd_sums"))) return rc;

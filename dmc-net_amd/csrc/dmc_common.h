@@ -77,6 +77,9 @@ __host__ __device__ constexpr int wb_off(int j) {
 }
 constexpr int PACKED_TOTAL = wb_off(5);   // 7788
 constexpr int ZERO_PAD = 256;             // zero words (1 KB: one LDS-DMA row) kept behind the packed parameters
+// row-splits of the per-channel BatchNorm reductions: partial sums live in scratch as [channel][BN_MAX_SPLIT][2] doubles
+// (dmc_bn_act_scratch_bytes); producers that reduce statistics in their epilogue (stem.hip) write the same layout
+constexpr int BN_MAX_SPLIT = 1024;
 
 // logical (reference, prepend order) input-channel index of physical channel p in layer k
 __host__ __device__ inline int logical_of(int k, int p) {

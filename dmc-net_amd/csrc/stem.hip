@@ -355,19 +355,37 @@ struct StemX3Args {
     float* y;              // [N][OH][OW][64]
     int N, OH, OW, Hp, Wp, tiles_x;
     long vol;              // N * Hp * Wp
+    double* stat_part;     // nullable: per-workgroup (sum y, sum y^2) per channel, [64][BN_MAX_SPLIT][2]
 };
 
-__global__ __launch_bounds__(512) void stem_fwd_x3_kernel(StemX3Args a) {
+// Epilogue through LDS (per-wave [32 pixels][32 channels] tile, pitch 36 floats, once per 32-channel half): the accumulator
+// layout gives every lane 32 channels of ONE pixel -- stored directly that is eight 32-byte pieces per 256-byte pixel row
+// and instruction; re-read as [8 pixels][8 lanes x float4] each instruction writes whole 128-byte lines, and a lane sees
+// EIGHT fixed channels of every pixel it stores, so bn1's batch statistics (a.stat_part) cost 16 accumulators instead of
+// 64.  16 waves per workgroup (four per SIMD: the loads of a tile are issued up front, other waves' MFMAs cover them).
+constexpr int SX_THREADS = 1024, SX_WAVES = SX_THREADS / 64;
+constexpr int SX_EP_PITCH = 36;
+constexpr int SX_EP_BYTES = 32 * SX_EP_PITCH * 4;         // 4,608 per wave
+constexpr int SX_LDS = SX_WLDS + SX_WAVES * SX_EP_BYTES;  // 116,736
+
+__global__ __launch_bounds__(SX_THREADS) void stem_fwd_x3_kernel(StemX3Args a) {
     extern __shared__ __attribute__((aligned(16))) char wlds3[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
-    for (int i = tid; i < SX_WLDS / 16; i += 512) reinterpret_cast<stem_u32x4*>(wlds3)[i] = reinterpret_cast<const stem_u32x4*>(a.wp)[i];
+    for (int i = tid; i < SX_WLDS / 16; i += SX_THREADS) reinterpret_cast<stem_u32x4*>(wlds3)[i] = reinterpret_cast<const stem_u32x4*>(a.wp)[i];
     __syncthreads();
     const long ntiles = (long)a.N * a.OH * a.tiles_x;
-    const long stride = (long)gridDim.x * 8;
+    const long stride = (long)gridDim.x * SX_WAVES;
     const int woff = l31 * 32 + half * 16;
-    for (long tile = (long)blockIdx.x * 8 + wave; tile < ntiles; tile += stride) {
+    float* ep = reinterpret_cast<float*>(wlds3 + SX_WLDS + wave * SX_EP_BYTES);
+    const int q8 = lane >> 3, c4 = (lane & 7) * 4;
+    float ssum[2][4], ssq[2][4];                            // channels 32 ct + c4 .. + 3, pixels = q8 (mod 8)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ssum[ct][j] = ssq[ct][j] = 0.f;
+    for (long tile = (long)blockIdx.x * SX_WAVES + wave; tile < ntiles; tile += stride) {
         const int xt = (int)(tile % a.tiles_x);
         const long r = tile / a.tiles_x;                    // n * OH + oy
         const int oy = (int)(r % a.OH);
@@ -403,15 +421,60 @@ __global__ __launch_bounds__(512) void stem_fwd_x3_kernel(StemX3Args a) {
                 };
                 mm(0, 2); mm(2, 0); mm(1, 1); mm(0, 1); mm(1, 0); mm(0, 0);      // small terms first
             }
-        if (ox < a.OW) {
-            float* dst = a.y + (r * a.OW + ox) * S_CO;
+        float* dst = a.y + (r * a.OW + 32 * xt) * S_CO + c4;
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < 2; ++ct) {
+            // accumulators of this channel half -> the wave's LDS tile [pixel l31][channel 8 g + 4 half ..]
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4*>(dst + 32 * ct + 8 * g + 4 * half) =
-                        make_float4(acc[ct][4 * g], acc[ct][4 * g + 1], acc[ct][4 * g + 2], acc[ct][4 * g + 3]);
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(ep + l31 * SX_EP_PITCH + 8 * g + 4 * half) =
+                    make_float4(acc[ct][4 * g], acc[ct][4 * g + 1], acc[ct][4 * g + 2], acc[ct][4 * g + 3]);
+            __builtin_amdgcn_wave_barrier();                 // same wave: LDS instructions complete in order
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int px = 8 * i + q8;
+                const float4 v = *reinterpret_cast<const float4*>(ep + px * SX_EP_PITCH + c4);
+                if (32 * xt + px < a.OW) {
+                    *reinterpret_cast<float4*>(dst + (long)px * S_CO + 32 * ct) = v;
+                    if (a.stat_part) {
+                        ssum[ct][0] += v.x; ssum[ct][1] += v.y; ssum[ct][2] += v.z; ssum[ct][3] += v.w;
+                        ssq[ct][0] = fmaf(v.x, v.x, ssq[ct][0]); ssq[ct][1] = fmaf(v.y, v.y, ssq[ct][1]);
+                        ssq[ct][2] = fmaf(v.z, v.z, ssq[ct][2]); ssq[ct][3] = fmaf(v.w, v.w, ssq[ct][3]);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
+    }
+    if (!a.stat_part) return;
+    // over the eight pixel groups of the wave (fixed order), then over the waves in fp64 (fixed order)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int m = 8; m < 64; m <<= 1) {
+                ssum[ct][j] += __shfl_xor(ssum[ct][j], m, 64);
+                ssq[ct][j] += __shfl_xor(ssq[ct][j], m, 64);
+            }
+    __syncthreads();                                          // every wave is done with the weights in LDS
+    float* red = reinterpret_cast<float*>(wlds3);             // [wave][which][channel]
+    if (lane < 8) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                red[(wave * 2 + 0) * S_CO + 32 * ct + c4 + j] = ssum[ct][j];
+                red[(wave * 2 + 1) * S_CO + 32 * ct + c4 + j] = ssq[ct][j];
+            }
+    }
+    __syncthreads();
+    if (tid < 2 * S_CO) {
+        const int c = tid & (S_CO - 1), which = tid >> 6;
+        double t = 0.0;
+#pragma unroll
+        for (int w8 = 0; w8 < SX_WAVES; ++w8) t += (double)red[(w8 * 2 + which) * S_CO + c];
+        a.stat_part[((size_t)c * BN_MAX_SPLIT + blockIdx.x) * 2 + which] = t;
     }
 }
 
@@ -474,8 +537,17 @@ size_t dmc_stem_fwd_x3_workspace_bytes(int N, int H, int W) {
     const long Wp = (W + 8 + 3) / 4 * 4;
     return (size_t)3 * N * (H + 6) * Wp * 4 + (size_t)3 * 7 * S_CO * 16 * 2 + 64;
 }
+int dmc_stem_fwd_x3_stat_blocks(int N, int H, int W) {
+    const long tiles = (long)N * ((H + 1) / 2) * (((W + 1) / 2 + 31) / 32);
+    const long blocks = (tiles + SX_WAVES - 1) / SX_WAVES;
+    return (int)(blocks > 256 ? 256 : blocks);             // one 16-wave workgroup per CU, every wave walks many tiles
+}
 int dmc_stem_fwd_x3(const float* x, const float* w, long ws_co, long ws_ci, long ws_ky, long ws_kx, void* workspace, float* y, int N,
                     int H, int W, dmc_stream_t stream) {
+    return dmc_stem_fwd_x3_stats(x, w, ws_co, ws_ci, ws_ky, ws_kx, workspace, y, nullptr, N, H, W, stream);
+}
+int dmc_stem_fwd_x3_stats(const float* x, const float* w, long ws_co, long ws_ci, long ws_ky, long ws_kx, void* workspace, float* y,
+                          void* stat_scratch, int N, int H, int W, dmc_stream_t stream) {
     if (!x || !w || !workspace || !y) return fail(DMC_E_INVALID, "dmc_stem_fwd_x3: null pointer");
     if (N <= 0 || H <= 0 || W <= 0) return fail(DMC_E_INVALID, "dmc_stem_fwd_x3: bad shape");
     hipStream_t s = (hipStream_t)stream;
@@ -491,10 +563,12 @@ int dmc_stem_fwd_x3(const float* x, const float* w, long ws_co, long ws_ci, long
     StemX3Args a;
     a.xs = xs; a.wp = wp; a.y = y; a.N = N; a.OH = (H + 1) / 2; a.OW = (W + 1) / 2; a.Hp = Hp; a.Wp = Wp;
     a.tiles_x = (a.OW + 31) / 32; a.vol = vol;
-    const long tiles = (long)N * a.OH * a.tiles_x;
-    long blocks = (tiles + 7) / 8;
-    if (blocks > 512) blocks = 512;
-    stem_fwd_x3_kernel<<<(int)blocks, 512, SX_WLDS, s>>>(a);
+    a.stat_part = static_cast<double*>(stat_scratch);
+    const long blocks = dmc_stem_fwd_x3_stat_blocks(N, H, W);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_x3_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, SX_LDS);
+    if (attr != hipSuccess) return fail(DMC_E_LAUNCH, "dmc_stem_fwd_x3: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
+    stem_fwd_x3_kernel<<<(int)blocks, SX_THREADS, SX_LDS, s>>>(a);
     return check_launch("stem_fwd_x3");
 }
 

@@ -440,7 +440,7 @@ class _BnReluPool(torch.autograd.Function):
     code/dmcnet/model.py:305,352) on a channels_last ``x``; the rectified tensor is never stored."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, eps, momentum, want_slices=False):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, eps, momentum, want_slices=False, stat_partials=None):
         lib = _lib.load()
         _need_cuda(x, gamma, beta)
         ctx.set_materialize_grads(False)
@@ -449,7 +449,11 @@ class _BnReluPool(torch.autograd.Function):
         y = torch.empty((n, c, ph, pw), dtype=x.dtype, device=x.device,
                         memory_format=torch.channels_last)
         stats = _floats(lib.dmc_bn_act_stats_bytes(c), x.device)
-        scratch = _floats(lib.dmc_bn_act_scratch_bytes(c), x.device) if training else None
+        stat_split = 0
+        if training and stat_partials is not None and want_slices and c % 16 == 0:
+            scratch, stat_split = stat_partials     # reduced by x's producer (dmc_stem_fwd_x3_stats)
+        else:
+            scratch = _floats(lib.dmc_bn_act_scratch_bytes(c), x.device) if training else None
         ys = codes = xmax = None
         with _span("bn_relu_pool_fwd"):
             if want_slices and c % 16 == 0:     # the pooled map also as a bf16x3 slice tensor (layer1's first convolution)
@@ -460,7 +464,7 @@ class _BnReluPool(torch.autograd.Function):
                     xmax = torch.empty_like(y)
                 _lib.check(lib.dmc_bn_relu_pool_fwd_arg(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean),
                                                         _lib.ptr(running_var), _lib.ptr(y), _lib.ptr(ys), _lib.ptr(codes),
-                                                        _lib.ptr(xmax), _lib.ptr(stats), _lib.ptr(scratch), n, h, w, c,
+                                                        _lib.ptr(xmax), _lib.ptr(stats), _lib.ptr(scratch), int(stat_split), n, h, w, c,
                                                         int(training), float(eps), float(momentum), _stream()),
                            "dmc_bn_relu_pool_fwd_arg")
             else:
@@ -484,7 +488,7 @@ class _BnReluPool(torch.autograd.Function):
         lib = _lib.load()
         x, gamma, beta, stats = ctx.saved_tensors[:4]
         if dy is None:
-            return (None,) * 9
+            return (None,) * 10
         if not ctx.training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not implemented")
         n, c, h, w = x.shape
@@ -505,7 +509,7 @@ class _BnReluPool(torch.autograd.Function):
                                                     _lib.ptr(stats), _lib.ptr(scratch), _lib.ptr(dy), _lib.ptr(dx),
                                                     _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(codes),
                                                     n, h, w, c, _stream()), "dmc_bn_relu_pool_bwd")
-        return dx, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 def bn_relu_pool_supported(x):
@@ -528,7 +532,8 @@ def bn_relu_pool(x, bn, want_slices=False):
         else:
             bn.num_batches_tracked.add_(1)
     y, ys = _BnReluPool.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps,
-                              bn.momentum if bn.momentum is not None else 0.1, bool(want_slices))
+                              bn.momentum if bn.momentum is not None else 0.1, bool(want_slices),
+                              getattr(x, "_dmc_stat_partials", None))
     if ys.numel():
         y._dmc_x3s = ys
         y._dmc_f32 = True
@@ -549,8 +554,9 @@ class _StemConv(torch.autograd.Function):
         generator) is a batched GEMM  W^T[98,64] x dy[64, OH*OW]  followed by ``fold`` (col2im)."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, want_stats=False):
         xc = x.detach().contiguous()
+        stat = None
         if STEM_FWD_HIP:
             n, _, h, w = xc.shape
             y = torch.empty((n, 64, (h + 1) // 2, (w + 1) // 2), dtype=torch.float32, device=x.device,
@@ -560,18 +566,23 @@ class _StemConv(torch.autograd.Function):
             with _span("stem_fwd"):
                 if lib.dmc_get_option(b"conv_arith") == 1:         # bf16x3 arithmetic, as the other classifier convolutions
                     work = _floats(lib.dmc_stem_fwd_x3_workspace_bytes(n, h, w), x.device)
-                    _lib.check(lib.dmc_stem_fwd_x3(_lib.ptr(xc), _lib.ptr(weight), so, si, sy, sx, _lib.ptr(work), _lib.ptr(y),
-                                                   n, h, w, _stream()), "dmc_stem_fwd_x3")
+                    if want_stats:      # bn1's batch statistics from the accumulators: partial sums for the stem tail
+                        stat = _floats(lib.dmc_bn_act_scratch_bytes(64), x.device)
+                    _lib.check(lib.dmc_stem_fwd_x3_stats(_lib.ptr(xc), _lib.ptr(weight), so, si, sy, sx, _lib.ptr(work), _lib.ptr(y),
+                                                         _lib.ptr(stat), n, h, w, _stream()), "dmc_stem_fwd_x3_stats")
                 else:
                     _lib.check(lib.dmc_stem_fwd(_lib.ptr(xc), _lib.ptr(weight), so, si, sy, sx, _lib.ptr(y), n, h, w,
                                                 _stream()), "dmc_stem_fwd")
         else:
             y = torch.nn.functional.conv2d(x, weight, None, 2, 3)
         ctx.save_for_backward(xc, weight)
-        return y
+        if stat is None:
+            stat = torch.empty(0, dtype=torch.float32, device=x.device)
+        ctx.mark_non_differentiable(stat)
+        return y, stat
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dstat=None):
         lib = _lib.load()
         x, weight = ctx.saved_tensors
         n, _, h, w = x.shape
@@ -590,7 +601,7 @@ class _StemConv(torch.autograd.Function):
             g = dy.permute(0, 2, 3, 1).reshape(n, oh * ow, 64)            # a view of the NHWC storage
             cols = torch.matmul(weight.reshape(64, 98).t(), g.transpose(1, 2))   # [N, 98, OH*OW]
             dx = torch.nn.functional.fold(cols, (h, w), kernel_size=7, padding=3, stride=2)
-        return dx, dw
+        return dx, dw, None
 
 
 def stem_conv_supported(x, weight):
@@ -601,10 +612,19 @@ def stem_conv_supported(x, weight):
             and bool(_lib.load().dmc_stem_wgrad_supported(int(x.shape[2]), int(x.shape[3]))))
 
 
-def stem_conv(x, weight):
-    """conv1(x) for ``x`` [N,2,H,W] (no gradient needed) and ``weight`` [64,2,7,7]."""
+#: True (default): conv1's forward also reduces bn1's batch statistics from its accumulators (dmc_stem_fwd_x3_stats)
+STEM_STATS = __import__("os").environ.get("DMC_STEM_STATS", "1") != "0"
+
+
+def stem_conv(x, weight, want_stats=False):
+    """conv1(x) for ``x`` [N,2,H,W] and ``weight`` [64,2,7,7].  ``want_stats``: the batch statistics' partial sums of the
+    result are attached to it for ``bn_relu_pool`` (training mode: the BatchNorm pass over the convolution output goes)."""
     _need_cuda(x, weight)
-    return _StemConv.apply(x, weight)
+    y, stat = _StemConv.apply(x, weight, bool(want_stats) and STEM_STATS)
+    if stat.numel():
+        lib = _lib.load()
+        y._dmc_stat_partials = (stat, lib.dmc_stem_fwd_x3_stat_blocks(int(x.shape[0]), int(x.shape[2]), int(x.shape[3])))
+    return y
 
 
 # ------------------------------------------------------------------ NHWC convolutions (conv_nhwc.hip)
@@ -1428,7 +1448,7 @@ class _Conv3dBf16(torch.autograd.Function):
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dstat=None):
         lib = _lib.load()
         x, weight = ctx.saved_tensors
         dy = _as_cl3(dy)

@@ -140,7 +140,8 @@ class ResNet(nn.Module):
                 and c.dilation == (1, 1) and c.groups == 1
                 and (not torch.is_grad_enabled() or c.weight.requires_grad or x.requires_grad)
                 and ops.stem_conv_supported(x, c.weight)):
-            return ops.stem_conv(x, c.weight)
+            # training: bn1's batch statistics come out of the convolution's epilogue (consumed by _stem_tail's fused op)
+            return ops.stem_conv(x, c.weight, want_stats=self.bn1.training and self.bn1.track_running_stats)
         return c(x)
 
     def _stem_tail(self, x):

@@ -376,10 +376,12 @@ int dmc_bn_relu_pool_fwd_x3s(const float* x, const float* gamma, const float* be
  * dmc_bn_relu_pool_fwd_x3s that also writes, when `codes` / `xmax` are given (both or neither), each window's arg-max
  * position per channel (codes: dmc_bn_relu_pool_codes_bytes) and the raw input there (xmax: fp32 [N][PH][PW][C]);
  * dmc_bn_relu_pool_bwd_arg = dmc_bn_relu_pool_bwd from that record: its BatchNorm-backward sums stream over the
- * pooled-size (d_pool, xmax) pair instead of gathering over the 4x larger input.  Same dx / dgamma / dbeta semantics. */
+ * pooled-size (d_pool, xmax) pair instead of gathering over the 4x larger input.  Same dx / dgamma / dbeta semantics.
+ * stat_split: 0 = reduce the batch statistics of x here; > 0 = `scratch` already holds that many partial sums per channel
+ * (written by x's producer, dmc_stem_fwd_x3_stats). */
 int dmc_bn_relu_pool_fwd_arg(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                             float* y_pool, void* ys, void* codes, float* xmax, float* stats, void* scratch, int N, int H, int W,
-                             int C, int training, float eps, float momentum, dmc_stream_t stream);
+                             float* y_pool, void* ys, void* codes, float* xmax, float* stats, void* scratch, int stat_split,
+                             int N, int H, int W, int C, int training, float eps, float momentum, dmc_stream_t stream);
 int dmc_bn_relu_pool_bwd_arg(const float* x, const float* gamma, const float* beta, const float* stats, void* scratch,
                              const float* d_pool, const void* codes, const float* xmax, float* dx, float* dgamma, float* dbeta,
                              int N, int H, int W, int C, dmc_stream_t stream);
@@ -439,6 +441,14 @@ int dmc_stem_fwd(const float* x, const float* w, long ws_co, long ws_ci, long ws
 size_t dmc_stem_fwd_x3_workspace_bytes(int N, int H, int W);
 int dmc_stem_fwd_x3(const float* x, const float* w, long ws_co, long ws_ci, long ws_ky, long ws_kx, void* workspace, float* y, int N,
                     int H, int W, dmc_stream_t stream);
+/* dmc_stem_fwd_x3 that also reduces the BatchNorm batch statistics of its output in the epilogue (the stem's bn1,
+ * /root/reference/code/dmcnet/model.py:305): stat_scratch (dmc_bn_act_scratch_bytes(64), nullable = plain forward)
+ * receives dmc_stem_fwd_x3_stat_blocks(N, H, W) partial (sum, sum of squares) pairs per channel in the layout the
+ * BatchNorm kernels reduce; pass that count as `stat_split` to dmc_bn_relu_pool_fwd_arg, which then skips its own
+ * statistics pass over the (4x pooled-size) convolution output. */
+int dmc_stem_fwd_x3_stat_blocks(int N, int H, int W);
+int dmc_stem_fwd_x3_stats(const float* x, const float* w, long ws_co, long ws_ci, long ws_ky, long ws_kx, void* workspace, float* y,
+                          void* stat_scratch, int N, int H, int W, dmc_stream_t stream);
 
 /* ---- I3D trunk: bf16 3-D convolutions on the matrix cores (BASELINE config 5) -------------------------
  * Replace nn.Conv3d and its autograd inside the reference's Unit3Dpy, code/dmcnet_I3D/network/i3d.py:328-403

@@ -213,6 +213,34 @@ def test_pool_argmax_record_backward(shape, monkeypatch):
     assert torch.equal(xg.grad, res[True][1]) and torch.equal(bn_m.weight.grad, res[True][2])
 
 
+@pytest.mark.parametrize("n,h,w", [(3, 224, 224), (2, 40, 36), (1, 8, 8), (2, 37, 44)])
+def test_stem_statistics_from_the_convolution_epilogue(n, h, w, monkeypatch):
+    """conv1 -> bn1 -> relu -> maxpool of the classifier: bn1's batch statistics reduced in conv1's epilogue
+    (dmc_stem_fwd_x3_stats -> stat_split of dmc_bn_relu_pool_fwd_arg) against the separate statistics pass: the same
+    convolution output (bitwise), statistics / pooled map / gradients equal to fp32 rounding, and against fp64."""
+    x = rnd(401, (n, 2, h, w)).to(DEV)
+    wt = (rnd(402, (64, 2, 7, 7)) * 0.1).to(DEV)
+    go = rnd(403, (n, 64, ((h + 1) // 2 - 1) // 2 + 1, ((w + 1) // 2 - 1) // 2 + 1)).to(DEV)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "STEM_STATS", fused)
+        bn = torch.nn.BatchNorm2d(64).to(DEV).train()
+        wg = wt.clone().requires_grad_(True)
+        y = ops.stem_conv(x, wg, want_stats=True)
+        assert (getattr(y, "_dmc_stat_partials", None) is not None) == fused
+        out = ops.bn_relu_pool(y, bn, want_slices=True)
+        (out * go).sum().backward()
+        res[fused] = (y.detach(), out.detach(), bn.running_mean.clone(), bn.running_var.clone(), wg.grad.clone(),
+                      bn.weight.grad.clone(), bn.bias.grad.clone())
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b in zip(res[True][1:], res[False][1:]):
+        assert rel_err(a, b) < 2e-6
+    yd = F.conv2d(x.double().cpu(), wt.double().cpu(), None, 2, 3)
+    mean, var = yd.mean((0, 2, 3)), yd.var((0, 2, 3), unbiased=True)
+    assert rel_err(res[True][2].cpu().double(), 0.1 * mean) < 1e-5
+    assert rel_err(res[True][3].cpu().double(), 0.9 + 0.1 * var) < 1e-5
+
+
 @pytest.mark.parametrize("cin,planes,hw,n,seed", [(64, 64, 14, 6, 331), (128, 128, 28, 3, 338), (64, 64, 56, 2, 342), (512, 512, 7, 5, 339)])
 def test_basic_block_presplit_vs_in_loop_split_and_stock(cin, planes, hw, n, seed, monkeypatch):
     """An identity-shortcut BasicBlock in training mode: (a) pre-split path (conv1 reads the input's slices, writes ONLY
