@@ -200,6 +200,8 @@ def bench_i3d(args, rank, world, dev):
 
     for _ in range(args.warmup):
         one()
+    from dmcnet_amd import train as _train
+    _train.settle_host()                             # host GC pauses out of the timed region (as the training driver does)
     probe = ops.EventProbe(None if args.all_spans else ("gen_tiny_fwd", "gen_tiny_bwd"))
     ops.PROBE = probe
     torch.cuda.synchronize()
@@ -322,6 +324,7 @@ def main():
 
     for i in range(args.warmup):
         one(i)
+    train.settle_host()                              # as driver.train_epoch does after its first steps (host GC pauses)
     if reducer is not None:
         reducer.time_waits = True                    # exposed communication of the timed steps (comm object below)
     probe = ops.EventProbe(None if args.all_spans else ("gen_tiny_fwd", "gen_tiny_bwd"))
@@ -403,6 +406,8 @@ def main():
     loss = float(out["loss"])
     spans = probe.summary()
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    if os.environ.get("DMC_BENCH_DUMP_STEPS"):      # diagnosis: device time of every timed step, in order
+        sys.stderr.write("bench: step ms " + " ".join("%.2f" % marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)) + "\n")
     if gan and args.steps > 1:      # D and G steps alternate: a "step" is their pair average
         pair = [marks[i].elapsed_time(marks[i + 2]) / 2 for i in range(0, args.steps - 1, 2)]
         step_ms = sorted(pair)

@@ -37,6 +37,8 @@ def train_epoch(loader, stepper, epoch, device="cuda:0", freeze=False, print_fre
     for i, batch in enumerate(loader):
         batch = prep(batch) if prep is not None else _to(batch, device)
         out = stepper.step(batch, i) if gan else stepper.step(batch, freeze=freeze)
+        if i == 1:
+            train.settle_host()      # both step kinds have run once: park the long-lived objects outside the collector
         n = batch[0].shape[0] * stepper.num_segments
         prec1, prec5 = train.accuracy(out["output"], batch[3], topk=(1, 5))
         meters["loss"].update(out["loss"], n)
@@ -55,7 +57,6 @@ def train_epoch(loader, stepper, epoch, device="cuda:0", freeze=False, print_fre
     return {k: float(m.avg) for k, m in meters.items()}
 
 
-@torch.no_grad()
 @torch.no_grad()
 def validate(loader, model, num_segments, lr_cls, lr_mse, device="cuda:0", log=print, loss_mse="MSELoss",
              prep=None):

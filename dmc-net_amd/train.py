@@ -276,3 +276,20 @@ class GanTrainStep(object):
         loss.backward()
         if self.reducer is not None:
             self.reducer.finish()
+
+
+_SETTLED = [False]
+
+
+def settle_host():
+    """Once per process, after the first steps: ``gc.collect(); gc.freeze()``.  The interpreter then holds ~10^6 long-lived
+    objects (torch, this package, the model, autograd closures); a full (generation-2) collection walks all of them --
+    40-100 ms of host time during which nothing is launched (measured: a 13 ms GAN step became 82 ms, the GPU idle for the
+    difference).  Frozen objects are skipped by later collections, which then cost well under a millisecond.  Host-side
+    only; no effect on results."""
+    if _SETTLED[0]:
+        return
+    import gc
+    gc.collect()
+    gc.freeze()
+    _SETTLED[0] = True
