@@ -403,17 +403,40 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(C3dWgradArgs a) {
     }
 }
 
-// dw[co][ci][t] (the parameter's contiguous layout) = sum over splits of part[s][co][t][ci], fixed order
+// dw[co][ci][t] (the parameter's contiguous layout) = sum over splits of part[s][co][t][ci], fixed order: a workgroup
+// owns 64 consecutive elements (16 float4 columns); its 16 thread rows sum the splits s = row, row + 16, .. in
+// parallel and are then added in row order.  (One thread per element walking all <= 256 splits serially was
+// latency-bound: 15.8 us per launch on average, 56 launches per I3D micro-step.)
 __global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                                   int splits, int Cout, int T, int Cin) {
-    const long total = (long)Cout * T * Cin;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += part[(size_t)k * total + i];
-        const int ci = (int)(i % Cin);
-        const int t = (int)((i / Cin) % T);
-        const int co = (int)(i / ((long)Cin * T));
-        dw[((size_t)co * Cin + ci) * T + t] = s;
+    __shared__ float4 red[16][17];
+    const long total = (long)Cout * T * Cin;                 // a multiple of 8 (Cin % 8 == 0)
+    const int o = threadIdx.x & 15, row = threadIdx.x >> 4;
+    for (long i0 = (long)blockIdx.x * 64; i0 < total; i0 += (long)gridDim.x * 64) {
+        const long i = i0 + 4 * o;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < total)
+            for (int k = row; k < splits; k += 16) {
+                const float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * total + i);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        red[row][o] = s;
+        __syncthreads();
+        if (row == 0 && i < total) {
+            float4 t = red[0][o];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) { const float4 v = red[k][o]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+            const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const long ie = i + e;
+                const int ci = (int)(ie % Cin);
+                const int tt = (int)((ie / Cin) % T);
+                const int co = (int)(ie / ((long)Cin * T));
+                dw[((size_t)co * Cin + ci) * T + tt] = tv[e];
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -623,7 +646,7 @@ int dmc_conv3d_bf16_wgrad(const void* x, const void* dy, float* dw, float* works
     if (rc) return rc;
     const int T = KD * KH * KW;
     const long total = (long)Cout * T * Cin;
-    conv3d_wgrad_reduce_kernel<<<(int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256), 256, 0, s>>>(
+    conv3d_wgrad_reduce_kernel<<<(int)((total + 63) / 64 > 8192 ? 8192 : (total + 63) / 64), 256, 0, s>>>(
         workspace, dw, p.splits, Cout, T, Cin);
     return check_launch("conv3d_wgrad_reduce");
 }
