@@ -200,7 +200,9 @@ bool bn3_ok(long M, int C) { return M > 0 && C > 0 && C % 8 == 0 && C <= 2048; }
 int bn3_blocks(long M, int C) {
     const int P = 256 / (C / 8);
     long b = (M + P - 1) / P;
-    b = (b + 7) / 8;                                       // >= 8 pixel groups per workgroup
+    b = (b + 1) / 2;                                       // two pixel groups per thread while BN3_MAXBLK allows: the Inception maps are
+                                                           // small (9,408 pixels x 128 channels = 2.4 MB) and eight dependent iterations on 74
+                                                           // workgroups left these kernels latency-bound (10-11 us each, 171 launches per micro-step)
     return (int)(b < 1 ? 1 : (b > BN3_MAXBLK ? BN3_MAXBLK : b));
 }
 
