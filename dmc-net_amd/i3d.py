@@ -22,6 +22,18 @@ import os as _os
 OWN_CONV3D = _os.environ.get("DMC_OWN_CONV3D", "1") != "0"
 
 
+#: True (default): the branches of an Inception block run on concurrent HIP streams (Mixed.forward); DMC_I3D_BRANCH_STREAMS=0: one stream
+BRANCH_STREAMS = _os.environ.get("DMC_I3D_BRANCH_STREAMS", "1") != "0"
+_SIDE_STREAMS = {}
+
+
+def _side_streams(device):
+    key = torch.device(device).index
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(3)]
+    return _SIDE_STREAMS[key]
+
+
 def _same_pad(kernel, stride):
     """TF 'SAME' padding per dimension (d, h, w) -> (front, back) pairs."""
     out = []
@@ -110,6 +122,23 @@ class Mixed(nn.Module):
                                       Unit3Dpy(in_channels, o[5]))
 
     def forward(self, x):
+        if BRANCH_STREAMS and OWN_CONV3D and x.is_cuda and x.dtype == torch.bfloat16:
+            # The four branches are independent and, from mixed_4b on, small (9,408 or 1,176 pixels: every kernel a
+            # fraction of the chip, bounded by its own latency): branches 1-3 run on side streams next to branch 0 and
+            # join before the concatenation.  Autograd replays each node on its forward stream, so the backward
+            # overlaps the same way.  Same kernels, same arithmetic, same results.
+            main = torch.cuda.current_stream(x.device)
+            sides = _side_streams(x.device)
+            outs = [None] * 4
+            fork = main.record_event()               # x is ready; the side pools' blocks are free of earlier main-stream readers
+            outs[0] = self.branch_0(x)               # (autograd nodes are created in the one-stream order: the same gradient sums)
+            for k, (branch, st) in enumerate(zip((self.branch_1, self.branch_2, self.branch_3), sides)):
+                st.wait_event(fork)
+                with torch.cuda.stream(st):
+                    outs[k + 1] = branch(x)
+            for st in sides:
+                main.wait_stream(st)
+            return torch.cat(outs, 1)
         return torch.cat((self.branch_0(x), self.branch_1(x), self.branch_2(x), self.branch_3(x)), 1)
 
 

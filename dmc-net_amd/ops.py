@@ -61,7 +61,16 @@ def _span(name):
     return PROBE.span(name)
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_CUR_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """The HIP stream PyTorch is launching on (every C-ABI call takes it).  Through the raw getter: 0.3 us instead of the
+    9 us of ``torch.cuda.current_stream()`` (a Stream object per call) -- at 2-3 calls per op that was ~2 ms of host time
+    per I3D micro-step, which is launch-bound."""
+    if _RAW_STREAM is not None and _CUR_DEVICE is not None:
+        return _lib._P(_RAW_STREAM(_CUR_DEVICE()))
     return _lib._P(torch.cuda.current_stream().cuda_stream)
 
 

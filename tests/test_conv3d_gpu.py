@@ -335,3 +335,32 @@ def test_i3d_trunk_end_to_end_own_vs_stock_bf16(clips, frames):
     for k in ("conv3d_2c_3x3.batch3d.running_var", "mixed_4d.branch_1.1.batch3d.running_mean", "mixed_5c.branch_0.batch3d.running_var"):
         assert float((bn[k] - b32[k]).abs().max() / b32[k].abs().max().clamp_min(1e-6)) < 1e-2, k
     assert int(bn["mixed_4b.branch_0.batch3d.num_batches_tracked"]) == 1
+
+
+@pytest.mark.parametrize("cin,outs,shape", [(480, (192, 96, 208, 16, 48, 64), (3, 16, 14, 14)), (832, (256, 160, 320, 32, 128, 128), (2, 8, 7, 7))])
+def test_mixed_block_branch_streams_are_transparent(cin, outs, shape, monkeypatch):
+    """An Inception block with its branches on concurrent HIP streams (i3d.BRANCH_STREAMS) against the same block on one
+    stream: the same kernels on the same data -- outputs, input gradient, every parameter gradient and the running
+    statistics are bitwise equal, over three repeated steps (stale-buffer reuse across steps would show here)."""
+    import copy
+    torch.manual_seed(5)
+    blk = i3d.Mixed(cin, outs).to(DEV).train()   # fp32 parameters under bf16 autocast, as I3D.forward runs its trunk
+    ref = copy.deepcopy(blk)
+    n, d, h, w = shape
+    for it in range(3):
+        x = torch.randn(n, cin, d, h, w, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last_3d)
+        go = torch.randn(n, outs[0] + outs[2] + outs[4] + outs[5], d, h, w, device=DEV).to(torch.bfloat16)
+        res = []
+        for model, streams in ((blk, True), (ref, False)):
+            monkeypatch.setattr(i3d, "BRANCH_STREAMS", streams)
+            model.zero_grad(set_to_none=True)
+            xi = x.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                assert ops.conv_bn_relu3d_supported(xi, model.branch_0.conv3d, model.branch_0.batch3d)   # the own kernels run
+                out = model(xi)
+            (out.float() * go.float()).sum().backward()
+            torch.cuda.synchronize()
+            res.append([out.detach(), xi.grad] + [p.grad for p in model.parameters()] +
+                       [b for nm, b in model.named_buffers() if "running" in nm])
+        for k, (a, b) in enumerate(zip(*res)):
+            assert torch.equal(a, b), (it, k, float((a.float() - b.float()).abs().max()))
