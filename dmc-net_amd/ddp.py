@@ -29,6 +29,8 @@ import time
 import torch
 import torch.distributed as dist
 
+from . import ops
+
 SET_TAGS = ("base_model", "gen_flow_model", "discriminator")
 
 
@@ -132,6 +134,7 @@ class GradBucketReducer(object):
         todo = [p for p, _, _ in self.buckets[b][1] if p in self._seen and p not in self._moved]
         if not todo:
             return
+        ops.join_wgrad_stream()      # weight gradients launched on the side stream (ops.WGRAD_STREAM) are read from here on
         views = [self._view(p) for p in todo]
         torch._foreach_copy_(views, [p.grad for p in todo])
         for p, v in zip(todo, views):

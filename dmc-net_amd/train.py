@@ -207,6 +207,7 @@ class DmcnetTrainStep(object):
             (loss_mse * self.lr_mse).backward()
         else:
             loss.backward()
+        ops.join_wgrad_stream()
         if self.reducer is not None:
             self.reducer.finish()
         if not freeze:

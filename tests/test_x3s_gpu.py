@@ -386,3 +386,30 @@ def test_bn_backward_sums_from_the_data_gradient_epilogue(monkeypatch):
             assert links == []
     for a, b in zip(res[True], res[False]):
         assert rel_err(a, b) < 1e-5
+
+
+def test_weight_gradients_on_the_side_stream_are_transparent(monkeypatch):
+    """ops.WGRAD_STREAM: the classifier's weight gradients run on a side HIP stream and the caller's stream re-joins when
+    backward() returns.  A ResNet-18 training pass with and without it: every gradient bitwise equal, read IMMEDIATELY
+    after backward() (no synchronize: the engine callback must already have ordered the streams), over three steps, and with
+    gradient accumulation (second backward without zero_grad: the side stream must not be used when .grad exists)."""
+    import copy
+    monkeypatch.setattr(resnet, "OWN_CONV", True)
+    torch.manual_seed(11)
+    net = resnet.build("resnet18")
+    net.conv1 = torch.nn.Conv2d(2, 64, 7, 2, 3, bias=False)
+    net = net.to(DEV).to(memory_format=CL).train()
+    ref = copy.deepcopy(net)
+    for it in range(3):
+        x = rnd(500 + it, (6, 2, 224, 224)).to(DEV)
+        outs = []
+        for model, side in ((net, True), (ref, False)):
+            monkeypatch.setattr(ops, "WGRAD_STREAM", side)
+            model.zero_grad(set_to_none=True)
+            model(x).square().mean().backward()
+            if it == 2:
+                model(x).square().mean().backward()          # accumulation into existing .grad
+            outs.append([p.grad.clone() for p in model.parameters()])      # cloned on the caller's stream, no sync
+        assert not ops._WGRAD_PENDING[0]
+        for (name, _), a, b in zip(net.named_parameters(), *outs):
+            assert torch.equal(a, b), (it, name)
