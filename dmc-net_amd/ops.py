@@ -874,9 +874,26 @@ class ResidualGradLink:
 #: a (matrix-bound) weight-gradient launch overlaps the (memory-bound) BatchNorm passes of the layers below it: 12.43 ->
 #: 12.25 ms per step.  The main stream re-joins when backward() returns (an autograd-engine callback), in the gradient
 #: exchange before a bucket is read, and in join_wgrad_stream().  DMC_WGRAD_STREAM=0: one stream.
+#: Used where a backward pass is wrapped in ``with ops.wgrad_side_stream():`` -- DmcnetTrainStep does (config 2: -0.32 ms);
+#: the GAN step does not (measured 0.1 ms slower there: its D step is closer to launch-bound and gains nothing back).
 WGRAD_STREAM = __import__("os").environ.get("DMC_WGRAD_STREAM", "1") != "0"
 _WGRAD_STREAMS = {}
 _WGRAD_PENDING = [False]
+_WGRAD_SCOPE = [0]
+
+
+class wgrad_side_stream(object):
+    """Context manager around ``loss.backward()``: weight gradients of the classifier convolutions inside it may run on
+    the side stream (see WGRAD_STREAM).  A plain global counter: backward functions run on the autograd engine's thread."""
+
+    def __enter__(self):
+        _WGRAD_SCOPE[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _WGRAD_SCOPE[0] -= 1
+        join_wgrad_stream()
+        return False
 
 
 def _wgrad_stream(device):
@@ -899,7 +916,7 @@ def _on_wgrad_stream(weight, reads, launch):
     """``launch()`` (allocates, launches, returns the weight gradient) on the side stream when that is safe: inside an
     autograd backward pass (the join is queued as an engine callback: it runs on the caller's stream before backward()
     returns) and with no gradient to accumulate into (``weight.grad += dw`` would run on the main stream at once)."""
-    if not WGRAD_STREAM or weight.grad is not None:
+    if not WGRAD_STREAM or _WGRAD_SCOPE[0] <= 0 or weight.grad is not None:
         return launch()
     if PROBE is not None and (PROBE.only is None or "conv_nhwc_wgrad" in PROBE.only or "stem_wgrad" in PROBE.only):
         return launch()                         # HIP-event spans around this call time the launch stream: stay on it

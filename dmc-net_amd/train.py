@@ -203,11 +203,11 @@ class DmcnetTrainStep(object):
         loss = loss_cls * self.lr_cls + loss_mse * self.lr_mse
         if self.reducer is not None:
             self.reducer.begin()
-        if freeze:
-            (loss_mse * self.lr_mse).backward()
-        else:
-            loss.backward()
-        ops.join_wgrad_stream()
+        with ops.wgrad_side_stream():            # the classifier's weight gradients overlap the rest of the backward pass
+            if freeze:
+                (loss_mse * self.lr_mse).backward()
+            else:
+                loss.backward()
         if self.reducer is not None:
             self.reducer.finish()
         if not freeze:

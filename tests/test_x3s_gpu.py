@@ -389,8 +389,8 @@ def test_bn_backward_sums_from_the_data_gradient_epilogue(monkeypatch):
 
 
 def test_weight_gradients_on_the_side_stream_are_transparent(monkeypatch):
-    """ops.WGRAD_STREAM: the classifier's weight gradients run on a side HIP stream and the caller's stream re-joins when
-    backward() returns.  A ResNet-18 training pass with and without it: every gradient bitwise equal, read IMMEDIATELY
+    """ops.WGRAD_STREAM inside ``with ops.wgrad_side_stream()`` (as DmcnetTrainStep wraps its backward): the classifier's
+    weight gradients run on a side HIP stream and the caller's stream re-joins when backward() returns.  A ResNet-18 training pass with and without it: every gradient bitwise equal, read IMMEDIATELY
     after backward() (no synchronize: the engine callback must already have ordered the streams), over three steps, and with
     gradient accumulation (second backward without zero_grad: the side stream must not be used when .grad exists)."""
     import copy
@@ -406,9 +406,10 @@ def test_weight_gradients_on_the_side_stream_are_transparent(monkeypatch):
         for model, side in ((net, True), (ref, False)):
             monkeypatch.setattr(ops, "WGRAD_STREAM", side)
             model.zero_grad(set_to_none=True)
-            model(x).square().mean().backward()
-            if it == 2:
-                model(x).square().mean().backward()          # accumulation into existing .grad
+            with ops.wgrad_side_stream():
+                model(x).square().mean().backward()
+                if it == 2:
+                    model(x).square().mean().backward()      # accumulation into existing .grad
             outs.append([p.grad.clone() for p in model.parameters()])      # cloned on the caller's stream, no sync
         assert not ops._WGRAD_PENDING[0]
         for (name, _), a, b in zip(net.named_parameters(), *outs):
