@@ -99,6 +99,9 @@ SIGNATURES = {
     "dmc_stem_fwd_x3_workspace_bytes": (_Z, [_I, _I, _I]),
     "dmc_stem_fwd_x3": (_I, [_P, _P, _L, _L, _L, _L, _P, _P, _I, _I, _I, _P]),
     "dmc_stem_fwd_x3_stat_blocks": (_I, [_I, _I, _I]),
+    "dmc_stem_dgrad_workspace_bytes": (_Z, []),
+    "dmc_stem_dgrad_supported": (_I, [_I, _I]),
+    "dmc_stem_dgrad": (_I, [_P, _P, _L, _L, _L, _L, _P, _P, _I, _I, _I, _P]),
     "dmc_stem_fwd_x3_stats": (_I, [_P, _P, _L, _L, _L, _L, _P, _P, _P, _I, _I, _I, _P]),
     "dmc_conv3d_bf16_supported": (_I, [_I] * 9),
     "dmc_conv3d_bf16_wpack_bytes": (_Z, [_I] * 5),

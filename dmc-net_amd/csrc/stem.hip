@@ -478,6 +478,131 @@ __global__ __launch_bounds__(SX_THREADS) void stem_fwd_x3_kernel(StemX3Args a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Data gradient of conv1 (the gradient of the 2-channel cue; needed when the classifier's loss reaches the generator: the
+// GAN variant, /root/reference/code/dmcnet_GAN/model.py:557-561), bf16x3 arithmetic.  Per INPUT row (n, h):
+//     Q[ow][(kx, c)] = sum over the ky whose stride-2 window reaches row h (3 or 4 of them), and over co, of
+//                      dy[oh][ow][co] * w[co][c][ky][kx]                       (oh = (h + 3 - ky) / 2)
+//     dx[c][h][w]    = sum over kx = w + 1 (mod 2) of Q[(w + 3 - kx) / 2][(kx, c)]
+// The first line is a GEMM with M = the OW output pixels of the row, N = 14 (+ 2 zero) columns, K = 64 channels x 3..4
+// window rows on v_mfma_f32_16x16x32_bf16 (A fragments: eight consecutive channels of a dy pixel, split into three bf16
+// slices in registers; B fragments: 16 contiguous bytes of the pre-split weights [slice][ky][(kx, c)][co]); the second
+// line is a 1-D fold of the row through LDS.  One wave per input row: nothing is scattered, the [pixels][98] column
+// matrix of the GEMM + col2im formulation (590 MB at 120 frames) never exists, deterministic.  (Scheme of
+// stem3d_dgrad_kernel, stem3d_bf16.hip.)
+// ------------------------------------------------------------------------------------------
+typedef float stem_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int SD_WAVES = 4, SD_MT = 8;                      // up to 128 output pixels per row
+
+// w [64][2][7][7] by element strides -> wq [3 slices][7 ky][16 j = 2 kx + c][64 co] bf16; j = 14, 15 zero
+__global__ __launch_bounds__(256) void stem_pack_wq3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wq, long s_co, long s_ci,
+                                                            long s_ky, long s_kx) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 7 * 16 * S_CO) return;
+    const int co = i & 63, j = (i >> 6) & 15, ky = i >> 10;
+    unsigned s0 = 0, s1 = 0, s2 = 0;
+    if (j < 14) stem_split3(w[co * s_co + (j & 1) * s_ci + ky * s_ky + (j >> 1) * s_kx], s0, s1, s2);
+    wq[i] = (unsigned short)s0; wq[7 * 16 * S_CO + i] = (unsigned short)s1; wq[2 * 7 * 16 * S_CO + i] = (unsigned short)s2;
+}
+
+struct StemDgArgs {
+    const float* dy;            // [N][OH][OW][64]
+    const unsigned short* wq;   // [3][7][16][64]
+    float* dx;                  // [N][2][H][W]
+    int N, H, W, OH, OW;
+};
+
+__device__ __forceinline__ void stem_split8(const float4 lo, const float4 hi, stem_u32x4 (&sl)[3]) {
+    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    unsigned u[3][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        u[0][e] = __float_as_uint(v[e]);
+        const float r1 = v[e] - __uint_as_float(u[0][e] & 0xffff0000u);
+        u[1][e] = __float_as_uint(r1);
+        u[2][e] = __float_as_uint(r1 - __uint_as_float(u[1][e] & 0xffff0000u));
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sl[k][e] = __builtin_amdgcn_perm(u[k][2 * e + 1], u[k][2 * e], 0x07060302u);
+}
+
+template <int MTC>                                          // 16-pixel row tiles when known at compile time; 0 = runtime
+__global__ __launch_bounds__(SD_WAVES * 64) void stem_dgrad_x3_kernel(StemDgArgs a) {
+    __shared__ float qlds[SD_WAVES][SD_MT * 16 * 16];       // Q tile of each wave: [ow][16]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int l15 = lane & 15, kg = lane >> 4;
+    float* Q = qlds[wave];
+    const long nrows = (long)a.N * a.H;
+    const int mtiles = MTC ? MTC : (a.OW + 15) / 16;
+    const long plane = (long)a.H * a.W;
+    for (long row = (long)blockIdx.x * SD_WAVES + wave; row < nrows; row += (long)gridDim.x * SD_WAVES) {
+        const int h = (int)(row % a.H);
+        const int n = (int)(row / a.H);
+        stem_f32x4 acc[SD_MT];
+#pragma unroll
+        for (int m = 0; m < SD_MT; ++m) acc[m] = stem_f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ky = (h + 1) & 1; ky < S_K; ky += 2) {
+            const int oh2 = h + 3 - ky;
+            if (oh2 < 0 || (oh2 >> 1) >= a.OH) continue;
+            const float* drow = a.dy + ((long)n * a.OH + (oh2 >> 1)) * a.OW * S_CO;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                stem_u32x4 bf[3];
+#pragma unroll
+                for (int sl = 0; sl < 3; ++sl)
+                    bf[sl] = *reinterpret_cast<const stem_u32x4*>(a.wq + ((sl * 7 + ky) * 16 + l15) * S_CO + 32 * kb + 8 * kg);
+                float4 lo[SD_MT], hi[SD_MT];
+#pragma unroll
+                for (int m = 0; m < SD_MT; ++m) {
+                    if (MTC ? m >= MTC : m >= mtiles) continue;
+                    int ow = 16 * m + l15;
+                    ow = ow < a.OW ? ow : a.OW - 1;          // clipped rows: valid memory, their Q rows are never read
+                    const float4* p = reinterpret_cast<const float4*>(drow + (long)ow * S_CO + 32 * kb + 8 * kg);
+                    lo[m] = p[0]; hi[m] = p[1];
+                }
+#pragma unroll
+                for (int m = 0; m < SD_MT; ++m) {
+                    if (MTC ? m >= MTC : m >= mtiles) continue;
+                    stem_u32x4 af[3];
+                    stem_split8(lo[m], hi[m], af);
+                    auto mm = [&](int i, int j) {
+                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(stem_bf16x8, af[i]), __builtin_bit_cast(stem_bf16x8, bf[j]),
+                                                                         acc[m], 0, 0, 0);
+                    };
+                    mm(0, 2); mm(2, 0); mm(1, 1); mm(0, 1); mm(1, 0); mm(0, 0);      // small terms first
+                }
+            }
+        }
+        // C layout of 16x16: lane (column l15 = j, rows 4 kg + q = ow within the tile)
+#pragma unroll
+        for (int m = 0; m < SD_MT; ++m) {
+            if (m >= mtiles) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Q[(16 * m + 4 * kg + q) * 16 + l15] = acc[m][q];
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // fold: dx[c][w] = sum over kx = w + 1 (mod 2) of Q[(w + 3 - kx) / 2][2 kx + c]
+        float* dst = a.dx + (long)n * 2 * plane + (long)h * a.W;
+        for (int i = lane; i < 2 * a.W; i += 64) {
+            const int c = i / a.W, w = i - c * a.W;
+            float sum = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kx = ((w + 1) & 1) + 2 * u;
+                const int ow2 = w + 3 - kx;
+                if (kx < S_K && ow2 >= 0 && (ow2 >> 1) < a.OW) sum += Q[(ow2 >> 1) * 16 + 2 * kx + c];
+            }
+            dst[c * plane + w] = sum;
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
 int stem_groups(int N, int H, int W) {
     const int OH = (H + 1) / 2, OW = (W + 1) / 2;
     const long tiles = (long)N * ((OH + S_TH - 1) / S_TH) * ((OW + S_TW - 1) / S_TW);
@@ -570,6 +695,30 @@ int dmc_stem_fwd_x3_stats(const float* x, const float* w, long ws_co, long ws_ci
     if (attr != hipSuccess) return fail(DMC_E_LAUNCH, "dmc_stem_fwd_x3: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
     stem_fwd_x3_kernel<<<(int)blocks, SX_THREADS, SX_LDS, s>>>(a);
     return check_launch("stem_fwd_x3");
+}
+
+// Data gradient of conv1 (see stem_dgrad_x3_kernel): dx [N][2][H][W] fp32 contiguous from dy [N][OH][OW][64] fp32 (the memory
+// of a channels_last [N,64,OH,OW] tensor) and w [64,2,7,7] by its element strides; stride 2, padding 3; bf16x3 arithmetic
+// (fp32-level error), deterministic.  W <= 256.  workspace: dmc_stem_dgrad_workspace_bytes().
+size_t dmc_stem_dgrad_workspace_bytes(void) { return (size_t)3 * 7 * 16 * S_CO * 2 + 64; }
+int dmc_stem_dgrad_supported(int H, int W) { return H > 0 && W > 0 && (W + 1) / 2 <= 16 * SD_MT ? 1 : 0; }
+int dmc_stem_dgrad(const float* dy, const float* w, long ws_co, long ws_ci, long ws_ky, long ws_kx, void* workspace, float* dx, int N,
+                   int H, int W, dmc_stream_t stream) {
+    if (!dy || !w || !workspace || !dx) return fail(DMC_E_INVALID, "dmc_stem_dgrad: null pointer");
+    if (N <= 0 || !dmc_stem_dgrad_supported(H, W)) return fail(DMC_E_INVALID, "dmc_stem_dgrad: unsupported shape N=%d H=%d W=%d (W <= 256)", N, H, W);
+    hipStream_t s = (hipStream_t)stream;
+    unsigned short* wq = static_cast<unsigned short*>(workspace);
+    stem_pack_wq3_kernel<<<(7 * 16 * S_CO + 255) / 256, 256, 0, s>>>(w, wq, ws_co, ws_ci, ws_ky, ws_kx);
+    int rc = check_launch("stem_pack_wq3");
+    if (rc) return rc;
+    StemDgArgs a;
+    a.dy = dy; a.wq = wq; a.dx = dx; a.N = N; a.H = H; a.W = W; a.OH = (H + 1) / 2; a.OW = (W + 1) / 2;
+    const long rows = (long)N * H;
+    long blocks = (rows + SD_WAVES - 1) / SD_WAVES;
+    if (blocks > 4096) blocks = 4096;
+    if (a.OW == 112) stem_dgrad_x3_kernel<7><<<(int)blocks, SD_WAVES * 64, 0, s>>>(a);      // 224-wide frames
+    else stem_dgrad_x3_kernel<0><<<(int)blocks, SD_WAVES * 64, 0, s>>>(a);
+    return check_launch("stem_dgrad_x3");
 }
 
 }  // extern "C"

@@ -553,6 +553,10 @@ def bn_relu_pool(x, bn, want_slices=False):
 STEM_FWD_HIP = __import__("os").environ.get("DMC_STEM_FWD", "1") != "0"
 
 
+#: True (default): conv1's data gradient (GAN variant) on dmc_stem_dgrad; DMC_STEM_DGRAD=0: library GEMM + col2im
+STEM_DGRAD_HIP = __import__("os").environ.get("DMC_STEM_DGRAD", "1") != "0"
+
+
 class _StemConv(torch.autograd.Function):
     """conv1 of the classifier for the 2-channel flow input (code/dmcnet/model.py:285-294): the
     forward convolution is dmc_stem_fwd (fp32 MFMA with the weights resident in registers); with 2 input
@@ -560,7 +564,9 @@ class _StemConv(torch.autograd.Function):
     120 frames), so
       * the weight gradient is dmc_stem_wgrad (0.24 ms, deterministic);
       * the data gradient (needed only by the GAN variant, whose classifier loss reaches the
-        generator) is a batched GEMM  W^T[98,64] x dy[64, OH*OW]  followed by ``fold`` (col2im)."""
+        generator) is dmc_stem_dgrad (one wave per input row: a [OW x 14] row GEMM over the 3-4 window rows that
+        reach it, in bf16x3 arithmetic, and a 1-D fold); frames wider than 256 fall back to a batched GEMM
+        W^T[98,64] x dy[64, OH*OW] followed by ``fold`` (col2im)."""
 
     @staticmethod
     def forward(ctx, x, weight, want_stats=False):
@@ -609,10 +615,19 @@ class _StemConv(torch.autograd.Function):
             with _span("stem_wgrad"):
                 dw = _on_wgrad_stream(weight, (x, dy), launch)
         if ctx.needs_input_grad[0]:
-            oh, ow = dy.shape[2], dy.shape[3]
-            g = dy.permute(0, 2, 3, 1).reshape(n, oh * ow, 64)            # a view of the NHWC storage
-            cols = torch.matmul(weight.reshape(64, 98).t(), g.transpose(1, 2))   # [N, 98, OH*OW]
-            dx = torch.nn.functional.fold(cols, (h, w), kernel_size=7, padding=3, stride=2)
+            if STEM_DGRAD_HIP and dy.dtype == torch.float32 and lib.dmc_stem_dgrad_supported(h, w):
+                # row GEMM + 1-D fold in one kernel, bf16x3 arithmetic (dmc_stem_dgrad): no [pixels][98] column matrix
+                dx = torch.empty((n, 2, h, w), dtype=torch.float32, device=x.device)
+                work = _floats(lib.dmc_stem_dgrad_workspace_bytes(), x.device)
+                so, si, sy, sx = weight.stride()
+                with _span("stem_dgrad"):
+                    _lib.check(lib.dmc_stem_dgrad(_lib.ptr(dy), _lib.ptr(weight), so, si, sy, sx, _lib.ptr(work), _lib.ptr(dx),
+                                                  n, h, w, _stream()), "dmc_stem_dgrad")
+            else:
+                oh, ow = dy.shape[2], dy.shape[3]
+                g = dy.permute(0, 2, 3, 1).reshape(n, oh * ow, 64)            # a view of the NHWC storage
+                cols = torch.matmul(weight.reshape(64, 98).t(), g.transpose(1, 2))   # [N, 98, OH*OW]
+                dx = torch.nn.functional.fold(cols, (h, w), kernel_size=7, padding=3, stride=2)
         return dx, dw, None
 
 

@@ -449,6 +449,16 @@ int dmc_stem_fwd_x3(const float* x, const float* w, long ws_co, long ws_ci, long
 int dmc_stem_fwd_x3_stat_blocks(int N, int H, int W);
 int dmc_stem_fwd_x3_stats(const float* x, const float* w, long ws_co, long ws_ci, long ws_ky, long ws_kx, void* workspace, float* y,
                           void* stat_scratch, int N, int H, int W, dmc_stream_t stream);
+/* Data gradient of the stem convolution (the gradient of the 2-channel cue: only the GAN variant needs it, where the
+ * classifier's loss reaches the generator -- /root/reference/code/dmcnet_GAN/model.py:557-561; replaces the library
+ * GEMM + col2im of autograd's conv2d backward): dx [N][2][H][W] fp32 contiguous from dy [N][OH][OW][64] fp32 (the memory
+ * of a channels_last [N,64,OH,OW] tensor, OH = (H + 1) / 2, OW = (W + 1) / 2) and w [64,2,7,7] addressed by its element
+ * strides; stride 2, padding 3; bf16x3 arithmetic (fp32-level error), deterministic; W <= 256.  workspace:
+ * dmc_stem_dgrad_workspace_bytes() (the pre-split weights). */
+size_t dmc_stem_dgrad_workspace_bytes(void);
+int dmc_stem_dgrad_supported(int H, int W);
+int dmc_stem_dgrad(const float* dy, const float* w, long ws_co, long ws_ci, long ws_ky, long ws_kx, void* workspace, float* dx, int N,
+                   int H, int W, dmc_stream_t stream);
 
 /* ---- I3D trunk: bf16 3-D convolutions on the matrix cores (BASELINE config 5) -------------------------
  * Replace nn.Conv3d and its autograd inside the reference's Unit3Dpy, code/dmcnet_I3D/network/i3d.py:328-403

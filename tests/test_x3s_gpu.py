@@ -414,3 +414,46 @@ def test_weight_gradients_on_the_side_stream_are_transparent(monkeypatch):
         assert not ops._WGRAD_PENDING[0]
         for (name, _), a, b in zip(net.named_parameters(), *outs):
             assert torch.equal(a, b), (it, name)
+
+
+@pytest.mark.parametrize("n,h,w", [(3, 224, 224), (2, 40, 36), (2, 37, 44), (1, 8, 8), (5, 112, 64), (1, 9, 255)])
+def test_stem_data_gradient_kernel(n, h, w, monkeypatch):
+    """conv1's data gradient (GAN variant: the classifier's loss reaches the generator, code/dmcnet_GAN/model.py:557-561)
+    on dmc_stem_dgrad -- one wave per input row, row GEMM in bf16x3 arithmetic + 1-D fold -- against fp64 autograd
+    (fp32-level bar) and against the library GEMM + col2im path it replaces; contiguous and channels_last weights;
+    odd sizes (border windows); deterministic."""
+    x = rnd(601, (n, 2, h, w))
+    wt = rnd(602, (64, 2, 7, 7)) * 0.1
+    go = rnd(603, (n, 64, (h + 1) // 2, (w + 1) // 2))
+    xo = x.double().requires_grad_(True)
+    (F.conv2d(xo, wt.double(), None, 2, 3) * go.double()).sum().backward()
+    if w % 4 != 0:       # the stem op wants W % 4 == 0 (its weight gradient): call the C entry point directly
+        L, lib = dmcnet_amd._lib, dmcnet_amd._lib.load()
+        assert lib.dmc_stem_dgrad_supported(h, w)
+        dy = go.to(DEV).contiguous(memory_format=CL)
+        wg = wt.to(DEV)
+        dx = torch.empty((n, 2, h, w), device=DEV)
+        work = torch.empty(lib.dmc_stem_dgrad_workspace_bytes(), dtype=torch.uint8, device=DEV)
+        so, si, sy, sx = wg.stride()
+        L.check(lib.dmc_stem_dgrad(L.ptr(dy), L.ptr(wg), so, si, sy, sx, L.ptr(work), L.ptr(dx), n, h, w, L._P(0)), "dmc_stem_dgrad")
+        torch.cuda.synchronize()
+        assert rel_err(dx, xo.grad.float()) < 2e-6
+        return
+    res = {}
+    for own in (True, False):
+        monkeypatch.setattr(ops, "STEM_DGRAD_HIP", own)
+        for cl in (False, True):
+            wg = wt.to(DEV)
+            if cl:
+                wg = wg.contiguous(memory_format=CL)
+            xg = x.to(DEV).requires_grad_(True)
+            (ops.stem_conv(xg, wg) * go.to(DEV)).sum().backward()
+            res[(own, cl)] = xg.grad
+            assert rel_err(xg.grad, xo.grad.float()) < (2e-6 if own else 2e-5)
+    assert torch.equal(res[(True, False)], res[(True, True)])
+    assert rel_err(res[(True, False)], res[(False, False)]) < 2e-5
+    monkeypatch.setattr(ops, "STEM_DGRAD_HIP", True)
+    xg = x.to(DEV).requires_grad_(True)
+    (ops.stem_conv(xg, wt.to(DEV)) * go.to(DEV)).sum().backward()
+    assert torch.equal(xg.grad, res[(True, False)])
+    assert not dmcnet_amd._lib.load().dmc_stem_dgrad_supported(224, 260)
