@@ -1644,42 +1644,31 @@ class _ConvBnRelu3d(torch.autograd.Function):
             raise _lib.DmcHipError("conv_bn_relu3d runs on the HIP extension only (no CPU fallback)")
         ctx.x_was_cl3 = x.is_contiguous(memory_format=_CL3)
         x = _as_cl3(x)
-        wc = weight.detach().contiguous()
+        wc = weight.detach()
+        if not wc.is_contiguous():
+            wc = wc.contiguous()
         n, cin, d, h, w = x.shape
         cout, _, kd, kh, kw = wc.shape
-        t = kd * kh * kw
-        m = n * d * h * w
+        geom = (n, d, h, w, cin, cout, kd, kh, kw)
+        # ONE foreign call (pack + convolution with the statistics in its epilogue + BatchNorm / ReLU pass) and one
+        # workspace: the trunk is bound by the host that issues its ~940 launches per micro-step (csrc/unit3d.hip)
         y = torch.empty((n, cout, d, h, w), dtype=torch.bfloat16, device=x.device, memory_format=_CL3)
-        nblk = lib.dmc_conv3d_bf16_stat_blocks(n, d, h, w, cout)
-        part = torch.empty((nblk, cout, 2), dtype=torch.float32, device=x.device)
-        nb = lib.dmc_conv3d_bf16_wpack_bytes(cin, cout, kd, kh, kw)
-        wpack, wpack_b = _floats(nb, x.device), _floats(nb, x.device)     # forward / data-gradient layouts, one pack launch
-        with _span("conv3d_bf16_fwd"):
-            _lib.check(lib.dmc_conv3d_bf16_pack(_lib.ptr(wc), cin * t, t, 1, _lib.ptr(wpack), _lib.ptr(wpack_b), cin, cout,
-                                                kd, kh, kw, _stream()), "dmc_conv3d_bf16_pack")
-            _lib.check(lib.dmc_conv3d_bf16_fwd(_lib.ptr(x), None, cin * t, t, 1, _lib.ptr(wpack), _lib.ptr(y),
-                                               _lib.ptr(part), n, d, h, w, cin, cout, kd, kh, kw, _stream()),
-                       "dmc_conv3d_bf16_fwd")
-        ctx.wpack_b = wpack_b
-        stats = torch.empty(2 * cout, dtype=torch.float32, device=x.device)
         out = torch.empty_like(y)
-        with _span("bn3d_fwd"):
-            _lib.check(lib.dmc_bn3d_bf16_fwd(_lib.ptr(y), _lib.ptr(part), nblk, _lib.ptr(gamma), _lib.ptr(beta),
-                                             _lib.ptr(stats), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(out),
-                                             m, cout, int(relu), float(eps), float(momentum), _stream()), "dmc_bn3d_bf16_fwd")
-        ctx.save_for_backward(x, weight, y, gamma, beta, stats)
-        ctx.relu = bool(relu)
+        ws = torch.empty(lib.dmc_unit3d_bf16_fwd_workspace_bytes(*geom), dtype=torch.uint8, device=x.device)
+        with _span("conv3d_bf16_fwd"):
+            _lib.check(lib.dmc_unit3d_bf16_fwd(_lib.ptr(x), _lib.ptr(wc), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean),
+                                               _lib.ptr(running_var), _lib.ptr(ws), _lib.ptr(y), _lib.ptr(out), *geom, int(relu),
+                                               float(eps), float(momentum), _stream()), "dmc_unit3d_bf16_fwd")
+        ctx.save_for_backward(x, weight, y, gamma, beta, ws)
+        ctx.relu, ctx.geom = bool(relu), geom
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
-        x, weight, y, gamma, beta, stats = ctx.saved_tensors
-        wc = weight.detach().contiguous()
-        n, cin, d, h, w = x.shape
-        cout, _, kd, kh, kw = wc.shape
-        t = kd * kh * kw
-        m = n * d * h * w
+        x, weight, y, gamma, beta, ws = ctx.saved_tensors
+        geom = ctx.geom
+        n, d, h, w, cin, cout, kd, kh, kw = geom
         # a channel slice of a concatenated (Inception) gradient is read in place: NDHWC memory with a wider pixel stride
         ld = dout.stride(4) if dout.dim() == 5 else 0
         if not (dout.dtype == torch.bfloat16 and ld >= cout and ld % 8 == 0 and dout.storage_offset() % 8 == 0
@@ -1687,27 +1676,16 @@ class _ConvBnRelu3d(torch.autograd.Function):
             dout, ld = _as_cl3(dout), cout
         dy = torch.empty_like(y)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
-        scratch = _floats(lib.dmc_bn3d_bf16_scratch_bytes(cout), y.device)
-        with _span("bn3d_bwd"):
-            _lib.check(lib.dmc_bn3d_bf16_bwd(_lib.ptr(dout), ld, _lib.ptr(y), _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta),
-                                             _lib.ptr(scratch), _lib.ptr(dy), _lib.ptr(dgamma), _lib.ptr(dbeta), m, cout,
-                                             int(ctx.relu), _stream()), "dmc_bn3d_bf16_bwd")
-        dx = dw = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            with _span("conv3d_bf16_dgrad"):                # weights packed by the forward's launch
-                _lib.check(lib.dmc_conv3d_bf16_dgrad(_lib.ptr(dy), None, cin * t, t, 1, _lib.ptr(ctx.wpack_b),
-                                                     _lib.ptr(dx), n, d, h, w, cin, cout, kd, kh, kw, _stream()),
-                           "dmc_conv3d_bf16_dgrad")
-            if not ctx.x_was_cl3:
-                dx = dx.contiguous()
-        if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(wc)
-            work = _floats(lib.dmc_conv3d_bf16_wgrad_bytes(n, d, h, w, cin, cout, kd, kh, kw), x.device)
-            with _span("conv3d_bf16_wgrad"):
-                _lib.check(lib.dmc_conv3d_bf16_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(work), n, d, h, w,
-                                                     cin, cout, kd, kh, kw, _stream()), "dmc_conv3d_bf16_wgrad")
-            dw = dw.view_as(weight)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device) if ctx.needs_input_grad[1] else None
+        bws = torch.empty(lib.dmc_unit3d_bf16_bwd_workspace_bytes(*geom), dtype=torch.uint8, device=x.device)
+        with _span("conv3d_bf16_bwd"):
+            _lib.check(lib.dmc_unit3d_bf16_bwd(_lib.ptr(dout), ld, _lib.ptr(x), _lib.ptr(y), _lib.ptr(ws), _lib.ptr(gamma),
+                                               _lib.ptr(beta), _lib.ptr(bws), _lib.ptr(dy), _lib.ptr(dx), _lib.ptr(dw),
+                                               _lib.ptr(dgamma), _lib.ptr(dbeta), *geom, int(ctx.relu), _stream()),
+                       "dmc_unit3d_bf16_bwd")
+        if dx is not None and not ctx.x_was_cl3:
+            dx = dx.contiguous()
         return dx, dw, dgamma, dbeta, None, None, None, None, None
 
 

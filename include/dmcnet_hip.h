@@ -523,6 +523,23 @@ int dmc_bn3d_bf16_fwd(const void* y, const float* partials, int nblk, const floa
 int dmc_bn3d_bf16_bwd(const void* dout, long dout_ld, const void* y, const float* stats, const float* gamma, const float* beta,
                       float* scratch, void* dy, float* dgamma, float* dbeta, long M, int C, int relu, dmc_stream_t stream);
 
+/* A whole Unit3Dpy (/root/reference/code/dmcnet_I3D/network/i3d.py:328-403: Conv3d -> BatchNorm3d(training) [-> ReLU]) per
+ * call: dmc_unit3d_bf16_fwd = dmc_conv3d_bf16_pack + dmc_conv3d_bf16_fwd (statistics in its epilogue) + dmc_bn3d_bf16_fwd,
+ * dmc_unit3d_bf16_bwd = dmc_bn3d_bf16_bwd + dmc_conv3d_bf16_dgrad (dx nullable) + dmc_conv3d_bf16_wgrad (dw nullable),
+ * with every intermediate carved out of one workspace per direction (dmc_unit3d_bf16_{fwd,bwd}_workspace_bytes; the
+ * backward reads the forward's workspace: statistics and the data-gradient weight layout).  w: fp32 [Cout][Cin][KD][KH][KW]
+ * contiguous; x, y (convolution output), out, dout (pixel stride dout_ld elements), dy, dx: bf16 NDHWC; dw fp32 in w's
+ * layout.  Same kernels in the same order as the separate calls: identical results; the trunk's ~940 launches per
+ * micro-step are bound by the host that issues them, and this is a third of the foreign calls and allocations. */
+size_t dmc_unit3d_bf16_fwd_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int KD, int KH, int KW);
+size_t dmc_unit3d_bf16_bwd_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int KD, int KH, int KW);
+int dmc_unit3d_bf16_fwd(const void* x, const float* w, const float* gamma, const float* beta, float* running_mean,
+                        float* running_var, void* workspace, void* y, void* out, int N, int D, int H, int W, int Cin, int Cout,
+                        int KD, int KH, int KW, int relu, float eps, float momentum, dmc_stream_t stream);
+int dmc_unit3d_bf16_bwd(const void* dout, long dout_ld, const void* x, const void* y, const void* fwd_workspace, const float* gamma,
+                        const float* beta, void* bwd_workspace, void* dy, void* dx, float* dw, float* dgamma, float* dbeta, int N,
+                        int D, int H, int W, int Cin, int Cout, int KD, int KH, int KW, int relu, dmc_stream_t stream);
+
 /* ---- I3D stem: forward of conv3d_1a_7x7 on the bf16 matrix cores -----------------------------------------
  * Replaces ConstantPad3d(TF-"SAME": front 2, back 3) + nn.Conv3d(2, 64, 7, stride 2) of the stem Unit3Dpy,
  * code/dmcnet_I3D/network/i3d.py:480-481 via :390-393, as run in 16-bit mixed precision: x [N,2,T,H,W] fp32 (the DMC
