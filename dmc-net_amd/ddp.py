@@ -151,6 +151,9 @@ class GradBucketReducer(object):
             self._gather(b)
             self._launch(b, "hook")
 
+    # ops.WGRAD_STREAM: this hook only counts; the gradient is read in _gather, behind ops.join_wgrad_stream()
+    _on_grad._dmc_defers_read = True
+
     def _launch(self, b, where):
         flat = self.buckets[b][0]
         self.last_reduced.append((self.bucket_set[b], b, flat.numel() * flat.element_size(), where))

@@ -895,6 +895,7 @@ WGRAD_STREAM = __import__("os").environ.get("DMC_WGRAD_STREAM", "1") != "0"
 _WGRAD_STREAMS = {}
 _WGRAD_PENDING = [False]
 _WGRAD_SCOPE = [0]
+_WGRAD_COUNT = [0]            # launches that went to the side stream (diagnostics / tests)
 
 
 class wgrad_side_stream(object):
@@ -933,6 +934,13 @@ def _on_wgrad_stream(weight, reads, launch):
     returns) and with no gradient to accumulate into (``weight.grad += dw`` would run on the main stream at once)."""
     if not WGRAD_STREAM or _WGRAD_SCOPE[0] <= 0 or weight.grad is not None:
         return launch()
+    # a hook that reads the gradient the moment it is accumulated would read it on the main stream, before the side stream
+    # has written it: only hooks that declare they defer the read (the gradient exchange's, ddp.py) are compatible
+    if getattr(weight, "_backward_hooks", None):
+        return launch()
+    post = getattr(weight, "_post_accumulate_grad_hooks", None)
+    if post and not all(getattr(h, "_dmc_defers_read", False) for h in post.values()):
+        return launch()
     if PROBE is not None and (PROBE.only is None or "conv_nhwc_wgrad" in PROBE.only or "stem_wgrad" in PROBE.only):
         return launch()                         # HIP-event spans around this call time the launch stream: stay on it
     if not _WGRAD_PENDING[0]:
@@ -945,6 +953,7 @@ def _on_wgrad_stream(weight, reads, launch):
     for t in reads:
         t.record_stream(side)                   # their memory is not reused before the side stream has read it
     _WGRAD_PENDING[0] = True
+    _WGRAD_COUNT[0] += 1
     with torch.cuda.stream(side):
         dw = launch()
     dw.record_stream(main)

@@ -457,3 +457,45 @@ def test_stem_data_gradient_kernel(n, h, w, monkeypatch):
     (ops.stem_conv(xg, wt.to(DEV)) * go.to(DEV)).sum().backward()
     assert torch.equal(xg.grad, res[(True, False)])
     assert not dmcnet_amd._lib.load().dmc_stem_dgrad_supported(224, 260)
+
+
+def test_side_stream_weight_gradients_and_gradient_hooks(monkeypatch):
+    """A hook that READS a gradient the moment it is accumulated (here: clones it, as the two-rank test's capture hooks do)
+    runs on the main stream: parameters with such a hook must not have their weight gradient on the side stream; the
+    gradient exchange's own hook (ddp.GradBucketReducer: it only counts, the bucket copy waits for the side stream) must
+    keep it.  Values equal to the one-stream run either way."""
+    import copy
+    from dmcnet_amd import ddp
+    monkeypatch.setattr(resnet, "OWN_CONV", True)
+    torch.manual_seed(12)
+    net = resnet.build("resnet18")
+    net.conv1 = torch.nn.Conv2d(2, 64, 7, 2, 3, bias=False)
+    net = net.to(DEV).to(memory_format=CL).train()
+    x = rnd(510, (6, 2, 224, 224)).to(DEV)
+    monkeypatch.setattr(ops, "WGRAD_STREAM", False)
+    ref = copy.deepcopy(net)
+    ref(x).square().mean().backward()
+    want = {k: p.grad.clone() for k, p in ref.named_parameters()}
+    monkeypatch.setattr(ops, "WGRAD_STREAM", True)
+    # (a) foreign hooks that read at accumulation time
+    a = copy.deepcopy(net)
+    seen = {}
+    for k, p in a.named_parameters():
+        p.register_post_accumulate_grad_hook(lambda q, k=k: seen.__setitem__(k, q.grad.clone()))
+    n0 = ops._WGRAD_COUNT[0]
+    with ops.wgrad_side_stream():
+        a(x).square().mean().backward()
+    assert ops._WGRAD_COUNT[0] == n0                     # no launch left the main stream
+    for k in want:
+        assert torch.equal(seen[k], want[k]), k
+    # (b) the gradient exchange's hooks (single process: the bucket copies still run)
+    b = copy.deepcopy(net)
+    red = ddp.GradBucketReducer([("base_model", list(b.parameters()))])
+    n0 = ops._WGRAD_COUNT[0]
+    red.begin()
+    with ops.wgrad_side_stream():
+        b(x).square().mean().backward()
+    red.finish()
+    assert ops._WGRAD_COUNT[0] > n0                      # the side stream was used
+    for k, p in b.named_parameters():
+        assert torch.equal(p.grad, want[k]), k
