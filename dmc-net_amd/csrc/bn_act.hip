@@ -146,16 +146,33 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
 }
 
+// One workgroup per channel: every thread fetches its <= 4 partials at once (one memory round trip), fixed-order tree.
+// (32 lanes per channel walked the partials in 8 dependent batches: 5 us alone, but this launch sits between the two
+// BatchNorm-backward passes on the step's critical path and its loads queue behind a concurrent weight gradient's --
+// 31 us per launch, 20 launches per step, under ops.WGRAD_STREAM.)
 __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restrict__ scratch,
                                                            float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int C,
                                                            int split) {
-    const int c = blockIdx.x * 8 + (threadIdx.x >> 5), sub = threadIdx.x & 31;
-    double s, ss;
-    reduce_partials(scratch, C, c, split, sub, s, ss);
-    if (c >= C || sub != 0) return;
-    dbeta[c] = (float)s;
-    dgamma[c] = (float)ss;
+    __shared__ double red[2][4];
+    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double2* row = reinterpret_cast<const double2*>(scratch) + (size_t)c * MAX_SPLIT;
+    double2 v[MAX_SPLIT / 256];
+#pragma unroll
+    for (int k = 0; k < MAX_SPLIT / 256; ++k) {
+        const int sp = (int)threadIdx.x + 256 * k;
+        v[k] = sp < split ? row[sp] : make_double2(0.0, 0.0);
+    }
+    double s = 0.0, ss = 0.0;
+#pragma unroll
+    for (int k = 0; k < MAX_SPLIT / 256; ++k) { s += v[k].x; ss += v[k].y; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o, 64); ss += __shfl_down(ss, o, 64); }
+    if (lane == 0) { red[0][wave] = s; red[1][wave] = ss; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    dbeta[c] = (float)(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    dgamma[c] = (float)(red[1][0] + red[1][1] + red[1][2] + red[1][3]);
 }
 
 __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(BnArgs a) {
@@ -659,7 +676,7 @@ int dmc_bn_act_bwd(const float* x, const float* residual, const float* gamma, co
     const int split = split_of(M, C);
     bn_partial_kernel<1><<<split, 256, 0, s>>>(a, scratch);
     if ((rc = check_launch("bn_bwd_partial"))) return rc;
-    bn_bwd_final_kernel<<<(C + 7) / 8, 256, 0, s>>>(scratch, dgamma, dbeta, C, split);
+    bn_bwd_final_kernel<<<C, 256, 0, s>>>(scratch, dgamma, dbeta, C, split);
     if ((rc = check_launch("bn_bwd_final"))) return rc;
     bn_apply_bwd_kernel<<<stream_blocks((size_t)M * (C / 4)), 256, 0, s>>>(a, dgamma, dbeta, 1.f / (float)M);
     return check_launch("bn_apply_bwd");
@@ -713,7 +730,7 @@ int dmc_bn_relu_pool_bwd(const float* x, const float* gamma, const float* beta, 
     int rc;
     pool_bwd_kernel<1><<<blocks, 256, 0, s>>>(p, scratch, nullptr, nullptr, 0.f, (unsigned*)codes);
     if ((rc = check_launch("pool_bwd_partial"))) return rc;
-    bn_bwd_final_kernel<<<(C + 7) / 8, 256, 0, s>>>(scratch, dgamma, dbeta, C, blocks);
+    bn_bwd_final_kernel<<<C, 256, 0, s>>>(scratch, dgamma, dbeta, C, blocks);
     if ((rc = check_launch("bn_bwd_final"))) return rc;
     pool_bwd_kernel<2><<<blocks * 4 > 8192 ? 8192 : blocks * 4, 256, 0, s>>>(p, nullptr, dgamma, dbeta,
                                                                              1.f / (float)((long)N * H * W), (unsigned*)codes);
@@ -760,7 +777,7 @@ int dmc_bn_bwd_act_nhwc(const float* z, const float* gamma, const float* beta, c
     const int split = split_of(M, C);
     bn_partial_kernel<1><<<split, 256, 0, s>>>(a, scratch);
     if ((rc = check_launch("bn_bwd_partial"))) return rc;
-    bn_bwd_final_kernel<<<(C + 7) / 8, 256, 0, s>>>(scratch, dgamma, dbeta, C, split);
+    bn_bwd_final_kernel<<<C, 256, 0, s>>>(scratch, dgamma, dbeta, C, split);
     if ((rc = check_launch("bn_bwd_final"))) return rc;
     bn_apply_bwd_kernel<<<stream_blocks((size_t)M * (C / 4)), 256, 0, s>>>(a, dgamma, dbeta, 1.f / (float)M);
     return check_launch("bn_apply_bwd_act");
@@ -805,7 +822,7 @@ int dmc_bn_act_bwd_x3s(const float* x, const float* residual, const float* gamma
     const int split = split_of(M, C);
     bn_partial_kernel<1><<<split, 256, 0, s>>>(a, scratch);
     if ((rc = check_launch("bn_bwd_partial"))) return rc;
-    bn_bwd_final_kernel<<<(C + 7) / 8, 256, 0, s>>>(scratch, dgamma, dbeta, C, split);
+    bn_bwd_final_kernel<<<C, 256, 0, s>>>(scratch, dgamma, dbeta, C, split);
     if ((rc = check_launch("bn_bwd_final"))) return rc;
     bn_apply_bwd_x3s_kernel<<<stream_blocks((size_t)M * (C / 8)), 256, 0, s>>>(a, dgamma, dbeta, 1.f / (float)M, static_cast<unsigned short*>(dxs));
     return check_launch("bn_apply_bwd_x3s");
@@ -867,7 +884,7 @@ int dmc_bn_relu_pool_bwd_arg(const float* x, const float* gamma, const float* be
     int rc;
     bn_partial_kernel<1><<<split, 256, 0, s>>>(a, scratch);
     if ((rc = check_launch("pool_bwd_sums"))) return rc;
-    bn_bwd_final_kernel<<<(C + 7) / 8, 256, 0, s>>>(scratch, dgamma, dbeta, C, split);
+    bn_bwd_final_kernel<<<C, 256, 0, s>>>(scratch, dgamma, dbeta, C, split);
     if ((rc = check_launch("bn_bwd_final"))) return rc;
     const long tiles = (long)N * ((p.PH + PT - 1) / PT) * ((p.PW + PT - 1) / PT);
     const long blocks = tiles * 4 > 8192 ? 8192 : tiles * 4;
