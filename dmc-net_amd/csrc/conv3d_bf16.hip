@@ -440,6 +440,213 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float* _
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// 3x3x3 weight gradient over a RING of input rows (option conv3d_wgrad = 1, the default where the geometry fits: W in
+// {56, 28, 14, 7}; the scheme of x3s_wgrad_kernel, conv_x3s.hip, on single bf16 NDHWC tensors).
+//
+// conv3d_wgrad_kernel above stages, per 32 pixels and tap, a transposed x tile (global loads, 16-bit LDS stores, a
+// barrier): 9 dependent tap steps per 32 pixels -- 126 of them per workgroup on the 9,408-pixel maps of mixed_4*, which
+// is where its time goes.  Here the pixel space is walked in PADDED rows (H + 2 per (n, d) plane); a step covers R
+// rows: its dy tile [R x W pixels][64 co] and the R + 2 input rows around it, which live in a ring of input rows in LDS
+// ([ring row][W + 2 pixels][64 ci], 128-byte pixel rows); each step transfers only the R rows that entered the window
+// (LDS-DMA, hardware zero fill for padding rows / halo columns / planes outside the volume / channels beyond C), and all
+// nine in-plane taps read their operands from the ring at shifted addresses through ds_read_b64_tr_b16 (the transposition
+// a GEMM over PIXELS needs from channel-contiguous tensors).  One barrier per step (56..63 pixels x 9 taps).
+// blockIdx.z = the depth tap kz: the ring holds rows of plane d + kz - 1.  12 waves = 4 quarters (32 co x 32 ci) x 3 tap
+// rows ky, three accumulators (kx) per wave.  The 64-byte halves of a pixel row are swapped when (pixel >> 1) & 1: the four
+// pixels a 16-lane group transposes then fall into different banks.  Same partial layout and reduction as above.
+// ------------------------------------------------------------------------------------------
+constexpr unsigned C3R_OOB = 0x80000000u;
+typedef const __attribute__((address_space(3))) char* c3r_lds_cptr;
+typedef short c3r_s16x4 __attribute__((ext_vector_type(4)));
+typedef float c3r_f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void c3r_dma16(const u32x4& srd, unsigned voff, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                 :: "v"(voff), "s"(srd), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ u32x4 c3r_srd(const void* base) {
+    const unsigned long long b = (unsigned long long)base;
+    u32x4 srd;
+    srd[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
+    srd[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu);
+    srd[2] = 0x7fffffffu;
+    srd[3] = 0x00020000u;
+    return srd;
+}
+__device__ __forceinline__ u32x4 c3r_tr2(c3r_lds_cptr p0, c3r_lds_cptr p1) {   // eight k-values (pixels) of this lane's channel
+    const c3r_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) c3r_s16x4*)p0);
+    const c3r_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) c3r_s16x4*)p1);
+    typedef unsigned c3r_u32x2 __attribute__((ext_vector_type(2)));
+    const c3r_u32x2 ua = __builtin_bit_cast(c3r_u32x2, a), ub = __builtin_bit_cast(c3r_u32x2, b);
+    return u32x4{ua[0], ua[1], ub[0], ub[1]};
+}
+
+struct C3dRingArgs {
+    const bf16_t* x;       // [N][D][H][W][Cin]
+    const bf16_t* dy;      // [N][D][H][W][Cout]
+    float* part;           // [splits][Cout][27][Cin]
+    int N, D, H, Cin, Cout;
+    int steps, per_group, tiles_ci;
+};
+
+template <int W_, int R>
+struct C3rGeom {
+    static constexpr int PW = W_ + 2;
+    static constexpr int NGRP = R >= W_ + 2 ? 2 : 4, LA = NGRP / 2;
+    static constexpr int NRING = NGRP * R;
+    static constexpr int XPX = ((NRING * PW + 7) / 8) * 8;             // ring pixels (transfers move 8 pixel rows of 128 B)
+    static constexpr int NPX = R * W_;                                 // pixel slots per step
+    static constexpr int NKB = (NPX + 15) / 16;
+    static constexpr int DYT = ((NKB * 16 + 7) / 8) * 8;
+    static constexpr int XI = (R * PW + 7) / 8;                        // transfers per step: input rows / dy tile
+    static constexpr int DI = DYT / 8;
+    static constexpr int XBYTES = ((XPX * 128 + 255) / 256) * 256, DYBYTES = ((DYT * 128 + 255) / 256) * 256;
+    static constexpr int LDS = XBYTES + 2 * DYBYTES;
+};
+
+template <int W_, int R>
+__global__ __launch_bounds__(768) void conv3d_wgrad_ring_kernel(C3dRingArgs a) {
+    using G = C3rGeom<W_, R>;
+    constexpr int PW = G::PW, NRING = G::NRING, NKB = G::NKB;
+    __shared__ __attribute__((aligned(1024))) char lds_r[G::LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, khalf = lane >> 5, L = lane & 15, grp = (lane >> 4) & 1;
+    const int quarter = wave & 3, trow = wave >> 2;
+    const int wi = quarter & 1, wj = quarter >> 1;
+    const int tci = blockIdx.x % a.tiles_ci, tco = blockIdx.x / a.tiles_ci;
+    const int dz = (int)blockIdx.z - 1;
+    const unsigned lds0 = lds_addr_of(lds_r);
+    const int HP = a.H + 2, NPL = a.N * a.D;
+    const int s_begin = blockIdx.y * a.per_group;
+    const int s_end = s_begin + a.per_group < a.steps ? s_begin + a.per_group : a.steps;
+    const u32x4 srd_x = c3r_srd(a.x), srd_d = c3r_srd(a.dy);
+    // transfer lane map: pixel lane >> 3 of the instruction's 8, 16-byte piece lane & 7 of its 128-byte row
+    const int tpx = lane >> 3, tpc = lane & 7;
+    const int ci0 = tci * 64, co0 = tco * 64;
+
+    // byte offset of (padded row g, column x, logical piece) in x / dy, or OOB
+    auto x_off = [&](int g, int x, int piece) -> unsigned {
+        const int pl = g / HP, y = g - pl * HP - 1;
+        const int d = pl % a.D;
+        const int c = ci0 + piece * 8;
+        return (g >= 0 && pl < NPL && y >= 0 && y < a.H && x >= 0 && x < W_ && d + dz >= 0 && d + dz < a.D && c < a.Cin)
+                   ? (unsigned)(((((long)(pl + dz) * a.H + y) * W_ + x) * a.Cin + c) * 2) : C3R_OOB;
+    };
+    auto d_off = [&](int g, int x, int piece) -> unsigned {
+        const int pl = g / HP, y = g - pl * HP - 1;
+        const int c = co0 + piece * 8;
+        return (g >= 0 && pl < NPL && y >= 0 && y < a.H && c < a.Cout) ? (unsigned)(((((long)pl * a.H + y) * W_ + x) * a.Cout + c) * 2) : C3R_OOB;
+    };
+    // input rows of group q (padded rows [R q, R q + R)) -> ring slots R (q mod NGRP) ..; instruction i by wave i % 12
+    auto issue_x = [&](int q) {
+        const int slot0 = (((q % G::NGRP) + G::NGRP) % G::NGRP) * R;
+#pragma unroll
+        for (int i = 0; i < G::XI; ++i) {
+            if (i % 12 != wave % 12) continue;
+            const int px = 8 * i + tpx;                                // pixel of the R x PW range
+            const int lpx = slot0 * PW + px;                           // its LDS pixel
+            const int piece = tpc ^ (((lpx >> 1) & 1) << 2);           // the row's 64-byte halves swapped on odd pixel pairs
+            const int r = px / PW, col = px - r * PW;
+            // lanes beyond the group's R x PW pixels stay out of the transfer: their LDS rows belong to the next group
+            if (px < R * PW) c3r_dma16(srd_x, x_off(R * q + r, col - 1, piece), lds0 + (unsigned)(slot0 * PW + 8 * i) * 128u);
+        }
+    };
+    auto issue_dy = [&](int s, int buf) {
+#pragma unroll
+        for (int i = 0; i < G::DI; ++i) {
+            if ((i + G::XI) % 12 != wave % 12) continue;
+            const int p = 8 * i + tpx;
+            const int piece = tpc ^ (((p >> 1) & 1) << 2);
+            const int r = p / W_, x = p - r * W_;
+            c3r_dma16(srd_d, p < G::NPX ? d_off(R * s + r, x, piece) : C3R_OOB, lds0 + G::XBYTES + (unsigned)buf * G::DYBYTES + (unsigned)(8 * i) * 128u);
+        }
+    };
+
+    c3r_f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    if (s_begin < s_end) {
+        // every ring row the first step can touch holds zeros or data (never uninitialised LDS: 0 x NaN pattern = NaN)
+#pragma unroll
+        for (int q = -1; q < G::LA; ++q) issue_x(s_begin + q);
+        issue_dy(s_begin, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    c3r_lds_cptr const LB = (c3r_lds_cptr)lds_r;
+#pragma unroll 1
+    for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        issue_x(s + G::LA);                                          // the group entering the window
+        if (s + 1 < s_end) issue_dy(s + 1, buf ^ 1);
+        const int dbase = G::XBYTES + buf * G::DYBYTES + (L & 3) * 8;
+        const int cd = 2 * wi + grp, cx = 2 * wj + grp;              // 16-channel chunk of this lane's group: co / ci
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            int dyo[2], xo[2][3];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                int P = 16 * kb + 8 * khalf + 4 * u + (L >> 2);
+                dyo[u] = dbase + P * 128 + ((cd ^ (((P >> 1) & 1) << 1)) << 5);
+                if (P >= G::NPX) P = G::NPX - 1;                     // beyond the tile: dy is zero there, any valid input address
+                const int r = P / W_, x = P - r * W_;
+                const int slot = (((R * s + r + trow - 1) % NRING) + NRING) % NRING;   // input row of this wave's tap row
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int lp = slot * PW + x + t;                // LDS pixel of tap column t
+                    xo[u][t] = lp * 128 + ((cx ^ (((lp >> 1) & 1) << 1)) << 5) + (L & 3) * 8;
+                }
+            }
+            const u32x4 A = c3r_tr2(LB + dyo[0], LB + dyo[1]);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const u32x4 B = c3r_tr2(LB + xo[0][t], LB + xo[1][t]);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), acc[t], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    float* out = a.part + (size_t)blockIdx.y * a.Cout * 27 * a.Cin;
+    const int ci = ci0 + 32 * wj + l31;
+    if (ci < a.Cin)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + 32 * wi + 8 * (e >> 2) + 4 * khalf + (e & 3);
+                if (co < a.Cout) out[((size_t)co * 27 + (int)blockIdx.z * 9 + 3 * trow + t) * a.Cin + ci] = acc[t][e];
+            }
+}
+
+struct C3rPlan { int R, steps, tiles, groups, per_group; };
+bool c3r_plan(int N, int D, int H, int W, int Cin, int Cout, C3rPlan& p) {
+    p.R = W == 56 ? 1 : W == 28 ? 2 : W == 14 ? 4 : W == 7 ? 9 : 0;
+    if (!p.R || (W == 7 && H != 7) || (long)N * D * H * W * (Cin > Cout ? Cin : Cout) * 2 >= 0x7fffffffL) return false;
+    const long rows = (long)N * D * (H + 2);
+    p.steps = (int)((rows + p.R - 1) / p.R);
+    p.tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
+    int groups = 512 / (p.tiles * 3);
+    if (groups < 1) groups = 1;
+    const int max_groups = p.steps / 4 > 0 ? p.steps / 4 : 1;          // at least four steps per workgroup
+    if (groups > max_groups) groups = max_groups;
+    p.per_group = (p.steps + groups - 1) / groups;
+    p.groups = (p.steps + p.per_group - 1) / p.per_group;
+    return true;
+}
+
+template <int W_, int R>
+int launch_c3r(const C3rPlan& p, C3dRingArgs a, hipStream_t s) {
+    static_assert(C3rGeom<W_, R>::LDS <= 64 * 1024, "ring + dy tiles within the static LDS limit");
+    conv3d_wgrad_ring_kernel<W_, R><<<dim3(p.tiles, p.groups, 3), 768, 0, s>>>(a);
+    return check_launch("conv3d_wgrad_ring");
+}
+
 struct C3dWgradPlan { int nt, ct, tiles_co, tiles_ci, groups, splits; long per_split; };
 C3dWgradPlan c3d_wgrad_plan(long M, int Cin, int Cout, int KD, int KH, int KW) {
     C3dWgradPlan p;
@@ -622,7 +829,10 @@ int dmc_conv3d_bf16_dgrad(const void* dy, const float* w, long w_s_co, long w_s_
 // bytes of the split-K partials of the weight gradient
 size_t dmc_conv3d_bf16_wgrad_bytes(int N, int D, int H, int W, int Cin, int Cout, int KD, int KH, int KW) {
     const C3dWgradPlan p = c3d_wgrad_plan((long)N * D * H * W, Cin, Cout, KD, KH, KW);
-    return (size_t)p.splits * Cout * KD * KH * KW * Cin * sizeof(float) + 16;
+    size_t splits = (size_t)p.splits;
+    C3rPlan r;
+    if (KD == 3 && KH == 3 && KW == 3 && c3r_plan(N, D, H, W, Cin, Cout, r) && (size_t)r.groups > splits) splits = (size_t)r.groups;
+    return splits * Cout * KD * KH * KW * Cin * sizeof(float) + 16;
 }
 
 // dw fp32 [Cout][Cin][KD][KH][KW] (contiguous, the parameter's layout) from x, dy bf16 NDHWC; deterministic
@@ -633,6 +843,20 @@ int dmc_conv3d_bf16_wgrad(const void* x, const void* dy, float* dw, float* works
         return fail(DMC_E_INVALID, "dmc_conv3d_bf16_wgrad: unsupported shape");
     hipStream_t s = (hipStream_t)stream;
     const long M = (long)N * D * H * W;
+    C3rPlan rp;
+    if (KD == 3 && KH == 3 && KW == 3 && option(OPT_CONV3D_WGRAD) == 1 && c3r_plan(N, D, H, W, Cin, Cout, rp)) {
+        C3dRingArgs ra;
+        ra.x = (const bf16_t*)x; ra.dy = (const bf16_t*)dy; ra.part = workspace;
+        ra.N = N; ra.D = D; ra.H = H; ra.Cin = Cin; ra.Cout = Cout;
+        ra.steps = rp.steps; ra.per_group = rp.per_group; ra.tiles_ci = (Cin + 63) / 64;
+        int rc = W == 56 ? launch_c3r<56, 1>(rp, ra, s) : W == 28 ? launch_c3r<28, 2>(rp, ra, s)
+               : W == 14 ? launch_c3r<14, 4>(rp, ra, s) : launch_c3r<7, 9>(rp, ra, s);
+        if (rc) return rc;
+        const long total = (long)Cout * 27 * Cin;
+        conv3d_wgrad_reduce_kernel<<<(int)((total + 63) / 64 > 8192 ? 8192 : (total + 63) / 64), 256, 0, s>>>(
+            workspace, dw, rp.groups, Cout, 27, Cin);
+        return check_launch("conv3d_wgrad_reduce");
+    }
     const C3dWgradPlan p = c3d_wgrad_plan(M, Cin, Cout, KD, KH, KW);
     C3dWgradArgs a;
     a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.part = workspace;

@@ -51,6 +51,13 @@ CASES = [
     (1, 208, 5, 4, 3, 48, 1),       # odd widths both sides
     (3, 64, 8, 14, 14, 64, 1),      # conv3d_2b-like, several pixel tiles
     (1, 96, 6, 12, 12, 128, 3),     # mixed_3b branch_1, >= 2 workgroup rows
+    # widths of the trunk's maps (56 / 28 / 14 / 7): the 3x3x3 weight gradient takes the row-ring kernel there
+    (1, 64, 2, 56, 56, 192, 3),     # conv3d_2c at its real plane size
+    (1, 24, 2, 28, 28, 64, 3),      # 28 wide, Cin % 16 != 0
+    (1, 32, 3, 5, 28, 40, 3),       # 28 wide, 7 padded rows per plane (odd against R = 2), Cout % 16 != 0
+    (1, 96, 3, 14, 14, 208, 3),     # mixed_4b branch_1 at its real plane size, two partial channel tiles
+    (2, 48, 3, 9, 14, 112, 3),      # 14 wide, 11 padded rows per plane (no multiple of R = 4)
+    (3, 160, 2, 7, 7, 320, 3),      # mixed_5b branch_1 at its real plane size (whole padded plane per step)
 ]
 
 
@@ -364,3 +371,33 @@ def test_mixed_block_branch_streams_are_transparent(cin, outs, shape, monkeypatc
                        [b for nm, b in model.named_buffers() if "running" in nm])
         for k, (a, b) in enumerate(zip(*res)):
             assert torch.equal(a, b), (it, k, float((a.float() - b.float()).abs().max()))
+
+
+@pytest.mark.parametrize("case", [(1, 96, 3, 14, 14, 208), (2, 16, 2, 7, 7, 32), (1, 40, 2, 6, 28, 24), (1, 64, 1, 56, 56, 64)])
+def test_conv3d_wgrad_ring_kernel_against_the_tap_stepping_kernel(case):
+    """The 3x3x3 weight gradient over a ring of input rows (option conv3d_wgrad = 1, default where the map is 56 / 28 /
+    14 / 7 wide) against the kernel it replaces (option 0) on the same tensors: the same bf16 products summed in another
+    order (fp32 accumulate), so equal to fp32 rounding; both deterministic."""
+    n, cin, d, h, w, cout = case
+    L, lib = dmcnet_amd._lib, dmcnet_amd._lib.load()
+    x = rnd(331, (n, cin, d, h, w)).bfloat16().to(DEV).contiguous(memory_format=CL3)
+    dy = rnd(332, (n, cout, d, h, w)).bfloat16().to(DEV).contiguous(memory_format=CL3)
+    out = {}
+    before = lib.dmc_get_option(b"conv3d_wgrad")
+    try:
+        for path in (1, 0, 1):
+            L.check(lib.dmc_set_option(b"conv3d_wgrad", path), "dmc_set_option")
+            dw = torch.empty((cout, cin, 3, 3, 3), device=DEV)
+            work = torch.empty(lib.dmc_conv3d_bf16_wgrad_bytes(n, d, h, w, cin, cout, 3, 3, 3) // 4 + 4, device=DEV)
+            L.check(lib.dmc_conv3d_bf16_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(work), n, d, h, w, cin, cout, 3, 3, 3, L._P(0)),
+                    "dmc_conv3d_bf16_wgrad")
+            torch.cuda.synchronize()
+            if path in out:
+                assert torch.equal(out[path], dw)
+            out[path] = dw
+    finally:
+        L.check(lib.dmc_set_option(b"conv3d_wgrad", before), "dmc_set_option")
+    assert float((out[0] - out[1]).abs().max() / out[0].abs().max()) < 2e-6
+    ref = torch.nn.grad.conv3d_weight(x.double().cpu(), (cout, cin, 3, 3, 3), dy.double().cpu(), padding=1) if n * d * h * w <= 4000 else None
+    if ref is not None:
+        assert float((out[1].double().cpu() - ref).abs().max() / ref.abs().max()) < 2e-5
