@@ -59,7 +59,12 @@ struct C3dArgs {
     long M;                // N * D * H * W
 };
 
-template <int BM, int BN, int WM, int WN>
+// NS = stages of the transfer ring.  A step is 32 input channels of one tap: 2 x TM x TN MFMAs per wave (2 for the 64 x 64
+// tile), far less than a global -> LDS round trip; with two stages every step waited for its successor's transfer to land
+// (~1 us each: 108 steps = 100 us for a 3x3x3 layer of 128 channels on a 9,408-pixel map, 83 such launches per I3D
+// micro-step).  With NS stages NS - 1 steps are in flight and a step only waits for the OLDEST of them
+// (s_waitcnt vmcnt(<transfers of the NS - 2 younger steps>)).
+template <int BM, int BN, int WM, int WN, int NS>
 __global__ __launch_bounds__(WM * WN * 64) void conv3d_bf16_kernel(C3dArgs a) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -67,7 +72,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_bf16_kernel(C3dArgs a) {
     constexpr int IP = BM / 16, IW = BN / 16;              // DMA instructions per step: pixel rows, weight rows
     constexpr int NDP = (IP + NW - 1) / NW, NDW = (IW + NW - 1) / NW;
     constexpr int PIXB = BM * 64, BUF = (BM + BN) * 64;
-    __shared__ __attribute__((aligned(1024))) char lds[2 * BUF];
+    static_assert(NS == 2 || (IP % NW == 0 && IW % NW == 0), "a deeper ring counts transfers per wave: every wave must issue the same number");
+    static_assert(NS * BUF <= 64 * 1024, "static LDS");
+    constexpr int PER_STEP = NDP + NDW;                     // transfers per wave and step
+    __shared__ __attribute__((aligned(1024))) char lds[NS * BUF];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -160,13 +168,17 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_bf16_kernel(C3dArgs a) {
     }
 
     const int T_steps = T * (a.Cp >> 5);
-    issue(0); advance();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < T_steps) { issue(p); advance(); }
+    if (NS - 1 <= T_steps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER_STEP * (NS - 2)) : "memory");   // step 0 has landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    int buf = 0, nbuf = NS - 1;                              // ring slots of step t / of the step issued in iteration t
 #pragma unroll 1
     for (int t = 0; t < T_steps; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < T_steps) { issue(buf ^ 1); advance(); }
+        const bool more = t + NS - 1 < T_steps;
+        if (more) { issue(nbuf); advance(); }
         const char* base = lds + buf * BUF;
         u32x4 xf[2][TM], wf[2][TN];
 #pragma unroll
@@ -184,8 +196,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_bf16_kernel(C3dArgs a) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[kb][j]),
                                                                         __builtin_bit_cast(bf16x8, xf[kb][i]), acc[i][j], 0, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // step t + 1 must have landed: the NS - 2 steps younger than it may stay in flight while the ring is full
+        if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(PER_STEP * (NS - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        buf = buf + 1 == NS ? 0 : buf + 1;
+        nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
     }
 
     // ---- epilogue: lane holds pixel column l31 of tile i, channels 8 gq + 4 khalf + e of tile j in acc[4 gq + e] ----
@@ -701,10 +717,10 @@ __global__ __launch_bounds__(256) void conv3d_pack_w2_kernel(const float* __rest
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NS>
 int launch_c3d(const C3dArgs& a, hipStream_t s) {
     dim3 grid((unsigned)((a.M + BM - 1) / BM), (a.Cout + BN - 1) / BN);
-    conv3d_bf16_kernel<BM, BN, WM, WN><<<grid, WM * WN * 64, 0, s>>>(a);
+    conv3d_bf16_kernel<BM, BN, WM, WN, NS><<<grid, WM * WN * 64, 0, s>>>(a);
     return check_launch("conv3d_bf16");
 }
 
@@ -728,11 +744,14 @@ int c3d_block_pixels(int cout, long M) {
 int launch_conv3d(const C3dArgs& a, hipStream_t s) {
     if (a.M <= 0) return DMC_OK;
     switch (c3d_choice(a.Cout, a.M)) {
-        case 0: return launch_c3d<128, 128, 2, 2>(a, s);
-        case 1: return launch_c3d<128, 64, 2, 2>(a, s);
-        case 2: return launch_c3d<64, 64, 2, 2>(a, s);
-        case 3: return launch_c3d<128, 32, 4, 1>(a, s);
-        default: return launch_c3d<256, 128, 4, 2>(a, s);
+        // transfer-ring depth: 4 where every wave issues the same number of transfers and 4 stages fit the static LDS
+        // (8 / 5 stages for the two small tiles: 20.11 vs 19.90 ms per I3D micro-step, three same-box pairs -- the LDS they take
+        // costs resident workgroups)
+        case 0: return launch_c3d<128, 128, 2, 2, 4>(a, s);
+        case 1: return launch_c3d<128, 64, 2, 2, 4>(a, s);
+        case 2: return launch_c3d<64, 64, 2, 2, 4>(a, s);
+        case 3: return launch_c3d<128, 32, 4, 1, 2>(a, s);
+        default: return launch_c3d<256, 128, 4, 2, 2>(a, s);
     }
 }
 
