@@ -521,7 +521,10 @@ struct C3rGeom {
     static constexpr int LDS = XBYTES + 2 * DYBYTES;
 };
 
-template <int W_, int R>
+// KT = 3: the 3x3x3 layers.  KT = 1: the 1x1x1 layers on the same machinery (centre tap only: the waves of tap rows 0 and 2
+// only help with the transfers) -- a GEMM over pixels with 56..63-pixel steps and transposing LDS reads instead of
+// conv3d_wgrad_kernel's 32-pixel steps with transposing 16-bit stores.
+template <int W_, int R, int KT>
 __global__ __launch_bounds__(768) void conv3d_wgrad_ring_kernel(C3dRingArgs a) {
     using G = C3rGeom<W_, R>;
     constexpr int PW = G::PW, NRING = G::NRING, NKB = G::NKB;
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(768) void conv3d_wgrad_ring_kernel(C3dRingArgs a) {
     const int quarter = wave & 3, trow = wave >> 2;
     const int wi = quarter & 1, wj = quarter >> 1;
     const int tci = blockIdx.x % a.tiles_ci, tco = blockIdx.x / a.tiles_ci;
-    const int dz = (int)blockIdx.z - 1;
+    const int dz = KT == 3 ? (int)blockIdx.z - 1 : 0;
     const unsigned lds0 = lds_addr_of(lds_r);
     const int HP = a.H + 2, NPL = a.N * a.D;
     const int s_begin = blockIdx.y * a.per_group;
@@ -618,36 +621,43 @@ __global__ __launch_bounds__(768) void conv3d_wgrad_ring_kernel(C3dRingArgs a) {
                     xo[u][t] = lp * 128 + ((cx ^ (((lp >> 1) & 1) << 1)) << 5) + (L & 3) * 8;
                 }
             }
-            const u32x4 A = c3r_tr2(LB + dyo[0], LB + dyo[1]);
+            if (KT == 3 || trow == 1) {                              // (wave-uniform)
+                const u32x4 A = c3r_tr2(LB + dyo[0], LB + dyo[1]);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const u32x4 B = c3r_tr2(LB + xo[0][t], LB + xo[1][t]);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), acc[t], 0, 0, 0);
+                for (int t = 0; t < 3; ++t) {
+                    if (KT == 1 && t != 1) continue;
+                    const u32x4 B = c3r_tr2(LB + xo[0][t], LB + xo[1][t]);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), acc[t], 0, 0, 0);
+                }
             }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
-    float* out = a.part + (size_t)blockIdx.y * a.Cout * 27 * a.Cin;
+    constexpr int T = KT == 3 ? 27 : 1;
+    float* out = a.part + (size_t)blockIdx.y * a.Cout * T * a.Cin;
     const int ci = ci0 + 32 * wj + l31;
-    if (ci < a.Cin)
+    if (ci < a.Cin && (KT == 3 || trow == 1))
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
+        for (int t = 0; t < 3; ++t) {
+            if (KT == 1 && t != 1) continue;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int co = co0 + 32 * wi + 8 * (e >> 2) + 4 * khalf + (e & 3);
-                if (co < a.Cout) out[((size_t)co * 27 + (int)blockIdx.z * 9 + 3 * trow + t) * a.Cin + ci] = acc[t][e];
+                const int tap = KT == 3 ? (int)blockIdx.z * 9 + 3 * trow + t : 0;
+                if (co < a.Cout) out[((size_t)co * T + tap) * a.Cin + ci] = acc[t][e];
             }
+        }
 }
 
 struct C3rPlan { int R, steps, tiles, groups, per_group; };
-bool c3r_plan(int N, int D, int H, int W, int Cin, int Cout, C3rPlan& p) {
+bool c3r_plan(int N, int D, int H, int W, int Cin, int Cout, C3rPlan& p, int nz = 3) {
     p.R = W == 56 ? 1 : W == 28 ? 2 : W == 14 ? 4 : W == 7 ? 9 : 0;
     if (!p.R || (W == 7 && H != 7) || (long)N * D * H * W * (Cin > Cout ? Cin : Cout) * 2 >= 0x7fffffffL) return false;
     const long rows = (long)N * D * (H + 2);
     p.steps = (int)((rows + p.R - 1) / p.R);
     p.tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
-    int groups = 512 / (p.tiles * 3);
+    int groups = 512 / (p.tiles * nz);
     if (groups < 1) groups = 1;
     const int max_groups = p.steps / 4 > 0 ? p.steps / 4 : 1;          // at least four steps per workgroup
     if (groups > max_groups) groups = max_groups;
@@ -656,10 +666,10 @@ bool c3r_plan(int N, int D, int H, int W, int Cin, int Cout, C3rPlan& p) {
     return true;
 }
 
-template <int W_, int R>
+template <int W_, int R, int KT>
 int launch_c3r(const C3rPlan& p, C3dRingArgs a, hipStream_t s) {
     static_assert(C3rGeom<W_, R>::LDS <= 64 * 1024, "ring + dy tiles within the static LDS limit");
-    conv3d_wgrad_ring_kernel<W_, R><<<dim3(p.tiles, p.groups, 3), 768, 0, s>>>(a);
+    conv3d_wgrad_ring_kernel<W_, R, KT><<<dim3(p.tiles, p.groups, KT), 768, 0, s>>>(a);
     return check_launch("conv3d_wgrad_ring");
 }
 
@@ -850,7 +860,8 @@ size_t dmc_conv3d_bf16_wgrad_bytes(int N, int D, int H, int W, int Cin, int Cout
     const C3dWgradPlan p = c3d_wgrad_plan((long)N * D * H * W, Cin, Cout, KD, KH, KW);
     size_t splits = (size_t)p.splits;
     C3rPlan r;
-    if (KD == 3 && KH == 3 && KW == 3 && c3r_plan(N, D, H, W, Cin, Cout, r) && (size_t)r.groups > splits) splits = (size_t)r.groups;
+    const bool k3 = KD == 3 && KH == 3 && KW == 3, k1 = KD == 1 && KH == 1 && KW == 1;
+    if ((k3 || k1) && c3r_plan(N, D, H, W, Cin, Cout, r, k3 ? 3 : 1) && (size_t)r.groups > splits) splits = (size_t)r.groups;
     return splits * Cout * KD * KH * KW * Cin * sizeof(float) + 16;
 }
 
@@ -863,17 +874,23 @@ int dmc_conv3d_bf16_wgrad(const void* x, const void* dy, float* dw, float* works
     hipStream_t s = (hipStream_t)stream;
     const long M = (long)N * D * H * W;
     C3rPlan rp;
-    if (KD == 3 && KH == 3 && KW == 3 && option(OPT_CONV3D_WGRAD) == 1 && c3r_plan(N, D, H, W, Cin, Cout, rp)) {
+    const bool k3 = KD == 3 && KH == 3 && KW == 3;
+    const int ring = option(OPT_CONV3D_WGRAD);               // 0: tap-stepping kernels; 1: row ring for 3x3x3; 2 (default): and for 1x1x1
+    if (((k3 && ring >= 1) || (!k3 && ring >= 2)) && c3r_plan(N, D, H, W, Cin, Cout, rp, k3 ? 3 : 1)) {
         C3dRingArgs ra;
         ra.x = (const bf16_t*)x; ra.dy = (const bf16_t*)dy; ra.part = workspace;
         ra.N = N; ra.D = D; ra.H = H; ra.Cin = Cin; ra.Cout = Cout;
         ra.steps = rp.steps; ra.per_group = rp.per_group; ra.tiles_ci = (Cin + 63) / 64;
-        int rc = W == 56 ? launch_c3r<56, 1>(rp, ra, s) : W == 28 ? launch_c3r<28, 2>(rp, ra, s)
-               : W == 14 ? launch_c3r<14, 4>(rp, ra, s) : launch_c3r<7, 9>(rp, ra, s);
+        int rc;
+        if (k3) rc = W == 56 ? launch_c3r<56, 1, 3>(rp, ra, s) : W == 28 ? launch_c3r<28, 2, 3>(rp, ra, s)
+                   : W == 14 ? launch_c3r<14, 4, 3>(rp, ra, s) : launch_c3r<7, 9, 3>(rp, ra, s);
+        else rc = W == 56 ? launch_c3r<56, 1, 1>(rp, ra, s) : W == 28 ? launch_c3r<28, 2, 1>(rp, ra, s)
+                : W == 14 ? launch_c3r<14, 4, 1>(rp, ra, s) : launch_c3r<7, 9, 1>(rp, ra, s);
         if (rc) return rc;
-        const long total = (long)Cout * 27 * Cin;
+        const int T = k3 ? 27 : 1;
+        const long total = (long)Cout * T * Cin;
         conv3d_wgrad_reduce_kernel<<<(int)((total + 63) / 64 > 8192 ? 8192 : (total + 63) / 64), 256, 0, s>>>(
-            workspace, dw, rp.groups, Cout, 27, Cin);
+            workspace, dw, rp.groups, Cout, T, Cin);
         return check_launch("conv3d_wgrad_reduce");
     }
     const C3dWgradPlan p = c3d_wgrad_plan(M, Cin, Cout, KD, KH, KW);

@@ -373,11 +373,13 @@ def test_mixed_block_branch_streams_are_transparent(cin, outs, shape, monkeypatc
             assert torch.equal(a, b), (it, k, float((a.float() - b.float()).abs().max()))
 
 
-@pytest.mark.parametrize("case", [(1, 96, 3, 14, 14, 208), (2, 16, 2, 7, 7, 32), (1, 40, 2, 6, 28, 24), (1, 64, 1, 56, 56, 64)])
-def test_conv3d_wgrad_ring_kernel_against_the_tap_stepping_kernel(case):
-    """The 3x3x3 weight gradient over a ring of input rows (option conv3d_wgrad = 1, default where the map is 56 / 28 /
-    14 / 7 wide) against the kernel it replaces (option 0) on the same tensors: the same bf16 products summed in another
-    order (fp32 accumulate), so equal to fp32 rounding; both deterministic."""
+@pytest.mark.parametrize("k", [3, 1])
+@pytest.mark.parametrize("case", [(1, 96, 3, 14, 14, 208), (2, 16, 2, 7, 7, 32), (1, 40, 2, 6, 28, 24), (1, 64, 1, 56, 56, 64),
+                                  (3, 528, 4, 14, 14, 160), (2, 832, 2, 7, 7, 48)])
+def test_conv3d_wgrad_ring_kernel_against_the_tap_stepping_kernel(case, k):
+    """The weight gradient over a ring of input rows (option conv3d_wgrad = 2, default where the map is 56 / 28 / 14 / 7
+    wide: 3x3x3 and 1x1x1 layers) against the kernels it replaces (option 0) on the same tensors: the same bf16 products
+    summed in another order (fp32 accumulate), so equal to fp32 rounding; both deterministic."""
     n, cin, d, h, w, cout = case
     L, lib = dmcnet_amd._lib, dmcnet_amd._lib.load()
     x = rnd(331, (n, cin, d, h, w)).bfloat16().to(DEV).contiguous(memory_format=CL3)
@@ -385,11 +387,11 @@ def test_conv3d_wgrad_ring_kernel_against_the_tap_stepping_kernel(case):
     out = {}
     before = lib.dmc_get_option(b"conv3d_wgrad")
     try:
-        for path in (1, 0, 1):
+        for path in (2, 0, 2):
             L.check(lib.dmc_set_option(b"conv3d_wgrad", path), "dmc_set_option")
-            dw = torch.empty((cout, cin, 3, 3, 3), device=DEV)
-            work = torch.empty(lib.dmc_conv3d_bf16_wgrad_bytes(n, d, h, w, cin, cout, 3, 3, 3) // 4 + 4, device=DEV)
-            L.check(lib.dmc_conv3d_bf16_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(work), n, d, h, w, cin, cout, 3, 3, 3, L._P(0)),
+            dw = torch.empty((cout, cin, k, k, k), device=DEV)
+            work = torch.empty(lib.dmc_conv3d_bf16_wgrad_bytes(n, d, h, w, cin, cout, k, k, k) // 4 + 4, device=DEV)
+            L.check(lib.dmc_conv3d_bf16_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(work), n, d, h, w, cin, cout, k, k, k, L._P(0)),
                     "dmc_conv3d_bf16_wgrad")
             torch.cuda.synchronize()
             if path in out:
@@ -397,7 +399,7 @@ def test_conv3d_wgrad_ring_kernel_against_the_tap_stepping_kernel(case):
             out[path] = dw
     finally:
         L.check(lib.dmc_set_option(b"conv3d_wgrad", before), "dmc_set_option")
-    assert float((out[0] - out[1]).abs().max() / out[0].abs().max()) < 2e-6
-    ref = torch.nn.grad.conv3d_weight(x.double().cpu(), (cout, cin, 3, 3, 3), dy.double().cpu(), padding=1) if n * d * h * w <= 4000 else None
-    if ref is not None:
-        assert float((out[1].double().cpu() - ref).abs().max() / ref.abs().max()) < 2e-5
+    assert float((out[0] - out[2]).abs().max() / out[0].abs().max()) < 2e-6
+    if n * d * h * w <= 4000 and cin * cout <= 100000:
+        ref = torch.nn.grad.conv3d_weight(x.double().cpu(), (cout, cin, k, k, k), dy.double().cpu(), padding=k // 2)
+        assert float((out[2].double().cpu() - ref).abs().max() / ref.abs().max()) < 2e-5
