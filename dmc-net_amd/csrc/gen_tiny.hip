@@ -458,11 +458,22 @@ constexpr int PT_H = 8;                             // tile rows
 constexpr int P_CONS = 7;                           // consumer waves; wave 7 is the producer
 constexpr int P_MAXW = P_CONS * M_SEGS * 64 / PT_H; // 224: widest image the 7 x 256 pixel slots cover
 constexpr int P_ROWS = PT_H + 2;                    // staged rows per channel
-constexpr int P_PLANE = P_ROWS * LTW;               // 2560 floats
-constexpr int P_BUF = LCH * P_PLANE;                // 10240 floats = 40,960 B per chunk
+// (a staged channel of the default geometry is P_ROWS * LTW = 2560 floats, a chunk buffer LCH of them = 40,960 B: RingGeo below)
 constexpr int RING = 3;                             // chunk buffers: one computing, two in flight
 constexpr int RING_DMA = LCH * P_ROWS;              // 40 row transfers per chunk, all by the producer
 static_assert(RING_DMA <= 63, "vmcnt is a 6-bit counter");
+
+// Tile geometry of the ring kernels.  HALF = false: 8-row tiles, four pixels per lane, one 8-wave workgroup per CU (the
+// default).  HALF = true (measurement variant, option gen_layer_path = 3, forward layers 2 and 3): 4-row tiles, TWO
+// pixels per lane -- 7 consumer waves x 128 pixels = 4 x 224 -- with the ring sized by the layer's chunk, so that two
+// workgroups fit a CU (<= 80 KB each, <= 128 VGPRs) and their push epilogues fall out of phase (round-2 verdict, variant ii).
+template <bool HALF>
+struct RingGeo {
+    static constexpr int ROWS = HALF ? 4 : PT_H;            // tile rows
+    static constexpr int SEGS = HALF ? 2 : M_SEGS;          // consecutive pixels per lane
+    static constexpr int SROWS = ROWS + 2;                  // staged rows per channel
+    static constexpr int PLANE = SROWS * LTW;               // floats per staged channel
+};
 
 // Scheduling fences around each stage's MFMA group: needed while the kernels were register-starved
 // (without them the compiler hoisted every LDS load of a chunk and spilled); since the producer /
@@ -517,10 +528,11 @@ struct RingArgs {
 // Only lanes left of the image's right edge are active (EXEC is restricted by the caller; the
 // consumers never read staged columns >= W).  Channels >= CIN and rows outside the image come
 // from the 1 KB of zero words behind the packed parameters.  All address arithmetic is scalar.
-template <int MODE, int K>
+template <int MODE, int K, bool HALF = false>
 __device__ __forceinline__ void ring_stage(const LayerArgs& a, unsigned slot_byte, int n, int ty0, int c,
                                            size_t HW, unsigned voff, const float* zero) {
     constexpr int CIN = MfmaGeom<MODE, K>::CIN;
+    constexpr int PT_H = RingGeo<HALF>::ROWS, P_ROWS = RingGeo<HALF>::SROWS;       // (shadow the default geometry)
     const unsigned long long zaddr = (unsigned long long)zero;
     const bool interior = ty0 >= 1 && ty0 + PT_H < a.H;                            // rows ty0-1 .. ty0+PT_H all inside
     constexpr int CH = MfmaGeom<MODE, K>::CH;
@@ -566,10 +578,11 @@ __device__ __forceinline__ void ring_stage(const LayerArgs& a, unsigned slot_byt
 // consumer: one staged chunk = CH stages of 3 K-steps (dy) x 4 segments x NT row tiles.  The LDS
 // operands of stage cc+1 are requested before the MFMAs of stage cc (register double buffer);
 // sched_barriers keep the compiler from hoisting every load of the chunk to the top.
-template <int MODE, int K, int NT_>
-__device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[M_SEGS][NT_], const float* buf, const float* wl,
+template <int MODE, int K, int NT_, bool HALF = false>
+__device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[RingGeo<HALF>::SEGS][NT_], const float* buf, const float* wl,
                                            int c0, int boffq, int lane) {
     using G = MfmaGeom<MODE, K>;
+    constexpr int M_SEGS = RingGeo<HALF>::SEGS, P_PLANE = RingGeo<HALF>::PLANE;    // (shadow the default geometry)
     float w[2][3][G::NTP], b[2][3][M_SEGS];
     auto load_stage = [&](int cc, int sel) {
 #pragma unroll
@@ -588,9 +601,14 @@ __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[M_SEGS][NT_], const floa
                     }
                 }
             }
-            // the lane's four consecutive pixels: one 16-byte read feeds the four "segments"
-            const float4 bq = *reinterpret_cast<const float4*>(buf + cc * P_PLANE + dy * LTW + boffq);
-            b[sel][dy][0] = bq.x; b[sel][dy][1] = bq.y; b[sel][dy][2] = bq.z; b[sel][dy][3] = bq.w;
+            // the lane's consecutive pixels: one 16-byte (8-byte) read feeds the four (two) "segments"
+            if constexpr (M_SEGS == 4) {
+                const float4 bq = *reinterpret_cast<const float4*>(buf + cc * P_PLANE + dy * LTW + boffq);
+                b[sel][dy][0] = bq.x; b[sel][dy][1] = bq.y; b[sel][dy][2] = bq.z; b[sel][dy][3] = bq.w;
+            } else {
+                const float2 bq = *reinterpret_cast<const float2*>(buf + cc * P_PLANE + dy * LTW + boffq);
+                b[sel][dy][0] = bq.x; b[sel][dy][1] = bq.y;
+            }
         }
     };
     load_stage(0, 0);
@@ -609,10 +627,13 @@ __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[M_SEGS][NT_], const floa
     }
 }
 
-template <int MODE, int K>
-__global__ __launch_bounds__(LTHREADS, 2) void gen_layer_mfma_kernel(RingArgs ra) {
+template <int MODE, int K, bool HALF = false>
+__global__ __launch_bounds__(LTHREADS, HALF ? 4 : 2) void gen_layer_mfma_kernel(RingArgs ra) {
     using G = MfmaGeom<MODE, K>;
     constexpr int CIN = G::CIN, COUT = G::COUT, NT = G::NT, NTP = G::NTP, NCHUNK = G::NCHUNK;
+    // (shadow the default geometry; the half-tile ring is sized by the layer's chunk so that two workgroups fit a CU)
+    constexpr int PT_H = RingGeo<HALF>::ROWS, M_SEGS = RingGeo<HALF>::SEGS;
+    constexpr int P_BUF = (HALF ? G::CH : LCH) * RingGeo<HALF>::PLANE;
     __shared__ __attribute__((aligned(16))) float lds[RING * P_BUF + G::WL + P_CONS * 2 * 8];
     const LayerArgs& a = ra.a;
     float* wl = lds + RING * P_BUF;
@@ -646,23 +667,23 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_layer_mfma_kernel(RingArgs ra
 
     if (r == P_CONS) {
         // ------------------------------ producer wave ------------------------------
-        if (4 * lane >= a.W) return;                                   // EXEC = lanes that hold image columns
+        if (4 * lane >= a.W) return;                                   // EXEC = lanes that hold image columns (a staged row = 64 lanes x 16 bytes either way)
         const unsigned voff = (unsigned)lane * 16;
 #pragma unroll 1
         for (int pre = 0; pre < 2 && pre < nitems; ++pre) {
             const int tile = t_begin + (pre / NCHUNK) * t_step, n = tile / ra.tiles_y;
-            ring_stage<MODE, K>(a, lds0 + pre * (P_BUF * 4), n, (tile - n * ra.tiles_y) * PT_H, pre % NCHUNK, HW, voff, zero);
+            ring_stage<MODE, K, HALF>(a, lds0 + pre * (P_BUF * 4), n, (tile - n * ra.tiles_y) * PT_H, pre % NCHUNK, HW, voff, zero);
         }
         int tile = t_begin, c = 0, slot = 0;
 #pragma unroll 1
         for (int q = 0; q < nitems; ++q) {
             // chunk q has landed (only chunk q+1 may still be in flight); consumers are done with q-1
-            if (q + 1 < nitems && !(ra.ablate & 1)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(G::DMA) : "memory");
+            if (q + 1 < nitems && !(ra.ablate & 1)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(G::CH * RingGeo<HALF>::SROWS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             if (q + 2 < nitems && !(ra.ablate & 1)) {
                 const int c2 = c + 2, tile2 = tile + (c2 / NCHUNK) * t_step, n2 = tile2 / ra.tiles_y;
                 int slot2 = slot + 2; slot2 = slot2 >= RING ? slot2 - RING : slot2;
-                ring_stage<MODE, K>(a, lds0 + (unsigned)slot2 * (P_BUF * 4), n2, (tile2 - n2 * ra.tiles_y) * PT_H,
+                ring_stage<MODE, K, HALF>(a, lds0 + (unsigned)slot2 * (P_BUF * 4), n2, (tile2 - n2 * ra.tiles_y) * PT_H,
                                     c2 % NCHUNK, HW, voff, zero);
             }
             slot = slot + 1 == RING ? 0 : slot + 1;
@@ -681,10 +702,10 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_layer_mfma_kernel(RingArgs ra
     // wasted on columns >= W).  MFMA "segment" e = element e of every lane's quad: its B operands come
     // from one 16-byte LDS read, the horizontal neighbours of pixels e = 1, 2 are the lane's own
     // accumulators (only e = 0 / e = 3 need a lane shift), and every global access is 16 bytes per lane.
-    const int p0 = r * (M_SEGS * 64) + 4 * lane;
+    const int p0 = r * (M_SEGS * 64) + M_SEGS * lane;
     const int yl0 = p0 / a.W, x0 = p0 - yl0 * a.W;
     const int boffq = p0 < PT_H * a.W ? yl0 * LTW + x0 : 0;   // LDS offset of the quad in staged row 0 (the row above it)
-    const bool at_left = x0 == 0, at_right = x0 + 4 == a.W;
+    const bool at_left = x0 == 0, at_right = x0 + M_SEGS == a.W;
     f32x4 acc[M_SEGS][NT];
 #pragma unroll
     for (int s = 0; s < M_SEGS; ++s)
@@ -695,7 +716,7 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_layer_mfma_kernel(RingArgs ra
 #pragma unroll 1
     for (int q = 0; q < nitems; ++q) {
         asm volatile("s_barrier" ::: "memory");
-        mfma_chunk<MODE, K, NT>(acc, lds + slot * P_BUF, wl, c * G::CH, boffq, lane);
+        mfma_chunk<MODE, K, NT, HALF>(acc, lds + slot * P_BUF, wl, c * G::CH, boffq, lane);
         slot = slot + 1 == RING ? 0 : slot + 1;
         if (++c < NCHUNK) continue;
         c = 0;
@@ -708,6 +729,7 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_layer_mfma_kernel(RingArgs ra
         const size_t pix = tile_pix + (inside ? p0 : 0);
         float4 extra[COUT];              // MODE 1: mv (delta add), MODE 2: y_K (LeakyReLU'): one batch of loads
         if (MODE != 0) {
+            static_assert(MODE == 0 || !HALF, "the half-tile variant is built for the forward's inner layers only");
 #pragma unroll
             for (int co = 0; co < COUT; ++co)
                 extra[co] = MODE == 1 ? (a.add_mv ? *reinterpret_cast<const float4*>(a.mv + ((size_t)n * 2 + co) * HW + pix)
@@ -757,7 +779,10 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_layer_mfma_kernel(RingArgs ra
                     v[e] *= ex[e] > 0.f ? 1.f : 0.1f;
                 }
             }
-            if (inside && !(ra.ablate & 2)) {
+            if constexpr (HALF) {
+                if (inside && !(ra.ablate & 2))
+                    *reinterpret_cast<float2*>(a.feat_out + ((size_t)n * NFEAT + (yoff(K) - NIN) + co) * HW + pix) = make_float2(v[0], v[1]);
+            } else if (inside && !(ra.ablate & 2)) {
                 const float4 o = make_float4(v[0], v[1], v[2], v[3]);
                 if (MODE == 0) *reinterpret_cast<float4*>(a.feat_out + ((size_t)n * NFEAT + (yoff(K) - NIN) + co) * HW + pix) = o;
                 else if (MODE == 1) *reinterpret_cast<float4*>(a.out + ((size_t)n * 2 + co) * HW + pix) = o;
@@ -2012,7 +2037,7 @@ int launch_layer(LayerArgs a, int n0, int N, hipStream_t s) {
     // Cout-6 layers lose (18 instead of 15 MFMAs per channel and pixel), the rest are at the HBM roof
     constexpr bool GATHER_FORM = (MODE == 0 && K <= 1) || (MODE == 2 && K == 1);
     const int gpath = option(OPT_GEN_GATHER);
-    if (GATHER_FORM && gpath == 1 && path == 1 && a.W % 4 == 0 && a.W <= P_MAXW) {
+    if (GATHER_FORM && gpath == 1 && (path == 1 || path == 3) && a.W % 4 == 0 && a.W <= P_MAXW) {
         RingArgs ra;
         ra.ablate = 0;
         ra.a = a;
@@ -2020,7 +2045,18 @@ int launch_layer(LayerArgs a, int n0, int N, hipStream_t s) {
         ra.ntiles = ra.tiles_y * N;
         const int wgs = ra.ntiles < num_cus() ? ra.ntiles : num_cus();
         if constexpr (GATHER_FORM) gen_layer_gather_kernel<MODE, K><<<wgs, G_THREADS, 0, s>>>(ra);
-    } else if (path == 1 && a.W % 4 == 0 && a.W <= P_MAXW) {
+    } else if (path == 3 && MODE == 0 && (K == 2 || K == 3) && a.W % 4 == 0 && a.W <= P_MAXW) {
+        // measurement variant (round-2 verdict, variant ii): 4-row tiles, two 8-wave workgroups per CU
+        if constexpr (MODE == 0 && (K == 2 || K == 3)) {
+            RingArgs ra;
+            ra.a = a;
+            ra.tiles_y = (a.H + RingGeo<true>::ROWS - 1) / RingGeo<true>::ROWS;
+            ra.ntiles = ra.tiles_y * N;
+            ra.ablate = option(OPT_GEN_ABLATE);
+            const int wgs = ra.ntiles < 2 * num_cus() ? ra.ntiles : 2 * num_cus();
+            gen_layer_mfma_kernel<MODE, K, true><<<wgs, LTHREADS, 0, s>>>(ra);
+        }
+    } else if ((path == 1 || path == 3) && a.W % 4 == 0 && a.W <= P_MAXW) {
         RingArgs ra;
         ra.ablate = 0;
         ra.a = a;
@@ -2086,7 +2122,7 @@ static int gen_tiny_fwd_impl(const float* mv, const float* res, const float* con
         if ((rc = launch_layer<0, 2>(a, n0, nn, s))) return rc;
         if ((rc = launch_layer<0, 3>(a, n0, nn, s))) return rc;
         const int fuse45 = option(OPT_GEN_FUSE45), lpath = option(OPT_GEN_LAYER_PATH);
-        if (fuse45 && lpath == 1 && W % 4 == 0 && W <= P_MAXW) {
+        if (fuse45 && (lpath == 1 || lpath == 3) && W % 4 == 0 && W <= P_MAXW) {
             RingArgs ra;
             ra.ablate = 0;
             ra.a = a;

@@ -1028,3 +1028,29 @@ def test_disc_block_unit(first, cin, cout, stride, use_bn, hw):
         ye = ops.disc_block(xg.detach(), conv_m, None, bn_m, False, first=first)
         ze = F.leaky_relu(conv_d(x.double()), 0.2)
         assert rel_err(ye, bn_d(ze) if use_bn else ze) < 1e-5
+
+
+@pytest.mark.gpu
+def test_generator_half_tile_variant_is_bit_identical():
+    """Option gen_layer_path = 3 (measurement variant: forward layers 2 and 3 on 4-row tiles, two pixels per lane, two
+    workgroups per CU) against the default kernels: the same products in the same order, so the forward output and the
+    saved features' effect (the backward's gradients) are bitwise equal; 224 x 224 and an edge shape."""
+    lib = dmcnet_amd._lib.load()
+    before = lib.dmc_get_option(b"gen_layer_path")
+    try:
+        for (n, h, w) in ((5, 224, 224), (2, 70, 92)):
+            torch.manual_seed(3)
+            m = dmcnet_amd.model.EstimatorDenseNetTiny(5).to(DEV)
+            mv, res = torch.randn(n, 2, h, w, device=DEV), torch.randn(n, 3, h, w, device=DEV)
+            go = torch.randn(n, 2, h, w, device=DEV)
+            outs = []
+            for path in (1, 3):
+                dmcnet_amd._lib.check(lib.dmc_set_option(b"gen_layer_path", path), "dmc_set_option")
+                m.zero_grad(set_to_none=True)
+                y = m.forward_mv_res(mv, res, True)
+                y.backward(go)
+                outs.append([y.detach()] + [p.grad.clone() for p in m.parameters()])
+            for a, b in zip(*outs):
+                assert torch.equal(a, b)
+    finally:
+        dmcnet_amd._lib.check(lib.dmc_set_option(b"gen_layer_path", before), "dmc_set_option")
