@@ -467,10 +467,14 @@ static_assert(RING_DMA <= 63, "vmcnt is a 6-bit counter");
 // default).  HALF = true (measurement variant, option gen_layer_path = 3, forward layers 2 and 3): 4-row tiles, TWO
 // pixels per lane -- 7 consumer waves x 128 pixels = 4 x 224 -- with the ring sized by the layer's chunk, so that two
 // workgroups fit a CU (<= 80 KB each, <= 128 VGPRs) and their push epilogues fall out of phase (round-2 verdict, variant ii).
-template <bool HALF>
+// VAR = 2 (measurement variant iii, option gen_layer_path = 4, forward layer 2): the default tile, but a TWO-stage ring sized by
+// the layer's chunk (61 KB + weights), so that two workgroups fit a CU with full-width accesses and no extra halo rows.
+template <int VAR>
 struct RingGeo {
+    static constexpr bool HALF = VAR == 1;
     static constexpr int ROWS = HALF ? 4 : PT_H;            // tile rows
     static constexpr int SEGS = HALF ? 2 : M_SEGS;          // consecutive pixels per lane
+    static constexpr int STAGES = VAR == 2 ? 2 : RING;      // chunk buffers of the ring
     static constexpr int SROWS = ROWS + 2;                  // staged rows per channel
     static constexpr int PLANE = SROWS * LTW;               // floats per staged channel
 };
@@ -480,7 +484,7 @@ struct RingGeo {
 // consumer split its own schedule is as good or better (layers 4+5: 286 -> 265 us), except for the
 // 6-tile (Cout 8) push kernels, which keep them.
 constexpr int FENCE_MIN_NT = 6;
-template <int MODE, int K>
+template <int MODE, int K, int VAR = 0>
 struct MfmaGeom {
     static constexpr int CIN = MODE == 2 ? gin_of(K) : cin_of(K);
     static constexpr int COUT = cout_of(K);
@@ -490,7 +494,8 @@ struct MfmaGeom {
     // channels per staged chunk: 4, except 3 for the compute-bound layer 2 (21 input channels pad
     // to nothing instead of 24: -12 % MFMAs; measured 242 -> 229 us).  Layer 3 (27 = 9 x 3) is at
     // the HBM roof and got slower with the smaller chunks (more barriers, less data in flight)
-    static constexpr int CH = (MODE != 2 && CIN == 21) ? 3 : LCH;
+    // (VAR = 2, two workgroups per CU: layer 3's 27 channels in 3-channel chunks too, so that its two-stage ring fits 80 KB)
+    static constexpr int CH = (MODE != 2 && (CIN == 21 || (VAR == 2 && CIN == 27))) ? 3 : LCH;
     static constexpr int NCHUNK = (CIN + CH - 1) / CH;
     static constexpr int DMA = CH * P_ROWS;                        // row transfers per chunk
     static constexpr bool FENCE = FENCE_MIN_NT <= NT;             // scheduling fences around the MFMA groups
@@ -528,14 +533,14 @@ struct RingArgs {
 // Only lanes left of the image's right edge are active (EXEC is restricted by the caller; the
 // consumers never read staged columns >= W).  Channels >= CIN and rows outside the image come
 // from the 1 KB of zero words behind the packed parameters.  All address arithmetic is scalar.
-template <int MODE, int K, bool HALF = false>
+template <int MODE, int K, int HALF = 0>
 __device__ __forceinline__ void ring_stage(const LayerArgs& a, unsigned slot_byte, int n, int ty0, int c,
                                            size_t HW, unsigned voff, const float* zero) {
-    constexpr int CIN = MfmaGeom<MODE, K>::CIN;
+    constexpr int CIN = MfmaGeom<MODE, K, HALF>::CIN;
     constexpr int PT_H = RingGeo<HALF>::ROWS, P_ROWS = RingGeo<HALF>::SROWS;       // (shadow the default geometry)
     const unsigned long long zaddr = (unsigned long long)zero;
     const bool interior = ty0 >= 1 && ty0 + PT_H < a.H;                            // rows ty0-1 .. ty0+PT_H all inside
-    constexpr int CH = MfmaGeom<MODE, K>::CH;
+    constexpr int CH = MfmaGeom<MODE, K, HALF>::CH;
 #pragma unroll
     for (int cc = 0; cc < CH; ++cc) {
         const int ch = c * CH + cc;
@@ -578,10 +583,10 @@ __device__ __forceinline__ void ring_stage(const LayerArgs& a, unsigned slot_byt
 // consumer: one staged chunk = CH stages of 3 K-steps (dy) x 4 segments x NT row tiles.  The LDS
 // operands of stage cc+1 are requested before the MFMAs of stage cc (register double buffer);
 // sched_barriers keep the compiler from hoisting every load of the chunk to the top.
-template <int MODE, int K, int NT_, bool HALF = false>
+template <int MODE, int K, int NT_, int HALF = 0>
 __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[RingGeo<HALF>::SEGS][NT_], const float* buf, const float* wl,
                                            int c0, int boffq, int lane) {
-    using G = MfmaGeom<MODE, K>;
+    using G = MfmaGeom<MODE, K, HALF>;
     constexpr int M_SEGS = RingGeo<HALF>::SEGS, P_PLANE = RingGeo<HALF>::PLANE;    // (shadow the default geometry)
     float w[2][3][G::NTP], b[2][3][M_SEGS];
     auto load_stage = [&](int cc, int sel) {
@@ -627,13 +632,14 @@ __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[RingGeo<HALF>::SEGS][NT_
     }
 }
 
-template <int MODE, int K, bool HALF = false>
+template <int MODE, int K, int HALF = 0>                  // HALF: the RingGeo variant (0 default, 1 half tiles, 2 two-stage ring)
 __global__ __launch_bounds__(LTHREADS, HALF ? 4 : 2) void gen_layer_mfma_kernel(RingArgs ra) {
-    using G = MfmaGeom<MODE, K>;
+    using G = MfmaGeom<MODE, K, HALF>;
     constexpr int CIN = G::CIN, COUT = G::COUT, NT = G::NT, NTP = G::NTP, NCHUNK = G::NCHUNK;
     // (shadow the default geometry; the half-tile ring is sized by the layer's chunk so that two workgroups fit a CU)
     constexpr int PT_H = RingGeo<HALF>::ROWS, M_SEGS = RingGeo<HALF>::SEGS;
     constexpr int P_BUF = (HALF ? G::CH : LCH) * RingGeo<HALF>::PLANE;
+    constexpr int RING = RingGeo<HALF>::STAGES, AHEAD = RING - 1;      // (shadow) chunks the producer runs ahead of the consumers
     __shared__ __attribute__((aligned(16))) float lds[RING * P_BUF + G::WL + P_CONS * 2 * 8];
     const LayerArgs& a = ra.a;
     float* wl = lds + RING * P_BUF;
@@ -670,7 +676,7 @@ __global__ __launch_bounds__(LTHREADS, HALF ? 4 : 2) void gen_layer_mfma_kernel(
         if (4 * lane >= a.W) return;                                   // EXEC = lanes that hold image columns (a staged row = 64 lanes x 16 bytes either way)
         const unsigned voff = (unsigned)lane * 16;
 #pragma unroll 1
-        for (int pre = 0; pre < 2 && pre < nitems; ++pre) {
+        for (int pre = 0; pre < AHEAD && pre < nitems; ++pre) {
             const int tile = t_begin + (pre / NCHUNK) * t_step, n = tile / ra.tiles_y;
             ring_stage<MODE, K, HALF>(a, lds0 + pre * (P_BUF * 4), n, (tile - n * ra.tiles_y) * PT_H, pre % NCHUNK, HW, voff, zero);
         }
@@ -678,11 +684,11 @@ __global__ __launch_bounds__(LTHREADS, HALF ? 4 : 2) void gen_layer_mfma_kernel(
 #pragma unroll 1
         for (int q = 0; q < nitems; ++q) {
             // chunk q has landed (only chunk q+1 may still be in flight); consumers are done with q-1
-            if (q + 1 < nitems && !(ra.ablate & 1)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(G::CH * RingGeo<HALF>::SROWS) : "memory");
+            if (AHEAD == 2 && q + 1 < nitems && !(ra.ablate & 1)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(G::CH * RingGeo<HALF>::SROWS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            if (q + 2 < nitems && !(ra.ablate & 1)) {
-                const int c2 = c + 2, tile2 = tile + (c2 / NCHUNK) * t_step, n2 = tile2 / ra.tiles_y;
-                int slot2 = slot + 2; slot2 = slot2 >= RING ? slot2 - RING : slot2;
+            if (q + AHEAD < nitems && !(ra.ablate & 1)) {
+                const int c2 = c + AHEAD, tile2 = tile + (c2 / NCHUNK) * t_step, n2 = tile2 / ra.tiles_y;
+                int slot2 = slot + AHEAD; slot2 = slot2 >= RING ? slot2 - RING : slot2;
                 ring_stage<MODE, K, HALF>(a, lds0 + (unsigned)slot2 * (P_BUF * 4), n2, (tile2 - n2 * ra.tiles_y) * PT_H,
                                     c2 % NCHUNK, HW, voff, zero);
             }
@@ -729,7 +735,7 @@ __global__ __launch_bounds__(LTHREADS, HALF ? 4 : 2) void gen_layer_mfma_kernel(
         const size_t pix = tile_pix + (inside ? p0 : 0);
         float4 extra[COUT];              // MODE 1: mv (delta add), MODE 2: y_K (LeakyReLU'): one batch of loads
         if (MODE != 0) {
-            static_assert(MODE == 0 || !HALF, "the half-tile variant is built for the forward's inner layers only");
+            static_assert(MODE == 0 || HALF != 1, "the half-tile variant is built for the forward's inner layers only");
 #pragma unroll
             for (int co = 0; co < COUT; ++co)
                 extra[co] = MODE == 1 ? (a.add_mv ? *reinterpret_cast<const float4*>(a.mv + ((size_t)n * 2 + co) * HW + pix)
@@ -779,7 +785,7 @@ __global__ __launch_bounds__(LTHREADS, HALF ? 4 : 2) void gen_layer_mfma_kernel(
                     v[e] *= ex[e] > 0.f ? 1.f : 0.1f;
                 }
             }
-            if constexpr (HALF) {
+            if constexpr (HALF == 1) {
                 if (inside && !(ra.ablate & 2))
                     *reinterpret_cast<float2*>(a.feat_out + ((size_t)n * NFEAT + (yoff(K) - NIN) + co) * HW + pix) = make_float2(v[0], v[1]);
             } else if (inside && !(ra.ablate & 2)) {
@@ -2037,7 +2043,7 @@ int launch_layer(LayerArgs a, int n0, int N, hipStream_t s) {
     // Cout-6 layers lose (18 instead of 15 MFMAs per channel and pixel), the rest are at the HBM roof
     constexpr bool GATHER_FORM = (MODE == 0 && K <= 1) || (MODE == 2 && K == 1);
     const int gpath = option(OPT_GEN_GATHER);
-    if (GATHER_FORM && gpath == 1 && (path == 1 || path == 3) && a.W % 4 == 0 && a.W <= P_MAXW) {
+    if (GATHER_FORM && gpath == 1 && (path == 1 || path == 3 || path == 4 || path == 5) && a.W % 4 == 0 && a.W <= P_MAXW) {
         RingArgs ra;
         ra.ablate = 0;
         ra.a = a;
@@ -2045,18 +2051,32 @@ int launch_layer(LayerArgs a, int n0, int N, hipStream_t s) {
         ra.ntiles = ra.tiles_y * N;
         const int wgs = ra.ntiles < num_cus() ? ra.ntiles : num_cus();
         if constexpr (GATHER_FORM) gen_layer_gather_kernel<MODE, K><<<wgs, G_THREADS, 0, s>>>(ra);
+    } else if (MODE == 0 && ((path == 1 && K == 2) || (path == 4 && (K == 2 || K == 3))) && a.W % 4 == 0 && a.W <= P_MAXW) {
+        // variant (iii): the default tile with a two-stage ring, two 8-wave workgroups per CU.  Forward layer 2 (the most
+        // matrix-bound layer) gains 7.5 % from the second resident workgroup (214.7 -> 198.5 us, matrix pipe busy 0.534 ->
+        // 0.573) and takes it by default; layer 3 (HBM-bound, needs 3-channel chunks to fit) loses 1.7 %: option value 4 only.
+        // Option value 5 = every layer on the three-stage single-workgroup kernel (the default before)
+        if constexpr (MODE == 0 && (K == 2 || K == 3)) {
+            RingArgs ra;
+            ra.a = a;
+            ra.tiles_y = (a.H + PT_H - 1) / PT_H;
+            ra.ntiles = ra.tiles_y * N;
+            ra.ablate = option(OPT_GEN_ABLATE);
+            const int wgs = ra.ntiles < 2 * num_cus() ? ra.ntiles : 2 * num_cus();
+            gen_layer_mfma_kernel<MODE, K, 2><<<wgs, LTHREADS, 0, s>>>(ra);
+        }
     } else if (path == 3 && MODE == 0 && (K == 2 || K == 3) && a.W % 4 == 0 && a.W <= P_MAXW) {
         // measurement variant (round-2 verdict, variant ii): 4-row tiles, two 8-wave workgroups per CU
         if constexpr (MODE == 0 && (K == 2 || K == 3)) {
             RingArgs ra;
             ra.a = a;
-            ra.tiles_y = (a.H + RingGeo<true>::ROWS - 1) / RingGeo<true>::ROWS;
+            ra.tiles_y = (a.H + RingGeo<1>::ROWS - 1) / RingGeo<1>::ROWS;
             ra.ntiles = ra.tiles_y * N;
             ra.ablate = option(OPT_GEN_ABLATE);
             const int wgs = ra.ntiles < 2 * num_cus() ? ra.ntiles : 2 * num_cus();
-            gen_layer_mfma_kernel<MODE, K, true><<<wgs, LTHREADS, 0, s>>>(ra);
+            gen_layer_mfma_kernel<MODE, K, 1><<<wgs, LTHREADS, 0, s>>>(ra);
         }
-    } else if ((path == 1 || path == 3) && a.W % 4 == 0 && a.W <= P_MAXW) {
+    } else if ((path == 1 || path == 3 || path == 4 || path == 5) && a.W % 4 == 0 && a.W <= P_MAXW) {
         RingArgs ra;
         ra.ablate = 0;
         ra.a = a;
@@ -2122,7 +2142,7 @@ static int gen_tiny_fwd_impl(const float* mv, const float* res, const float* con
         if ((rc = launch_layer<0, 2>(a, n0, nn, s))) return rc;
         if ((rc = launch_layer<0, 3>(a, n0, nn, s))) return rc;
         const int fuse45 = option(OPT_GEN_FUSE45), lpath = option(OPT_GEN_LAYER_PATH);
-        if (fuse45 && (lpath == 1 || lpath == 3) && W % 4 == 0 && W <= P_MAXW) {
+        if (fuse45 && (lpath == 1 || lpath == 3 || lpath == 4 || lpath == 5) && W % 4 == 0 && W <= P_MAXW) {
             RingArgs ra;
             ra.ablate = 0;
             ra.a = a;

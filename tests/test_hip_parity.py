@@ -1032,9 +1032,10 @@ def test_disc_block_unit(first, cin, cout, stride, use_bn, hw):
 
 @pytest.mark.gpu
 def test_generator_half_tile_variant_is_bit_identical():
-    """Option gen_layer_path = 3 (measurement variant: forward layers 2 and 3 on 4-row tiles, two pixels per lane, two
-    workgroups per CU) against the default kernels: the same products in the same order, so the forward output and the
-    saved features' effect (the backward's gradients) are bitwise equal; 224 x 224 and an edge shape."""
+    """Option gen_layer_path: 5 = every ring layer on the three-stage single-workgroup kernel, 1 (default) = forward layer 2 on
+    the two-stage ring with two workgroups per CU, 4 = layers 2 and 3 so, 3 = layers 2 and 3 on 4-row tiles with two pixels
+    per lane.  The same products in the same order: the forward output and the backward's gradients are bitwise equal;
+    224 x 224 and an edge shape."""
     lib = dmcnet_amd._lib.load()
     before = lib.dmc_get_option(b"gen_layer_path")
     try:
@@ -1044,13 +1045,14 @@ def test_generator_half_tile_variant_is_bit_identical():
             mv, res = torch.randn(n, 2, h, w, device=DEV), torch.randn(n, 3, h, w, device=DEV)
             go = torch.randn(n, 2, h, w, device=DEV)
             outs = []
-            for path in (1, 3):
+            for path in (5, 1, 3, 4):
                 dmcnet_amd._lib.check(lib.dmc_set_option(b"gen_layer_path", path), "dmc_set_option")
                 m.zero_grad(set_to_none=True)
                 y = m.forward_mv_res(mv, res, True)
                 y.backward(go)
                 outs.append([y.detach()] + [p.grad.clone() for p in m.parameters()])
-            for a, b in zip(*outs):
-                assert torch.equal(a, b)
+            for other in outs[1:]:
+                for a, b in zip(outs[0], other):
+                    assert torch.equal(a, b)
     finally:
         dmcnet_amd._lib.check(lib.dmc_set_option(b"gen_layer_path", before), "dmc_set_option")

@@ -5,7 +5,7 @@
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for p in 1 3; do
+for p in 5 1 3 4; do
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gv_$p -o x -- python $R/tools/gen_microbench.py 120 gen_layer_path=$p > $OUT/microbench_path$p.txt 2>/dev/null
   python - $(find /tmp/gv_$p -name "x_kernel_stats.csv" | head -1) > $OUT/kernels_path$p.csv <<'PY'
 import csv, sys
@@ -18,4 +18,4 @@ PY
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/gp_$p -o x -- python $R/tools/gen_microbench.py 120 gen_layer_path=$p > /dev/null 2>&1
   python $R/tools/pmc_table.py $(find /tmp/gp_$p -name "x_counter_collection.csv" | head -1) "gen_layer_mfma_kernel<0" > $OUT/pmc_path$p.csv
 done
-cat $OUT/kernels_path1.csv $OUT/kernels_path3.csv $OUT/pmc_path1.csv $OUT/pmc_path3.csv
+cat $OUT/kernels_path5.csv $OUT/kernels_path1.csv $OUT/kernels_path3.csv $OUT/kernels_path4.csv $OUT/pmc_path5.csv $OUT/pmc_path1.csv $OUT/pmc_path3.csv $OUT/pmc_path4.csv
