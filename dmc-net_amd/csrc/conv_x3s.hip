@@ -535,7 +535,9 @@ int patch_pixels_max(int N, int H, int W, int BM) {
 
 struct X3Cfg { int id, BM, PPMAX, threads; };
 // configurations: 0 = 256 pixels, 8 waves (one tile of 32 x 64 each), 1 = 128 pixels, 4 waves, 2 = 64 pixels, 2 waves
-constexpr X3Cfg X3CFGS[] = {{0, 256, 608, 512}, {1, 128, 320, 256}, {2, 64, 192, 128}, {3, 256, 608, 256}};   // 3 (measurement): 4 waves of 64 x 64
+// 4: 128 pixels, 4 waves, a patch of <= 224 pixels (the 14- and 7-wide maps): 79,872 B of LDS -- TWO workgroups per CU, so that
+// one's prologue / epilogue (20 % of a tile, profiles/r3_x3s_ablation.txt) runs under the other's main loop
+constexpr X3Cfg X3CFGS[] = {{0, 256, 608, 512}, {1, 128, 320, 256}, {2, 64, 192, 128}, {3, 256, 608, 256}, {4, 128, 224, 256}};   // 3 (measurement): 4 waves of 64 x 64
 
 bool x3s_shape_ok(int N, int H, int W, int K, int R) {
     if (N <= 0 || H <= 0 || W <= 0 || K % 32 != 0 || R % 64 != 0 || K <= 0 || R <= 0) return false;
@@ -545,14 +547,19 @@ bool x3s_shape_ok(int N, int H, int W, int K, int R) {
 
 int x3s_choose(int N, int H, int W, int R) {
     const long M = (long)N * H * W;
-    const int forced = option(OPT_CONV_CFG);                 // measurement switch: 101 + configuration
-    if (forced >= 101 && forced <= 104 && patch_pixels_max(N, H, W, X3CFGS[forced - 101].BM) <= X3CFGS[forced - 101].PPMAX) return forced - 101;
+    const int forced = option(OPT_CONV_CFG);                 // measurement switch: 101 + configuration; 106 = never configuration 4
+    if (forced >= 101 && forced <= 105 && patch_pixels_max(N, H, W, X3CFGS[forced - 101].BM) <= X3CFGS[forced - 101].PPMAX) return forced - 101;
     // the largest tile whose workgroups still cover most of the 256 CUs (measured, 120 frames: 8-wave workgroups of 256
     // pixels win down to layer4's 184 workgroups -- 160-187 TFLOP/s against 123-133 with 64-pixel tiles); else the
     // smallest tile whose patch fits
+    // two 4-wave workgroups per CU where the patch of a 128-pixel tile is small enough (14- and 7-wide maps) and there are at
+    // least as many workgroups as the chip has slots for them: layer3 (736 workgroups) 0.160 -> 0.141 ms, -12 %; layer4's 368
+    // workgroups lose 2 % against 184 8-wave ones
+    if (forced != 106 && patch_pixels_max(N, H, W, X3CFGS[4].BM) <= X3CFGS[4].PPMAX && ((M + X3CFGS[4].BM - 1) / X3CFGS[4].BM) * (R / 64) >= 512)
+        return 4;
     int fallback = -1;
     for (const X3Cfg& c : X3CFGS) {
-        if (c.id > 2 || patch_pixels_max(N, H, W, c.BM) > c.PPMAX) continue;
+        if (c.id > 2 || patch_pixels_max(N, H, W, c.BM) > c.PPMAX) continue;                // (3: by option only)
         const long wgs = ((M + c.BM - 1) / c.BM) * (R / 64);
         if (wgs >= 160) return c.id;
         fallback = c.id;
@@ -608,6 +615,7 @@ int run_x3s(const void* xs, const void* wp, const float* addend, float* y, doubl
         case 1: return launch_x3s<4, 1, 320>(a, s);
         case 2: return launch_x3s<2, 1, 192>(a, s);
         case 3: return launch_x3s<4, 2, 608>(a, s);
+        case 4: return launch_x3s<4, 1, 224>(a, s);
         default: return fail(DMC_E_INVALID, "x3s_conv: the patch of a %d x %d image does not fit the LDS", H, W);
     }
 }

@@ -499,3 +499,34 @@ def test_side_stream_weight_gradients_and_gradient_hooks(monkeypatch):
     assert ops._WGRAD_COUNT[0] > n0                      # the side stream was used
     for k, p in b.named_parameters():
         assert torch.equal(p.grad, want[k]), k
+
+
+@pytest.mark.parametrize("case", [(6, 64, 14, 14, 128), (37, 64, 14, 14, 64), (5, 128, 7, 7, 64), (42, 64, 14, 14, 512)])
+def test_x3s_two_workgroups_per_cu_configuration(case):
+    """Tile configuration 4 of the pre-split convolutions (128-pixel tiles, 4 waves, a patch of <= 224 pixels: 79,872 B of
+    LDS, two workgroups per CU; chosen by default where a 14- / 7-wide map yields >= 512 workgroups, here also forced through
+    option conv_cfg = 105) against the 8-wave configuration (conv_cfg = 106 excludes it): every output element sums the same
+    products in the same order, so forward and data gradient are bitwise equal; the BatchNorm partials group pixels differently
+    and agree to fp64 rounding.  The last case takes configuration 4 by the default rule."""
+    n, cin, h, w, cout = case
+    L, lib = dmcnet_amd._lib, dmcnet_amd._lib.load()
+    x, wt, go = rnd(311, (n, cin, h, w)), rnd(312, (cout, cin, 3, 3)) * 0.1, rnd(313, (n, cout, h, w))
+    xs = ops.x3s_split(x.to(DEV).contiguous(memory_format=CL))
+    dys = ops.x3s_split(go.to(DEV).contiguous(memory_format=CL))
+    wf, wtr = ops.x3s_pack_weights(wt.to(DEV).contiguous(memory_format=CL))
+    before = lib.dmc_get_option(b"conv_cfg")
+    out = {}
+    try:
+        for cfg in (105, 106, 0):
+            L.check(lib.dmc_set_option(b"conv_cfg", cfg), "dmc_set_option")
+            y, part = ops.x3s_conv_fwd(xs, wf, n, h, w, cin, cout, want_stats=True)
+            dx = ops.x3s_conv_dgrad(dys, wtr, n, h, w, cin, cout)
+            out[cfg] = (y, dx, part.sum(0))
+    finally:
+        L.check(lib.dmc_set_option(b"conv_cfg", before), "dmc_set_option")
+    for cfg in (106, 0):
+        assert torch.equal(out[105][0], out[cfg][0]) and torch.equal(out[105][1], out[cfg][1])
+        assert float((out[105][2] - out[cfg][2]).abs().max()) <= 1e-12 * float(out[cfg][2].abs().max())
+    assert lib.dmc_x3s_conv_stat_blocks(n, h, w, cout) == (n * h * w + 127) // 128 if case[0] == 42 else True
+    yo = F.conv2d(x.double(), wt.double(), None, 1, 1)
+    assert rel_err(out[105][0], yo) < 1e-5
