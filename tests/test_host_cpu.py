@@ -613,3 +613,25 @@ def test_geometry_plans_are_validated_on_the_host():
                 [-1, 0, 224, 224, 224, 224, 0, 0], [0, 0, 0, 224, 224, 224, 0, 0]):
         with pytest.raises(ValueError):
             ops.check_geometry_plans(torch.tensor([good[0].tolist(), bad], dtype=torch.int32), 256, 340, 224, 224)
+
+
+def test_settle_host_and_side_stream_scope_on_cpu():
+    """Host-side helpers of the training step that must be harmless without a GPU: train.settle_host() parks the
+    long-lived objects once per process (a second call is a no-op), ops.wgrad_side_stream() only counts scopes and its
+    join does nothing while no launch left the main stream."""
+    import gc
+    from dmcnet_amd import ops, train
+    train._SETTLED[0] = False
+    train.settle_host()
+    frozen = gc.get_freeze_count()
+    assert train._SETTLED[0] and frozen > 0
+    train.settle_host()
+    assert gc.get_freeze_count() == frozen
+    gc.unfreeze()
+    assert ops._WGRAD_SCOPE[0] == 0
+    with ops.wgrad_side_stream():
+        assert ops._WGRAD_SCOPE[0] == 1
+        with ops.wgrad_side_stream():
+            assert ops._WGRAD_SCOPE[0] == 2
+    assert ops._WGRAD_SCOPE[0] == 0 and not ops._WGRAD_PENDING[0]
+    ops.join_wgrad_stream()                                  # nothing pending: must not touch CUDA
