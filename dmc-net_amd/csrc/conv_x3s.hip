@@ -172,7 +172,9 @@ template <int WM, int WN, int TM, int TN, int PPMAX, bool STAG = false, int CLS 
 __global__ __launch_bounds__(WM * WN * 64) void x3s_conv_kernel(X3Args a) {
     constexpr int NW = WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN;
     static_assert(BN == 64, "packed weight image is 64 rows wide");
-    static_assert(PPMAX % 32 == 0, "patch transfers move 32 pixel rows");
+    // patch transfers move 32 pixel rows: the staged pixels (<= PPMAX - 1) end on a transfer boundary or the zero row is the
+    // first row behind the last full transfer (PPMAX = 32 k + 1: the tightest fit, configuration 4)
+    static_assert(PPMAX % 32 == 0 || PPMAX % 32 == 1, "patch transfers move 32 pixel rows");
     constexpr int PSL = PPMAX * 32;                        // bytes of one slice of a patch buffer
     constexpr int PB = 3 * PSL;                            // one patch buffer
     constexpr int WB = 3 * 3 * BN * 32;                    // one weight buffer: tap row x 3 slices x 64 rows x 32 B
@@ -195,15 +197,19 @@ __global__ __launch_bounds__(WM * WN * 64) void x3s_conv_kernel(X3Args a) {
     // pattern the half-swap swizzle makes conflict-free (with W + 2 columns every image-row end shifted the later lanes by
     // two rows: 13 % of the LDS cycles were bank conflicts at W = 56, 37 % at W = 7).  A tap that leaves the image sideways
     // reads the patch's last row instead, which is kept zero.
-    const int HW = a.H * a.W, PW = a.W, HP = a.H + 2;
+    // The patch is a CONTIGUOUS run of real pixels: from the start of the image row above the tile's first pixel to the end of
+    // the row below its last one (rows of consecutive images follow each other in memory).  No padding rows are staged: a
+    // tap that leaves the image upwards / downwards reads the zero row too (the row it would otherwise hit belongs to the
+    // neighbouring image and is simply not used) -- a 128-pixel tile of a 28-wide map needs 224 rows instead of 280, which
+    // is what lets two workgroups share a CU there.
+    const int HW = a.H * a.W, PW = a.W;
     constexpr int ZROW = PPMAX - 1;
     const int m0 = blockIdx.x * BM;
     const int mlast = (m0 + BM < a.M ? m0 + BM : a.M) - 1;
-    const int n0 = m0 / HW, y0 = (m0 - n0 * HW) / a.W;
-    const int n1 = mlast / HW, y1 = (mlast - n1 * HW) / a.W;
-    const int g0m1 = n0 * HP + y0;                         // padded global row of the patch's first row
-    const int NR = n1 * HP + y1 + 1 - g0m1 + 2;
-    const int PP = NR * PW;
+    const int r_first = m0 / PW, r_last = mlast / PW;      // global pixel rows (n * H + y) of the tile's first / last pixel
+    const int f0 = (r_first > 0 ? r_first - 1 : 0) * PW;   // first staged pixel
+    const int f1 = (r_last + 2) * PW < a.M ? (r_last + 2) * PW : a.M;   // one past the last staged pixel
+    const int PP = f1 - f0;
     const int ND = (PP + 31) >> 5;                         // transfers per slice
 
     // ---- this lane's patch transfers: instruction d = wave + NW k moves patch rows 32 d .. 32 d + 31 ----
@@ -211,14 +217,7 @@ __global__ __launch_bounds__(WM * WN * 64) void x3s_conv_kernel(X3Args a) {
 #pragma unroll
     for (int k = 0; k < NDW; ++k) {
         const int pr = 32 * (wave + NA * k) + (lane >> 1), h = lane & 1;
-        pvoff[k] = OOB;
-        if (pr < PP) {
-            const int prow = pr / PW, col = pr - prow * PW;
-            const int g = g0m1 + prow;
-            const int n = g / HP, yy = g - n * HP - 1, xx = col;
-            if (n < a.N && yy >= 0 && yy < a.H)
-                pvoff[k] = (unsigned)((n * a.H + yy) * a.W + xx) * 32u + (unsigned)((h ^ ((pr >> 3) & 1)) << 4);
-        }
+        pvoff[k] = pr < PP ? (unsigned)(f0 + pr) * 32u + (unsigned)((h ^ ((pr >> 3) & 1)) << 4) : OOB;
     }
     // ---- fragment addresses: B operand (activations) per tile and tap; A operand (weights) per lane ----
     int xaddr[TM][9];
@@ -227,11 +226,11 @@ __global__ __launch_bounds__(WM * WN * 64) void x3s_conv_kernel(X3Args a) {
         int m = m0 + (wm * TM + i) * 32 + l31;
         if (m > mlast) m = mlast;                          // rows beyond M: a valid address, result not stored
         const int n = m / HW, rem = m - n * HW, yy = rem / a.W, xx = rem - yy * a.W;
-        const int pp = (n * HP + yy + 1 - g0m1) * PW + xx;
+        const int pp = m - f0;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int dx = CLS == 4 ? (t % 3 == 0 ? 1 : 0) : t % 3 - 1, dy = CLS == 4 ? (t / 3 == 0 ? 1 : 0) : t / 3 - 1;
-            const int row = (xx + dx >= 0 && xx + dx < a.W) ? pp + dy * PW + dx : ZROW;
+            const int row = (xx + dx >= 0 && xx + dx < a.W && yy + dy >= 0 && yy + dy < a.H) ? pp + dy * PW + dx : ZROW;
             xaddr[i][t] = row * 32 + ((khalf ^ ((row >> 3) & 1)) << 4);
         }
     }
@@ -518,26 +517,24 @@ __global__ __launch_bounds__(WM * WN * 64) void x3s_conv_kernel(X3Args a) {
 // patch pixels the tiles of BM consecutive output pixels need at most: rows spanned + halo + the zero rows between images
 int patch_pixels_max(int N, int H, int W, int BM) {
     const long M = (long)N * H * W;
-    const int HW = H * W, HP = H + 2;
     int worst = 0;
-    // tile starts repeat with period lcm(BM, HW) pixels; scanning one period (at most HW tiles) is exact
+    // tile starts repeat with period lcm(BM, W) pixels; scanning W tiles (or all of them) is exact
     long tiles = (M + BM - 1) / BM;
-    if (tiles > HW) tiles = HW;
+    if (tiles > W) tiles = W;
     for (long t = 0; t < tiles; ++t) {
         const long m0 = t * BM, ml = (m0 + BM < M ? m0 + BM : M) - 1;
-        const int n0 = (int)(m0 / HW), y0 = (int)((m0 - (long)n0 * HW) / W);
-        const int n1 = (int)(ml / HW), y1 = (int)((ml - (long)n1 * HW) / W);
-        const int NR = n1 * HP + y1 + 1 - (n0 * HP + y0) + 2;
-        if (NR * W + 1 > worst) worst = NR * W + 1;              // rows of W pixels (no halo columns) + the zero row
+        const long r0 = m0 / W, r1 = ml / W;
+        const long f0 = (r0 > 0 ? r0 - 1 : 0) * W, f1 = (r1 + 2) * W;       // (interior tiles: the clipped ones are smaller)
+        if ((int)(f1 - f0) + 1 > worst) worst = (int)(f1 - f0) + 1;        // staged pixels + the zero row
     }
     return worst;
 }
 
 struct X3Cfg { int id, BM, PPMAX, threads; };
 // configurations: 0 = 256 pixels, 8 waves (one tile of 32 x 64 each), 1 = 128 pixels, 4 waves, 2 = 64 pixels, 2 waves
-// 4: 128 pixels, 4 waves, a patch of <= 224 pixels (the 14- and 7-wide maps): 79,872 B of LDS -- TWO workgroups per CU, so that
+// 4: 128 pixels, 4 waves, a patch of <= 224 pixels (the 28-, 14- and 7-wide maps): 80,064 B of LDS -- TWO workgroups per CU, so that
 // one's prologue / epilogue (20 % of a tile, profiles/r3_x3s_ablation.txt) runs under the other's main loop
-constexpr X3Cfg X3CFGS[] = {{0, 256, 608, 512}, {1, 128, 320, 256}, {2, 64, 192, 128}, {3, 256, 608, 256}, {4, 128, 224, 256}};   // 3 (measurement): 4 waves of 64 x 64
+constexpr X3Cfg X3CFGS[] = {{0, 256, 608, 512}, {1, 128, 320, 256}, {2, 64, 192, 128}, {3, 256, 608, 256}, {4, 128, 225, 256}};   // 3 (measurement): 4 waves of 64 x 64
 
 bool x3s_shape_ok(int N, int H, int W, int K, int R) {
     if (N <= 0 || H <= 0 || W <= 0 || K % 32 != 0 || R % 64 != 0 || K <= 0 || R <= 0) return false;
@@ -615,7 +612,7 @@ int run_x3s(const void* xs, const void* wp, const float* addend, float* y, doubl
         case 1: return launch_x3s<4, 1, 320>(a, s);
         case 2: return launch_x3s<2, 1, 192>(a, s);
         case 3: return launch_x3s<4, 2, 608>(a, s);
-        case 4: return launch_x3s<4, 1, 224>(a, s);
+        case 4: return launch_x3s<4, 1, 225>(a, s);
         default: return fail(DMC_E_INVALID, "x3s_conv: the patch of a %d x %d image does not fit the LDS", H, W);
     }
 }
