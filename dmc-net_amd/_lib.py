@@ -56,7 +56,7 @@ SIGNATURES = {
     "dmc_bn_relu_pool_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dmc_conv_nhwc_supported": (_I, [_I] * 9),
     "dmc_conv_nhwc_stat_blocks": (_I, [_I] * 8),
-    "dmc_conv_nhwc_fwd": (_I, [_P] * 7 + [_I] * 10 + [_P]),
+    "dmc_conv_nhwc_fwd": (_I, [_P] * 7 + [_I] * 11 + [_P]),
     "dmc_conv_nhwc_stats_final": (_I, [_P, _I, _I, ctypes.c_long, _P, _P, _P, _F, _F, _P]),
     "dmc_conv_nhwc_wt_bytes": (_Z, [_I] * 4),
     "dmc_conv_nhwc_presplit_supported": (_I, [_I, _I]),
@@ -72,7 +72,7 @@ SIGNATURES = {
     "dmc_x3s_pack_weights": (_I, [_P, _P, _P, _I, _I, _P]),
     "dmc_x3s_conv_supported": (_I, [_I] * 5),
     "dmc_x3s_conv_stat_blocks": (_I, [_I] * 4),
-    "dmc_x3s_conv_fwd": (_I, [_P] * 4 + [_I] * 5 + [_P]),
+    "dmc_x3s_conv_fwd": (_I, [_P] * 4 + [_I] * 6 + [_P]),
     "dmc_x3s_conv_dgrad": (_I, [_P] * 4 + [_I] * 5 + [_P]),
     "dmc_x3s_conv_wgrad_supported": (_I, [_I] * 5),
     "dmc_x3s_conv_wgrad_bytes": (_Z, [_I] * 5),
@@ -82,7 +82,7 @@ SIGNATURES = {
     "dmc_x3s_conv_dgrad_s2": (_I, [_P] * 3 + [_I] * 5 + [_P]),
     "dmc_bn_apply_act_x3s": (_I, [_P] * 8 + [_I, _I, _I, _P]),
     "dmc_bn_act_bwd_x3s": (_I, [_P] * 13 + [_I, _I, _I, _P]),
-    "dmc_x3s_conv_dgrad_bnb": (_I, [_P] * 9 + [_I] + [_P] * 3 + [_I] * 5 + [_P]),
+    "dmc_x3s_conv_dgrad_bnb": (_I, [_P] * 9 + [_I] + [_P] + [_I] + [_P] * 2 + [_I] * 5 + [_P]),
     "dmc_bn_act_bwd_x3s_apply": (_I, [_P] * 12 + [_I, _I, _I, _P]),
     "dmc_bn_relu_pool_fwd_x3s": (_I, [_P] * 9 + [_I, _I, _I, _I, _I, _F, _F, _P]),
     "dmc_bn_relu_pool_fwd_arg": (_I, [_P] * 11 + [_I, _I, _I, _I, _I, _I, _F, _F, _P]),

@@ -57,6 +57,7 @@ struct ConvArgs {
     unsigned long long tap_dy, tap_dx, tap_w;
     int M;                 // N * OHs * OWs
     int ablate;            // measurement only (option conv_ablate): 1 = no transfers, 2 = no barriers
+    int stat_blocks = -1;  // host only: rows of stat_part the caller allocated (checked against the launch grid; -1 = no check)
 
     __host__ void set_tap(int t, int dy, int dx, int wi) {
         const unsigned long long m = ~(15ull << (4 * t));
@@ -1405,8 +1406,8 @@ int launch_wgrad2(const float* x, const float* dy, float* dw, float* workspace, 
         a.dma_per_it = (slots + its - 1) / its;
     }
     // more than 64 KB of dynamic LDS needs the attribute; set once per instantiation (thread-safe static)
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad2_kernel<KS, STRIDE>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static LdsLimit lim_attr;
+    const hipError_t attr = lim_attr.raise(reinterpret_cast<const void*>(&conv_wgrad2_kernel<KS, STRIDE>), 160 * 1024);
     if (attr != hipSuccess) return fail(DMC_E_LAUNCH, "conv_wgrad2: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
     conv_wgrad2_kernel<KS, STRIDE><<<dim3(p.tiles, p.groups), Wg2<KS>::WAVES * 64, p.lds_bytes, s>>>(a);
     int rc = check_launch("conv_wgrad2");
@@ -1650,8 +1651,8 @@ int launch_wgrad3(const float* x, const float* dy, float* dw, float* workspace, 
         const int slots = (p.dyrows / 4 + (p.XR * p.XC + 3) / 4 + 11) / 12, its = (p.G + 1) / 2;
         a.dma_per_it = (slots + its - 1) / its;
     }
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3_kernel<STRIDE>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static LdsLimit lim_attr;
+    const hipError_t attr = lim_attr.raise(reinterpret_cast<const void*>(&conv_wgrad3_kernel<STRIDE>), 160 * 1024);
     if (attr != hipSuccess) return fail(DMC_E_LAUNCH, "conv_wgrad3: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
     conv_wgrad3_kernel<STRIDE><<<dim3(p.tiles, p.groups), 768, p.lds_bytes, s>>>(a);
     int rc = check_launch("conv_wgrad3");
@@ -1749,13 +1750,23 @@ int block_pixels(int cin, int cout, long M) {
     return use_v2(cin, cout) ? block_pixels_v2(cout, M) : block_pixels_v1(cout, M);
 }
 
+// the statistics partials are [gridDim.x][Cout][2]: the caller sized them with dmc_conv_nhwc_stat_blocks(); the tile choice is
+// taken again at launch time (it reads the conv_cfg / conv_arith options), so the launch refuses a buffer of another height
+// instead of writing past it
+int stat_rows_ok(const ConvArgs& a, unsigned grid_x) {
+    if (!a.stat_part || a.stat_blocks < 0 || (unsigned)a.stat_blocks == grid_x) return DMC_OK;
+    return fail(DMC_E_INVALID, "conv_nhwc: statistics partials have %d rows but this launch writes %u (dmc_conv_nhwc_stat_blocks was "
+                               "called under other options?)", a.stat_blocks, grid_x);
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_cfg3(const ConvArgs& a, hipStream_t s) {
     constexpr size_t lds_bytes = 2 * (BM * 128 + 3 * BN * 64);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_kernel<BM, BN, WM, WN>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    static LdsLimit lim_attr;
+    const hipError_t attr = lim_attr.raise(reinterpret_cast<const void*>(&conv3_kernel<BM, BN, WM, WN>), (int)lds_bytes);
     if (attr != hipSuccess) return fail(DMC_E_LAUNCH, "conv3: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
     dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN);
+    if (int rc = stat_rows_ok(a, grid.x)) return rc;
     if constexpr (BM == 128 && BN == 128 && WM == 4 && WN == 2) {       // ablation variants of ONE configuration (measurement only)
         const int abl = a.ablate & 12;
         if (abl) {
@@ -1802,6 +1813,7 @@ int split_weights(const float* w, void* wpack, int Cout, int KK, int Cin, int tr
 template <int BM, int BN, int BK, int WM, int WN>
 int launch_cfg(const ConvArgs& a, hipStream_t s) {
     dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN);
+    if (int rc = stat_rows_ok(a, grid.x)) return rc;
     conv_nhwc_kernel<BM, BN, BK, WM, WN><<<grid, 256, 0, s>>>(a);
     return check_launch("conv_nhwc");
 }
@@ -1809,6 +1821,7 @@ int launch_cfg(const ConvArgs& a, hipStream_t s) {
 template <int BM, int BN, int WM, int WN>
 int launch_cfg2(const ConvArgs& a, hipStream_t s) {
     dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN);
+    if (int rc = stat_rows_ok(a, grid.x)) return rc;
     conv2_kernel<BM, BN, WM, WN><<<grid, WM * WN * 64, 0, s>>>(a);
     return check_launch("conv2");
 }
@@ -1857,15 +1870,17 @@ int dmc_conv_nhwc_stat_blocks(int N, int H, int W, int Cin, int Cout, int KH, in
 }
 
 int dmc_conv_nhwc_fwd(const float* x, const float* w, void* wpack, const float* bias, const float* keep, float* y,
-                      double* stat_partials, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                      double* stat_partials, int stat_blocks, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                       int pad, int act, dmc_stream_t stream) {
     if (!x || !y || (!w && !wpack)) return fail(DMC_E_INVALID, "dmc_conv_nhwc_fwd: null pointer");
+    if (stat_partials && stat_blocks <= 0) return fail(DMC_E_INVALID, "dmc_conv_nhwc_fwd: stat_blocks must be the row count of stat_partials");
     ConvShape sh = {N, H, W, Cin, Cout, KH, KW, stride, pad, 0, 0};
     if (!shape_supported(sh))
         return fail(DMC_E_INVALID, "dmc_conv_nhwc_fwd: unsupported shape N=%d H=%d W=%d Cin=%d Cout=%d k=%dx%d s=%d p=%d",
                     N, H, W, Cin, Cout, KH, KW, stride, pad);
     ConvArgs a;
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.keep = keep; a.stat_part = stat_partials;
+    a.stat_blocks = stat_partials ? stat_blocks : -1;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.OH = (H + 2 * pad - KH) / stride + 1; a.OW = (W + 2 * pad - KW) / stride + 1;
     a.KK = KH * KW; a.ntaps = KH * KW; a.stride = stride;

@@ -154,6 +154,7 @@ struct X3Args {
     const unsigned char* bnb_mask = nullptr;   // ReLU sign bits (4 per float4) or null: recomputed
     int bnb_relu = 0;
     double* bnb_part = nullptr;          // [gridDim.x][R][2]
+    int part_blocks = -1;  // host only: rows of stat_part / bnb_part the caller allocated (checked against the grid; -1 = no check)
     int ablate;            // measurement only (option conv_ablate): 16 = no wait for transfers, 32 = no statistics, 64 = no transfers,
                            // 128 = no output stores, 256 = no main loop (results wrong / missing)
 };
@@ -574,17 +575,22 @@ int launch_x3s(const X3Args& a, hipStream_t s) {
     constexpr size_t op_bytes = 2 * 3 * PPMAX * 32 + 2 * 3 * 3 * 64 * 32, ep_bytes = 2 * (size_t)BM * 272 + 8192;   // d tiles, sums, xhat tiles
     constexpr size_t lds_bytes = op_bytes > ep_bytes ? op_bytes : ep_bytes;
     dim3 grid((a.M + BM - 1) / BM, a.R / 64);
+    // the partials are [gridDim.x][R][2]: sized by the caller with dmc_x3s_conv_stat_blocks(), while the tile configuration is
+    // chosen again here (option conv_cfg): refuse a buffer of another height instead of writing past it
+    if ((a.stat_part || a.bnb_part) && a.part_blocks >= 0 && (unsigned)a.part_blocks != grid.x)
+        return fail(DMC_E_INVALID, "x3s_conv: statistics partials have %d rows but this launch writes %u (dmc_x3s_conv_stat_blocks was "
+                                   "called under another conv_cfg option?)", a.part_blocks, grid.x);
     if constexpr (WM >= 4) {
         if (!(option(OPT_CONV_ABLATE) & 512)) {               // 512: measurement, every wave issues its share behind the barrier
-            static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&x3s_conv_kernel<WM, 1, TM, 2, PPMAX, true>),
-                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            static LdsLimit lim_attr2;
+    const hipError_t attr2 = lim_attr2.raise(reinterpret_cast<const void*>(&x3s_conv_kernel<WM, 1, TM, 2, PPMAX, true>), (int)lds_bytes);
             if (attr2 != hipSuccess) return fail(DMC_E_LAUNCH, "x3s_conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr2));
             x3s_conv_kernel<WM, 1, TM, 2, PPMAX, true><<<grid, WM * 64, lds_bytes, s>>>(a);
             return check_launch("x3s_conv");
         }
     }
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&x3s_conv_kernel<WM, 1, TM, 2, PPMAX>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    static LdsLimit lim_attr;
+    const hipError_t attr = lim_attr.raise(reinterpret_cast<const void*>(&x3s_conv_kernel<WM, 1, TM, 2, PPMAX>), (int)lds_bytes);
     if (attr != hipSuccess) return fail(DMC_E_LAUNCH, "x3s_conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
     x3s_conv_kernel<WM, 1, TM, 2, PPMAX><<<grid, WM * 64, lds_bytes, s>>>(a);
     return check_launch("x3s_conv");
@@ -592,8 +598,8 @@ int launch_x3s(const X3Args& a, hipStream_t s) {
 
 struct X3Bnb { const float *y, *stats, *gamma, *beta; const unsigned char* mask; int relu; double* part; };
 
-int run_x3s(const void* xs, const void* wp, const float* addend, float* y, double* stat_part, int N, int H, int W, int K, int R,
-            hipStream_t s, const X3Bnb* bnb = nullptr) {
+int run_x3s(const void* xs, const void* wp, const float* addend, float* y, double* stat_part, int part_blocks, int N, int H, int W,
+            int K, int R, hipStream_t s, const X3Bnb* bnb = nullptr) {
     if (!xs || !wp || !y) return fail(DMC_E_INVALID, "x3s_conv: null pointer");
     if (!x3s_shape_ok(N, H, W, K, R)) return fail(DMC_E_INVALID, "x3s_conv: unsupported shape N=%d H=%d W=%d K=%d R=%d", N, H, W, K, R);
     const int cfg = x3s_choose(N, H, W, R);
@@ -601,6 +607,8 @@ int run_x3s(const void* xs, const void* wp, const float* addend, float* y, doubl
     a.xs = xs; a.wp = wp; a.y = y; a.addend = addend; a.stat_part = stat_part;
     a.N = N; a.H = H; a.W = W; a.K = K; a.R = R; a.M = N * H * W;
     a.plane_bytes = (unsigned)a.M * 32u;
+    a.part_blocks = part_blocks;
+    if ((stat_part || bnb) && part_blocks <= 0) return fail(DMC_E_INVALID, "x3s_conv: stat_blocks must be the row count of the partials");
     if (bnb) {
         a.bnb_y = bnb->y; a.bnb_stats = bnb->stats; a.bnb_gamma = bnb->gamma; a.bnb_beta = bnb->beta; a.bnb_mask = bnb->mask;
         a.bnb_relu = bnb->relu; a.bnb_part = bnb->part;
@@ -828,8 +836,8 @@ template <int W_, int R>
 int launch_x3s_wgrad(const X3WgPlan& p, X3WgArgs a, float* dw, hipStream_t s) {
     using G = WgGeom<W_, R>;
     static_assert(G::LDS <= 160 * 1024, "weight-gradient tiles exceed the LDS");
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&x3s_wgrad_kernel<W_, R>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    static LdsLimit lim_attr;
+    const hipError_t attr = lim_attr.raise(reinterpret_cast<const void*>(&x3s_wgrad_kernel<W_, R>), G::LDS);
     if (attr != hipSuccess) return fail(DMC_E_LAUNCH, "x3s_wgrad: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
     x3s_wgrad_kernel<W_, R><<<dim3(p.tiles, p.groups), 768, G::LDS, s>>>(a);
     int rc = check_launch("x3s_wgrad");
@@ -906,14 +914,14 @@ int dmc_x3s_conv_stat_blocks(int N, int H, int W, int Cout) {
     return (int)((M + X3CFGS[cfg].BM - 1) / X3CFGS[cfg].BM);
 }
 
-int dmc_x3s_conv_fwd(const void* xs, const void* wpack_f, float* y, double* stat_partials, int N, int H, int W, int Cin, int Cout,
-                     dmc_stream_t stream) {
-    return run_x3s(xs, wpack_f, nullptr, y, stat_partials, N, H, W, Cin, Cout, (hipStream_t)stream);
+int dmc_x3s_conv_fwd(const void* xs, const void* wpack_f, float* y, double* stat_partials, int stat_blocks, int N, int H, int W,
+                     int Cin, int Cout, dmc_stream_t stream) {
+    return run_x3s(xs, wpack_f, nullptr, y, stat_partials, stat_blocks, N, H, W, Cin, Cout, (hipStream_t)stream);
 }
 
 int dmc_x3s_conv_dgrad(const void* dys, const void* wpack_t, const float* addend, float* dx, int N, int H, int W, int Cin, int Cout,
                        dmc_stream_t stream) {
-    return run_x3s(dys, wpack_t, addend, dx, nullptr, N, H, W, Cout, Cin, (hipStream_t)stream);
+    return run_x3s(dys, wpack_t, addend, dx, nullptr, -1, N, H, W, Cout, Cin, (hipStream_t)stream);
 }
 
 int dmc_x3s_conv_wgrad_supported(int N, int H, int W, int Cin, int Cout) {
@@ -976,8 +984,8 @@ int dmc_x3s_conv_dgrad_s2(const void* dys, const void* wpack_t2, float* dx, int 
     a.plane_bytes = (unsigned)a.M * 32u;
     a.ablate = option(OPT_CONV_ABLATE);
     constexpr size_t lds_bytes = 2 * 3 * 320 * 32 + 2 * 3 * 3 * 64 * 32;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&x3s_conv_kernel<4, 1, 1, 2, 320, true, 4>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    static LdsLimit lim_attr;
+    const hipError_t attr = lim_attr.raise(reinterpret_cast<const void*>(&x3s_conv_kernel<4, 1, 1, 2, 320, true, 4>), (int)lds_bytes);
     if (attr != hipSuccess) return fail(DMC_E_LAUNCH, "x3s_conv_dgrad_s2: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
     dim3 grid((a.M + 127) / 128, Cin / 64);
     x3s_conv_kernel<4, 1, 1, 2, 320, true, 4><<<grid, 256, lds_bytes, (hipStream_t)stream>>>(a);
@@ -986,18 +994,18 @@ int dmc_x3s_conv_dgrad_s2(const void* dys, const void* wpack_t2, float* dx, int 
 
 /* dmc_x3s_conv_dgrad that ALSO reduces the BatchNorm-backward sums of the unit whose output gradient it writes (dx is that
  * unit's dout): bn_y / bn_stats / bn_gamma / bn_beta / bn_relu_mask (nullable) / bn_relu describe that unit's BatchNorm
- * [+ ReLU]; partials = dmc_x3s_conv_stat_blocks(N, H, W, Cin) x Cin x 2 doubles of workspace; dgamma / dbeta [Cin] receive
+ * [+ ReLU]; partials = stat_blocks = dmc_x3s_conv_stat_blocks(N, H, W, Cin) rows x Cin x 2 doubles of workspace; dgamma / dbeta [Cin] receive
  * sum(d * xhat) / sum(d) with d = dx [zeroed where the ReLU was off] -- what dmc_bn_act_bwd's first pass computes. */
 int dmc_x3s_conv_dgrad_bnb(const void* dys, const void* wpack_t, const float* addend, float* dx, const float* bn_y,
                            const float* bn_stats, const float* bn_gamma, const float* bn_beta, const unsigned char* bn_relu_mask,
-                           int bn_relu, double* partials, float* dgamma, float* dbeta, int N, int H, int W, int Cin, int Cout,
-                           dmc_stream_t stream) {
+                           int bn_relu, double* partials, int stat_blocks, float* dgamma, float* dbeta, int N, int H, int W, int Cin,
+                           int Cout, dmc_stream_t stream) {
     if (!bn_y || !bn_stats || !bn_gamma || !bn_beta || !partials || !dgamma || !dbeta)
         return fail(DMC_E_INVALID, "dmc_x3s_conv_dgrad_bnb: null pointer");
     X3Bnb b = {bn_y, bn_stats, bn_gamma, bn_beta, bn_relu_mask, bn_relu, partials};
-    int rc = run_x3s(dys, wpack_t, addend, dx, nullptr, N, H, W, Cout, Cin, (hipStream_t)stream, &b);
+    int rc = run_x3s(dys, wpack_t, addend, dx, nullptr, stat_blocks, N, H, W, Cout, Cin, (hipStream_t)stream, &b);
     if (rc) return rc;
-    x3s_bnb_final_kernel<<<Cin, 256, 0, (hipStream_t)stream>>>(partials, dmc_x3s_conv_stat_blocks(N, H, W, Cin), Cin, dgamma, dbeta);
+    x3s_bnb_final_kernel<<<Cin, 256, 0, (hipStream_t)stream>>>(partials, stat_blocks, Cin, dgamma, dbeta);
     return check_launch("x3s_bnb_final");
 }
 

@@ -4,6 +4,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "dmcnet_hip.h"
 
 namespace dmc {
@@ -25,6 +27,23 @@ inline int check_launch(const char* what) {
     if (e != hipSuccess) return fail(DMC_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
     return DMC_OK;
 }
+
+// ---- dynamic LDS above 64 KB -----------------------------------------------------------------
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE): one function-static per launch site
+// remembers on which devices of this process it has been raised (a process that drives a second GPU would otherwise
+// fail every > 64 KB launch there).  Thread-safe: a relaxed bit mask; setting the attribute twice is harmless.
+struct LdsLimit {
+    std::atomic<unsigned long long> raised{0};
+    hipError_t raise(const void* kernel, int bytes) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64 && ((raised.load(std::memory_order_relaxed) >> dev) & 1ull)) return hipSuccess;
+        e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess && dev >= 0 && dev < 64) raised.fetch_or(1ull << dev, std::memory_order_relaxed);
+        return e;
+    }
+};
 
 // ---- kernel-selection options (dmc_set_option / dmc_get_option, storage in losses.hip) ----------
 // The library never reads the environment.  These few integers select between kernel variants for

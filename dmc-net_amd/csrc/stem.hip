@@ -380,11 +380,16 @@ __global__ __launch_bounds__(SX_THREADS) void stem_fwd_x3_kernel(StemX3Args a) {
     const int woff = l31 * 32 + half * 16;
     float* ep = reinterpret_cast<float*>(wlds3 + SX_WLDS + wave * SX_EP_BYTES);
     const int q8 = lane >> 3, c4 = (lane & 7) * 4;
-    float ssum[2][4], ssq[2][4];                            // channels 32 ct + c4 .. + 3, pixels = q8 (mod 8)
+    // Statistics: per lane, sums of (v - K) and (v - K)^2 in fp32 around a PIVOT K = the lane's first value of each channel
+    // (|v - K| is of the order of the standard deviation, so E[x^2] - E[x]^2 does not cancel when |mean| >> std as plain
+    // fp32 sums of v and v^2 would); the pivot is removed in fp64 before the lanes / waves are combined.
+    float ssum[2][4], ssq[2][4], piv[2][4];                 // channels 32 ct + c4 .. + 3, pixels = q8 (mod 8)
+    int cnt = 0;                                            // values per channel this lane has added
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ssum[ct][j] = ssq[ct][j] = 0.f;
+        for (int j = 0; j < 4; ++j) ssum[ct][j] = ssq[ct][j] = piv[ct][j] = 0.f;
+    bool first_tile = true;
     for (long tile = (long)blockIdx.x * SX_WAVES + wave; tile < ntiles; tile += stride) {
         const int xt = (int)(tile % a.tiles_x);
         const long r = tile / a.tiles_x;                    // n * OH + oy
@@ -434,46 +439,51 @@ __global__ __launch_bounds__(SX_THREADS) void stem_fwd_x3_kernel(StemX3Args a) {
             for (int i = 0; i < 4; ++i) {
                 const int px = 8 * i + q8;
                 const float4 v = *reinterpret_cast<const float4*>(ep + px * SX_EP_PITCH + c4);
+                if (first_tile && i == 0) {                  // (wave-uniform) any finite pivot is exact; this one is close to the mean
+                    piv[ct][0] = v.x; piv[ct][1] = v.y; piv[ct][2] = v.z; piv[ct][3] = v.w;
+                }
                 if (32 * xt + px < a.OW) {
                     *reinterpret_cast<float4*>(dst + (long)px * S_CO + 32 * ct) = v;
                     if (a.stat_part) {
-                        ssum[ct][0] += v.x; ssum[ct][1] += v.y; ssum[ct][2] += v.z; ssum[ct][3] += v.w;
-                        ssq[ct][0] = fmaf(v.x, v.x, ssq[ct][0]); ssq[ct][1] = fmaf(v.y, v.y, ssq[ct][1]);
-                        ssq[ct][2] = fmaf(v.z, v.z, ssq[ct][2]); ssq[ct][3] = fmaf(v.w, v.w, ssq[ct][3]);
+                        const float d0 = v.x - piv[ct][0], d1 = v.y - piv[ct][1], d2 = v.z - piv[ct][2], d3 = v.w - piv[ct][3];
+                        ssum[ct][0] += d0; ssum[ct][1] += d1; ssum[ct][2] += d2; ssum[ct][3] += d3;
+                        ssq[ct][0] = fmaf(d0, d0, ssq[ct][0]); ssq[ct][1] = fmaf(d1, d1, ssq[ct][1]);
+                        ssq[ct][2] = fmaf(d2, d2, ssq[ct][2]); ssq[ct][3] = fmaf(d3, d3, ssq[ct][3]);
+                        if (ct == 0) ++cnt;
                     }
                 }
             }
             __builtin_amdgcn_wave_barrier();
         }
+        first_tile = false;
     }
     if (!a.stat_part) return;
-    // over the eight pixel groups of the wave (fixed order), then over the waves in fp64 (fixed order)
+    // pivot removed in fp64 (sum v = S1 + n K, sum v^2 = S2 + 2 K S1 + n K^2), then over the eight pixel groups of the wave
+    // and over the waves, all in fp64 and in a fixed order
+    __syncthreads();                                          // every wave is done with the weights in LDS
+    double* red = reinterpret_cast<double*>(wlds3);           // [wave][which][channel]
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
+            const double k = (double)piv[ct][j], s1 = (double)ssum[ct][j], nn = (double)cnt;
+            double t1 = s1 + nn * k, t2 = (double)ssq[ct][j] + 2.0 * k * s1 + nn * k * k;
 #pragma unroll
             for (int m = 8; m < 64; m <<= 1) {
-                ssum[ct][j] += __shfl_xor(ssum[ct][j], m, 64);
-                ssq[ct][j] += __shfl_xor(ssq[ct][j], m, 64);
+                t1 += __shfl_xor(t1, m, 64);
+                t2 += __shfl_xor(t2, m, 64);
             }
-    __syncthreads();                                          // every wave is done with the weights in LDS
-    float* red = reinterpret_cast<float*>(wlds3);             // [wave][which][channel]
-    if (lane < 8) {
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                red[(wave * 2 + 0) * S_CO + 32 * ct + c4 + j] = ssum[ct][j];
-                red[(wave * 2 + 1) * S_CO + 32 * ct + c4 + j] = ssq[ct][j];
+            if (lane < 8) {
+                red[(wave * 2 + 0) * S_CO + 32 * ct + c4 + j] = t1;
+                red[(wave * 2 + 1) * S_CO + 32 * ct + c4 + j] = t2;
             }
-    }
+        }
     __syncthreads();
     if (tid < 2 * S_CO) {
         const int c = tid & (S_CO - 1), which = tid >> 6;
         double t = 0.0;
 #pragma unroll
-        for (int w8 = 0; w8 < SX_WAVES; ++w8) t += (double)red[(w8 * 2 + which) * S_CO + c];
+        for (int w8 = 0; w8 < SX_WAVES; ++w8) t += red[(w8 * 2 + which) * S_CO + c];
         a.stat_part[((size_t)c * BN_MAX_SPLIT + blockIdx.x) * 2 + which] = t;
     }
 }
@@ -690,8 +700,8 @@ int dmc_stem_fwd_x3_stats(const float* x, const float* w, long ws_co, long ws_ci
     a.tiles_x = (a.OW + 31) / 32; a.vol = vol;
     a.stat_part = static_cast<double*>(stat_scratch);
     const long blocks = dmc_stem_fwd_x3_stat_blocks(N, H, W);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_x3_kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, SX_LDS);
+    static LdsLimit lim_attr;
+    const hipError_t attr = lim_attr.raise(reinterpret_cast<const void*>(&stem_fwd_x3_kernel), SX_LDS);
     if (attr != hipSuccess) return fail(DMC_E_LAUNCH, "dmc_stem_fwd_x3: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
     stem_fwd_x3_kernel<<<(int)blocks, SX_THREADS, SX_LDS, s>>>(a);
     return check_launch("stem_fwd_x3");

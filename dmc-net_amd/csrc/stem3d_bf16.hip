@@ -470,8 +470,8 @@ int dmc_stem3d_bf16_fwd(const float* x, const float* w, void* workspace, void* y
     a.xq = xq; a.wp = wp; a.y = (bf16_t*)y; a.stat_part = stat_partials;
     a.N = N; a.OD = (T + 5 - 7) / 2 + 1; a.OH = (H + 5 - 7) / 2 + 1; a.OW = (W + 5 - 7) / 2 + 1;
     a.Tp = Tp; a.Hp = Hp; a.Wp = Wp; a.tiles_x = (a.OW + 31) / 32;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&stem3d_fwd_kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, S3_WLDS);
+    static LdsLimit lim_attr;
+    const hipError_t attr = lim_attr.raise(reinterpret_cast<const void*>(&stem3d_fwd_kernel), S3_WLDS);
     if (attr != hipSuccess) return fail(DMC_E_LAUNCH, "stem3d: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
     const long tiles = (long)N * a.OD * a.OH * a.tiles_x;
     stem3d_fwd_kernel<<<s3_blocks(tiles), S3_WAVES * 64, S3_WLDS, s>>>(a);

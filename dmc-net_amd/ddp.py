@@ -92,6 +92,7 @@ class GradBucketReducer(object):
         #: from HIP events on the compute stream when the buckets live on the GPU, host time otherwise)
         self.time_waits = False
         self._wait_events = []
+        self._wait_ms_folded = 0.0       # elapsed time of event pairs already folded away (bounded memory in long runs)
         self._wait_host_s = 0.0
         self._finished_steps = 0
         if self.world > 1 and broadcast_from is not None:
@@ -190,6 +191,16 @@ class GradBucketReducer(object):
         if on_gpu:
             e1.record()
             self._wait_events.append((e0, e1))
+            if len(self._wait_events) >= 256:
+                # fold the pairs that have completed into a running sum: a long run that never calls comm_summary() keeps
+                # at most a few hundred events (query() does not block; the newest pairs may still be in flight)
+                keep = []
+                for a, b in self._wait_events:
+                    if b.query():
+                        self._wait_ms_folded += a.elapsed_time(b)
+                    else:
+                        keep.append((a, b))
+                self._wait_events = keep
         if timed:
             self._wait_host_s += time.perf_counter() - t0
         if self.time_waits:
@@ -202,9 +213,10 @@ class GradBucketReducer(object):
         in finish(); everything else overlapped the backward pass) accumulated since ``time_waits`` was set."""
         exposed_ms = None
         steps = self._finished_steps
-        if self._wait_events:
-            torch.cuda.synchronize()
-            exposed_ms = sum(a.elapsed_time(b) for a, b in self._wait_events)
+        if self._wait_events or self._wait_ms_folded:
+            if self._wait_events:
+                self._wait_events[-1][1].synchronize()       # the newest pair's end: every earlier pair has completed too
+            exposed_ms = self._wait_ms_folded + sum(a.elapsed_time(b) for a, b in self._wait_events)
         out = {
             "backend": dist.get_backend(self.group) if dist.is_initialized() else None,
             "world_size": self.world,
@@ -217,7 +229,7 @@ class GradBucketReducer(object):
             "exposed_wait_host_ms_per_step": round(1e3 * self._wait_host_s / steps, 4) if steps else None,
         }
         if reset:
-            self._wait_events, self._wait_host_s, self._finished_steps = [], 0.0, 0
+            self._wait_events, self._wait_host_s, self._finished_steps, self._wait_ms_folded = [], 0.0, 0, 0.0
         return out
 
     def reduced_bytes(self, by_set=False):

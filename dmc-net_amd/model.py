@@ -4,9 +4,11 @@ Same constructor, attribute names (``base_model``, ``gen_flow_model``, ``discrim
 ``data_bn``, ``downsample``), state-dict keys, ``forward`` contracts, ``crop_size`` /
 ``scale_size`` / ``get_augmentation`` as code/dmcnet/model.py:253-378 and
 code/dmcnet_GAN/model.py:442-585 (paths relative to the reference root).  What differs is
-where the arithmetic runs: the DenseNetTiny generator (+ cat + delta add) and the
-discriminator block tails are hand-written HIP kernels (``ops``), the convolutions of the
-ResNet / discriminator go to PyTorch-ROCm.  Passing ``arch_d`` selects the GAN variant.
+where the arithmetic runs: the DenseNetTiny generator (+ cat + delta add), the ResNet's
+convolutions / BatchNorms / stem (``resnet.py`` -> ``ops.conv_bn_act``, ``ops.stem_conv``, ...) and
+the Discriminator3 blocks (``ops.disc_block``) are hand-written HIP kernels behind the C ABI; only
+the API-only estimator / discriminator variants and the two ``nn.Linear`` heads stay on
+PyTorch-ROCm ops.  Passing ``arch_d`` selects the GAN variant.
 """
 import torch
 from torch import nn

@@ -692,7 +692,7 @@ def _conv_fwd(x, weight, bias, keep, stride, padding, act, want_stats, presplit=
     wpack = presplit if presplit is not None else _floats(lib.dmc_conv_nhwc_wt_bytes(cin, cout, kh, kw), x.device)
     wptr = None if presplit is not None else _lib.ptr(weight)      # NULL: wpack already holds the slices
     _lib.check(lib.dmc_conv_nhwc_fwd(_lib.ptr(x), wptr, _lib.ptr(wpack), _lib.ptr(bias), _lib.ptr(keep), _lib.ptr(y),
-                                     _lib.ptr(part), n, h, w, cin, cout, kh, kw, stride, padding, int(act),
+                                     _lib.ptr(part), nblk, n, h, w, cin, cout, kh, kw, stride, padding, int(act),
                                      _stream()), "dmc_conv_nhwc_fwd")
     return y, part, nblk
 
@@ -833,10 +833,11 @@ def x3s_conv_fwd(xs, wpack_f, n, h, w, cin, cout, want_stats=False):
     partials [blocks, Cout, 2] float64 or None)."""
     lib = _lib.load()
     y = torch.empty((n, cout, h, w), dtype=torch.float32, device=xs.device, memory_format=torch.channels_last)
-    part = None
+    part, nblk = None, 0
     if want_stats:
-        part = torch.empty((lib.dmc_x3s_conv_stat_blocks(n, h, w, cout), cout, 2), dtype=torch.float64, device=xs.device)
-    _lib.check(lib.dmc_x3s_conv_fwd(_lib.ptr(xs), _lib.ptr(wpack_f), _lib.ptr(y), _lib.ptr(part), n, h, w, cin, cout, _stream()),
+        nblk = lib.dmc_x3s_conv_stat_blocks(n, h, w, cout)
+        part = torch.empty((nblk, cout, 2), dtype=torch.float64, device=xs.device)
+    _lib.check(lib.dmc_x3s_conv_fwd(_lib.ptr(xs), _lib.ptr(wpack_f), _lib.ptr(y), _lib.ptr(part), nblk, n, h, w, cin, cout, _stream()),
                "dmc_x3s_conv_fwd")
     return y, part
 
@@ -896,6 +897,7 @@ _WGRAD_STREAMS = {}
 _WGRAD_PENDING = [False]
 _WGRAD_SCOPE = [0]
 _WGRAD_COUNT = [0]            # launches that went to the side stream (diagnostics / tests)
+_WGRAD_SEEN = set()           # id() of the weights whose gradient went to the side stream since the last join
 
 
 class wgrad_side_stream(object):
@@ -904,6 +906,7 @@ class wgrad_side_stream(object):
 
     def __enter__(self):
         _WGRAD_SCOPE[0] += 1
+        _WGRAD_SEEN.clear()
         return self
 
     def __exit__(self, *exc):
@@ -921,6 +924,7 @@ def _wgrad_stream(device):
 
 def join_wgrad_stream():
     """The current stream waits for the weight gradients launched on the side stream (no-op when none are pending)."""
+    _WGRAD_SEEN.clear()
     if _WGRAD_PENDING[0]:
         cur = torch.cuda.current_stream()
         for st in _WGRAD_STREAMS.values():
@@ -934,6 +938,19 @@ def _on_wgrad_stream(weight, reads, launch):
     returns) and with no gradient to accumulate into (``weight.grad += dw`` would run on the main stream at once)."""
     if not WGRAD_STREAM or _WGRAD_SCOPE[0] <= 0 or weight.grad is not None:
         return launch()
+    # a weight used TWICE in one backward pass (a shared convolution, a module called twice): the engine sums the two
+    # gradients on the main stream -- in its input buffer or in AccumulateGrad -- believing the main stream produced the
+    # first one.  The second sighting therefore re-joins (the first gradient is complete on the main stream) and stays there.
+    if id(weight) in _WGRAD_SEEN:
+        join_wgrad_stream()
+        return launch()
+    # C++-level gradient hooks (torch's DistributedDataParallel reducer) read the gradient on the main stream the moment it
+    # is accumulated and are not visible from Python: with a process group up, only parameters that carry THIS package's
+    # deferring hook (ddp.GradBucketReducer) may use the side stream
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        post_ = getattr(weight, "_post_accumulate_grad_hooks", None)
+        if not post_ or not all(getattr(h, "_dmc_defers_read", False) for h in post_.values()):
+            return launch()
     # a hook that reads the gradient the moment it is accumulated would read it on the main stream, before the side stream
     # has written it: only hooks that declare they defer the read (the gradient exchange's, ddp.py) are compatible
     if getattr(weight, "_backward_hooks", None):
@@ -954,6 +971,7 @@ def _on_wgrad_stream(weight, reads, launch):
         t.record_stream(side)                   # their memory is not reused before the side stream has read it
     _WGRAD_PENDING[0] = True
     _WGRAD_COUNT[0] += 1
+    _WGRAD_SEEN.add(id(weight))
     with torch.cuda.stream(side):
         dw = launch()
     dw.record_stream(main)
@@ -1011,7 +1029,7 @@ class _ConvBnAct(torch.autograd.Function):
                 y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device, memory_format=_CL)
                 nblk = lib.dmc_x3s_conv_stat_blocks(n, h, w, cout)
                 part = torch.empty((nblk, cout, 2), dtype=torch.float64, device=x.device)
-                _lib.check(lib.dmc_x3s_conv_fwd(_lib.ptr(xs), _lib.ptr(wf), _lib.ptr(y), _lib.ptr(part), n, h, w, cin, cout,
+                _lib.check(lib.dmc_x3s_conv_fwd(_lib.ptr(xs), _lib.ptr(wf), _lib.ptr(y), _lib.ptr(part), nblk, n, h, w, cin, cout,
                                                 _stream()), "dmc_x3s_conv_fwd")
             wf_ok = True
             if bn_in is not None and stride == 1 and ctx.needs_input_grad[0]:
@@ -1151,7 +1169,7 @@ class _ConvBnAct(torch.autograd.Function):
                         bl.dgamma, bl.dbeta = torch.empty_like(bl.gamma), torch.empty_like(bl.gamma)
                         _lib.check(lib.dmc_x3s_conv_dgrad_bnb(_lib.ptr(dys), _lib.ptr(ctx.wsplit_t), _lib.ptr(addend), _lib.ptr(dx),
                                                               _lib.ptr(bl.y), _lib.ptr(bl.stats), _lib.ptr(bl.gamma), _lib.ptr(bl.beta),
-                                                              _lib.ptr(bl.mask), int(bl.relu), _lib.ptr(part), _lib.ptr(bl.dgamma),
+                                                              _lib.ptr(bl.mask), int(bl.relu), _lib.ptr(part), nblk, _lib.ptr(bl.dgamma),
                                                               _lib.ptr(bl.dbeta), nn_, h, w, cin, cout, _stream()),
                                    "dmc_x3s_conv_dgrad_bnb")
                         bl.ready = True

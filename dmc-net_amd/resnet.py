@@ -36,10 +36,20 @@ OWN_CONV = _os.environ.get("DMC_OWN_CONV", "1") != "0"
 RESIDUAL_GRAD_LINK = _os.environ.get("DMC_RESIDUAL_GRAD_LINK", "1") != "0"
 
 
-def _conv_bn_act(conv, bn, x, residual=None, relu=True, link=None, next_conv=None, only_consumer=False, bn_link=None):
+def _same_bn_mode(bn, other):
+    """True if ``other`` (the consumer's BatchNorm) will qualify for the same fused op as ``bn`` does now: the producer may
+    then leave the fp32 form of its result unwritten.  A block whose BatchNorms are in mixed states (one in eval mode,
+    momentum=None, affine=False ...) keeps the fp32 form and the consumer falls back to the stock modules."""
+    return (other is not None and other.training == bn.training and other.track_running_stats and other.affine
+            and other.momentum is not None)
+
+
+def _conv_bn_act(conv, bn, x, residual=None, relu=True, link=None, next_conv=None, only_consumer=False, bn_link=None,
+                 next_bn=None):
     """relu?(bn(conv(x)) [+ residual]).  ``next_conv``: a convolution that reads the result -- when it takes the
     pre-split bf16x3 path (ops.x3s_usable) the result's slice tensor is written alongside; ``only_consumer``: nothing
-    else reads the result, so its fp32 form is not written at all."""
+    else reads the result, so its fp32 form is not written at all (only when ``next_bn``, the consumer's BatchNorm, is
+    in the same mode as ``bn``: the consumer then takes the fused op that reads slices)."""
     train_op = OWN_CONV and x.is_cuda and ops.conv_bn_act_supported(x, conv, bn)
     eval_op = OWN_CONV and x.is_cuda and not train_op and ops.conv_bn_eval_supported(x, conv, bn)
     if train_op or eval_op:
@@ -48,6 +58,7 @@ def _conv_bn_act(conv, bn, x, residual=None, relu=True, link=None, next_conv=Non
             n, _, h, w = x.shape
             k, s_, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
             slices = ops.x3s_usable(n, (h + 2 * p - k) // s_ + 1, (w + 2 * p - k) // s_ + 1, next_conv)
+            only_consumer = only_consumer and _same_bn_mode(bn, next_bn)
         if eval_op:     # evaluation / validation: running statistics, forward only, the same convolution kernels
             return ops.conv_bn_act_eval(x, conv, bn, residual, relu, want_f32=not (slices and only_consumer), want_slices=slices)
         return ops.conv_bn_act(x, conv, bn, residual, relu, link, want_f32=not (slices and only_consumer), want_slices=slices,
@@ -103,11 +114,12 @@ class ResidualUnit(nn.Module):
         # conv1's result is read by conv2 alone: slices only when conv2 takes the pre-split path
         # (bn_link: conv2's data gradient is conv1-unit's whole output gradient; the block's output gradient is the next
         # block's conv1 data gradient + its residual gradient when that block has an identity shortcut -- ops.BnBwdLink)
-        y = _conv_bn_act(self.conv1, self.bn1, x, link=link, next_conv=self.conv2, only_consumer=True, bn_link="inner")
+        y = _conv_bn_act(self.conv1, self.bn1, x, link=link, next_conv=self.conv2, only_consumer=True, bn_link="inner",
+                         next_bn=self.bn2)
         if self.kind == "basic":
             return _conv_bn_act(self.conv2, self.bn2, y, residual=shortcut, link=link, next_conv=self.next_conv[0],
                                 bn_link="block" if (self.next_identity[0] and RESIDUAL_GRAD_LINK) else None)
-        y = _conv_bn_act(self.conv2, self.bn2, y, next_conv=self.conv3, only_consumer=True)
+        y = _conv_bn_act(self.conv2, self.bn2, y, next_conv=self.conv3, only_consumer=True, next_bn=self.bn3)
         return _conv_bn_act(self.conv3, self.bn3, y, residual=shortcut, link=link, next_conv=self.next_conv[0])
 
 

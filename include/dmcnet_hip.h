@@ -281,7 +281,8 @@ int dmc_bn_relu_pool_bwd(const float* x, const float* gamma, const float* beta, 
  *
  * fwd: y = conv(x, w) [+ bias] [LeakyReLU(0.2) if act == 1] [* keep[n][co]] -- the Dropout2d keep mask
  * [N][Cout], already divided by 1 - p -- and, if stat_partials != NULL, per-channel (sum, sum of squares)
- * of y per workgroup row, [dmc_conv_nhwc_stat_blocks()][Cout][2] doubles, which
+ * of y per workgroup row, [stat_blocks = dmc_conv_nhwc_stat_blocks()][Cout][2] doubles (the launch FAILS if its grid has
+ * another number of rows -- e.g. the tile-configuration option changed between the two calls -- instead of overrunning), which
  * dmc_conv_nhwc_stats_final() turns into the (mean, invstd) pair [2*C] and the running-statistics
  * update of the nn.BatchNorm2d that follows (count = N*OH*OW).
  * wpack: workspace of dmc_conv_nhwc_wt_bytes() bytes for the weights as the kernel wants them (needed when the
@@ -300,7 +301,7 @@ int dmc_bn_relu_pool_bwd(const float* x, const float* gamma, const float* beta, 
 int dmc_conv_nhwc_supported(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 int dmc_conv_nhwc_stat_blocks(int N, int H, int W, int Cin, int Cout, int KH, int stride, int pad);
 int dmc_conv_nhwc_fwd(const float* x, const float* w, void* wpack, const float* bias, const float* keep, float* y,
-                      double* stat_partials, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                      double* stat_partials, int stat_blocks, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                       int pad, int act, dmc_stream_t stream);
 int dmc_conv_nhwc_stats_final(const double* partials, int nblk, int C, long count, float* stats,
                               float* running_mean, float* running_var, float eps, float momentum,
@@ -329,8 +330,8 @@ int dmc_conv_nhwc_wgrad(const float* x, const float* dy, float* dw, float* works
  * Weights: dmc_x3s_pack_weights() packs w [Cout][3][3][Cin] (channels_last memory of the PyTorch weight) once per step
  *           into the forward's and / or the data gradient's image (dmc_x3s_wpack_bytes() each; either may be NULL).
  * fwd:     y [M][Cout] fp32 = conv3x3(x, w), padding 1, stride 1; stat_partials (nullable) receives the per-channel
- *           (sum, sum of squares) of y per workgroup row, [dmc_x3s_conv_stat_blocks()][Cout][2] doubles, for
- *           dmc_conv_nhwc_stats_final().
+ *           (sum, sum of squares) of y per workgroup row, [stat_blocks = dmc_x3s_conv_stat_blocks()][Cout][2] doubles, for
+ *           dmc_conv_nhwc_stats_final(); a launch whose grid has another number of rows is refused (no overrun).
  * dgrad:   dx [M][Cin] fp32 = conv_transpose(dy, w) [+ addend, nullable: the residual branch's gradient].
  * Cin % 64 == 0, Cout % 64 == 0; dmc_x3s_conv_supported() says whether a shape is handled.  Deterministic. */
 size_t dmc_x3s_slices_bytes(long M, int C);
@@ -340,8 +341,8 @@ size_t dmc_x3s_wpack_bytes(int Cin, int Cout);
 int dmc_x3s_pack_weights(const float* w, void* wpack_f, void* wpack_t, int Cin, int Cout, dmc_stream_t stream);
 int dmc_x3s_conv_supported(int N, int H, int W, int Cin, int Cout);
 int dmc_x3s_conv_stat_blocks(int N, int H, int W, int Cout);
-int dmc_x3s_conv_fwd(const void* xs, const void* wpack_f, float* y, double* stat_partials, int N, int H, int W, int Cin,
-                     int Cout, dmc_stream_t stream);
+int dmc_x3s_conv_fwd(const void* xs, const void* wpack_f, float* y, double* stat_partials, int stat_blocks, int N, int H, int W,
+                     int Cin, int Cout, dmc_stream_t stream);
 int dmc_x3s_conv_dgrad(const void* dys, const void* wpack_t, const float* addend, float* dx, int N, int H, int W, int Cin,
                        int Cout, dmc_stream_t stream);
 /* wgrad: dw [Cout][3][3][Cin] fp32 (channels_last memory of the PyTorch gradient) from the slice tensors of x and dy;
@@ -391,8 +392,8 @@ int dmc_bn_relu_pool_bwd_arg(const float* x, const float* gamma, const float* be
  * dmc_bn_act_bwd_x3s_apply = the second half of dmc_bn_act_bwd_x3s with those sums as inputs (no reduction pass). */
 int dmc_x3s_conv_dgrad_bnb(const void* dys, const void* wpack_t, const float* addend, float* dx, const float* bn_y,
                            const float* bn_stats, const float* bn_gamma, const float* bn_beta, const unsigned char* bn_relu_mask,
-                           int bn_relu, double* partials, float* dgamma, float* dbeta, int N, int H, int W, int Cin, int Cout,
-                           dmc_stream_t stream);
+                           int bn_relu, double* partials, int stat_blocks, float* dgamma, float* dbeta, int N, int H, int W, int Cin,
+                           int Cout, dmc_stream_t stream);
 int dmc_bn_act_bwd_x3s_apply(const float* x, const float* residual, const float* gamma, const float* beta, const float* stats,
                              const float* dy, float* dx, void* dxs, float* dresidual, const float* dgamma, const float* dbeta,
                              const unsigned char* relu_mask, int M, int C, int relu, dmc_stream_t stream);

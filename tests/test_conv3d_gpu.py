@@ -337,7 +337,10 @@ def test_i3d_trunk_end_to_end_own_vs_stock_bf16(clips, frames):
         c_stock = sum(cos(pr[k].grad, p32[k].grad) for pr in prs) / len(prs)
         print("  grad cos vs fp32  %-42s own %.4f  stock bf16 (mean of 3) %.4f" % (k, c_own, c_stock))
         assert c_own > c_stock - 0.08, (k, c_own, c_stock)
-        assert c_own > 0.25, (k, c_own)                      # recorded values: 0.43 (stem) .. 0.99 (head)
+        # 0.25 is a SMOKE floor, not a parity bar: a random-init bf16 trunk on 3 clips decorrelates from fp32 by itself (the
+        # stock bf16 path scores the same: recorded 0.43 at the stem .. 0.99 at the head).  The parity bars are the per-unit
+        # fp64 tests above and test_i3d_trunk_conditioned_gradients_vs_fp32 below, where the cosine is well-conditioned.
+        assert c_own > 0.25, (k, c_own)
     bn, b32 = dict(net.named_buffers()), dict(ref32.named_buffers())
     for k in ("conv3d_2c_3x3.batch3d.running_var", "mixed_4d.branch_1.1.batch3d.running_mean", "mixed_5c.branch_0.batch3d.running_var"):
         assert float((bn[k] - b32[k]).abs().max() / b32[k].abs().max().clamp_min(1e-6)) < 1e-2, k

@@ -834,7 +834,8 @@ def test_driver_fit_epochs_and_checkpoint(tmp_path):
 def test_driver_epoch_from_raw_uint8_batches_matches_float_loader():
     """The wired GPU-side input path: RawView + collate_raw + DevicePrep feed the same epoch as the
     float loader (dataset tensors made on the CPU): identical inputs, so the deterministic generator /
-    MSE side is bit-identical and the classifier side agrees to MIOpen's run-to-run level."""
+    MSE side is bit-identical; the classifier side is compared at 1e-4 (its kernels are deterministic too -- the bar
+    dates from the MIOpen-convolution days and is kept as the north_star's tolerance)."""
     from dmcnet_amd import dataset, driver
     ds = dataset.SyntheticCoviarDataSet(4, 51, num_segments=3, flow_ds_factor=16, size=224)
     float_loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False)

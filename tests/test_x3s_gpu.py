@@ -99,7 +99,7 @@ def test_x3s_conv_unsupported_shapes_are_refused():
     assert not lib.dmc_x3s_conv_wgrad_supported(2, 13, 13, 64, 64)    # width without a weight-gradient configuration
     xs = torch.zeros(16, dtype=torch.uint8, device=DEV)
     y = torch.zeros(16, device=DEV)
-    assert lib.dmc_x3s_conv_fwd(dmcnet_amd._lib.ptr(xs), dmcnet_amd._lib.ptr(xs), dmcnet_amd._lib.ptr(y), None, 2, 14, 14, 48, 64,
+    assert lib.dmc_x3s_conv_fwd(dmcnet_amd._lib.ptr(xs), dmcnet_amd._lib.ptr(xs), dmcnet_amd._lib.ptr(y), None, 0, 2, 14, 14, 48, 64,
                                 None) != 0
 
 
@@ -239,6 +239,25 @@ def test_stem_statistics_from_the_convolution_epilogue(n, h, w, monkeypatch):
     mean, var = yd.mean((0, 2, 3)), yd.var((0, 2, 3), unbiased=True)
     assert rel_err(res[True][2].cpu().double(), 0.1 * mean) < 1e-5
     assert rel_err(res[True][3].cpu().double(), 0.9 + 0.1 * var) < 1e-5
+
+
+def test_stem_statistics_with_a_large_mean_offset():
+    """|mean| >> std in conv1's output (a constant-ish cue through weights with a common sign): the epilogue's statistics are
+    pivoted sums (sum of v - K and (v - K)^2 around the lane's first value, the pivot removed in fp64), so the variance
+    E[x^2] - E[x]^2 keeps its digits.  Checked against the fp64 statistics of the SAME stored output (isolates the reduction
+    from the convolution's own rounding): plain fp32 sums of v^2 would lose ~|mean|^2 / var x 1e-6 here."""
+    n, h, w = 6, 224, 224
+    x = (4.0 + 0.02 * rnd(431, (n, 2, h, w))).to(DEV)
+    wt = (0.05 + 0.01 * rnd(432, (64, 2, 7, 7))).to(DEV)
+    bn = torch.nn.BatchNorm2d(64, momentum=1.0).to(DEV).train()       # momentum 1: the running statistics ARE the batch's
+    y = ops.stem_conv(x, wt, want_stats=True)
+    assert getattr(y, "_dmc_stat_partials", None) is not None
+    ops.bn_relu_pool(y, bn)
+    yd = y.detach().double()
+    mean, var = yd.mean((0, 2, 3)), yd.var((0, 2, 3), unbiased=True)
+    assert float((mean.abs() / var.sqrt()).min()) > 3.0                # the regime the test is about
+    assert rel_err(bn.running_mean.double(), mean) < 1e-6
+    assert float(((bn.running_var.double() - var).abs() / var).max()) < 5e-6
 
 
 @pytest.mark.parametrize("cin,planes,hw,n,seed", [(64, 64, 14, 6, 331), (128, 128, 28, 3, 338), (64, 64, 56, 2, 342), (512, 512, 7, 5, 339)])
@@ -501,6 +520,37 @@ def test_side_stream_weight_gradients_and_gradient_hooks(monkeypatch):
         assert torch.equal(p.grad, want[k]), k
 
 
+def test_side_stream_with_a_weight_used_twice_in_one_backward(monkeypatch):
+    """A convolution applied TWICE in one forward (shared weight): autograd sums the two weight gradients on the main stream;
+    the first one may be on the side stream, so the second sighting re-joins and stays on the main stream.  Bitwise the
+    one-stream result, and repeatedly so."""
+    monkeypatch.setattr(resnet, "OWN_CONV", True)
+    torch.manual_seed(13)
+    conv = torch.nn.Conv2d(64, 64, 3, 1, 1, bias=False).to(DEV).to(memory_format=CL)
+    bn1, bn2 = torch.nn.BatchNorm2d(64).to(DEV).train(), torch.nn.BatchNorm2d(64).to(DEV).train()
+    x = rnd(520, (24, 64, 56, 56)).to(DEV).contiguous(memory_format=CL)
+
+    def run(side):
+        monkeypatch.setattr(ops, "WGRAD_STREAM", side)
+        for m in (conv, bn1, bn2):
+            m.zero_grad(set_to_none=True)
+        xin = x.clone().requires_grad_(True)
+        y = resnet._conv_bn_act(conv, bn1, xin, next_conv=conv)
+        z = resnet._conv_bn_act(conv, bn2, y)
+        n0 = ops._WGRAD_COUNT[0]
+        with ops.wgrad_side_stream():
+            z.square().mean().backward()
+        torch.cuda.synchronize()
+        return conv.weight.grad.clone(), xin.grad.clone(), ops._WGRAD_COUNT[0] - n0
+
+    w0, x0, n_main = run(False)
+    assert n_main == 0
+    for _ in range(3):
+        w1, x1, n_side = run(True)
+        assert n_side == 1                                   # the first sighting only
+        assert torch.equal(w1, w0) and torch.equal(x1, x0)
+
+
 @pytest.mark.parametrize("case", [(6, 64, 14, 14, 128), (37, 64, 14, 14, 64), (5, 128, 7, 7, 64), (42, 64, 14, 14, 512)])
 def test_x3s_two_workgroups_per_cu_configuration(case):
     """Tile configuration 4 of the pre-split convolutions (128-pixel tiles, 4 waves, a patch of <= 224 pixels: 79,872 B of
@@ -530,3 +580,38 @@ def test_x3s_two_workgroups_per_cu_configuration(case):
     assert lib.dmc_x3s_conv_stat_blocks(n, h, w, cout) == (n * h * w + 127) // 128 if case[0] == 42 else True
     yo = F.conv2d(x.double(), wt.double(), None, 1, 1)
     assert rel_err(out[105][0], yo) < 1e-5
+
+
+def test_statistics_partials_sized_under_another_option_are_refused():
+    """dmc_x3s_conv_stat_blocks / dmc_conv_nhwc_stat_blocks and the forward each read the tile-configuration option: a
+    buffer sized before an option change must be REFUSED by the launch (it would be overrun), not written."""
+    L, lib = dmcnet_amd._lib, dmcnet_amd._lib.load()
+    n, cin, h, w, cout = 6, 64, 14, 14, 128
+    x = rnd(411, (n, cin, h, w)).to(DEV).contiguous(memory_format=CL)
+    xs = ops.x3s_split(x)
+    wt = (rnd(412, (cout, cin, 3, 3)) * 0.1).to(DEV).contiguous(memory_format=CL)
+    wf, _ = ops.x3s_pack_weights(wt)
+    y = torch.empty((n, cout, h, w), device=DEV).contiguous(memory_format=CL)
+    before = lib.dmc_get_option(b"conv_cfg")
+    try:
+        L.check(lib.dmc_set_option(b"conv_cfg", 106), "dmc_set_option")          # 8-wave tiles: 256 pixels per row of partials
+        nblk = lib.dmc_x3s_conv_stat_blocks(n, h, w, cout)
+        part = torch.empty((nblk, cout, 2), dtype=torch.float64, device=DEV)
+        L.check(lib.dmc_set_option(b"conv_cfg", 105), "dmc_set_option")          # 128-pixel tiles: twice as many rows
+        assert lib.dmc_x3s_conv_stat_blocks(n, h, w, cout) != nblk
+        rc = lib.dmc_x3s_conv_fwd(L.ptr(xs), L.ptr(wf), L.ptr(y), L.ptr(part), nblk, n, h, w, cin, cout, None)
+        assert rc != 0 and b"rows" in lib.dmc_last_error()
+        L.check(lib.dmc_set_option(b"conv_cfg", 106), "dmc_set_option")
+        L.check(lib.dmc_x3s_conv_fwd(L.ptr(xs), L.ptr(wf), L.ptr(y), L.ptr(part), nblk, n, h, w, cin, cout, None), "fwd")
+        # the in-loop-split kernels: a wrong row count is refused as well
+        nb2 = lib.dmc_conv_nhwc_stat_blocks(n, h, w, cin, cout, 3, 1, 1)
+        p2 = torch.empty((nb2 + 1, cout, 2), dtype=torch.float64, device=DEV)
+        wp = torch.empty(lib.dmc_conv_nhwc_wt_bytes(cin, cout, 3, 3), dtype=torch.uint8, device=DEV)
+        rc = lib.dmc_conv_nhwc_fwd(L.ptr(x), L.ptr(wt), L.ptr(wp), None, None, L.ptr(y), L.ptr(p2), nb2 + 1, n, h, w, cin, cout,
+                                   3, 3, 1, 1, 0, None)
+        assert rc != 0 and b"rows" in lib.dmc_last_error()
+        L.check(lib.dmc_conv_nhwc_fwd(L.ptr(x), L.ptr(wt), L.ptr(wp), None, None, L.ptr(y), L.ptr(p2), nb2, n, h, w, cin, cout,
+                                      3, 3, 1, 1, 0, None), "conv_nhwc_fwd")
+        torch.cuda.synchronize()
+    finally:
+        L.check(lib.dmc_set_option(b"conv_cfg", before), "dmc_set_option")

@@ -81,8 +81,8 @@ int main(int argc, char** argv) {
     }
     std::vector<float> hy(M * Cout), hy3(M * Cout), hdx(M * Cin), hdx3(M * Cin);
     if (what & 1) {
-        DK(dmc_x3s_conv_fwd(xs, wf, y, part, N, H, W, Cin, Cout, 0));
-        DK(dmc_conv_nhwc_fwd(x, nullptr, w3f, nullptr, nullptr, y3, nullptr, N, H, W, Cin, Cout, 3, 3, 1, 1, 0, 0));
+        DK(dmc_x3s_conv_fwd(xs, wf, y, part, dmc_x3s_conv_stat_blocks(N, H, W, Cout), N, H, W, Cin, Cout, 0));
+        DK(dmc_conv_nhwc_fwd(x, nullptr, w3f, nullptr, nullptr, y3, nullptr, 0, N, H, W, Cin, Cout, 3, 3, 1, 1, 0, 0));
         CK(hipMemcpy(hy.data(), y, M * Cout * 4, hipMemcpyDeviceToHost));
         CK(hipMemcpy(hy3.data(), y3, M * Cout * 4, hipMemcpyDeviceToHost));
         double ymax = 0, e4 = 0, e3 = 0;
@@ -116,9 +116,9 @@ int main(int argc, char** argv) {
         }
         printf("fwd   : max|y| %.3f  err vs fp64: x3s %.3e  conv3 %.3e (rel %.2e / %.2e)   x3s vs conv3: %ld differing, max %.3e   stats rel err %.2e\n",
                ymax, e4, e3, e4 / ymax, e3 / ymax, ndiff, dmax, serr);
-        const float t4 = time_ms([&] { DK(dmc_x3s_conv_fwd(xs, wf, y, part, N, H, W, Cin, Cout, 0)); }, iters);
-        const float t3 = time_ms([&] { DK(dmc_conv_nhwc_fwd(x, nullptr, w3f, nullptr, nullptr, y3, part, N, H, W, Cin, Cout, 3, 3, 1, 1, 0, 0)); }, iters);
-        const float t4b = time_ms([&] { DK(dmc_x3s_conv_fwd(xs, wf, y, part, N, H, W, Cin, Cout, 0)); }, iters);
+        const float t4 = time_ms([&] { DK(dmc_x3s_conv_fwd(xs, wf, y, part, dmc_x3s_conv_stat_blocks(N, H, W, Cout), N, H, W, Cin, Cout, 0)); }, iters);
+        const float t3 = time_ms([&] { DK(dmc_conv_nhwc_fwd(x, nullptr, w3f, nullptr, nullptr, y3, part, dmc_conv_nhwc_stat_blocks(N, H, W, Cin, Cout, 3, 1, 1), N, H, W, Cin, Cout, 3, 3, 1, 1, 0, 0)); }, iters);
+        const float t4b = time_ms([&] { DK(dmc_x3s_conv_fwd(xs, wf, y, part, dmc_x3s_conv_stat_blocks(N, H, W, Cout), N, H, W, Cin, Cout, 0)); }, iters);
         printf("fwd   : x3s %.3f ms (%.1f TF)  conv3 %.3f ms (%.1f TF)  x3s again %.3f ms (%.1f TF)\n", t4, gf / t4, t3, gf / t3, t4b, gf / t4b);
     }
     if (what & 2) {
