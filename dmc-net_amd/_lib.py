@@ -80,6 +80,18 @@ SIGNATURES = {
     "dmc_x3s_conv_dgrad_s2_supported": (_I, [_I] * 5),
     "dmc_x3s_pack_weights_s2": (_I, [_P, _P, _I, _I, _P]),
     "dmc_x3s_conv_dgrad_s2": (_I, [_P] * 3 + [_I] * 5 + [_P]),
+    "dmc_x3q_wpack_bytes": (_Z, [_I, _I]),
+    "dmc_x3q_supported": (_I, [_I] * 5),
+    "dmc_x3q_stat_blocks": (_I, [_I] * 3),
+    "dmc_x3q_split": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "dmc_x3q_merge": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "dmc_x3q_pack_weights": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "dmc_x3q_conv_fwd": (_I, [_P] * 6 + [_I] * 6 + [_P]),
+    "dmc_x3q_conv_dgrad": (_I, [_P] * 4 + [_I] * 5 + [_P]),
+    "dmc_bn_apply_act_x3q": (_I, [_P] * 8 + [_I] * 5 + [_P]),
+    "dmc_x3q_conv_wgrad_supported": (_I, [_I] * 5),
+    "dmc_x3q_conv_wgrad_bytes": (_Z, [_I] * 5),
+    "dmc_x3q_conv_wgrad": (_I, [_P] * 6 + [_I] * 5 + [_P]),
     "dmc_bn_apply_act_x3s": (_I, [_P] * 8 + [_I, _I, _I, _P]),
     "dmc_bn_act_bwd_x3s": (_I, [_P] * 13 + [_I, _I, _I, _P]),
     "dmc_x3s_conv_dgrad_bnb": (_I, [_P] * 9 + [_I] + [_P] + [_I] + [_P] * 2 + [_I] * 5 + [_P]),

@@ -497,7 +497,9 @@ __device__ __forceinline__ void store8(float* p, size_t i8, const float (&v)[8])
     reinterpret_cast<float4*>(p)[2 * i8 + 1] = make_float4(v[4], v[5], v[6], v[7]);
 }
 
-__global__ __launch_bounds__(256) void bn_apply_fwd_x3s_kernel(BnArgs a, unsigned short* __restrict__ ys) {
+// s2d_h / s2d_w > 0: the slices are written SPACE-TO-DEPTH for a stride-2 consumer (conv_x3q.hip): pixel (n, y, x) of the
+// H x W map goes to parity class 2 (y & 1) + (x & 1), position (n, y / 2, x / 2) of [3][4][C/16][M/4][16].
+__global__ __launch_bounds__(256) void bn_apply_fwd_x3s_kernel(BnArgs a, unsigned short* __restrict__ ys, int s2d_h, int s2d_w) {
     const int c8 = a.C >> 3;
     const size_t total = (size_t)a.M * c8;
     for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
@@ -525,7 +527,16 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_x3s_kernel(BnArgs a, unsigne
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if (a.y) store8(a.y, o, v);
-        if (ys) x3s_store8(ys, v, (size_t)a.M, a.C >> 4, m, tx);
+        if (ys) {
+            if (s2d_w) {
+                const int xx = (int)(m % (size_t)s2d_w), yy = (int)((m / (size_t)s2d_w) % (size_t)s2d_h);
+                const size_t n = m / ((size_t)s2d_w * s2d_h);
+                const int cls = (yy & 1) * 2 + (xx & 1), nchunk = a.C >> 4;
+                x3s_store8(ys, v, (size_t)a.M >> 2, 4 * nchunk, (n * (s2d_h >> 1) + (yy >> 1)) * (s2d_w >> 1) + (xx >> 1), tx + cls * 2 * nchunk);
+            } else {
+                x3s_store8(ys, v, (size_t)a.M, a.C >> 4, m, tx);
+            }
+        }
     }
 }
 
@@ -804,8 +815,21 @@ int dmc_bn_apply_act_x3s(const float* x, const float* residual, const float* gam
     if (!x || !gamma || !beta || !stats || (!y && !ys)) return fail(DMC_E_INVALID, "dmc_bn_apply_act_x3s: null pointer");
     if (!shape_ok8(M, C)) return fail(DMC_E_INVALID, "dmc_bn_apply_act_x3s: unsupported shape M=%d C=%d", M, C);
     BnArgs a = {x, residual, gamma, beta, stats, nullptr, y, nullptr, nullptr, M, C, relu, relu_mask};
-    bn_apply_fwd_x3s_kernel<<<stream_blocks((size_t)M * (C / 8)), 256, 0, (hipStream_t)stream>>>(a, static_cast<unsigned short*>(ys));
+    bn_apply_fwd_x3s_kernel<<<stream_blocks((size_t)M * (C / 8)), 256, 0, (hipStream_t)stream>>>(a, static_cast<unsigned short*>(ys), 0, 0);
     return check_launch("bn_apply_act_x3s");
+}
+
+/* dmc_bn_apply_act_x3s whose slice output is SPACE-TO-DEPTH over the [N][H][W] pixel grid (H, W even): the layout the
+ * stride-2 block pair reads (dmc_x3q_*, include/dmcnet_hip.h); y (fp32, nullable) keeps the ordinary NHWC layout. */
+int dmc_bn_apply_act_x3q(const float* x, const float* residual, const float* gamma, const float* beta, const float* stats,
+                         float* y, void* yq, unsigned char* relu_mask, int N, int H, int W, int C, int relu, dmc_stream_t stream) {
+    if (!x || !gamma || !beta || !stats || !yq) return fail(DMC_E_INVALID, "dmc_bn_apply_act_x3q: null pointer");
+    if (N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || (long)N * H * W >= (1L << 31)) return fail(DMC_E_INVALID, "dmc_bn_apply_act_x3q: bad geometry");
+    const int M = N * H * W;
+    if (!shape_ok8(M, C)) return fail(DMC_E_INVALID, "dmc_bn_apply_act_x3q: unsupported shape M=%d C=%d", M, C);
+    BnArgs a = {x, residual, gamma, beta, stats, nullptr, y, nullptr, nullptr, M, C, relu, relu_mask};
+    bn_apply_fwd_x3s_kernel<<<stream_blocks((size_t)M * (C / 8)), 256, 0, (hipStream_t)stream>>>(a, static_cast<unsigned short*>(yq), H, W);
+    return check_launch("bn_apply_act_x3q");
 }
 
 /* dmc_bn_act_bwd with the BatchNorm input gradient as fp32 (dx, nullable) and / or as a slice tensor (dxs, nullable). */

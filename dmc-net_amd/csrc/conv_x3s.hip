@@ -26,50 +26,13 @@
 //   the LDS image stays lane-linear).
 //   Data gradient = the same kernel on the dy slices with the weights packed transposed and the taps mirrored.
 #include "dmc_common.h"
+#include "x3s_common.h"
 #include <type_traits>
 
 using namespace dmc;
+using namespace dmc::x3;
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(3))) char* lds_cptr;
-
-__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-// fp32 -> three bf16 slices (truncation split: s0 = upper 16 bits, s1 = upper 16 bits of the exact remainder, s2 = the rest)
-__device__ __forceinline__ void split3(float v, unsigned& u0, unsigned& u1, unsigned& u2) {
-    u0 = __float_as_uint(v);
-    const float r1 = v - __uint_as_float(u0 & 0xffff0000u);
-    u1 = __float_as_uint(r1);
-    u2 = __float_as_uint(r1 - __uint_as_float(u1 & 0xffff0000u));
-}
-__device__ __forceinline__ unsigned pack_hi(unsigned hi_of_second, unsigned hi_of_first) {   // (upper half of b, upper half of a)
-    return __builtin_amdgcn_perm(hi_of_second, hi_of_first, 0x07060302u);
-}
-
-constexpr unsigned OOB = 0x80000000u;          // a transfer offset beyond num_records: the lane's 16 bytes arrive as zeros
-
-// 16 bytes per lane global -> LDS through a buffer descriptor (range-checked: offsets >= num_records write zeros).
-// LDS destination = lds_byte_addr + 16 * lane.  srd / soff / lds_byte_addr must be wave-uniform; the s_nops cover the
-// M0 -> LDS-DMA wait state and an SGPR written by v_readfirstlane just in front of the statement.
-__device__ __forceinline__ void dma_buf16(const u32x4& srd, unsigned voff, unsigned soff, unsigned lds_byte_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
-                 :: "v"(voff), "s"(srd), "s"(lds_byte_addr), "s"(soff) : "memory");
-}
-__device__ __forceinline__ u32x4 make_srd(const void* base) {
-    const unsigned long long b = (unsigned long long)base;
-    u32x4 srd;
-    srd[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
-    srd[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu);
-    srd[2] = 0x7fffffffu;
-    srd[3] = 0x00020000u;
-    return srd;
-}
 
 // ---- producers of the slice tensors ------------------------------------------------------------------
 // x [M][C] fp32 (channels_last memory) -> xs [3][C/16][M][16] bf16.  One thread = 8 channels of one pixel.
@@ -669,15 +632,6 @@ struct WgGeom {
     static constexpr int XBYTES = 12 * XPL * 32, DYBYTES = 12 * DYPL * 32;
     static constexpr int LDS = XBYTES + 2 * DYBYTES;
 };
-
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void tr_read2(lds_cptr p0, lds_cptr p1, u32x4& f) {   // eight k-values = two transposed reads
-    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
-    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
-    f[0] = ua[0]; f[1] = ua[1]; f[2] = ub[0]; f[3] = ub[1];
-}
 
 template <int W_, int R>
 __global__ __launch_bounds__(768) void x3s_wgrad_kernel(X3WgArgs a) {

@@ -871,6 +871,70 @@ def x3s_usable(n, h, w, conv):
     return bool(lib.dmc_x3s_conv_supported(n, h, w, cin, cout)) and bool(lib.dmc_x3s_conv_wgrad_supported(n, h, w, cin, cout))
 
 
+# ------------------------------------------------------------------ stride-2 block pair on s2d slice tensors (conv_x3q.hip)
+def x3q_split(x):
+    """Space-to-depth slice tensor of a channels_last fp32 activation with even H, W (stand-alone producer: tests)."""
+    n, c, h, w = x.shape
+    xq = _x3s_buffer(n * h * w, c, x.device)
+    _lib.check(_lib.load().dmc_x3q_split(_lib.ptr(x), _lib.ptr(xq), n, h, w, c, _stream()), "dmc_x3q_split")
+    return xq
+
+
+def x3q_merge(xq, shape):
+    n, c, h, w = shape
+    x = torch.empty(shape, dtype=torch.float32, device=xq.device, memory_format=torch.channels_last)
+    _lib.check(_lib.load().dmc_x3q_merge(_lib.ptr(xq), _lib.ptr(x), n, h, w, c, _stream()), "dmc_x3q_merge")
+    return x
+
+
+def x3q_pack_weights(w3, w1, forward=True, transposed=True):
+    """(wpack_f, wpack_t) of the channels_last [Cout, Cin, 3, 3] / [Cout, Cin, 1, 1] weight pair of a stride-2 block."""
+    lib = _lib.load()
+    cout, cin = w3.shape[0], w3.shape[1]
+    nb = lib.dmc_x3q_wpack_bytes(cin, cout)
+    wf = torch.empty(nb, dtype=torch.uint8, device=w3.device) if forward else None
+    wt = torch.empty(nb, dtype=torch.uint8, device=w3.device) if transposed else None
+    _lib.check(lib.dmc_x3q_pack_weights(_lib.ptr(_as_cl(w3)), _lib.ptr(_as_cl(w1)), _lib.ptr(wf), _lib.ptr(wt), cin, cout, _stream()),
+               "dmc_x3q_pack_weights")
+    return wf, wt
+
+
+def x3q_conv_fwd(xq, wpack_f, n, oh, ow, cin, cout, want_stats=False):
+    """(y3, y1, partials3, partials1): the 3x3 / stride-2 convolution and the 1x1 / stride-2 shortcut of the activation whose
+    s2d slice tensor is ``xq``, both [n, cout, oh, ow] channels_last fp32, from ONE launch."""
+    lib = _lib.load()
+    y3 = torch.empty((n, cout, oh, ow), dtype=torch.float32, device=xq.device, memory_format=torch.channels_last)
+    y1 = torch.empty_like(y3)
+    p3 = p1 = None
+    nblk = 0
+    if want_stats:
+        nblk = lib.dmc_x3q_stat_blocks(n, oh, ow)
+        p3 = torch.empty((nblk, cout, 2), dtype=torch.float64, device=xq.device)
+        p1 = torch.empty_like(p3)
+    _lib.check(lib.dmc_x3q_conv_fwd(_lib.ptr(xq), _lib.ptr(wpack_f), _lib.ptr(y3), _lib.ptr(y1), _lib.ptr(p3), _lib.ptr(p1), nblk,
+                                    n, oh, ow, cin, cout, _stream()), "dmc_x3q_conv_fwd")
+    return y3, y1, p3, p1
+
+
+def x3q_conv_dgrad(dys3, dys1, wpack_t, n, oh, ow, cin, cout):
+    """dx [n, cin, 2 oh, 2 ow] of the pair from the slice tensors of the two output gradients."""
+    dx = torch.empty((n, cin, 2 * oh, 2 * ow), dtype=torch.float32, device=dys3.device, memory_format=torch.channels_last)
+    _lib.check(_lib.load().dmc_x3q_conv_dgrad(_lib.ptr(dys3), _lib.ptr(dys1), _lib.ptr(wpack_t), _lib.ptr(dx), n, oh, ow, cin, cout,
+                                              _stream()), "dmc_x3q_conv_dgrad")
+    return dx
+
+
+def x3q_conv_wgrad(xq, dys3, dys1, n, oh, ow, cin, cout):
+    """(dw3 [cout, cin, 3, 3], dw1 [cout, cin, 1, 1]), channels_last memory, of the stride-2 pair."""
+    lib = _lib.load()
+    dw3 = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=xq.device, memory_format=torch.channels_last)
+    dw1 = torch.empty((cout, cin, 1, 1), dtype=torch.float32, device=xq.device, memory_format=torch.channels_last)
+    work = _floats(lib.dmc_x3q_conv_wgrad_bytes(n, oh, ow, cin, cout), xq.device)
+    _lib.check(lib.dmc_x3q_conv_wgrad(_lib.ptr(xq), _lib.ptr(dys3), _lib.ptr(dys1), _lib.ptr(dw3), _lib.ptr(dw1), _lib.ptr(work),
+                                      n, oh, ow, cin, cout, _stream()), "dmc_x3q_conv_wgrad")
+    return dw3, dw1
+
+
 class ResidualGradLink:
     """Couples the two fused ops of an identity-shortcut residual block (torchvision BasicBlock: `out += identity`, behind
     code/dmcnet/model.py:305): the block input feeds the first convolution AND the residual add, so autograd would sum the
@@ -932,31 +996,39 @@ def join_wgrad_stream():
         _WGRAD_PENDING[0] = False
 
 
-def _on_wgrad_stream(weight, reads, launch):
-    """``launch()`` (allocates, launches, returns the weight gradient) on the side stream when that is safe: inside an
-    autograd backward pass (the join is queued as an engine callback: it runs on the caller's stream before backward()
-    returns) and with no gradient to accumulate into (``weight.grad += dw`` would run on the main stream at once)."""
-    if not WGRAD_STREAM or _WGRAD_SCOPE[0] <= 0 or weight.grad is not None:
-        return launch()
+def _wgrad_side_ok(weight):
+    """True if ``weight``'s gradient may be produced on the side stream (see _on_wgrad_stream)."""
+    if weight.grad is not None:                 # ``weight.grad += dw`` would run on the main stream at once
+        return False
     # a weight used TWICE in one backward pass (a shared convolution, a module called twice): the engine sums the two
     # gradients on the main stream -- in its input buffer or in AccumulateGrad -- believing the main stream produced the
     # first one.  The second sighting therefore re-joins (the first gradient is complete on the main stream) and stays there.
     if id(weight) in _WGRAD_SEEN:
         join_wgrad_stream()
-        return launch()
+        return False
     # C++-level gradient hooks (torch's DistributedDataParallel reducer) read the gradient on the main stream the moment it
     # is accumulated and are not visible from Python: with a process group up, only parameters that carry THIS package's
     # deferring hook (ddp.GradBucketReducer) may use the side stream
+    post = getattr(weight, "_post_accumulate_grad_hooks", None)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
-        post_ = getattr(weight, "_post_accumulate_grad_hooks", None)
-        if not post_ or not all(getattr(h, "_dmc_defers_read", False) for h in post_.values()):
-            return launch()
+        if not post or not all(getattr(h, "_dmc_defers_read", False) for h in post.values()):
+            return False
     # a hook that reads the gradient the moment it is accumulated would read it on the main stream, before the side stream
     # has written it: only hooks that declare they defer the read (the gradient exchange's, ddp.py) are compatible
     if getattr(weight, "_backward_hooks", None):
-        return launch()
-    post = getattr(weight, "_post_accumulate_grad_hooks", None)
+        return False
     if post and not all(getattr(h, "_dmc_defers_read", False) for h in post.values()):
+        return False
+    return True
+
+
+def _on_wgrad_stream(weight, reads, launch):
+    """``launch()`` (allocates, launches, returns the weight gradient -- a tuple of them when ``weight`` is a tuple of
+    parameters served by one call) on the side stream when that is safe: inside an autograd backward pass (the join is
+    queued as an engine callback: it runs on the caller's stream before backward() returns) and with no gradient to
+    accumulate into."""
+    weights = weight if isinstance(weight, tuple) else (weight,)
+    if not WGRAD_STREAM or _WGRAD_SCOPE[0] <= 0 or not all(_wgrad_side_ok(w) for w in weights):
         return launch()
     if PROBE is not None and (PROBE.only is None or "conv_nhwc_wgrad" in PROBE.only or "stem_wgrad" in PROBE.only):
         return launch()                         # HIP-event spans around this call time the launch stream: stay on it
@@ -965,16 +1037,18 @@ def _on_wgrad_stream(weight, reads, launch):
             torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)
         except RuntimeError:                    # not inside a backward pass (a direct call): stay on this stream
             return launch()
-    main, side = torch.cuda.current_stream(), _wgrad_stream(weight.device)
+    main, side = torch.cuda.current_stream(), _wgrad_stream(weights[0].device)
     side.wait_stream(main)                      # the operands were written on the main stream
     for t in reads:
         t.record_stream(side)                   # their memory is not reused before the side stream has read it
     _WGRAD_PENDING[0] = True
     _WGRAD_COUNT[0] += 1
-    _WGRAD_SEEN.add(id(weight))
+    for w in weights:
+        _WGRAD_SEEN.add(id(w))
     with torch.cuda.stream(side):
         dw = launch()
-    dw.record_stream(main)
+    for t in (dw if isinstance(dw, tuple) else (dw,)):
+        t.record_stream(main)
     return dw
 
 
@@ -1001,7 +1075,8 @@ class _ConvBnAct(torch.autograd.Function):
     backward (two passes) and feeds the data- and weight-gradient kernels (deterministic).
 
     ``xs``: the slice tensor of ``x`` (or None); ``mode`` bit 0: write the fp32 result, bit 1: write its slice tensor
-    (returned second, non-differentiable), bit 2: take the pre-split convolution path (conv_x3s.hip)."""
+    (returned second, non-differentiable), bit 2: take the pre-split convolution path (conv_x3s.hip), bit 3: the slice
+    tensor is written SPACE-TO-DEPTH (its consumer is a stride-2 block pair, conv_x3q.hip)."""
 
     @staticmethod
     def forward(ctx, x, weight, residual, gamma, beta, running_mean, running_var, stride, padding, relu, eps,
@@ -1078,7 +1153,11 @@ class _ConvBnAct(torch.autograd.Function):
             _lib.check(lib.dmc_conv_nhwc_stats_final(_lib.ptr(part), nblk, cout, m, _lib.ptr(stats),
                                                      _lib.ptr(running_mean), _lib.ptr(running_var), float(eps),
                                                      float(momentum), _stream()), "dmc_conv_nhwc_stats_final")
-            if want_xs or not want_f32:
+            if want_xs and (mode & 8):
+                _lib.check(lib.dmc_bn_apply_act_x3q(_lib.ptr(y), _lib.ptr(residual), _lib.ptr(gamma), _lib.ptr(beta),
+                                                    _lib.ptr(stats), _lib.ptr(out) if want_f32 else None, _lib.ptr(out_xs),
+                                                    _lib.ptr(mask), n, oh, ow, cout, int(relu), _stream()), "dmc_bn_apply_act_x3q")
+            elif want_xs or not want_f32:
                 _lib.check(lib.dmc_bn_apply_act_x3s(_lib.ptr(y), _lib.ptr(residual), _lib.ptr(gamma), _lib.ptr(beta),
                                                     _lib.ptr(stats), _lib.ptr(out) if want_f32 else None, _lib.ptr(out_xs),
                                                     _lib.ptr(mask), m, cout, int(relu), _stream()), "dmc_bn_apply_act_x3s")
@@ -1273,7 +1352,7 @@ def conv_bn_act_eval(x, conv, bn, residual=None, relu=True, want_f32=True, want_
     return out
 
 
-def conv_bn_act(x, conv, bn, residual=None, relu=True, link=None, want_f32=True, want_slices=False, bn_link=None):
+def conv_bn_act(x, conv, bn, residual=None, relu=True, link=None, want_f32=True, want_slices=False, bn_link=None, s2d=False):
     """relu?(bn(conv(x)) [+ residual]) for a channels_last ``x`` (see conv_bn_act_supported); ``link``: the
     ResidualGradLink shared by the first and the last op of an identity-shortcut block.  ``want_slices``: also write
     the result's bf16x3 slice tensor (attached to the returned tensor, see x3s_of) for a pre-split consumer;
@@ -1289,18 +1368,178 @@ def conv_bn_act(x, conv, bn, residual=None, relu=True, link=None, want_f32=True,
         want_f32 = True
     n, _, h, w = x.shape
     use_x3s = x3s_usable(n, h, w, conv)
-    mode = int(want_f32) | (int(want_slices) << 1) | (int(use_x3s) << 2)
-    bn_out = BnBwdLink(bn_link) if (bn_link and BN_BWD_LINK and want_slices) else None
+    mode = int(want_f32) | (int(want_slices) << 1) | (int(use_x3s) << 2) | (int(bool(s2d and want_slices)) << 3)
+    bn_out = BnBwdLink(bn_link) if (bn_link and BN_BWD_LINK and want_slices and not s2d) else None
     bn_in = getattr(x, "_dmc_bnlink", None) if use_x3s else None
     out, out_xs = _ConvBnAct.apply(x, conv.weight, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                    conv.stride[0], conv.padding[0], relu, bn.eps,
                                    bn.momentum if bn.momentum is not None else 0.1, link,
                                    x3s_of(x) if use_x3s else None, mode, bn_out, bn_in)
-    if want_slices:
+    if want_slices and s2d:
+        out._dmc_x3q, out._dmc_f32 = out_xs, want_f32
+    elif want_slices:
         _attach_x3s(out, out_xs, want_f32)
     if bn_out is not None:
         out._dmc_bnlink = bn_out
     return out
+
+
+# ------------------------------------------------------------------ the stride-2 block pair (conv_x3q.hip)
+#: True (default): a BasicBlock with a stride-2 conv1 and a 1x1 / stride-2 downsample runs both convolutions -- which read
+#: the same block input -- as ONE launch per direction on the input's space-to-depth slice tensor.  DMC_X3Q=0: the separate
+#: in-loop-split launches of conv_nhwc.hip (+ the stride-2 data gradient of conv_x3s.hip).
+X3Q = __import__("os").environ.get("DMC_X3Q", "1") != "0"
+
+
+def x3q_of(t):
+    """The space-to-depth slice tensor attached to activation ``t`` by its producer (or None)."""
+    return getattr(t, "_dmc_x3q", None)
+
+
+def _bn_trains(bn):
+    return bn.training and bn.track_running_stats and bn.affine and bn.momentum is not None
+
+
+def s2_pair_usable(x_shape, unit):
+    """True if ``unit`` (a resnet.ResidualUnit of kind "basic" with a downsample branch) on an input of ``x_shape`` takes the
+    fused stride-2 pair path: conv1 3x3 / stride 2 / padding 1 and downsample = (1x1 / stride 2, BatchNorm2d), both bias-free,
+    BatchNorms in training mode, autograd on, shapes the kernels cover.  The producer of the block input asks the same
+    question to decide the layout (and the absence of an fp32 copy) of what it writes."""
+    if not (X3Q and X3S and torch.is_grad_enabled()):
+        return False
+    ds = getattr(unit, "downsample", None)
+    if getattr(unit, "kind", None) != "basic" or ds is None or len(ds) != 2:
+        return False
+    c3, c1 = unit.conv1, ds[0]
+    for c, k, p in ((c3, (3, 3), (1, 1)), (c1, (1, 1), (0, 0))):
+        if not isinstance(c, torch.nn.Conv2d) or c.kernel_size != k or c.stride != (2, 2) or c.padding != p or c.bias is not None:
+            return False
+        if c.dilation != (1, 1) or c.groups != 1 or c.padding_mode != "zeros" or c.weight.dtype != torch.float32:
+            return False
+    if not isinstance(ds[1], torch.nn.BatchNorm2d) or not _bn_trains(unit.bn1) or not _bn_trains(ds[1]):
+        return False
+    n, cin, h, w = x_shape
+    cout = c3.out_channels
+    if c3.in_channels != cin or c1.in_channels != cin or c1.out_channels != cout or (h & 1) or (w & 1):
+        return False
+    lib = _lib.load()
+    if lib.dmc_get_option(b"conv_arith") != 1 or lib.dmc_get_option(b"conv_path") != 1:
+        return False
+    return bool(lib.dmc_x3q_supported(n, h // 2, w // 2, cin, cout)) and bool(lib.dmc_x3q_conv_wgrad_supported(n, h // 2, w // 2, cin, cout)) \
+        and bool(lib.dmc_bn_act_supported(n * (h // 2) * (w // 2), cout))
+
+
+class _ConvBnS2Pair(torch.autograd.Function):
+    """(relu(bn1(conv1(x))), bn_d(downsample_conv(x))) of a stride-2 BasicBlock (torchvision, behind code/dmcnet/model.py:305,352)
+    in training mode: ONE convolution launch for both branches (conv_x3q.hip: the shortcut reads the centre tap's operand), both
+    BatchNorms' statistics from its epilogue; the backward runs the two BatchNorm backwards (slice outputs), ONE data-gradient
+    launch for the sum of both branches and the two weight gradients from one call.  ``xq``: the space-to-depth slice tensor
+    of ``x``; ``x`` itself only carries the autograd edge (its fp32 memory may be unwritten).  ``want_xs``: the main branch's
+    result is written as a slice tensor ONLY (its consumer, conv2, takes the pre-split path)."""
+
+    @staticmethod
+    def forward(ctx, x, xq, w3, w1, g3, b3, rm3, rv3, eps3, mom3, g1, b1, rm1, rv1, eps1, mom1, want_xs):
+        lib = _lib.load()
+        _need_cuda(x, w3, w1, g3, b3, g1, b1)
+        ctx.set_materialize_grads(False)
+        n, cin, h, w = x.shape
+        cout, oh, ow = w3.shape[0], h // 2, w // 2
+        m = n * oh * ow
+        dev = x.device
+        with _span("conv_nhwc_fwd"):
+            nb = lib.dmc_x3q_wpack_bytes(cin, cout)
+            wf = torch.empty(nb, dtype=torch.uint8, device=dev)
+            ctx.wt = torch.empty(nb, dtype=torch.uint8, device=dev) if ctx.needs_input_grad[0] else None
+            _lib.check(lib.dmc_x3q_pack_weights(_lib.ptr(_as_cl(w3)), _lib.ptr(_as_cl(w1)), _lib.ptr(wf), _lib.ptr(ctx.wt), cin, cout,
+                                                _stream()), "dmc_x3q_pack_weights")
+            y3 = torch.empty((n, cout, oh, ow), dtype=torch.float32, device=dev, memory_format=_CL)
+            y1 = torch.empty_like(y3)
+            nblk = lib.dmc_x3q_stat_blocks(n, oh, ow)
+            part = torch.empty((2, nblk, cout, 2), dtype=torch.float64, device=dev)
+            _lib.check(lib.dmc_x3q_conv_fwd(_lib.ptr(xq), _lib.ptr(wf), _lib.ptr(y3), _lib.ptr(y1), _lib.ptr(part[0]), _lib.ptr(part[1]),
+                                            nblk, n, oh, ow, cin, cout, _stream()), "dmc_x3q_conv_fwd")
+        stats3 = _floats(lib.dmc_bn_act_stats_bytes(cout), dev)
+        stats1 = _floats(lib.dmc_bn_act_stats_bytes(cout), dev)
+        out3 = torch.empty_like(y3)                         # not written when conv2 reads slices only
+        out3_xs = _x3s_buffer(m, cout, dev) if want_xs else None
+        out1 = torch.empty_like(y1)
+        with _span("bn_apply_fwd"):
+            _lib.check(lib.dmc_conv_nhwc_stats_final(_lib.ptr(part[0]), nblk, cout, m, _lib.ptr(stats3), _lib.ptr(rm3), _lib.ptr(rv3),
+                                                     float(eps3), float(mom3), _stream()), "dmc_conv_nhwc_stats_final")
+            _lib.check(lib.dmc_conv_nhwc_stats_final(_lib.ptr(part[1]), nblk, cout, m, _lib.ptr(stats1), _lib.ptr(rm1), _lib.ptr(rv1),
+                                                     float(eps1), float(mom1), _stream()), "dmc_conv_nhwc_stats_final")
+            _lib.check(lib.dmc_bn_apply_act_x3s(_lib.ptr(y3), None, _lib.ptr(g3), _lib.ptr(b3), _lib.ptr(stats3),
+                                                None if want_xs else _lib.ptr(out3), _lib.ptr(out3_xs), None, m, cout, 1, _stream()),
+                       "dmc_bn_apply_act_x3s")
+            _lib.check(lib.dmc_bn_apply_act_nhwc(_lib.ptr(y1), None, _lib.ptr(g1), _lib.ptr(b1), _lib.ptr(stats1), _lib.ptr(out1), None,
+                                                 m, cout, 0, _stream()), "dmc_bn_apply_act_nhwc")
+        ctx.save_for_backward(xq, w3, w1, y3, y1, g3, b3, stats3, g1, b1, stats1)
+        ctx.shape = (n, cin, h, w, cout)
+        if out3_xs is None:
+            out3_xs = torch.empty(0, dtype=torch.uint8, device=dev)
+        ctx.mark_non_differentiable(out3_xs)
+        return out3, out3_xs, out1
+
+    @staticmethod
+    def backward(ctx, dout3, _dxs, dout1):
+        lib = _lib.load()
+        xq, w3, w1, y3, y1, g3, b3, stats3, g1, b1, stats1 = ctx.saved_tensors
+        n, cin, h, w, cout = ctx.shape
+        oh, ow = h // 2, w // 2
+        m = n * oh * ow
+        if dout3 is None and dout1 is None:
+            return (None,) * 17
+        dout3 = torch.zeros_like(y3) if dout3 is None else _as_cl(dout3)
+        dout1 = torch.zeros_like(y1) if dout1 is None else _as_cl(dout1)
+        dg3, db3, dg1, db1 = torch.empty_like(g3), torch.empty_like(g3), torch.empty_like(g1), torch.empty_like(g1)
+        dys3, dys1 = _x3s_buffer(m, cout, y3.device), _x3s_buffer(m, cout, y3.device)
+        with _span("bn_act_bwd"):
+            for y, g, b, st, dout, dys, dg, db, relu in ((y3, g3, b3, stats3, dout3, dys3, dg3, db3, 1),
+                                                          (y1, g1, b1, stats1, dout1, dys1, dg1, db1, 0)):
+                scratch = _floats(lib.dmc_bn_act_scratch_bytes(cout), y.device)
+                _lib.check(lib.dmc_bn_act_bwd_x3s(_lib.ptr(y), None, _lib.ptr(g), _lib.ptr(b), _lib.ptr(st), _lib.ptr(scratch),
+                                                  _lib.ptr(dout), None, _lib.ptr(dys), None, _lib.ptr(dg), _lib.ptr(db), None,
+                                                  m, cout, relu, _stream()), "dmc_bn_act_bwd_x3s")
+        dx = dw3 = dw1 = None
+        if ctx.needs_input_grad[0]:
+            with _span("conv_nhwc_dgrad"):
+                dx = torch.empty((n, cin, h, w), dtype=torch.float32, device=y3.device, memory_format=_CL)
+                _lib.check(lib.dmc_x3q_conv_dgrad(_lib.ptr(dys3), _lib.ptr(dys1), _lib.ptr(ctx.wt), _lib.ptr(dx), n, oh, ow, cin, cout,
+                                                  _stream()), "dmc_x3q_conv_dgrad")
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            with _span("conv_nhwc_wgrad"):
+                def launch():
+                    d3 = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=y3.device, memory_format=_CL)
+                    d1 = torch.empty((cout, cin, 1, 1), dtype=torch.float32, device=y3.device, memory_format=_CL)
+                    work = _floats(lib.dmc_x3q_conv_wgrad_bytes(n, oh, ow, cin, cout), y3.device)
+                    _lib.check(lib.dmc_x3q_conv_wgrad(_lib.ptr(xq), _lib.ptr(dys3), _lib.ptr(dys1), _lib.ptr(d3), _lib.ptr(d1),
+                                                      _lib.ptr(work), n, oh, ow, cin, cout, _stream()), "dmc_x3q_conv_wgrad")
+                    return _grad_like(d3, w3), _grad_like(d1, w1)
+                dw3, dw1 = _on_wgrad_stream((w3, w1), (xq, dys3, dys1), launch)
+        return dx, None, dw3, dw1, dg3, db3, None, None, None, None, dg1, db1, None, None, None, None, None
+
+
+def conv_bn_s2_pair(x, unit, want_slices):
+    """(relu(bn1(conv1(x))), downsample(x)) of a stride-2 BasicBlock ``unit`` (see s2_pair_usable); ``want_slices``: conv2 of
+    the unit takes the pre-split path, the first result is returned as slices only (x3s_of)."""
+    bn3, bn1 = unit.bn1, unit.downsample[1]
+    for bn in (bn3, bn1):
+        if bn.num_batches_tracked is not None:
+            if _PENDING_COUNTERS is not None:
+                _PENDING_COUNTERS.append(bn.num_batches_tracked)
+            else:
+                bn.num_batches_tracked.add_(1)
+    xq = x3q_of(x)
+    if xq is None:
+        if not f32_valid(x):
+            raise RuntimeError("conv_bn_s2_pair: the input carries neither s2d slices nor valid fp32 memory")
+        xq = x3q_split(_as_cl(x))
+    out3, out3_xs, out1 = _ConvBnS2Pair.apply(x, xq, unit.conv1.weight, unit.downsample[0].weight, bn3.weight, bn3.bias,
+                                              bn3.running_mean, bn3.running_var, bn3.eps, bn3.momentum, bn1.weight, bn1.bias,
+                                              bn1.running_mean, bn1.running_var, bn1.eps, bn1.momentum, bool(want_slices))
+    if want_slices:
+        _attach_x3s(out3, out3_xs, False)
+    return out3, out1
 
 
 class _DiscBlock(torch.autograd.Function):

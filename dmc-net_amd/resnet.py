@@ -45,13 +45,21 @@ def _same_bn_mode(bn, other):
 
 
 def _conv_bn_act(conv, bn, x, residual=None, relu=True, link=None, next_conv=None, only_consumer=False, bn_link=None,
-                 next_bn=None):
+                 next_bn=None, next_unit=None):
     """relu?(bn(conv(x)) [+ residual]).  ``next_conv``: a convolution that reads the result -- when it takes the
     pre-split bf16x3 path (ops.x3s_usable) the result's slice tensor is written alongside; ``only_consumer``: nothing
     else reads the result, so its fp32 form is not written at all (only when ``next_bn``, the consumer's BatchNorm, is
     in the same mode as ``bn``: the consumer then takes the fused op that reads slices)."""
     train_op = OWN_CONV and x.is_cuda and ops.conv_bn_act_supported(x, conv, bn)
     eval_op = OWN_CONV and x.is_cuda and not train_op and ops.conv_bn_eval_supported(x, conv, bn)
+    if train_op and next_unit is not None:
+        # the result is the input of a stride-2 block: its conv1 and its shortcut convolution both read the space-to-depth
+        # slice tensor (ops.conv_bn_s2_pair) and nothing reads the fp32 form
+        n, _, h, w = x.shape
+        k, s_, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        oshape = (n, conv.out_channels, (h + 2 * p - k) // s_ + 1, (w + 2 * p - k) // s_ + 1)
+        if ops.s2_pair_usable(oshape, next_unit):
+            return ops.conv_bn_act(x, conv, bn, residual, relu, link, want_f32=False, want_slices=True, s2d=True)
     if train_op or eval_op:
         slices = False
         if next_conv is not None:
@@ -102,6 +110,7 @@ class ResidualUnit(nn.Module):
         self.out_channels = cout
         self.next_conv = [None]      # the next unit's first convolution (set by ResNet; in a list: not a sub-module)
         self.next_identity = [False] # ... and whether that unit has an identity shortcut
+        self.next_unit = [None]      # ... and the unit itself when it has a downsample branch (stride-2 pair path)
 
     def forward(self, x):
         link = None
@@ -109,6 +118,14 @@ class ResidualUnit(nn.Module):
             shortcut = x
             # identity shortcut: x feeds conv1 and the add; the two gradients are summed in conv1's data-gradient epilogue
             link = ops.ResidualGradLink() if RESIDUAL_GRAD_LINK and x.requires_grad else None
+        elif OWN_CONV and x.is_cuda and ops.s2_pair_usable(tuple(x.shape), self) and (ops.x3q_of(x) is not None or ops.f32_valid(x)):
+            # stride-2 block: conv1 and the shortcut convolution read the same input -- one launch per direction for the pair
+            n, _, h, w = x.shape
+            y, shortcut = ops.conv_bn_s2_pair(x, self, want_slices=ops.x3s_usable(n, h // 2, w // 2, self.conv2) and
+                                              _same_bn_mode(self.bn1, self.bn2))
+            return _conv_bn_act(self.conv2, self.bn2, y, residual=shortcut, next_conv=self.next_conv[0],
+                                bn_link="block" if (self.next_identity[0] and RESIDUAL_GRAD_LINK) else None,
+                                next_unit=self.next_unit[0])
         else:
             shortcut = _conv_bn_act(self.downsample[0], self.downsample[1], x, relu=False)
         # conv1's result is read by conv2 alone: slices only when conv2 takes the pre-split path
@@ -118,7 +135,8 @@ class ResidualUnit(nn.Module):
                          next_bn=self.bn2)
         if self.kind == "basic":
             return _conv_bn_act(self.conv2, self.bn2, y, residual=shortcut, link=link, next_conv=self.next_conv[0],
-                                bn_link="block" if (self.next_identity[0] and RESIDUAL_GRAD_LINK) else None)
+                                bn_link="block" if (self.next_identity[0] and RESIDUAL_GRAD_LINK) else None,
+                                next_unit=self.next_unit[0])
         y = _conv_bn_act(self.conv2, self.bn2, y, next_conv=self.conv3, only_consumer=True, next_bn=self.bn3)
         return _conv_bn_act(self.conv3, self.bn3, y, residual=shortcut, link=link, next_conv=self.next_conv[0])
 
@@ -142,6 +160,7 @@ class ResNet(nn.Module):
         for u, nxt in zip(chain, chain[1:]):
             u.next_conv[0] = nxt.conv1
             u.next_identity[0] = nxt.downsample is None
+            u.next_unit[0] = nxt if (nxt.downsample is not None and kind == "basic") else None
         self.avgpool = nn.AvgPool2d(7, stride=1)
         self.fc = nn.Linear(width, num_classes)
 

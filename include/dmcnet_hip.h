@@ -386,6 +386,45 @@ int dmc_bn_relu_pool_fwd_arg(const float* x, const float* gamma, const float* be
 int dmc_bn_relu_pool_bwd_arg(const float* x, const float* gamma, const float* beta, const float* stats, void* scratch,
                              const float* d_pool, const void* codes, const float* xmax, float* dx, float* dgamma, float* dbeta,
                              int N, int H, int W, int C, dmc_stream_t stream);
+/* ---- the stride-2 residual blocks on PRE-SPLIT operands (conv_x3q.hip) ------------------------------------------------
+ * Replaces: torchvision BasicBlock `conv1` (3x3, stride 2, padding 1) together with `downsample[0]` (1x1, stride 2) of
+ *           layer2.0 / layer3.0 / layer4.0 -- the two convolutions that read the block input, built at
+ *           code/dmcnet/model.py:305 and run at :352 -- and their autograd, in the bf16x3 arithmetic of dmc_x3s_*, ONE
+ *           launch per direction for the pair (the shortcut reads x[2a][2b] = the centre tap's operand).
+ * Input:    the block input as a SPACE-TO-DEPTH slice tensor ("s2d"; H, W even, OH = H / 2, OW = W / 2, Mq = N OH OW):
+ *               bf16 [3 slices][4 parity classes 2 py + px][Cin / 16][Mq pixels][16 channels]       (6 N H W Cin bytes)
+ *           class (py, px) holds the pixels (2a + py, 2b + px); written by the input's producer (dmc_bn_apply_act_x3q) or
+ *           by dmc_x3q_split; dmc_x3q_merge is the exact inverse.
+ * Weights:  dmc_x3q_pack_weights(w3 [Cout][3][3][Cin], w1 [Cout][Cin] -- channels_last memory of the two PyTorch weights)
+ *           fills the forward's and / or the data gradient's image (dmc_x3q_wpack_bytes() each; either may be NULL).
+ * fwd:      y3 [Mq][Cout] = conv3x3 stride 2 (x, w3), y1 [Mq][Cout] = conv1x1 stride 2 (x, w1), fp32; stat_partials3 / 1
+ *           (nullable) receive the per-channel (sum, sum of squares) per workgroup row, [stat_blocks =
+ *           dmc_x3q_stat_blocks()][Cout][2] doubles each, for dmc_conv_nhwc_stats_final().
+ * dgrad:    dx [N][H][W][Cin] fp32 = conv_transpose(dy3, w3) + conv_transpose(dy1, w1) from the ORDINARY slice tensors of
+ *           the two output gradients ([3][Cout / 16][Mq][16], e.g. from dmc_bn_act_bwd_x3s); every element of dx is written.
+ * wgrad:    dw3 [Cout][3][3][Cin], dw1 [Cout][Cin] from the s2d input and the two output-gradient slice tensors;
+ *           workspace of dmc_x3q_conv_wgrad_bytes(); deterministic (fixed-order reduction of per-workgroup partials).
+ * Cin, Cout multiples of 64; dmc_x3q_supported() says whether a shape is handled (OW in {28, 14, 7} for the weight
+ * gradient, as the classifier has them). */
+size_t dmc_x3q_wpack_bytes(int Cin, int Cout);
+int dmc_x3q_supported(int N, int OH, int OW, int Cin, int Cout);
+int dmc_x3q_stat_blocks(int N, int OH, int OW);
+int dmc_x3q_split(const float* x, void* xq, int N, int H, int W, int C, dmc_stream_t stream);
+int dmc_x3q_merge(const void* xq, float* x, int N, int H, int W, int C, dmc_stream_t stream);
+int dmc_x3q_pack_weights(const float* w3, const float* w1, void* wpack_f, void* wpack_t, int Cin, int Cout, dmc_stream_t stream);
+int dmc_x3q_conv_fwd(const void* xq, const void* wpack_f, float* y3, float* y1, double* stat_partials3, double* stat_partials1,
+                     int stat_blocks, int N, int OH, int OW, int Cin, int Cout, dmc_stream_t stream);
+int dmc_x3q_conv_dgrad(const void* dys3, const void* dys1, const void* wpack_t, float* dx, int N, int OH, int OW, int Cin, int Cout,
+                       dmc_stream_t stream);
+/* dmc_bn_apply_act_x3s (BatchNorm apply [+ residual] [+ ReLU] with given statistics) whose slice output yq is the s2d
+ * tensor over the [N][H][W] grid; y (fp32 NHWC, nullable) as usual. */
+int dmc_bn_apply_act_x3q(const float* x, const float* residual, const float* gamma, const float* beta, const float* stats,
+                         float* y, void* yq, unsigned char* relu_mask, int N, int H, int W, int C, int relu, dmc_stream_t stream);
+int dmc_x3q_conv_wgrad_supported(int N, int OH, int OW, int Cin, int Cout);
+size_t dmc_x3q_conv_wgrad_bytes(int N, int OH, int OW, int Cin, int Cout);
+int dmc_x3q_conv_wgrad(const void* xq, const void* dys3, const void* dys1, float* dw3, float* dw1, float* workspace, int N, int OH,
+                       int OW, int Cin, int Cout, dmc_stream_t stream);
+
 /* BatchNorm-backward sums from the data gradient's epilogue: dmc_x3s_conv_dgrad_bnb = dmc_x3s_conv_dgrad that also
  * reduces, for the unit whose output gradient it writes (dx), dbeta = sum(d) and dgamma = sum(d * xhat) (d = dx, zeroed
  * where that unit's ReLU was off; partials: dmc_x3s_conv_stat_blocks(N, H, W, Cin) x Cin x 2 doubles);

@@ -1,0 +1,60 @@
+"""Trajectory parity: many training steps of the HIP path against the CPU oracle from ONE seeded state on identical
+batches -- the only "matched accuracy" evidence available offline (the reference's published numbers are accuracies,
+/root/reference/README.md:73-76, and need its datasets and ImageNet weights).
+
+Reference lines: code/dmcnet/train.py:221-266 (dmcnet), code/dmcnet_GAN/train.py:261-371 (alternating D / G steps).
+
+What is asserted, and why in this form.  Two fp32 evaluations of the same recipe drift apart by themselves: rounding
+differences pass through Adam (eps = 1e-3) and grow roughly linearly over the first dozens of steps.  So
+  * dmcnet: per-step loss / loss_cls within a stated, GROWING envelope of the oracle's (1.5e-4 (i + 1): the north_star's
+    1e-4 bar at the first step, 3e-3 at step 20; recorded on MI355X: 4e-6 at step 1, 9e-4 at step 17), loss_mse (the
+    generator's short graph, no BatchNorm chain) within 1e-5 throughout, consensus-logit cosine >= 0.9998 at the end
+    (recorded 0.99995);
+  * dmcnet_GAN: the adversarial game with the discriminator at lr 0.01 is chaotic for ANY fp32 implementation (two D steps
+    multiply a 1e-6 difference by ~1e3: tools/trajectory_check.py gan 20 4 fp64), so the yardstick is the oracle run in
+    DOUBLE precision on the same batches and Dropout2d masks: at every step the HIP run may be at most 10x further from the
+    fp64 trajectory than the fp32 CPU oracle has been so far (running maximum; recorded ratios 0.5 .. 5.7, the two fp32 runs
+    leave the fp64 one at the same exponential rate), i.e. it is an fp32 evaluation of the reference's recipe of the same
+    quality as the reference's own arithmetic -- until the oracle itself is > 10 % away, where nothing is left to compare.
+tools/trajectory_check.py prints the full curves (profiles/r4_loss_curves.txt holds 100 steps)."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+pytestmark = [pytest.mark.gpu, pytest.mark.slow]
+
+
+def test_dmcnet_twenty_steps_follow_the_oracle():
+    import trajectory_check as TC
+    recs = TC.run("dmcnet", steps=20, batch=8, seed=700)
+    for i, r in enumerate(recs):
+        bar = 1.5e-4 * (i + 1)
+        assert r["rel"]["loss"] <= bar and r["rel"]["loss_cls"] <= bar, (i, r["rel"], bar)
+        assert r["rel"]["loss_mse"] <= 1e-5, (i, r["rel"])
+        assert r["cos"] >= 1.0 - 1e-5 * (i + 1) ** 1.5, (i, r["cos"])           # 0.99991 at step 20; recorded 0.99995
+    assert recs[-1]["cos"] >= 0.9998
+    # the run learns: the reconstruction loss falls by an order of magnitude in 20 steps (on both sides, identically)
+    assert recs[-1]["got"]["loss_mse"] < 0.1 * recs[0]["got"]["loss_mse"]
+
+
+def test_gan_six_pairs_as_close_to_fp64_as_the_oracle():
+    import trajectory_check as TC
+    recs = TC.run("gan", steps=12, batch=4, seed=700, fp64=True)
+    worst_ref = {}
+    for i, r in enumerate(recs):
+        for k, gap in r["rel64_hip"].items():
+            worst_ref[k] = max(worst_ref.get(k, 0.0), r["rel64_ref"][k])
+            if worst_ref[k] > 0.1:
+                continue        # the fp32 ORACLE has left the fp64 trajectory by > 10 % in this quantity: nothing left to compare
+            # floor: the first steps, where the oracle's own gap to fp64 is at rounding level
+            bar = max(10.0 * worst_ref[k], 5e-4 * (i + 1))
+            assert gap <= bar, (i, k, gap, bar, r["rel64_ref"][k])
+        # the first D step and the first G step are plain one-step parity (2e-4, as test_gan_step_pair_full_batch_vs_oracle)
+        if i < 2:
+            assert all(v <= 2e-4 for v in r["rel"].values()), (i, r["rel"])
+    # the classifier's logits stay aligned with the fp64 run about as well as the oracle's do
+    assert 1.0 - recs[-1]["cos64_hip"] <= max(10.0 * max(1.0 - r["cos64_ref"] for r in recs), 1e-4)
