@@ -393,17 +393,33 @@ def main():
         # median over the steps (a span also contains whatever the host did between its two event records: one stalled
         # step must not decide the figure)
         conv_spans = {k: sorted(st[k] for st in per_step if k in st)[len(per_step) // 2] for k in per_step[0]}
+    # CLEAN host cost of a step: each step enqueued on an EMPTY launch queue (synchronize() in front, outside the clock), so
+    # the figure holds no queue back-pressure -- host_enqueue_ms_per_step above is read while the queue is full and mostly
+    # measures the GPU.  With N ranks every rank does this at the same time (a barrier in front): the ranks contend for the
+    # host's cores exactly as in the timed region.
+    clean = []
+    for i in range(9):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        one(i)
+        clean.append((time.perf_counter() - t1) * 1e3)
+    torch.cuda.synchronize()
+    host_clean_ms = sorted(clean)[len(clean) // 2]
     comm = {"backend": None, "world_size": 1, "note": "single process: no gradient exchange"}
     if world > 1:
         # self-diagnosing multi-GPU line: which communicator, what travelled, how much of it was exposed, rank spread
         comm = reducer.comm_summary()
-        mine = torch.tensor([elapsed / args.steps * 1e3, comm["exposed_wait_ms_per_step"] or 0.0], device=dev, dtype=torch.float64)
+        mine = torch.tensor([elapsed / args.steps * 1e3, comm["exposed_wait_ms_per_step"] or 0.0, host_clean_ms], device=dev, dtype=torch.float64)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         comm["ms_per_step_by_rank"] = [round(float(t[0]), 3) for t in every]
         comm["ms_per_step_rank_min"] = round(min(float(t[0]) for t in every), 3)
         comm["ms_per_step_rank_max"] = round(max(float(t[0]) for t in every), 3)
         comm["exposed_wait_ms_per_step_rank_max"] = round(max(float(t[1]) for t in every), 4)
+        comm["host_clean_ms_per_step_by_rank"] = [round(float(t[2]), 3) for t in every]
+        comm["host_cores_usable"] = usable_cores()
         comm["device_of_rank0"] = torch.cuda.get_device_name(dev)
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -430,7 +446,8 @@ def main():
             "value": round(world * args.batch * args.steps / elapsed, 3), "unit": "clips/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "ms_per_step_median": round(median_ms, 3), "host_enqueue_ms_per_step": round(host_ms, 3), "higher_is_better": True,
+            "ms_per_step_median": round(median_ms, 3), "host_enqueue_ms_per_step": round(host_ms, 3),
+            "host_clean_ms_per_step": round(host_clean_ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("dmcnet_GAN HMDB-51 split1 (Discriminator3, alternating D/G)" if gan else
                                     "HMDB-51 split1 dmcnet (no GAN), 3 segments, ResNet-18, DenseNetTiny "
@@ -438,8 +455,11 @@ def main():
                                    ", batch %d clips/GPU, random-init weights" % args.batch,
                        "global_batch": world * args.batch, "num_class": args.num_class,
                        "parallelism": "dp%d" % world, "final_loss": round(loss, 6),
-                       "classifier_convs": ("libdmcnet_hip conv_x3s (3x3 stride 1: operands pre-split into bf16x3 slice tensors by "
-                                            "their producers; stride-2 data gradient likewise) + conv_nhwc (stride-2 / 1x1), "
+                       "classifier_convs": (("libdmcnet_hip conv_x3s (3x3 stride 1) + conv_x3q (the stride-2 blocks: 3x3 stride 2 fused with "
+                                             "the 1x1 shortcut on space-to-depth slice tensors): every operand pre-split into "
+                                             "bf16x3 slice tensors by its producer, " if ops.X3Q else
+                                             "libdmcnet_hip conv_x3s (3x3 stride 1: operands pre-split into bf16x3 slice tensors by "
+                                             "their producers; stride-2 data gradient likewise) + conv_nhwc (stride-2 / 1x1), ")
                                             if (args.conv_arith and ops.X3S) else "libdmcnet_hip conv_nhwc, ") +
                                            ("bf16x3 arithmetic (fp32 values; every fp32 "
                                             "product formed from three bf16 slices by six bf16 MFMAs, fp32 accumulate: "
