@@ -225,6 +225,16 @@ def bench_i3d(args, rank, world, dev):
         elapsed = float(tmax)
     ops.PROBE = None
     spans = probe.summary()
+    clean = []                                       # clean host cost: each micro-step enqueued on an empty queue (see main())
+    for _ in range(7):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        one()
+        clean.append((time.perf_counter() - t1) * 1e3)
+    torch.cuda.synchronize()
+    host_clean_ms = sorted(clean)[len(clean) // 2]
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -235,7 +245,7 @@ def bench_i3d(args, rank, world, dev):
         "metric": "clips/sec (%d-frame 224x224 clips) dmcnet_I3D train micro-step" % args.clip_length,
         "value": round(world * b * args.steps / elapsed, 3), "unit": "clips/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-        "host_enqueue_ms_per_step": round(host_ms, 3),
+        "host_enqueue_ms_per_step": round(host_ms, 3), "host_clean_ms_per_step": round(host_clean_ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 trunk / f32 generator",
         "data": "synthetic",
         "config": {"workload": "dmcnet_I3D HMDB-51, DenseNetTiny generator per frame + I3D trunk + Discriminator, "
@@ -315,7 +325,11 @@ def main():
     torch.backends.cudnn.benchmark = bool(args.miopen_find)   # (enable_find above also set the db path)
     if os.environ.get("DMC_CHANNELS_LAST") == "0":
         model.base_model.to(memory_format=torch.contiguous_format)
-    reducer = ddp.for_model(model) if world > 1 else None
+    # DMC_BENCH_REPLICAS=1 (test hook, tools/host_contention.sh): the N ranks run INDEPENDENT replicas -- no gradient exchange --
+    # so that what N processes cost each other on the HOST can be measured on a box whose transport (gloo through host memory
+    # when N ranks share one GPU) would otherwise dominate
+    replicas = os.environ.get("DMC_BENCH_REPLICAS") == "1"
+    reducer = ddp.for_model(model) if (world > 1 and not replicas) else None
     if gan:
         stepper = train.GanTrainStep(model, S, 1.0, 1.0, 0.01, 10.0, lr_d_mult=1.0, reducer=reducer, **HP)
     else:
@@ -410,7 +424,9 @@ def main():
     comm = {"backend": None, "world_size": 1, "note": "single process: no gradient exchange"}
     if world > 1:
         # self-diagnosing multi-GPU line: which communicator, what travelled, how much of it was exposed, rank spread
-        comm = reducer.comm_summary()
+        comm = reducer.comm_summary() if reducer is not None else {
+            "backend": dist.get_backend(), "world_size": world, "exposed_wait_ms_per_step": None,
+            "note": "DMC_BENCH_REPLICAS=1: independent replicas, no gradient exchange (host-contention measurement)"}
         mine = torch.tensor([elapsed / args.steps * 1e3, comm["exposed_wait_ms_per_step"] or 0.0, host_clean_ms], device=dev, dtype=torch.float64)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)

@@ -406,3 +406,51 @@ def test_conv3d_wgrad_ring_kernel_against_the_tap_stepping_kernel(case, k):
     if n * d * h * w <= 4000 and cin * cout <= 100000:
         ref = torch.nn.grad.conv3d_weight(x.double().cpu(), (cout, cin, k, k, k), dy.double().cpu(), padding=k // 2)
         assert float((out[2].double().cpu() - ref).abs().max() / ref.abs().max()) < 2e-5
+
+
+def test_i3d_trunk_conditioned_gradients_vs_fp32():
+    """The CONDITIONED end-to-end case next to test_i3d_trunk_end_to_end_own_vs_stock_bf16 (whose 0.25 is a smoke floor): the
+    trunk cut behind mixed_3c (stem, two pools, conv3d_2b / 2c, two Inception blocks: 17 conv -> BatchNorm3d -> ReLU units)
+    with a fixed linear read-out of the pooled features -- shallow enough that bf16 gradients still follow the fp32 ones, so an
+    ABSOLUTE bar can be set: per watched tensor the own path's gradient cosine against the fp32 trunk is >= 0.9 (recorded
+    0.973 .. 1.000, the stock bf16 path 0.974 .. 1.000) and within 0.03 of the stock bf16 path's; features cosine > 0.999."""
+    import copy
+    torch.manual_seed(23)
+    net = i3d.I3D(51, modality="flow").to(DEV).train()
+    head = torch.randn(480, 51, device=DEV) * 0.05
+    order = net._ORDER[:net._ORDER.index("mixed_3c") + 1]
+    x = torch.randn(3, 2, 16, 224, 224, device=DEV)
+    tgt = torch.tensor([3, 40, 17], device=DEV)
+
+    def run(model, own, dtype):
+        i3d.OWN_CONV3D = own
+        try:
+            model.zero_grad(set_to_none=True)
+            h = x
+            if dtype is not None:
+                with torch.autocast("cuda", dtype=dtype), ops.batched_bn_counters():
+                    for nm in order:
+                        h = getattr(model, nm)(h)
+            else:
+                for nm in order:
+                    h = getattr(model, nm)(h)
+            feat = h.float()
+            F.cross_entropy(feat.mean((2, 3, 4)) @ head, tgt).backward()
+        finally:
+            i3d.OWN_CONV3D = True
+        return feat.detach(), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    def cos(a, b):
+        a, b = a.flatten().double(), b.flatten().double()
+        return float((a * b).sum() / (a.norm() * b.norm()).clamp_min(1e-30))
+
+    f_own, g_own = run(copy.deepcopy(net), True, torch.bfloat16)
+    f_stock, g_stock = run(copy.deepcopy(net), False, torch.bfloat16)
+    f_32, g_32 = run(copy.deepcopy(net), False, None)
+    assert cos(f_own, f_32) > 0.999 and cos(f_stock, f_32) > 0.999, (cos(f_own, f_32), cos(f_stock, f_32))
+    for k in ("conv3d_1a_7x7.conv3d.weight", "conv3d_2b_1x1.conv3d.weight", "conv3d_2c_3x3.conv3d.weight",
+              "conv3d_2c_3x3.batch3d.weight", "mixed_3b.branch_1.1.conv3d.weight", "mixed_3b.branch_3.1.conv3d.weight",
+              "mixed_3c.branch_0.conv3d.weight", "mixed_3c.branch_2.1.conv3d.weight", "mixed_3c.branch_1.1.batch3d.bias"):
+        c_own, c_stock = cos(g_own[k], g_32[k]), cos(g_stock[k], g_32[k])
+        print("  conditioned grad cos vs fp32  %-40s own %.4f  stock bf16 %.4f" % (k, c_own, c_stock))
+        assert c_own >= 0.9 and c_own >= c_stock - 0.03, (k, c_own, c_stock)
