@@ -316,12 +316,17 @@ __global__ __launch_bounds__(256) void prepare_crop_band_kernel(CropArgs a) {
             const float o[4] = {lut.t[k][v[0][c]], lut.t[k][v[1][c]], lut.t[k][v[2][c]], lut.t[k][v[3][c]]};
             store_plane_quad(a, plane_of(a, n, c, OHW), pix, x0, o);
         }
+        if ((a.factor & 3) == 0 && x0 + 3 < a.OW) {                    // the quad lies in one block column; integer sums: any grouping
+            atomicAdd(&bsum[2 * (x0 / a.factor) + 0], v[0][0] + v[1][0] + v[2][0] + v[3][0]);
+            atomicAdd(&bsum[2 * (x0 / a.factor) + 1], v[0][1] + v[1][1] + v[2][1] + v[3][1]);
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (x0 + j < a.OW) {
-                atomicAdd(&bsum[2 * ((x0 + j) / a.factor) + 0], v[j][0]);
-                atomicAdd(&bsum[2 * ((x0 + j) / a.factor) + 1], v[j][1]);
-            }
+            for (int j = 0; j < 4; ++j)
+                if (x0 + j < a.OW) {
+                    atomicAdd(&bsum[2 * ((x0 + j) / a.factor) + 0], v[j][0]);
+                    atomicAdd(&bsum[2 * ((x0 + j) / a.factor) + 1], v[j][1]);
+                }
+        }
     }
     __syncthreads();
     const double denom = (double)(a.factor * a.factor);
