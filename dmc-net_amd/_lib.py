@@ -82,7 +82,7 @@ SIGNATURES = {
     "dmc_x3s_conv_dgrad_s2": (_I, [_P] * 3 + [_I] * 5 + [_P]),
     "dmc_x3q_wpack_bytes": (_Z, [_I, _I]),
     "dmc_x3q_supported": (_I, [_I] * 5),
-    "dmc_x3q_stat_blocks": (_I, [_I] * 3),
+    "dmc_x3q_stat_blocks": (_I, [_I] * 4),
     "dmc_x3q_split": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dmc_x3q_merge": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dmc_x3q_pack_weights": (_I, [_P, _P, _P, _P, _I, _I, _P]),

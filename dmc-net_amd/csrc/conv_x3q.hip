@@ -26,7 +26,9 @@ using namespace dmc::x3;
 namespace {
 
 // ---- tile geometry ------------------------------------------------------------------------------------------
-constexpr int QNW = 8, QBM = 32 * QNW, QBN = 64;   // 8 waves x 32 pixels, 64 output rows (channels) per workgroup
+constexpr int QNW = 8, QBM = 32 * QNW, QBN = 64;   // 8 waves; TN = 2: 8 x (32 pixels x 64 rows) = 256 pixels per workgroup,
+                                                    // TN = 1: 4 x 2 waves of 32 pixels x 32 rows = 128 pixels (half-size workgroups
+                                                    // where 256-pixel tiles leave CUs idle: tile quantisation, q_choose_tn)
 constexpr int QNT = 12;                             // patch transfers per slice (32 pixel rows each): 384 staged rows
 constexpr int QZROW = 32 * QNT;                     // the zero row behind them (taps that leave the image read it)
 constexpr int QPSL = (QZROW + 1) * 32;              // bytes of one slice region of a patch buffer
@@ -87,15 +89,18 @@ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl<N>(f, std::make_integer_sequence<int, N>{}); }
 
-template <class P>
+template <class P, int TN>
 __global__ __launch_bounds__(QNW * 64) void x3q_conv_kernel(X3qArgs a) {
     constexpr int NSH = P::NSH, NACC = P::NACC, NSTEP = P::NSTEP, NUNIT = P::NUNIT;
+    constexpr int WN = 2 / TN, WM = QNW / WN, BM = 32 * WM;  // waves along rows (channels) / pixels; pixels per workgroup
+    static_assert(TN == 1 || TN == 2, "a wave owns 32 or 64 of the workgroup's 64 rows");
     constexpr int CHB = P::NSLOTS * QWSLOT;                  // packed weight bytes per (64-row block, chunk)
     static_assert(P::NSLOTS % 2 == 0, "the fragment registers alternate per slot: an even number per chunk keeps the roles fixed");
     extern __shared__ __attribute__((aligned(1024))) char lds_q[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
     const int l31 = lane & 31, khalf = lane >> 5;
     const unsigned lds0 = lds_addr_of(lds_q);
 
@@ -103,8 +108,8 @@ __global__ __launch_bounds__(QNW * 64) void x3q_conv_kernel(X3qArgs a) {
     // (forward) the tile's first pixel to the end of the row of (below: data gradient) its last one; no halo columns,
     // taps that leave the image read the zero row (conv_x3s.hip) ----
     const int HW = a.H * a.W, PW = a.W;
-    const int m0 = blockIdx.x * QBM;
-    const int mlast = (m0 + QBM < a.M ? m0 + QBM : a.M) - 1;
+    const int m0 = blockIdx.x * BM;
+    const int mlast = (m0 + BM < a.M ? m0 + BM : a.M) - 1;
     const int r_first = m0 / PW, r_last = mlast / PW;
     const int f0 = (r_first - P::HALO_UP > 0 ? r_first - P::HALO_UP : 0) * PW;
     const int f1 = (r_last + 1 + P::HALO_DN) * PW < a.M ? (r_last + 1 + P::HALO_DN) * PW : a.M;
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(QNW * 64) void x3q_conv_kernel(X3qArgs a) {
     // ---- fragment addresses ----
     int xaddr[NSH];
     {
-        int m = m0 + wave * 32 + l31;
+        int m = m0 + wm * 32 + l31;
         if (m > mlast) m = mlast;                            // rows beyond M: a valid address, result not stored
         const int n = m / HW, rem = m - n * HW, yy = rem / a.W, xx = rem - yy * a.W;
         const int pp = m - f0;
@@ -156,24 +161,24 @@ __global__ __launch_bounds__(QNW * 64) void x3q_conv_kernel(X3qArgs a) {
             xaddr[sh] = row * 32 + ((khalf ^ ((row >> 3) & 1)) << 4);
         });
     }
-    const int waddr = QWOFF + l31 * 32 + ((khalf ^ ((l31 >> 3) & 1)) << 4);
+    const int waddr = QWOFF + (wn * TN * 32 + l31) * 32 + ((khalf ^ ((l31 >> 3) & 1)) << 4);
 
-    f32x16 acc[NACC][2];
+    f32x16 acc[NACC][TN];
 #pragma unroll
     for (int s = 0; s < NACC; ++s)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[s][j][e] = 0.f;
 
     lds_cptr const L = (lds_cptr)lds_q;
-    struct Frag { u32x4 X[3], W[2][3]; };                    // one tap slot's operands: 9 reads, 12 MFMAs
+    struct Frag { u32x4 X[3], W[TN][3]; };                   // one tap slot's operands: 3 + 3 TN reads, 6 TN MFMAs
     auto load_frags = [&](Frag& f, int xa, int wa, auto kc) {
         constexpr int k = decltype(kc)::value;
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < TN; ++j)
                 f.W[j][s] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(L + wa + ((k * 3 + s) * QBN + 32 * j) * 32);
             f.X[s] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(L + xa + s * QPSL);
         }
@@ -185,18 +190,19 @@ __global__ __launch_bounds__(QNW * 64) void x3q_conv_kernel(X3qArgs a) {
         for (int p = 0; p < 6; ++p) {
             constexpr int WS[6] = {0, 0, 0, 1, 1, 2}, XS[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[A][j] = mfma_bf16(f.W[j][WS[p]], f.X[XS[p]], acc[A][j]);
+            for (int j = 0; j < TN; ++j) acc[A][j] = mfma_bf16(f.W[j][WS[p]], f.X[XS[p]], acc[A][j]);
             between(p);
         }
     };
     auto nothing = [](int) {};
-    auto interleave = [&]() {                                // one fragment read behind each of the first 9 MFMAs
+    constexpr int NRD = 3 + 3 * TN, NMF = 6 * TN;
+    auto interleave = [&]() {                                // one fragment read behind each of the first MFMAs
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
+        for (int k = 0; k < (NRD < NMF ? NRD : NMF); ++k) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        if constexpr (NMF > NRD) __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
     };
 
     // ---- prologue: zero rows, the first three patches, the first two steps' weights ----
@@ -294,17 +300,19 @@ __global__ __launch_bounds__(QNW * 64) void x3q_conv_kernel(X3qArgs a) {
         });
     }
 
-    // ---- epilogue (as x3s_conv_kernel): per accumulator set the wave's tile goes through its piece of the (dead) operand
-    // LDS -- stored row-major (whole 256-byte pixel rows), summed column-wise in fp64 for the BatchNorm statistics ----
+    // ---- epilogue (as x3s_conv_kernel): per accumulator set the wave's tile [32 pixels][CW = 32 TN channels] goes through its
+    // piece of the (dead) operand LDS -- stored row-major (whole 128- / 256-byte pixel rows), summed column-wise in fp64 for
+    // the BatchNorm statistics ----
     __syncthreads();                                          // every wave has read its last fragments
+    constexpr int CW = 32 * TN, LPR = CW / 4, RPI = 64 / LPR; // channels per wave; lanes per pixel row; pixel rows per iteration
     char* etile = lds_q + wave * QETILE;
-    const int mw0 = m0 + wave * 32;
-    const int rbase = blockIdx.y * QBN;
+    const int mw0 = m0 + wm * 32;
+    const int rbase = blockIdx.y * QBN + wn * CW;
     const bool ok = mw0 + l31 <= mlast;
 #pragma unroll
     for (int A = 0; A < NACC; ++A) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 float4 v = make_float4(acc[A][j][4 * g4], acc[A][j][4 * g4 + 1], acc[A][j][4 * g4 + 2], acc[A][j][4 * g4 + 3]);
@@ -313,38 +321,40 @@ __global__ __launch_bounds__(QNW * 64) void x3q_conv_kernel(X3qArgs a) {
             }
         float* const yout = (NACC == 2 && A == 1) ? a.y1 : a.y0;
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int prow = 4 * it + (lane >> 4);
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int prow = RPI * it + lane / LPR;
             const int m = mw0 + prow;
-            const float4 v = *reinterpret_cast<const float4*>(etile + prow * QEP + (lane & 15) * 16);
+            const float4 v = *reinterpret_cast<const float4*>(etile + prow * QEP + (lane % LPR) * 16);
             if (m <= mlast) {
                 size_t opix = (size_t)m;
                 if (NACC == 4) {                              // position (n, ya, xb) of dy -> input pixel (2 ya + py, 2 xb + px)
                     const int n = m / HW, rem = m - n * HW, ya = rem / a.W, xb = rem - ya * a.W;
                     opix = ((size_t)n * (2 * a.H) + 2 * ya + (A >> 1)) * (2 * a.W) + 2 * xb + (A & 1);
                 }
-                *reinterpret_cast<float4*>(yout + opix * a.R + rbase + (lane & 15) * 4) = v;
+                *reinterpret_cast<float4*>(yout + opix * a.R + rbase + (lane % LPR) * 4) = v;
             }
         }
         if (NACC == 2) {
             double* const part = A == 1 ? a.part1 : a.part0;
             if (part) {
-                double* red = reinterpret_cast<double*>(lds_q + QNW * QETILE);   // [wave][64][2]
-                double d1 = 0.0, d2 = 0.0;
+                double* red = reinterpret_cast<double*>(lds_q + QNW * QETILE);   // [wm][64 channels][2]
+                if (lane < CW) {
+                    double d1 = 0.0, d2 = 0.0;
 #pragma unroll 8
-                for (int p = 0; p < 32; ++p) {
-                    const double v = (double)*reinterpret_cast<const float*>(etile + p * QEP + lane * 4);
-                    d1 += v;
-                    d2 += v * v;
+                    for (int p = 0; p < 32; ++p) {
+                        const double v = (double)*reinterpret_cast<const float*>(etile + p * QEP + lane * 4);
+                        d1 += v;
+                        d2 += v * v;
+                    }
+                    red[(wm * 64 + wn * CW + lane) * 2 + 0] = d1;
+                    red[(wm * 64 + wn * CW + lane) * 2 + 1] = d2;
                 }
-                red[(wave * 64 + lane) * 2 + 0] = d1;
-                red[(wave * 64 + lane) * 2 + 1] = d2;
                 __syncthreads();
                 for (int cc = tid; cc < QBN; cc += QNW * 64) {
                     double e1 = 0.0, e2 = 0.0;
 #pragma unroll
-                    for (int w = 0; w < QNW; ++w) { e1 += red[(w * 64 + cc) * 2 + 0]; e2 += red[(w * 64 + cc) * 2 + 1]; }
-                    double* dst = part + ((size_t)blockIdx.x * a.R + rbase + cc) * 2;
+                    for (int w = 0; w < WM; ++w) { e1 += red[(w * 64 + cc) * 2 + 0]; e2 += red[(w * 64 + cc) * 2 + 1]; }
+                    double* dst = part + ((size_t)blockIdx.x * a.R + blockIdx.y * QBN + cc) * 2;
                     dst[0] = e1; dst[1] = e2;
                 }
                 __syncthreads();                              // `red` and the tiles are rewritten by the next set
@@ -427,7 +437,8 @@ int stream_blocks_q(long total) {
     return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
-// staged pixels the tiles of QBM consecutive pixels of a W-wide grid need at most (tile rows + one halo row)
+// staged pixels the tiles of QBM consecutive pixels of a W-wide grid need at most (tile rows + one halo row); the 128-pixel
+// tiles of the TN = 1 variant need fewer
 int q_patch_pixels_max(long M, int W) {
     int worst = 0;
     long tiles = (M + QBM - 1) / QBM;
@@ -447,13 +458,28 @@ bool q_shape_ok(int N, int OH, int OW, int Cin, int Cout) {
     return q_patch_pixels_max(M, OW) <= QZROW;
 }
 
-template <class P>
+// Tile quantisation: one workgroup per CU (147 KB of LDS), so a launch takes ceil(workgroups / 256) rounds.  The half-size
+// workgroups (TN = 1: 128 pixels, the same 8 waves on 32 x 32 tiles, 4/3 of the LDS reads per MFMA) cost ~0.73 of a full-size
+// one instead of 0.5 (measured, 120 frames: layer4.0's data gradient -- 92 full-size workgroups on 256 CUs -- 158 -> 115 us;
+// but layer3.0's forward, 368 -> 736 workgroups, 107 -> 116 us): they are taken only where they save more than that.
+// option conv_cfg = 201 / 202 forces TN = 2 / 1 (measurement).
+int q_choose_tn(long M, int R) {
+    const int forced = option(OPT_CONV_CFG);
+    if (forced == 201) return 2;
+    if (forced == 202) return 1;
+    const long n2 = ((M + 255) / 256) * (R / QBN), n1 = ((M + 127) / 128) * (R / QBN);
+    const double t2 = (double)((n2 + 255) / 256), t1 = 0.75 * (double)((n1 + 255) / 256);
+    return t1 < t2 ? 1 : 2;
+}
+
+template <class P, int TN>
 int launch_q(const X3qArgs& a, hipStream_t s) {
     static LdsLimit lim;
-    const hipError_t attr = lim.raise(reinterpret_cast<const void*>(&x3q_conv_kernel<P>), QLDS);
+    const hipError_t attr = lim.raise(reinterpret_cast<const void*>(&x3q_conv_kernel<P, TN>), QLDS);
     if (attr != hipSuccess) return fail(DMC_E_LAUNCH, "x3q_conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
-    dim3 grid((a.M + QBM - 1) / QBM, a.R / QBN);
-    x3q_conv_kernel<P><<<grid, QNW * 64, QLDS, s>>>(a);
+    constexpr int BM = TN == 2 ? 256 : 128;
+    dim3 grid((a.M + BM - 1) / BM, a.R / QBN);
+    x3q_conv_kernel<P, TN><<<grid, QNW * 64, QLDS, s>>>(a);
     return check_launch("x3q_conv");
 }
 
@@ -773,7 +799,11 @@ size_t dmc_x3q_wpack_bytes(int Cin, int Cout) { return (size_t)Cin * (size_t)Cou
 
 int dmc_x3q_supported(int N, int OH, int OW, int Cin, int Cout) { return q_shape_ok(N, OH, OW, Cin, Cout) ? 1 : 0; }
 
-int dmc_x3q_stat_blocks(int N, int OH, int OW) { return (int)(((long)N * OH * OW + QBM - 1) / QBM); }
+int dmc_x3q_stat_blocks(int N, int OH, int OW, int Cout) {
+    const long M = (long)N * OH * OW;
+    const int bm = q_choose_tn(M, Cout) == 2 ? 256 : 128;
+    return (int)((M + bm - 1) / bm);
+}
 
 int dmc_x3q_split(const float* x, void* xq, int N, int H, int W, int C, dmc_stream_t stream) {
     if (!x || !xq || N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || C % 16 != 0)
@@ -804,15 +834,17 @@ int dmc_x3q_conv_fwd(const void* xq, const void* wpack_f, float* y3, float* y1, 
     if (!xq || !wpack_f || !y3 || !y1) return fail(DMC_E_INVALID, "dmc_x3q_conv_fwd: null pointer");
     if (!q_shape_ok(N, OH, OW, Cin, Cout))
         return fail(DMC_E_INVALID, "dmc_x3q_conv_fwd: unsupported shape N=%d OH=%d OW=%d Cin=%d Cout=%d", N, OH, OW, Cin, Cout);
-    if ((stat_partials3 || stat_partials1) && stat_blocks != dmc_x3q_stat_blocks(N, OH, OW))
-        return fail(DMC_E_INVALID, "dmc_x3q_conv_fwd: statistics partials have %d rows but this launch writes %d", stat_blocks,
-                    dmc_x3q_stat_blocks(N, OH, OW));
+    const int tn = q_choose_tn((long)N * OH * OW, Cout);
+    const int rows = (int)(((long)N * OH * OW + (tn == 2 ? 255 : 127)) / (tn == 2 ? 256 : 128));
+    if ((stat_partials3 || stat_partials1) && stat_blocks != rows)
+        return fail(DMC_E_INVALID, "dmc_x3q_conv_fwd: statistics partials have %d rows but this launch writes %d (dmc_x3q_stat_blocks "
+                                   "was called under another conv_cfg option?)", stat_blocks, rows);
     X3qArgs a;
     a.t0 = xq; a.t1 = nullptr; a.wp = wpack_f; a.y0 = y3; a.y1 = y1; a.part0 = stat_partials3; a.part1 = stat_partials1;
     a.N = N; a.H = OH; a.W = OW; a.K = Cin; a.R = Cout; a.M = N * OH * OW;
     a.plane_bytes = (unsigned)a.M * 32u;
     a.pps0 = 4 * (Cin / 16); a.pps1 = 0;
-    return launch_q<ProgFwd>(a, (hipStream_t)stream);
+    return tn == 2 ? launch_q<ProgFwd, 2>(a, (hipStream_t)stream) : launch_q<ProgFwd, 1>(a, (hipStream_t)stream);
 }
 
 int dmc_x3q_conv_dgrad(const void* dys3, const void* dys1, const void* wpack_t, float* dx, int N, int OH, int OW, int Cin, int Cout,
@@ -825,7 +857,7 @@ int dmc_x3q_conv_dgrad(const void* dys3, const void* dys1, const void* wpack_t, 
     a.N = N; a.H = OH; a.W = OW; a.K = Cout; a.R = Cin; a.M = N * OH * OW;
     a.plane_bytes = (unsigned)a.M * 32u;
     a.pps0 = a.pps1 = Cout / 16;
-    return launch_q<ProgDgrad>(a, (hipStream_t)stream);
+    return q_choose_tn(a.M, Cin) == 2 ? launch_q<ProgDgrad, 2>(a, (hipStream_t)stream) : launch_q<ProgDgrad, 1>(a, (hipStream_t)stream);
 }
 
 int dmc_x3q_conv_wgrad_supported(int N, int OH, int OW, int Cin, int Cout) {

@@ -908,7 +908,7 @@ def x3q_conv_fwd(xq, wpack_f, n, oh, ow, cin, cout, want_stats=False):
     p3 = p1 = None
     nblk = 0
     if want_stats:
-        nblk = lib.dmc_x3q_stat_blocks(n, oh, ow)
+        nblk = lib.dmc_x3q_stat_blocks(n, oh, ow, cout)
         p3 = torch.empty((nblk, cout, 2), dtype=torch.float64, device=xq.device)
         p1 = torch.empty_like(p3)
     _lib.check(lib.dmc_x3q_conv_fwd(_lib.ptr(xq), _lib.ptr(wpack_f), _lib.ptr(y3), _lib.ptr(y1), _lib.ptr(p3), _lib.ptr(p1), nblk,
@@ -1454,7 +1454,7 @@ class _ConvBnS2Pair(torch.autograd.Function):
                                                 _stream()), "dmc_x3q_pack_weights")
             y3 = torch.empty((n, cout, oh, ow), dtype=torch.float32, device=dev, memory_format=_CL)
             y1 = torch.empty_like(y3)
-            nblk = lib.dmc_x3q_stat_blocks(n, oh, ow)
+            nblk = lib.dmc_x3q_stat_blocks(n, oh, ow, cout)
             part = torch.empty((2, nblk, cout, 2), dtype=torch.float64, device=dev)
             _lib.check(lib.dmc_x3q_conv_fwd(_lib.ptr(xq), _lib.ptr(wf), _lib.ptr(y3), _lib.ptr(y1), _lib.ptr(part[0]), _lib.ptr(part[1]),
                                             nblk, n, oh, ow, cin, cout, _stream()), "dmc_x3q_conv_fwd")

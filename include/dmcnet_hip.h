@@ -408,7 +408,7 @@ int dmc_bn_relu_pool_bwd_arg(const float* x, const float* gamma, const float* be
  * gradient, as the classifier has them). */
 size_t dmc_x3q_wpack_bytes(int Cin, int Cout);
 int dmc_x3q_supported(int N, int OH, int OW, int Cin, int Cout);
-int dmc_x3q_stat_blocks(int N, int OH, int OW);
+int dmc_x3q_stat_blocks(int N, int OH, int OW, int Cout);
 int dmc_x3q_split(const float* x, void* xq, int N, int H, int W, int C, dmc_stream_t stream);
 int dmc_x3q_merge(const void* xq, float* x, int N, int H, int W, int C, dmc_stream_t stream);
 int dmc_x3q_pack_weights(const float* w3, const float* w1, void* wpack_f, void* wpack_t, int Cin, int Cout, dmc_stream_t stream);
