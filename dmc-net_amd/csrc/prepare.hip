@@ -109,19 +109,27 @@ struct CropArgs {
 
 // box (y0, x0, h, w) of the frame is resized to rh x rw, of which the window at (cy, cx) of the output
 // size is kept (GroupScale + GroupCenterCrop); rh x rw == h x w means "no resampling"
-struct Box { int y0, x0, h, w, rh, rw, cy, cx; };
+struct Box { int y0, x0, h, w, rh, rw, cy, cx; float sy, sx; };      // sy, sx: the fp32 scales n_in / n_out of tap_of, once per box
 __device__ __forceinline__ Box box_of(const CropArgs& a, int n) {
-    Box b = {0, 0, a.H0, a.W0, a.OH, a.OW, 0, 0};
+    Box b = {0, 0, a.H0, a.W0, a.OH, a.OW, 0, 0, 1.f, 1.f};
     if (a.boxes) {
         const int* p = a.boxes + (size_t)n * 8;
         b.y0 = p[0]; b.x0 = p[1]; b.h = p[2]; b.w = p[3]; b.rh = p[4]; b.rw = p[5]; b.cy = p[6]; b.cx = p[7];
+    }
+    if (b.h != b.rh || b.w != b.rw) {
+        b.sy = (float)((double)b.h / (double)b.rh);
+        b.sx = (float)((double)b.w / (double)b.rw);
     }
     return b;
 }
 
 struct Tap { int lo, hi; double f; };
+__device__ __forceinline__ Tap tap_scaled(int i, float scale, int n_in);
 __device__ __forceinline__ Tap tap_of(int i, int n_out, int n_in) {
-    const float scale = (float)((double)n_in / (double)n_out);
+    return tap_scaled(i, (float)((double)n_in / (double)n_out), n_in);
+}
+// tap_of with the scale given (an fp64 division per PIXEL was a tenth of the resize path's instructions)
+__device__ __forceinline__ Tap tap_scaled(int i, float scale, int n_in) {
     const float pos = ((float)i + 0.5f) * scale - 0.5f;
     const float fl = floorf(pos);
     const int lo = (int)fl;
@@ -170,11 +178,18 @@ __device__ __forceinline__ void quad_values(const CropArgs& a, const unsigned ch
             bytes[4 * k + 0] = u & 255; bytes[4 * k + 1] = (u >> 8) & 255;
             bytes[4 * k + 2] = (u >> 16) & 255; bytes[4 * k + 3] = u >> 24;
         }
+        // (two unrolled copies: with a run-time `flipped` the index js * 7 + c is a dynamic index into a register array, which the
+        // compiler lowers to a 28-way select chain per value -- 1,000 of the kernel's 1,500 VALU instructions per quad)
+        if (flipped) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int js = flipped ? 3 - j : j;
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int c = 0; c < 7; ++c) v[j][c] = flip_value(bytes[js * 7 + c], c, flipped);
+                for (int c = 0; c < 7; ++c) v[j][c] = flip_value(bytes[(3 - j) * 7 + c], c, true);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < 7; ++c) v[j][c] = bytes[j * 7 + c];
         }
     } else if (identity) {
 #pragma unroll
@@ -189,14 +204,14 @@ __device__ __forceinline__ void quad_values(const CropArgs& a, const unsigned ch
         // adjacent source pixels of a row (14 contiguous bytes) arrive as 5 aligned dwords + byte
         // alignment instead of 14 byte loads -- the byte gathers were the kernel's bottleneck.  The
         // arithmetic is resized_u8's, operation for operation.
-        const Tap ty = tap_of(y + b.cy, b.rh, b.h);
+        const Tap ty = tap_scaled(y + b.cy, b.sy, b.h);
         const unsigned char* row0 = fr + ((size_t)(b.y0 + ty.lo) * a.W0 + b.x0) * 7;
         const unsigned char* row1 = fr + ((size_t)(b.y0 + ty.hi) * a.W0 + b.x0) * 7;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int x = x0 + j < a.OW ? x0 + j : a.OW - 1;
             const int xs = flipped ? a.OW - 1 - x : x;
-            const Tap tx = tap_of(xs + b.cx, b.rw, b.w);
+            const Tap tx = tap_scaled(xs + b.cx, b.sx, b.w);
             const int hi_off = (tx.hi - tx.lo) * 7;               // 7, or 0 at the clamped right edge
             unsigned char pb[2][16];
 #pragma unroll
