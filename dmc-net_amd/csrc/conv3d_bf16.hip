@@ -598,27 +598,54 @@ __global__ __launch_bounds__(768) void conv3d_wgrad_ring_kernel(C3dRingArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     c3r_lds_cptr const LB = (c3r_lds_cptr)lds_r;
+    // Loop-invariant part of the fragment addresses (round 4; 14-17 VALU instructions per MFMA before, profiles/
+    // r3_pmc_i3d_kernels.csv: two modulo operations and a swizzle per unit and tap inside the step loop).  Unit (kb, u) of this
+    // lane is pixel slot P = 16 kb + 8 khalf + 4 u + L / 4 of EVERY step: row r, column x and, per tap column t, the byte offset
+    // of LDS pixel x + t with its half-row swizzle are fixed; only the ring slot of row R s + r + trow - 1 depends on s, and
+    // (R s + trow - 1) mod NRING is wave-uniform.  With an even row pitch the swizzle bit of pixel slot PW + x + t is that of
+    // x + t, flipped when slot (PW / 2) is odd: one xor.
+    constexpr bool EVEN = (PW % 2) == 0;
+    int rr[NKB][2], dyoff[NKB][2], pre[NKB][2][3], xx[NKB][2];
+    const int cd = 2 * wi + grp, cx = 2 * wj + grp;                  // 16-channel chunk of this lane's group: co / ci
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int P = 16 * kb + 8 * khalf + 4 * u + (L >> 2);
+            dyoff[kb][u] = G::XBYTES + (L & 3) * 8 + P * 128 + ((cd ^ (((P >> 1) & 1) << 1)) << 5);
+            if (P >= G::NPX) P = G::NPX - 1;                         // beyond the tile: dy is zero there, any valid input address
+            rr[kb][u] = P / W_;
+            xx[kb][u] = P - rr[kb][u] * W_;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int lp = xx[kb][u] + t;                        // LDS pixel of tap column t within its ring row
+                pre[kb][u][t] = lp * 128 + ((cx ^ (((lp >> 1) & 1) << 1)) << 5) + (L & 3) * 8;
+            }
+        }
 #pragma unroll 1
     for (int s = s_begin; s < s_end; ++s) {
         const int buf = (s - s_begin) & 1;
         issue_x(s + G::LA);                                          // the group entering the window
         if (s + 1 < s_end) issue_dy(s + 1, buf ^ 1);
-        const int dbase = G::XBYTES + buf * G::DYBYTES + (L & 3) * 8;
-        const int cd = 2 * wi + grp, cx = 2 * wj + grp;              // 16-channel chunk of this lane's group: co / ci
+        const int sb = (((R * s + trow - 1) % NRING) + NRING) % NRING;   // ring row of step row 0 for this wave's tap row (wave-uniform)
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
             int dyo[2], xo[2][3];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                int P = 16 * kb + 8 * khalf + 4 * u + (L >> 2);
-                dyo[u] = dbase + P * 128 + ((cd ^ (((P >> 1) & 1) << 1)) << 5);
-                if (P >= G::NPX) P = G::NPX - 1;                     // beyond the tile: dy is zero there, any valid input address
-                const int r = P / W_, x = P - r * W_;
-                const int slot = (((R * s + r + trow - 1) % NRING) + NRING) % NRING;   // input row of this wave's tap row
+                dyo[u] = dyoff[kb][u] + buf * G::DYBYTES;
+                int slot = sb + rr[kb][u];
+                slot = slot >= NRING ? slot - NRING : slot;
+                if (EVEN) {
+                    const int base = slot * (PW * 128), flip = ((slot * (PW / 2)) & 1) << 6;
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const int lp = slot * PW + x + t;                // LDS pixel of tap column t
-                    xo[u][t] = lp * 128 + ((cx ^ (((lp >> 1) & 1) << 1)) << 5) + (L & 3) * 8;
+                    for (int t = 0; t < 3; ++t) xo[u][t] = base + (pre[kb][u][t] ^ flip);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const int lp = slot * PW + xx[kb][u] + t;    // LDS pixel of tap column t
+                        xo[u][t] = lp * 128 + ((cx ^ (((lp >> 1) & 1) << 1)) << 5) + (L & 3) * 8;
+                    }
                 }
             }
             if (KT == 3 || trow == 1) {                              // (wave-uniform)

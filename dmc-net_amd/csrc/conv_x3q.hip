@@ -597,34 +597,48 @@ __global__ __launch_bounds__(768) void x3q_wgrad_kernel(X3qWgArgs a) {
     const int DR = (py ? G::D1 : G::D0) * R, xpl = py ? G::XPL1 : G::XPL0;
     const int cls_a = py ? G::CLS_OFF[3] : G::CLS_OFF[1];                // class (py, 1)
     const int cls_b = py ? G::CLS_OFF[2] : G::CLS_OFF[0];                // class (py, 0)
-    const int tapoff[3] = {cls_a + 0, cls_b + 32, cls_a + 32};
     lds_cptr const LB = (lds_cptr)lds_qw;
+    // Loop-invariant part of the fragment addresses.  Unit (kb, u) of this lane is pixel slot P = 16 kb + 8 khalf + 4 u + L / 4
+    // of every step: its row r = P / OW and column x = P % OW within the step do not depend on s; only the ring slot of row
+    // R s + r + da does, and (R s + da) mod DR is wave-uniform: one compare + select per unit instead of two modulo operations.
+    // The class bases are folded into two per-unit bases (taps kx = 0, 2 read class (py, 1), kx = 1 class (py, 0)), so that the
+    // tap / slice offsets of the 18 B-fragment reads per k-block are instruction immediates.
+    int rr[NKB][2], xcol[NKB][2], dyoff[NKB][2];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int P = 16 * kb + 8 * khalf + 4 * u + (L >> 2);
+            dyoff[kb][u] = (2 * wi + grp) * DYPL * 32 + G::XBYTES + (L & 3) * 8 + P * 32;
+            if (P >= G::NPX) P = G::NPX - 1;                             // beyond the tile: dy is zero there, any valid input address
+            rr[kb][u] = P / OW_;
+            xcol[kb][u] = (2 * wj + grp) * xpl * 32 + (L & 3) * 8 + (P - rr[kb][u] * OW_) * 32;
+        }
 #pragma unroll 1
     for (int s = s_begin; s < s_end; ++s) {
         const int buf = (s - s_begin) & 1;
         issue_x(s + 1);                                                  // the group entering the window
         if (s + 1 < s_end) issue_dy(s + 1, buf ^ 1);
-        const int dchunk = (2 * wi + grp) * DYPL * 32 + buf * G::DYBYTES + G::XBYTES + (L & 3) * 8;
-        const int xchunk = (2 * wj + grp) * xpl * 32 + (L & 3) * 8;
+        const int sb = (((R * s + da) % DR) + DR) % DR;                  // ring row of step row 0 for this wave's tap row (wave-uniform)
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            int dyo[2], xo[2];
+            int dyo[2], xa[2], xb[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                int P = 16 * kb + 8 * khalf + 4 * u + (L >> 2);
-                dyo[u] = dchunk + P * 32;
-                if (P >= G::NPX) P = G::NPX - 1;                         // beyond the tile: dy is zero there, any valid input address
-                const int r = P / OW_, x = P - r * OW_;
-                const int slot = (((R * s + r + da) % DR) + DR) % DR;   // ring row of this wave's tap row
-                xo[u] = xchunk + (slot * PW + x) * 32;
+                dyo[u] = dyoff[kb][u] + buf * G::DYBYTES;
+                int slot = sb + rr[kb][u];
+                slot = slot >= DR ? slot - DR : slot;
+                const int xo = xcol[kb][u] + slot * PW * 32;
+                xa[u] = xo + cls_a;
+                xb[u] = xo + cls_b;
             }
             u32x4 A[3], B[3][3];
 #pragma unroll
             for (int sl = 0; sl < 3; ++sl) {
                 tr_read2(LB + dyo[0] + sl * 4 * DYPL * 32, LB + dyo[1] + sl * 4 * DYPL * 32, A[sl]);
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-                    tr_read2(LB + xo[0] + sl * G::SLB + tapoff[t], LB + xo[1] + sl * G::SLB + tapoff[t], B[t][sl]);
+                tr_read2(LB + xa[0] + sl * G::SLB, LB + xa[1] + sl * G::SLB, B[0][sl]);
+                tr_read2(LB + xb[0] + sl * G::SLB + 32, LB + xb[1] + sl * G::SLB + 32, B[1][sl]);
+                tr_read2(LB + xa[0] + sl * G::SLB + 32, LB + xa[1] + sl * G::SLB + 32, B[2][sl]);
             }
 #pragma unroll
             for (int t = 0; t < 3; ++t) {

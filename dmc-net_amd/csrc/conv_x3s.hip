@@ -696,25 +696,36 @@ __global__ __launch_bounds__(768) void x3s_wgrad_kernel(X3WgArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     lds_cptr const LB = (lds_cptr)lds_wg;
+    // loop-invariant part of the fragment addresses: unit (kb, u) of this lane is pixel slot P = 16 kb + 8 khalf + 4 u + L / 4 of
+    // EVERY step -- its row r and column x within the step do not depend on s; only the ring slot of row R s + r + trow - 1
+    // does, and (R s + trow - 1) mod NRING is wave-uniform: one compare + select per unit instead of two modulo operations
+    // (VALU instructions per MFMA were 2.7-5.5, profiles/r3_pmc_mfma_busy.csv)
+    int rr[NKB][2], xcol[NKB][2], dyoff[NKB][2];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int P = 16 * kb + 8 * khalf + 4 * u + (L >> 2);
+            dyoff[kb][u] = (2 * wi + grp) * DYPL * 32 + G::XBYTES + (L & 3) * 8 + P * 32;
+            if (P >= G::NPX) P = G::NPX - 1;                         // beyond the tile: dy is zero there, any valid input address
+            rr[kb][u] = P / W_;
+            xcol[kb][u] = (2 * wj + grp) * XPL * 32 + (L & 3) * 8 + (P - rr[kb][u] * W_) * 32;   // + tap column dx * 32 below
+        }
 #pragma unroll 1
     for (int s = s_begin; s < s_end; ++s) {
         const int buf = (s - s_begin) & 1;
         issue_x(s + G::LA);                                          // the group entering the window
         if (s + 1 < s_end) issue_dy(s + 1, buf ^ 1);
-        // fragment addresses of this step.  Unit (kb, u) of this lane: pixel slot P = 16 kb + 8 khalf + 4 u + L / 4
-        const int dchunk = (2 * wi + grp) * DYPL * 32 + buf * G::DYBYTES + G::XBYTES + (L & 3) * 8;
-        const int xchunk = (2 * wj + grp) * XPL * 32 + (L & 3) * 8;
+        const int sb = (((R * s + trow - 1) % NRING) + NRING) % NRING;   // ring row of step row 0 for this wave's tap row (wave-uniform)
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
             int dyo[2], xo[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                int P = 16 * kb + 8 * khalf + 4 * u + (L >> 2);
-                dyo[u] = dchunk + P * 32;
-                if (P >= G::NPX) P = G::NPX - 1;                     // beyond the tile: dy is zero there, any valid input address
-                const int r = P / W_, x = P - r * W_;
-                const int slot = (((R * s + r + trow - 1) % NRING) + NRING) % NRING;   // input row of this wave's tap row
-                xo[u] = xchunk + (slot * PW + x) * 32;               // + tap column dx * 32 below
+                dyo[u] = dyoff[kb][u] + buf * G::DYBYTES;
+                int slot = sb + rr[kb][u];
+                slot = slot >= NRING ? slot - NRING : slot;
+                xo[u] = xcol[kb][u] + slot * PW * 32;
             }
             u32x4 A[3], B[3][3];
 #pragma unroll
