@@ -28,6 +28,7 @@
 // (sum, sum of squares) partials of the result for the BatchNorm that follows (fp64 across lanes,
 // waves and workgroups, fixed order).
 #include "dmc_common.h"
+#include "conv_small.h"
 #include <type_traits>
 
 using namespace dmc;
@@ -1863,6 +1864,7 @@ int dmc_conv_nhwc_supported(int N, int H, int W, int Cin, int Cout, int KH, int 
 
 // number of [Cout][2] double partial rows the forward writes when asked for statistics
 int dmc_conv_nhwc_stat_blocks(int N, int H, int W, int Cin, int Cout, int KH, int stride, int pad) {
+    if (csm_supported(N, H, W, Cin, Cout, KH, KH, stride, pad)) return csm_stat_blocks(N, H, W);
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
     const long M = (long)N * OH * OW;
     const int bm = block_pixels(Cin, Cout, M);
@@ -1878,6 +1880,9 @@ int dmc_conv_nhwc_fwd(const float* x, const float* w, void* wpack, const float* 
     if (!shape_supported(sh))
         return fail(DMC_E_INVALID, "dmc_conv_nhwc_fwd: unsupported shape N=%d H=%d W=%d Cin=%d Cout=%d k=%dx%d s=%d p=%d",
                     N, H, W, Cin, Cout, KH, KW, stride, pad);
+    // 16- / 32-channel stride-1 3x3 layers (the discriminator's high-resolution blocks): the small-channel bf16x3 kernel
+    if (w && wpack && csm_supported(N, H, W, Cin, Cout, KH, KW, stride, pad))
+        return csm_fwd(x, w, wpack, bias, keep, y, stat_partials, stat_blocks, N, H, W, Cin, act, (hipStream_t)stream);
     ConvArgs a;
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.keep = keep; a.stat_part = stat_partials;
     a.stat_blocks = stat_partials ? stat_blocks : -1;
@@ -1921,7 +1926,11 @@ int dmc_conv_nhwc_split(const float* w, void* wpack_f, void* wpack_t, int Cin, i
 }
 
 // packed-weight workspace of the forward and the data gradient: fp32 transposed weights or three bf16 slices
-size_t dmc_conv_nhwc_wt_bytes(int Cin, int Cout, int KH, int KW) { return (size_t)Cin * Cout * KH * KW * 6; }
+size_t dmc_conv_nhwc_wt_bytes(int Cin, int Cout, int KH, int KW) {
+    const size_t plain = (size_t)Cin * Cout * KH * KW * 6;
+    const size_t small = (Cin == Cout && (Cin == 16 || Cin == 32) && KH == 3 && KW == 3) ? csm_wpack_bytes(Cin) : 0;   // k padded to 32
+    return plain > small ? plain : small;
+}
 
 // dx [N,H,W,Cin] from dy [N,OH,OW,Cout]; wt: workspace of dmc_conv_nhwc_wt_bytes() (the packed weights)
 static int conv_dgrad(const float* dy, const float* w, float* wt, const float* addend, float* dx, int N, int H, int W, int Cin,
@@ -1930,6 +1939,8 @@ static int conv_dgrad(const float* dy, const float* w, float* wt, const float* a
     ConvShape sh = {N, H, W, Cin, Cout, KH, KW, stride, pad, 0, 0};
     if (!shape_supported(sh)) return fail(DMC_E_INVALID, "dmc_conv_nhwc_dgrad: unsupported shape");
     hipStream_t s = (hipStream_t)stream;
+    if (w && !addend && csm_supported(N, H, W, Cin, Cout, KH, KW, stride, pad))
+        return csm_dgrad(dy, w, wt, dx, N, H, W, Cin, s);
     const int KK = KH * KW;
     const long total = (long)Cin * Cout * KK;
     const bool v3 = use_v3(Cout, Cin);                    // the GEMM contracts over Cout and produces Cin channels

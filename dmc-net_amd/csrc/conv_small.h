@@ -1,0 +1,14 @@
+// Internal interface of conv_small.hip (16- / 32-channel 3x3 stride-1 convolutions in bf16x3 arithmetic); called from the
+// dmc_conv_nhwc_* entry points of conv_nhwc.hip, which dispatch the shapes it covers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace dmc {
+bool csm_supported(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int csm_stat_blocks(int N, int H, int W);
+size_t csm_wpack_bytes(int C);
+int csm_fwd(const float* x, const float* w, void* wpack, const float* bias, const float* keep, float* y, double* stat_part,
+            int stat_blocks, int N, int H, int W, int C, int act, hipStream_t s);
+int csm_dgrad(const float* dy, const float* w, void* wpack, float* dx, int N, int H, int W, int C, hipStream_t s);
+}  // namespace dmc

@@ -1,0 +1,289 @@
+// 3x3 / stride-1 / padding-1 NHWC convolutions with 16 or 32 channels in bf16x3 arithmetic (gfx950).
+//
+// The PatchGAN discriminator's high-resolution blocks -- Conv2d(16, 16, 3, 1, 1) on 112 x 112 maps and Conv2d(32, 32, 3, 1, 1)
+// on 56 x 56 maps, code/dmcnet_GAN/model.py:254-279 as chained in Discriminator3, :332-366 -- at 240 / 120 frames per step:
+// 386 / 193 MB of activations per launch against 13.9 GFLOP.  On the fp32 matrix cores (v_mfma_f32_16x16x4_f32, K = 144:
+// conv_nhwc_kernel / conv2_kernel) they sit at the fp32-MFMA roof (0.36 ms for a 240-frame block: 0.49 of 157 TFLOP/s); in
+// bf16x3 arithmetic (conv_nhwc.hip: an fp32 value = the exact sum of three bf16 slices, six slice products per product
+// block, fp32 accumulate: fp32-level error) the matrix work shrinks 2.67x and the layers become HBM streams.
+//
+// One kernel, no LDS staging of activations.  v_mfma_f32_16x16x32_bf16: rows = the 16 output channels of a row tile, columns =
+// 16 consecutive output pixels, a k-block = 32 contraction values = two taps x 16 channels (C = 16: five k-blocks, the last
+// half empty) or one tap x 32 channels (C = 32: nine).  Lane (n = lane % 16, kq = lane / 16) of the B operand holds eight
+// consecutive channels of pixel n's tap: 32 contiguous bytes of the fp32 NHWC activation, loaded straight from global memory
+// (the nine taps re-read lines that are in L1 / L2; taps that leave the image are zeros), split into the three slices in
+// registers.  The weights are packed once per call in fragment order and live in LDS for the whole launch (15 / 54 fragments
+// of 1 KB, lane-linear, conflict-free reads).  Persistent waves walk 16-pixel tiles.
+// Epilogue as conv_tile_epilogue of conv_nhwc.hip: + bias, LeakyReLU(0.2), Dropout2d keep mask, per-channel (sum, sum of
+// squares) of the result in fp64 for the BatchNorm that follows, 16-byte stores (a wave writes 1 KB of consecutive memory).
+// The data gradient is the same kernel on dy with the weights packed transposed and mirrored.
+#include "dmc_common.h"
+#include "x3s_common.h"
+#include "conv_small.h"
+
+using namespace dmc;
+using namespace dmc::x3;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// 16 bytes through a buffer descriptor: an offset beyond num_records returns zeros -- the zero padding of the convolution
+// costs neither a branch nor a register move (the branchy form spent a quarter of the kernel's instructions on it)
+__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t srd, unsigned voff) {
+    const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, voff, 0, 0));
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+
+struct CsmArgs {
+    const float* x;        // [M][C] fp32 NHWC
+    const void* wp;        // packed weights [3 slices][KB][MT][16 rows][32 k] bf16
+    const float* bias;     // [C] or null
+    const float* keep;     // [N][C] or null
+    float* y;              // [M][C]
+    double* stat_part;     // [gridDim.x][C][2] or null
+    int N, H, W, M, act;
+    float rW, rH;          // 1 / W, 1 / H (pixel -> row / image by a float multiply + correction: M < 2^24)
+};
+
+template <int C> struct Csm {
+    static constexpr int KB = C == 16 ? 5 : 9;          // k-blocks of 32 contraction values
+    static constexpr int MT = C / 16;                   // row tiles of 16 output channels
+    static constexpr int NFRAG = 3 * KB * MT;           // weight fragments (1 KB each)
+};
+
+__device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// eight fp32 values -> three bf16x8 fragments (truncation split, as split3)
+__device__ __forceinline__ void split8(const float4& lo, const float4& hi, u32x4& s0, u32x4& s1, u32x4& s2) {
+    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    unsigned u0[8], u1[8], u2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split3(v[e], u0[e], u1[e], u2[e]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        s0[e] = pack_hi(u0[2 * e + 1], u0[2 * e]);
+        s1[e] = pack_hi(u1[2 * e + 1], u1[2 * e]);
+        s2[e] = pack_hi(u2[2 * e + 1], u2[2 * e]);
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256, 2) void csm_conv_kernel(CsmArgs a) {
+    using G = Csm<C>;
+    constexpr int KB = G::KB, MT = G::MT;
+    __shared__ __attribute__((aligned(16))) u32x4 wlds[G::NFRAG * 64];       // 15 / 54 KB: every weight fragment, lane-linear
+    __shared__ double red[4][C][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wp);
+    // weights: fragment f = (slice * KB + kb) * MT + mt, lane-linear (row n, k-quarter kq): in LDS for the whole launch (in
+    // registers they cost C = 16 two of its four resident waves per SIMD)
+    for (int i = tid; i < G::NFRAG * 64; i += 256) wlds[i] = wsrc[i];
+    __syncthreads();
+    // this lane's slice of the epilogue: channels 4 kq .. 4 kq + 3 of row tile mt, pixel n
+    float bias_r[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias_r[mt][i] = a.bias ? a.bias[mt * 16 + 4 * kq + i] : 0.f;
+    double ssum[MT][4], ssq[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ssum[mt][i] = ssq[mt][i] = 0.0;
+
+    const int ntiles = (a.M + 15) >> 4;
+    const int stride = (int)gridDim.x * 4;
+    // raw buffer descriptor of x (wave-uniform): offsets >= num_records read zeros
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0x7fffffff, 0x00020000);
+    // which tap / channel offset this lane supplies in k-block kb: C = 16: tap 2 kb + (kq >> 1), channels 8 (kq & 1) ..;
+    // C = 32: tap kb, channels 8 kq ..
+    const int chan = C == 16 ? 8 * (kq & 1) : 8 * kq;
+#pragma unroll 1
+    for (int tile = (int)blockIdx.x * 4 + wave; tile < ntiles; tile += stride) {
+        asm volatile("" ::: "memory");                       // the weight fragments are re-read from LDS per tile, not hoisted into 60-216 registers
+        int p = tile * 16 + n;
+        const bool pvalid = p < a.M;
+        p = pvalid ? p : a.M - 1;
+        // p -> (image row r = p / W, x), r -> (img, y): float reciprocal + one correction step each (exact below 2^24)
+        int r = (int)((float)p * a.rW);
+        r -= (r * a.W > p);
+        r += ((r + 1) * a.W <= p);
+        const int x = p - r * a.W;
+        int img = (int)((float)r * a.rH);
+        img -= (img * a.H > r);
+        img += ((img + 1) * a.H <= r);
+        const int yy = r - img * a.H;
+        const unsigned pbyte = (unsigned)(p * C + chan) * 4u;     // (M * C * 4 < 2^31: checked by the host)
+        // k-blocks in groups of GK with the next group's loads in flight during the current group's MFMAs
+        constexpr int GK = C == 16 ? 5 : 3, NG = KB / GK;
+        float4 lo[2][GK], hi[2][GK];
+        auto load_group = [&](int g, float4 (&l)[GK], float4 (&h)[GK]) {
+#pragma unroll
+            for (int j = 0; j < GK; ++j) {
+                const int kb = g * GK + j;
+                const int tap = C == 16 ? 2 * kb + (kq >> 1) : kb;
+                const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+                const bool ok = tap < 9 && yy + dy >= 0 && yy + dy < a.H && x + dx >= 0 && x + dx < a.W;
+                const unsigned off = ok ? pbyte + (unsigned)((dy * a.W + dx) * C * 4) : 0x80000000u;
+                l[j] = buf_load16(srd, off);
+                h[j] = buf_load16(srd, off + 16u);
+            }
+        };
+        f32x4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        load_group(0, lo[0], hi[0]);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) load_group(g + 1, lo[(g + 1) & 1], hi[(g + 1) & 1]);
+#pragma unroll
+            for (int j = 0; j < GK; ++j) {
+                const int kb = g * GK + j;
+                u32x4 b0, b1, b2;
+                split8(lo[g & 1][j], hi[g & 1][j], b0, b1, b2);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const u32x4 w0 = wlds[((0 * KB + kb) * MT + mt) * 64 + lane];
+                    const u32x4 w1 = wlds[((1 * KB + kb) * MT + mt) * 64 + lane];
+                    const u32x4 w2 = wlds[((2 * KB + kb) * MT + mt) * 64 + lane];
+                    // slice products (weight, input): small terms first
+                    acc[mt] = mfma16(w0, b2, acc[mt]);
+                    acc[mt] = mfma16(w2, b0, acc[mt]);
+                    acc[mt] = mfma16(w1, b1, acc[mt]);
+                    acc[mt] = mfma16(w0, b1, acc[mt]);
+                    acc[mt] = mfma16(w1, b0, acc[mt]);
+                    acc[mt] = mfma16(w0, b0, acc[mt]);
+                }
+            }
+        }
+        // epilogue: lane holds channels mt * 16 + 4 kq + i of pixel n
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float t = acc[mt][i] + bias_r[mt][i];
+                if (a.act) t = t > 0.f ? t : 0.2f * t;
+                v[i] = t;
+            }
+            if (a.keep) {
+                const float4 k = *reinterpret_cast<const float4*>(a.keep + (size_t)img * C + mt * 16 + 4 * kq);
+                v[0] *= k.x; v[1] *= k.y; v[2] *= k.z; v[3] *= k.w;
+            }
+            if (pvalid) {
+                *reinterpret_cast<float4*>(a.y + (size_t)p * C + mt * 16 + 4 * kq) = make_float4(v[0], v[1], v[2], v[3]);
+                if (a.stat_part) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        ssum[mt][i] += (double)v[i];
+                        ssq[mt][i] += (double)v[i] * (double)v[i];
+                    }
+                }
+            }
+        }
+    }
+    if (!a.stat_part) return;
+    // over the 16 pixel lanes of a channel group (fixed order), then over the four waves (fixed order)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) {
+                ssum[mt][i] += __shfl_xor(ssum[mt][i], m, 64);
+                ssq[mt][i] += __shfl_xor(ssq[mt][i], m, 64);
+            }
+            if (n == 0) {
+                red[wave][mt * 16 + 4 * kq + i][0] = ssum[mt][i];
+                red[wave][mt * 16 + 4 * kq + i][1] = ssq[mt][i];
+            }
+        }
+    __syncthreads();
+    if (tid < 2 * C) {
+        const int c = tid >> 1, which = tid & 1;
+        a.stat_part[((size_t)blockIdx.x * C + c) * 2 + which] = red[0][c][which] + red[1][c][which] + red[2][c][which] + red[3][c][which];
+    }
+}
+
+// w [Cout][9][Cin] fp32 (OHWI) -> fragment order [3 slices][KB][MT][16 rows][32 k] bf16
+//   forward:        row = co, k-block value (tap, ci) = w[co][tap][ci]
+//   data gradient:  row = ci, k-block value (tap, co) = w[co][8 - tap][ci]          (mirrored taps)
+template <int C>
+__global__ __launch_bounds__(256) void csm_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int transposed) {
+    using G = Csm<C>;
+    const int total = G::KB * G::MT * 16 * 32;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        int t = i;
+        const int kk = t & 31; t >>= 5;
+        const int row = t & 15; t >>= 4;
+        const int mt = t % G::MT;
+        const int kb = t / G::MT;
+        const int tap = C == 16 ? 2 * kb + (kk >> 4) : kb;
+        const int kc = C == 16 ? (kk & 15) : kk;                    // contraction channel
+        const int r = mt * 16 + row;                                // result channel of this direction
+        float v = 0.f;
+        if (tap < 9) v = transposed ? w[((size_t)kc * 9 + (8 - tap)) * C + r] : w[((size_t)r * 9 + tap) * C + kc];
+        unsigned u0, u1, u2;
+        split3(v, u0, u1, u2);
+        // fragment (slice, kb, mt): lane (row, kq = kk / 8) holds eight k-values: element index within the fragment
+        const size_t e = (size_t)((kk >> 3) * 16 + row) * 8 + (kk & 7);
+        const size_t f = (size_t)(kb * G::MT + mt) * 512;
+        const size_t sl = (size_t)G::KB * G::MT * 512;
+        wp[f + e] = (unsigned short)(u0 >> 16);
+        wp[sl + f + e] = (unsigned short)(u1 >> 16);
+        wp[2 * sl + f + e] = (unsigned short)(u2 >> 16);
+    }
+}
+
+template <int C>
+int csm_launch(const float* x, const float* w, void* wpack, const float* bias, const float* keep, float* y, double* stat_part,
+               int stat_blocks, int N, int H, int W, int act, int transposed, hipStream_t s) {
+    csm_pack_kernel<C><<<8, 256, 0, s>>>(w, static_cast<unsigned short*>(wpack), transposed);
+    int rc = check_launch("csm_pack");
+    if (rc) return rc;
+    CsmArgs a;
+    a.x = x; a.wp = wpack; a.bias = bias; a.keep = keep; a.y = y; a.stat_part = stat_part;
+    a.N = N; a.H = H; a.W = W; a.M = N * H * W; a.act = act;
+    a.rW = 1.0f / (float)W; a.rH = 1.0f / (float)H;
+    const int grid = dmc::csm_stat_blocks(N, H, W);
+    if (stat_part && stat_blocks != grid)
+        return fail(DMC_E_INVALID, "conv_small: statistics partials have %d rows but this launch writes %d", stat_blocks, grid);
+    csm_conv_kernel<C><<<grid, 256, 0, s>>>(a);
+    return check_launch("csm_conv");
+}
+
+}  // namespace
+
+namespace dmc {
+
+bool csm_supported(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    if (option(OPT_CONV_ARITH) != 1 || option(OPT_CONV_PATH) != 1 || option(OPT_CONV_CFG) == 301) return false;   // 301: off (A/B runs)
+    if (Cin != Cout || (Cin != 16 && Cin != 32) || KH != 3 || KW != 3 || stride != 1 || pad != 1) return false;
+    return N > 0 && H > 0 && W > 0 && (long)N * H * W < (1L << 24) && (long)N * H * W * Cin * 4 < (1L << 31);
+}
+
+// persistent waves: enough workgroups for ~8 per CU, at most one 16-pixel tile per wave and round below that
+int csm_stat_blocks(int N, int H, int W) {
+    const long tiles = ((long)N * H * W + 15) / 16;
+    long g = (tiles + 3) / 4;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+size_t csm_wpack_bytes(int C) { return (size_t)3 * (C == 16 ? 5 : 9) * (C / 16) * 512 * 2; }
+
+int csm_fwd(const float* x, const float* w, void* wpack, const float* bias, const float* keep, float* y, double* stat_part,
+            int stat_blocks, int N, int H, int W, int C, int act, hipStream_t s) {
+    return C == 16 ? csm_launch<16>(x, w, wpack, bias, keep, y, stat_part, stat_blocks, N, H, W, act, 0, s)
+                   : csm_launch<32>(x, w, wpack, bias, keep, y, stat_part, stat_blocks, N, H, W, act, 0, s);
+}
+
+int csm_dgrad(const float* dy, const float* w, void* wpack, float* dx, int N, int H, int W, int C, hipStream_t s) {
+    return C == 16 ? csm_launch<16>(dy, w, wpack, nullptr, nullptr, dx, nullptr, 0, N, H, W, 0, 1, s)
+                   : csm_launch<32>(dy, w, wpack, nullptr, nullptr, dx, nullptr, 0, N, H, W, 0, 1, s);
+}
+
+}  // namespace dmc

@@ -874,6 +874,10 @@ CONV_CASES = [  # (N, Cin, H, W, Cout, k, stride)
     (3, 64, 13, 9, 128, 3, 2),       # second-generation kernels on ragged sizes (odd rows / columns, partial tiles)
     (2, 64, 5, 3, 64, 3, 1),
     (1, 128, 6, 2, 64, 1, 1),
+    (3, 16, 9, 7, 16, 3, 1),         # the small-channel bf16x3 kernel (conv_small.hip) on ragged sizes: 16-pixel tiles that
+    (1, 32, 5, 3, 32, 3, 1),         # straddle rows and images, a last tile with invalid pixels, a 1 x 1 image
+    (2, 16, 1, 1, 16, 3, 1),
+    (5, 32, 4, 30, 32, 3, 1),
 ]
 
 
