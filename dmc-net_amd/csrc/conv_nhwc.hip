@@ -1864,7 +1864,7 @@ int dmc_conv_nhwc_supported(int N, int H, int W, int Cin, int Cout, int KH, int 
 
 // number of [Cout][2] double partial rows the forward writes when asked for statistics
 int dmc_conv_nhwc_stat_blocks(int N, int H, int W, int Cin, int Cout, int KH, int stride, int pad) {
-    if (csm_supported(N, H, W, Cin, Cout, KH, KH, stride, pad)) return csm_stat_blocks(N, H, W);
+    if (csm_supported(N, H, W, Cin, Cout, KH, KH, stride, pad)) return csm_stat_blocks(N, H, W, Cin);
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
     const long M = (long)N * OH * OW;
     const int bm = block_pixels(Cin, Cout, M);

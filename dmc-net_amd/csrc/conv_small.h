@@ -6,7 +6,7 @@
 
 namespace dmc {
 bool csm_supported(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
-int csm_stat_blocks(int N, int H, int W);
+int csm_stat_blocks(int N, int H, int W, int C);
 size_t csm_wpack_bytes(int C);
 int csm_fwd(const float* x, const float* w, void* wpack, const float* bias, const float* keep, float* y, double* stat_part,
             int stat_blocks, int N, int H, int W, int C, int act, hipStream_t s);

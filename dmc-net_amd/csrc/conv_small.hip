@@ -7,13 +7,13 @@
 // bf16x3 arithmetic (conv_nhwc.hip: an fp32 value = the exact sum of three bf16 slices, six slice products per product
 // block, fp32 accumulate: fp32-level error) the matrix work shrinks 2.67x and the layers become HBM streams.
 //
-// One kernel, no LDS staging of activations.  v_mfma_f32_16x16x32_bf16: rows = the 16 output channels of a row tile, columns =
-// 16 consecutive output pixels, a k-block = 32 contraction values = two taps x 16 channels (C = 16: five k-blocks, the last
-// half empty) or one tap x 32 channels (C = 32: nine).  Lane (n = lane % 16, kq = lane / 16) of the B operand holds eight
-// consecutive channels of pixel n's tap: 32 contiguous bytes of the fp32 NHWC activation, loaded straight from global memory
-// (the nine taps re-read lines that are in L1 / L2; taps that leave the image are zeros), split into the three slices in
-// registers.  The weights are packed once per call in fragment order and live in LDS for the whole launch (15 / 54 fragments
-// of 1 KB, lane-linear, conflict-free reads).  Persistent waves walk 16-pixel tiles.
+// v_mfma_f32_16x16x32_bf16: rows = the 16 output channels of a row tile, columns = 16 consecutive output pixels of an image row,
+// a k-block = 32 contraction values = two taps x 16 channels (C = 16: five k-blocks, the last half empty) or one tap x 32
+// channels (C = 32: nine).  Lane (n = lane % 16, kq = lane / 16) of the B operand holds eight consecutive channels of pixel
+// n's tap.  The fp32 NHWC activation is loaded straight from global memory (range-checked buffer loads: zeros outside the
+// image), split into the three slices in registers ONCE per input piece and parked in a wave-private mini patch in LDS; the
+// weights are packed once per call in fragment order and live in LDS for the whole launch (15 / 54 fragments of 1 KB,
+// lane-linear, conflict-free reads).  Persistent waves walk the tiles; no workgroup barrier in the loop.
 // Epilogue as conv_tile_epilogue of conv_nhwc.hip: + bias, LeakyReLU(0.2), Dropout2d keep mask, per-channel (sum, sum of
 // squares) of the result in fp64 for the BatchNorm that follows, 16-byte stores (a wave writes 1 KB of consecutive memory).
 // The data gradient is the same kernel on dy with the weights packed transposed and mirrored.
@@ -50,6 +50,7 @@ template <int C> struct Csm {
     static constexpr int KB = C == 16 ? 5 : 9;          // k-blocks of 32 contraction values
     static constexpr int MT = C / 16;                   // row tiles of 16 output channels
     static constexpr int NFRAG = 3 * KB * MT;           // weight fragments (1 KB each)
+    static constexpr int NW = C == 16 ? 4 : 8;          // waves per workgroup (C = 32: eight waves share the 54 KB of weights)
 };
 
 __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f32x4& c) {
@@ -70,20 +71,27 @@ __device__ __forceinline__ void split8(const float4& lo, const float4& hi, u32x4
     }
 }
 
+// Tiles are 16-pixel segments of one image row ((W + 15) / 16 per row; the last one of a row may be partial).  The nine taps
+// of a tile touch 3 rows x 18 columns of the input: every lane loads and splits its share of those 54 x C / 8 eight-channel
+// pieces ONCE (C = 16: 1.7 pieces per lane instead of 5 k-blocks' worth, C = 32: 3.4 instead of 9 -- the in-register split is
+// 45 VALU instructions per piece and bounded the first version of this kernel) into a wave-private mini patch in LDS
+// ([3 slices][3 rows][18 pixels][C] bf16, zeros where the window leaves the image: range-checked loads), from which the B
+// fragments of all taps are 16-byte reads.  No workgroup barrier in the tile loop.
 template <int C>
-__global__ __launch_bounds__(256, 2) void csm_conv_kernel(CsmArgs a) {
+__global__ __launch_bounds__(Csm<C>::NW * 64) void csm_conv_kernel(CsmArgs a) {
     using G = Csm<C>;
-    constexpr int KB = G::KB, MT = G::MT;
+    constexpr int KB = G::KB, MT = G::MT, NW = G::NW;
+    constexpr int OC = C / 8;                                 // 16-byte pieces (8 bf16) per pixel and slice
+    constexpr int NPC = 3 * 18 * OC;                          // pieces of a tile's patch
+    constexpr int SS = NPC * 16;                              // bytes of one slice of a wave's patch
     __shared__ __attribute__((aligned(16))) u32x4 wlds[G::NFRAG * 64];       // 15 / 54 KB: every weight fragment, lane-linear
-    __shared__ double red[4][C][2];
+    __shared__ __attribute__((aligned(16))) char patch[NW][3 * SS];
+    __shared__ double red[NW][C][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, kq = lane >> 4;
     const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wp);
-    // weights: fragment f = (slice * KB + kb) * MT + mt, lane-linear (row n, k-quarter kq): in LDS for the whole launch (in
-    // registers they cost C = 16 two of its four resident waves per SIMD)
-    for (int i = tid; i < G::NFRAG * 64; i += 256) wlds[i] = wsrc[i];
+    for (int i = tid; i < G::NFRAG * 64; i += NW * 64) wlds[i] = wsrc[i];
     __syncthreads();
-    // this lane's slice of the epilogue: channels 4 kq .. 4 kq + 3 of row tile mt, pixel n
     float bias_r[MT][4];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -95,72 +103,112 @@ __global__ __launch_bounds__(256, 2) void csm_conv_kernel(CsmArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) ssum[mt][i] = ssq[mt][i] = 0.0;
 
-    const int ntiles = (a.M + 15) >> 4;
-    const int stride = (int)gridDim.x * 4;
-    // raw buffer descriptor of x (wave-uniform): offsets >= num_records read zeros
+    const int segs = (a.W + 15) >> 4;
+    const int ntiles = a.N * a.H * segs;
+    const int stride = (int)gridDim.x * NW;
     const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0x7fffffff, 0x00020000);
-    // which tap / channel offset this lane supplies in k-block kb: C = 16: tap 2 kb + (kq >> 1), channels 8 (kq & 1) ..;
-    // C = 32: tap kb, channels 8 kq ..
-    const int chan = C == 16 ? 8 * (kq & 1) : 8 * kq;
-#pragma unroll 1
-    for (int tile = (int)blockIdx.x * 4 + wave; tile < ntiles; tile += stride) {
-        asm volatile("" ::: "memory");                       // the weight fragments are re-read from LDS per tile, not hoisted into 60-216 registers
-        int p = tile * 16 + n;
-        const bool pvalid = p < a.M;
-        p = pvalid ? p : a.M - 1;
-        // p -> (image row r = p / W, x), r -> (img, y): float reciprocal + one correction step each (exact below 2^24)
-        int r = (int)((float)p * a.rW);
-        r -= (r * a.W > p);
-        r += ((r + 1) * a.W <= p);
-        const int x = p - r * a.W;
-        int img = (int)((float)r * a.rH);
+    char* const mp = patch[wave];
+    // this lane's pieces of the patch: piece f = lane + 64 k -> (row f / (18 OC), column (f / OC) % 18, octet f % OC)
+    constexpr int NPL = (NPC + 63) / 64;
+    int prow[NPL], pcol[NPL], poct[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int f = lane + 64 * k;
+        prow[k] = f / (18 * OC);
+        pcol[k] = (f / OC) % 18;
+        poct[k] = f % OC;
+    }
+    // fragment read offsets: k-block kb, lane (n, kq): C = 16: tap 2 kb + (kq >> 1), octet kq & 1; C = 32: tap kb, octet kq.
+    // (tap 9 of the last C = 16 k-block has zero weights: it re-reads tap 8's finite values)
+    int boff[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        int tap = C == 16 ? 2 * kb + (kq >> 1) : kb;
+        tap = tap < 9 ? tap : 8;
+        const int dy = tap / 3, dx = tap - dy * 3;            // patch row dy (= image row y + dy - 1), patch column n + dx
+        boff[kb] = ((dy * 18 + n + dx) * OC + (C == 16 ? (kq & 1) : kq)) * 16;
+    }
+    const float rS = 1.0f / (float)segs;
+    // tile -> (image, row, first column): float reciprocal + one correction step each (exact below 2^24)
+    auto geom = [&](int tile, int& img, int& yy, int& x0) {
+        int r = (int)((float)tile * rS);
+        r -= (r * segs > tile);
+        r += ((r + 1) * segs <= tile);
+        x0 = (tile - r * segs) * 16;
+        img = (int)((float)r * a.rH);
         img -= (img * a.H > r);
         img += ((img + 1) * a.H <= r);
-        const int yy = r - img * a.H;
-        const unsigned pbyte = (unsigned)(p * C + chan) * 4u;     // (M * C * 4 < 2^31: checked by the host)
-        // k-blocks in groups of GK with the next group's loads in flight during the current group's MFMAs
-        constexpr int GK = C == 16 ? 5 : 3, NG = KB / GK;
-        float4 lo[2][GK], hi[2][GK];
-        auto load_group = [&](int g, float4 (&l)[GK], float4 (&h)[GK]) {
+        yy = r - img * a.H;
+    };
+    // this lane's pieces of a tile's patch, as loaded (fp32): the NEXT tile's are in flight while the current tile computes --
+    // one tile per wave at a time left the kernel bound by the memory round trip (4 waves per SIMD x ~2 us per tile)
+    float4 plo[2][NPL], phi[2][NPL];
+    auto load_patch = [&](int tile, float4 (&lo)[NPL], float4 (&hi)[NPL]) {
+        int img, yy, x0;
+        geom(tile, img, yy, x0);
 #pragma unroll
-            for (int j = 0; j < GK; ++j) {
-                const int kb = g * GK + j;
-                const int tap = C == 16 ? 2 * kb + (kq >> 1) : kb;
-                const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-                const bool ok = tap < 9 && yy + dy >= 0 && yy + dy < a.H && x + dx >= 0 && x + dx < a.W;
-                const unsigned off = ok ? pbyte + (unsigned)((dy * a.W + dx) * C * 4) : 0x80000000u;
-                l[j] = buf_load16(srd, off);
-                h[j] = buf_load16(srd, off + 16u);
+        for (int k = 0; k < NPL; ++k) {
+            const int f = lane + 64 * k;
+            const int iy = yy + prow[k] - 1, ix = x0 + pcol[k] - 1;
+            const bool ok = (NPC % 64 == 0 || f < NPC) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const unsigned off = ok ? (unsigned)(((img * a.H + iy) * a.W + ix) * C + 8 * poct[k]) * 4u : 0x80000000u;
+            lo[k] = buf_load16(srd, off);
+            hi[k] = buf_load16(srd, off + 16u);
+        }
+    };
+    int it = 0;
+    const int tile0 = (int)blockIdx.x * NW + wave;
+    if (tile0 < ntiles) load_patch(tile0, plo[0], phi[0]);
+#pragma unroll 1
+    for (int tile = tile0; tile < ntiles; tile += 2 * stride) {
+        // two tiles per iteration so that the register double buffer has compile-time indices
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int tcur = tile + half * stride;
+            if (tcur >= ntiles) break;
+            asm volatile("" ::: "memory");                   // the weight fragments are re-read from LDS per tile, not hoisted into registers
+            if (tcur + stride < ntiles) load_patch(tcur + stride, plo[half ^ 1], phi[half ^ 1]);
+            int img, yy, x0;
+            geom(tcur, img, yy, x0);
+            // ---- the patch: split, store ----
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                const int f = lane + 64 * k;
+                u32x4 s0, s1, s2;
+                split8(plo[half][k], phi[half][k], s0, s1, s2);
+                if (NPC % 64 == 0 || f < NPC) {
+                    *reinterpret_cast<u32x4*>(mp + f * 16) = s0;
+                    *reinterpret_cast<u32x4*>(mp + SS + f * 16) = s1;
+                    *reinterpret_cast<u32x4*>(mp + 2 * SS + f * 16) = s2;
+                }
             }
-        };
+        __builtin_amdgcn_wave_barrier();                     // same wave: its LDS instructions complete in order
         f32x4 acc[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        load_group(0, lo[0], hi[0]);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG) load_group(g + 1, lo[(g + 1) & 1], hi[(g + 1) & 1]);
+        for (int kb = 0; kb < KB; ++kb) {
+            const u32x4 b0 = *reinterpret_cast<const u32x4*>(mp + boff[kb]);
+            const u32x4 b1 = *reinterpret_cast<const u32x4*>(mp + SS + boff[kb]);
+            const u32x4 b2 = *reinterpret_cast<const u32x4*>(mp + 2 * SS + boff[kb]);
 #pragma unroll
-            for (int j = 0; j < GK; ++j) {
-                const int kb = g * GK + j;
-                u32x4 b0, b1, b2;
-                split8(lo[g & 1][j], hi[g & 1][j], b0, b1, b2);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const u32x4 w0 = wlds[((0 * KB + kb) * MT + mt) * 64 + lane];
-                    const u32x4 w1 = wlds[((1 * KB + kb) * MT + mt) * 64 + lane];
-                    const u32x4 w2 = wlds[((2 * KB + kb) * MT + mt) * 64 + lane];
-                    // slice products (weight, input): small terms first
-                    acc[mt] = mfma16(w0, b2, acc[mt]);
-                    acc[mt] = mfma16(w2, b0, acc[mt]);
-                    acc[mt] = mfma16(w1, b1, acc[mt]);
-                    acc[mt] = mfma16(w0, b1, acc[mt]);
-                    acc[mt] = mfma16(w1, b0, acc[mt]);
-                    acc[mt] = mfma16(w0, b0, acc[mt]);
-                }
+            for (int mt = 0; mt < MT; ++mt) {
+                const u32x4 w0 = wlds[((0 * KB + kb) * MT + mt) * 64 + lane];
+                const u32x4 w1 = wlds[((1 * KB + kb) * MT + mt) * 64 + lane];
+                const u32x4 w2 = wlds[((2 * KB + kb) * MT + mt) * 64 + lane];
+                // slice products (weight, input): small terms first
+                acc[mt] = mfma16(w0, b2, acc[mt]);
+                acc[mt] = mfma16(w2, b0, acc[mt]);
+                acc[mt] = mfma16(w1, b1, acc[mt]);
+                acc[mt] = mfma16(w0, b1, acc[mt]);
+                acc[mt] = mfma16(w1, b0, acc[mt]);
+                acc[mt] = mfma16(w0, b0, acc[mt]);
             }
         }
-        // epilogue: lane holds channels mt * 16 + 4 kq + i of pixel n
+        __builtin_amdgcn_wave_barrier();                     // the next tile's stores follow this tile's reads
+        // epilogue: lane holds channels mt * 16 + 4 kq + i of pixel (yy, x0 + n)
+        const bool pvalid = x0 + n < a.W;
+        const size_t p = (size_t)(img * a.H + yy) * a.W + x0 + n;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             float v[4];
@@ -175,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void csm_conv_kernel(CsmArgs a) {
                 v[0] *= k.x; v[1] *= k.y; v[2] *= k.z; v[3] *= k.w;
             }
             if (pvalid) {
-                *reinterpret_cast<float4*>(a.y + (size_t)p * C + mt * 16 + 4 * kq) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(a.y + p * C + mt * 16 + 4 * kq) = make_float4(v[0], v[1], v[2], v[3]);
                 if (a.stat_part) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -185,7 +233,9 @@ __global__ __launch_bounds__(256, 2) void csm_conv_kernel(CsmArgs a) {
                 }
             }
         }
+        }
     }
+    (void)it;
     if (!a.stat_part) return;
     // over the 16 pixel lanes of a channel group (fixed order), then over the four waves (fixed order)
 #pragma unroll
@@ -205,7 +255,10 @@ __global__ __launch_bounds__(256, 2) void csm_conv_kernel(CsmArgs a) {
     __syncthreads();
     if (tid < 2 * C) {
         const int c = tid >> 1, which = tid & 1;
-        a.stat_part[((size_t)blockIdx.x * C + c) * 2 + which] = red[0][c][which] + red[1][c][which] + red[2][c][which] + red[3][c][which];
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[w][c][which];
+        a.stat_part[((size_t)blockIdx.x * C + c) * 2 + which] = t;
     }
 }
 
@@ -249,10 +302,10 @@ int csm_launch(const float* x, const float* w, void* wpack, const float* bias, c
     a.x = x; a.wp = wpack; a.bias = bias; a.keep = keep; a.y = y; a.stat_part = stat_part;
     a.N = N; a.H = H; a.W = W; a.M = N * H * W; a.act = act;
     a.rW = 1.0f / (float)W; a.rH = 1.0f / (float)H;
-    const int grid = dmc::csm_stat_blocks(N, H, W);
+    const int grid = dmc::csm_stat_blocks(N, H, W, C);
     if (stat_part && stat_blocks != grid)
         return fail(DMC_E_INVALID, "conv_small: statistics partials have %d rows but this launch writes %d", stat_blocks, grid);
-    csm_conv_kernel<C><<<grid, 256, 0, s>>>(a);
+    csm_conv_kernel<C><<<grid, Csm<C>::NW * 64, 0, s>>>(a);
     return check_launch("csm_conv");
 }
 
@@ -267,9 +320,10 @@ bool csm_supported(int N, int H, int W, int Cin, int Cout, int KH, int KW, int s
 }
 
 // persistent waves: enough workgroups for ~8 per CU, at most one 16-pixel tile per wave and round below that
-int csm_stat_blocks(int N, int H, int W) {
-    const long tiles = ((long)N * H * W + 15) / 16;
-    long g = (tiles + 3) / 4;
+int csm_stat_blocks(int N, int H, int W, int C) {
+    const long tiles = (long)N * H * ((W + 15) / 16);
+    const int nw = C == 16 ? 4 : 8;
+    long g = (tiles + nw - 1) / nw;
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
 }
 
