@@ -26,22 +26,35 @@ using namespace dmc::x3;
 namespace {
 
 // ---- tile geometry ------------------------------------------------------------------------------------------
-constexpr int QNW = 8, QBM = 32 * QNW, QBN = 64;   // 8 waves; TN = 2: 8 x (32 pixels x 64 rows) = 256 pixels per workgroup,
-                                                    // TN = 1: 4 x 2 waves of 32 pixels x 32 rows = 128 pixels (half-size workgroups
-                                                    // where 256-pixel tiles leave CUs idle: tile quantisation, q_choose_tn)
-constexpr int QNT = 12;                             // patch transfers per slice (32 pixel rows each): 384 staged rows
-constexpr int QZROW = 32 * QNT;                     // the zero row behind them (taps that leave the image read it)
-constexpr int QPSL = (QZROW + 1) * 32;              // bytes of one slice region of a patch buffer
-constexpr int QPB = 3 * QPSL;                       // one patch buffer (three slices)
-constexpr int QNPB = 3;                             // patch buffers: the unit in use, the next one, the one arriving
+constexpr int QBM = 256, QBN = 64;                  // the full-size tile: 256 pixels x 64 output rows (channels) per workgroup
 constexpr int QWSLOT = 3 * QBN * 32;                // one tap slot's weights: 3 slices x 64 rows x 16 k = 6 KB
 constexpr int QWB = 3 * QWSLOT;                     // a weight buffer holds a step of up to three slots
-constexpr int QWOFF = QNPB * QPB;
-constexpr int QLDS_OP = QWOFF + 2 * QWB;            // 147,744 B
 constexpr int QEP = 272, QETILE = 32 * QEP;         // epilogue: a wave's [32 pixels][64 channels] fp32 tile, rows padded
-constexpr int QLDS_EP = QNW * QETILE + 8192;
-constexpr int QLDS = QLDS_OP > QLDS_EP ? QLDS_OP : QLDS_EP;
-constexpr int QPT = 9;                              // patch transfers per issuing wave and unit (3 slices x 3)
+
+// Geometry of a kernel variant: NW waves, NPB patch buffers, NT patch transfers (32 pixel rows each) per slice.
+//   QG<8, 3, 12>: 8 waves, 256 (TN = 2) / 128 (TN = 1) pixels, three patch buffers: 147.7 KB, one workgroup per CU;
+//   QG<4, 2, 7>:  4 waves x (32 pixels x 64 rows) = 128 pixels, two patch buffers of <= 224 pixels: 80,064 B -- TWO workgroups
+//                 per CU, one's prologue / epilogue under the other's main loop (the x3s configuration-4 recipe): the short K
+//                 loops of these layers (4-32 chunks) spend a third of a workgroup's time outside the main loop.
+template <int NW_, int NPB_, int NT_>
+struct QG {
+    static constexpr int NW = NW_, NPB = NPB_, NT = NT_;
+    static constexpr int NA = NW / 2;                   // waves that move patches (the others move weights)
+    static constexpr int KP = (NT + NA - 1) / NA;       // patch transfers per issuing wave and slice
+    static constexpr int PT = 3 * KP;                   // ... per unit
+    static constexpr int KW = (18 + NA - 1) / NA;       // weight transfers per issuing wave and step (<= 18)
+    static constexpr int ZROW = 32 * NT;                // the zero row behind the staged rows
+    static constexpr int PSL = (ZROW + 1) * 32;         // bytes of one slice region of a patch buffer
+    static constexpr int PB = 3 * PSL;
+    static constexpr int WOFF = NPB * PB;
+    static constexpr int LDS_OP = WOFF + 2 * QWB;
+    static constexpr int LDS_EP = NW * QETILE + 8192;
+    static constexpr int LDS = LDS_OP > LDS_EP ? LDS_OP : LDS_EP;
+    static constexpr bool COUNTED = NPB == 3;           // three buffers: the newest patch may stay in flight (vmcnt(PT))
+    static_assert(!COUNTED || NT % NA == 0, "counted waits need the same number of transfers from every patch wave");
+};
+using QGBig = QG<8, 3, 12>;
+using QGTwo = QG<4, 2, 7>;
 
 struct QSlot { int sh, acc; };                      // address shift (index into the program's shift table), accumulator set
 struct QStep { int unit, nslot; QSlot s[3]; };
@@ -89,9 +102,11 @@ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl<N>(f, std::make_integer_sequence<int, N>{}); }
 
-template <class P, int TN>
-__global__ __launch_bounds__(QNW * 64) void x3q_conv_kernel(X3qArgs a) {
+template <class P, int TN, class GEO>
+__global__ __launch_bounds__(GEO::NW * 64) void x3q_conv_kernel(X3qArgs a) {
     constexpr int NSH = P::NSH, NACC = P::NACC, NSTEP = P::NSTEP, NUNIT = P::NUNIT;
+    constexpr int QNW = GEO::NW, QNPB = GEO::NPB, QZROW = GEO::ZROW, QPSL = GEO::PSL, QPB = GEO::PB, QWOFF = GEO::WOFF, QPT = GEO::PT;
+    constexpr int NA = GEO::NA, KP = GEO::KP, KW = GEO::KW;
     constexpr int WN = 2 / TN, WM = QNW / WN, BM = 32 * WM;  // waves along rows (channels) / pixels; pixels per workgroup
     static_assert(TN == 1 || TN == 2, "a wave owns 32 or 64 of the workgroup's 64 rows");
     constexpr int CHB = P::NSLOTS * QWSLOT;                  // packed weight bytes per (64-row block, chunk)
@@ -118,12 +133,12 @@ __global__ __launch_bounds__(QNW * 64) void x3q_conv_kernel(X3qArgs a) {
     // ---- transfers.  Waves 0-3 move patches (wave w: rows 32 (w + 4 k) .., k = 0..2, of each slice: ALWAYS nine
     // transfers per unit -- rows beyond the patch arrive as zeros -- so that s_waitcnt vmcnt(9) means "all but the newest
     // patch"); waves 4-7 move the weights ----
-    const bool grp_a = wave < 4;
-    const int wq = wave & 3;
-    unsigned pvoff[3];
+    const bool grp_a = wave < NA;
+    const int wq = wave % NA;
+    unsigned pvoff[KP];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int pr = 32 * (wq + 4 * k) + (lane >> 1), h = lane & 1;
+    for (int k = 0; k < KP; ++k) {
+        const int pr = 32 * (wq + NA * k) + (lane >> 1), h = lane & 1;
         pvoff[k] = pr < PP ? (unsigned)(f0 + pr) * 32u + (unsigned)((h ^ ((pr >> 3) & 1)) << 4) : OOB;
     }
     const int nchunk = a.K >> 4;
@@ -136,9 +151,10 @@ __global__ __launch_bounds__(QNW * 64) void x3q_conv_kernel(X3qArgs a) {
     auto dma_patch = [&](int c, auto uc, int pbuf, int i) {
         constexpr int u = decltype(uc)::value;
         constexpr int ut = P::UNIT_T[u], ug = P::UNIT_G[u];
-        const int s = i / 3, k = i - 3 * s;
+        const int s = i / KP, k = i - KP * s;
         const unsigned soff = (unsigned)(s * (ut ? a.pps1 : a.pps0) + ug * nchunk + c) * a.plane_bytes;
-        dma_buf16(ut ? srd1 : srd0, pvoff[k], soff, lds0 + pbuf * QPB + s * QPSL + (wq + 4 * k) * 1024);
+        if (GEO::COUNTED || wq + NA * k < GEO::NT)            // (counted waits: always issued, rows beyond the patch arrive as zeros)
+            dma_buf16(ut ? srd1 : srd0, pvoff[k], soff, lds0 + pbuf * QPB + s * QPSL + (wq + NA * k) * 1024);
     };
     // transfer e of step (c, j)'s weights into weight buffer wbuf
     auto dma_weight = [&](int c, auto jc, int wbuf, int e) {
@@ -209,7 +225,7 @@ __global__ __launch_bounds__(QNW * 64) void x3q_conv_kernel(X3qArgs a) {
     if (tid < 2 * 3 * QNPB)
         *reinterpret_cast<float4*>(lds_q + (tid >> 1) / 3 * QPB + ((tid >> 1) % 3) * QPSL + QZROW * 32 + (tid & 1) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
     if (grp_a) {
-        static_for<3>([&](auto uc) {
+        static_for<QNPB>([&](auto uc) {
             constexpr int U = decltype(uc)::value;           // global unit U = chunk U / NUNIT, unit U % NUNIT
             if (U < total_units) {
 #pragma unroll
@@ -221,7 +237,7 @@ __global__ __launch_bounds__(QNW * 64) void x3q_conv_kernel(X3qArgs a) {
             constexpr int g = decltype(gc)::value;
             if (g < total_steps) {
 #pragma unroll
-                for (int i = 0; i < 5; ++i) dma_weight(g / NSTEP, std::integral_constant<int, g % NSTEP>{}, g, wq + 4 * i);
+                for (int i = 0; i < KW; ++i) dma_weight(g / NSTEP, std::integral_constant<int, g % NSTEP>{}, g, wq + NA * i);
             }
         });
     }
@@ -265,7 +281,7 @@ __global__ __launch_bounds__(QNW * 64) void x3q_conv_kernel(X3qArgs a) {
             });
             // this wave's transfers for the next step have landed (patch waves: all but the newest patch, which is two units
             // ahead; at the end of the run nothing newer is in flight)
-            if (grp_a && U + 2 < total_units) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+            if (GEO::COUNTED && grp_a && U + 2 < total_units) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(QPT) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             const int pb_old = pb, wb_old = wb;
@@ -282,13 +298,13 @@ __global__ __launch_bounds__(QNW * 64) void x3q_conv_kernel(X3qArgs a) {
                 load_frags(frag_of(std::integral_constant<int, (par + kl + 1) & 1>{}), xcur[sh_first], wcur, std::integral_constant<int, 0>{});
             // step g + 2's weights -> the buffer this step used; unit U + 3's patch -> the buffer this unit used
             constexpr int J2 = (J + 2) % NSTEP, C2 = (J + 2) / NSTEP;
-            constexpr int U3 = (unit + 3) % NUNIT, CU3 = (unit + 3) / NUNIT;
+            constexpr int U3 = (unit + QNPB) % NUNIT, CU3 = (unit + QNPB) / NUNIT;   // the unit whose patch takes the freed buffer
             const bool wgo = !grp_a && g + 2 < total_steps;
-            const bool pgo = grp_a && unit_last && U + 3 < total_units;
+            const bool pgo = grp_a && unit_last && U + QNPB < total_units;
             mfma_slot(frag_of(std::integral_constant<int, (par + kl) & 1>{}), std::integral_constant<int, acc_last>{}, [&](int p) {
                 if (wgo) {
 #pragma unroll
-                    for (int i = p; i < 5; i += 6) dma_weight(c + C2, std::integral_constant<int, J2>{}, wb_old, wq + 4 * i);
+                    for (int i = p; i < KW; i += 6) dma_weight(c + C2, std::integral_constant<int, J2>{}, wb_old, wq + NA * i);
                 }
                 if constexpr (unit_last) {
                     if (pgo) {
@@ -451,11 +467,23 @@ int q_patch_pixels_max(long M, int W) {
     return worst;
 }
 
+int q_patch_pixels_max128(long M, int W) {
+    int worst = 0;
+    long tiles = (M + 127) / 128;
+    if (tiles > W) tiles = W;
+    for (long t = 0; t < tiles; ++t) {
+        const long m0 = t * 128, ml = (m0 + 128 < M ? m0 + 128 : M) - 1;
+        const int pp = (int)((ml / W - m0 / W + 2) * W);
+        if (pp > worst) worst = pp;
+    }
+    return worst;
+}
+
 bool q_shape_ok(int N, int OH, int OW, int Cin, int Cout) {
     if (N <= 0 || OH <= 0 || OW <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 != 0 || Cout % 64 != 0) return false;
     const long M = (long)N * OH * OW;
     if (M * 4 * Cin * 6 >= (1L << 31) || M * Cout * 6 >= (1L << 31)) return false;     // slice tensors below the descriptor's 2 GB
-    return q_patch_pixels_max(M, OW) <= QZROW;
+    return q_patch_pixels_max(M, OW) <= QGBig::ZROW;
 }
 
 // Tile quantisation: one workgroup per CU (147 KB of LDS), so a launch takes ceil(workgroups / 256) rounds.  The half-size
@@ -472,16 +500,31 @@ int q_choose_tn(long M, int R) {
     return t1 < t2 ? 1 : 2;
 }
 
-template <class P, int TN>
+template <class P, int TN, class GEO>
 int launch_q(const X3qArgs& a, hipStream_t s) {
     static LdsLimit lim;
-    const hipError_t attr = lim.raise(reinterpret_cast<const void*>(&x3q_conv_kernel<P, TN>), QLDS);
+    const hipError_t attr = lim.raise(reinterpret_cast<const void*>(&x3q_conv_kernel<P, TN, GEO>), GEO::LDS);
     if (attr != hipSuccess) return fail(DMC_E_LAUNCH, "x3q_conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
-    constexpr int BM = TN == 2 ? 256 : 128;
+    constexpr int BM = 32 * GEO::NW / (2 / TN);
     dim3 grid((a.M + BM - 1) / BM, a.R / QBN);
-    x3q_conv_kernel<P, TN><<<grid, QNW * 64, QLDS, s>>>(a);
+    x3q_conv_kernel<P, TN, GEO><<<grid, GEO::NW * 64, GEO::LDS, s>>>(a);
     return check_launch("x3q_conv");
 }
+
+// variant of a launch: 0 = QGBig, TN = 2 (256 pixels); 1 = QGBig, TN = 1 (128 pixels, 32 x 32 wave tiles); 2 = QGTwo (128 pixels,
+// 4 waves, two workgroups per CU).  option conv_cfg: 201 / 202 / 203 force variant 0 / 1 / 2 (203 only where the patch fits).
+int q_patch_pixels_max128(long M, int W);
+int q_variant(long M, int W, int R) {
+    const int forced = option(OPT_CONV_CFG);
+    const bool two_ok = q_patch_pixels_max128(M, W) <= QGTwo::ZROW;
+    if (forced == 201) return 0;
+    if (forced == 202) return 1;
+    if (forced == 203 && two_ok) return 2;
+    // two workgroups per CU wherever the patch fits and the launch has at least as many workgroups as the chip has slots
+    if (forced != 204 && two_ok && ((M + 127) / 128) * (R / QBN) >= 512) return 2;
+    return q_choose_tn(M, R) == 2 ? 0 : 1;
+}
+int q_block_pixels(int variant) { return variant == 0 ? 256 : 128; }
 
 
 // ---- weight gradient of the 3x3 / stride-2 convolution -------------------------------------------------------------
@@ -815,7 +858,7 @@ int dmc_x3q_supported(int N, int OH, int OW, int Cin, int Cout) { return q_shape
 
 int dmc_x3q_stat_blocks(int N, int OH, int OW, int Cout) {
     const long M = (long)N * OH * OW;
-    const int bm = q_choose_tn(M, Cout) == 2 ? 256 : 128;
+    const int bm = q_block_pixels(q_variant(M, OW, Cout));
     return (int)((M + bm - 1) / bm);
 }
 
@@ -848,8 +891,8 @@ int dmc_x3q_conv_fwd(const void* xq, const void* wpack_f, float* y3, float* y1, 
     if (!xq || !wpack_f || !y3 || !y1) return fail(DMC_E_INVALID, "dmc_x3q_conv_fwd: null pointer");
     if (!q_shape_ok(N, OH, OW, Cin, Cout))
         return fail(DMC_E_INVALID, "dmc_x3q_conv_fwd: unsupported shape N=%d OH=%d OW=%d Cin=%d Cout=%d", N, OH, OW, Cin, Cout);
-    const int tn = q_choose_tn((long)N * OH * OW, Cout);
-    const int rows = (int)(((long)N * OH * OW + (tn == 2 ? 255 : 127)) / (tn == 2 ? 256 : 128));
+    const int var = q_variant((long)N * OH * OW, OW, Cout);
+    const int rows = (int)(((long)N * OH * OW + q_block_pixels(var) - 1) / q_block_pixels(var));
     if ((stat_partials3 || stat_partials1) && stat_blocks != rows)
         return fail(DMC_E_INVALID, "dmc_x3q_conv_fwd: statistics partials have %d rows but this launch writes %d (dmc_x3q_stat_blocks "
                                    "was called under another conv_cfg option?)", stat_blocks, rows);
@@ -858,7 +901,8 @@ int dmc_x3q_conv_fwd(const void* xq, const void* wpack_f, float* y3, float* y1, 
     a.N = N; a.H = OH; a.W = OW; a.K = Cin; a.R = Cout; a.M = N * OH * OW;
     a.plane_bytes = (unsigned)a.M * 32u;
     a.pps0 = 4 * (Cin / 16); a.pps1 = 0;
-    return tn == 2 ? launch_q<ProgFwd, 2>(a, (hipStream_t)stream) : launch_q<ProgFwd, 1>(a, (hipStream_t)stream);
+    return var == 0 ? launch_q<ProgFwd, 2, QGBig>(a, (hipStream_t)stream) : var == 1 ? launch_q<ProgFwd, 1, QGBig>(a, (hipStream_t)stream)
+                                                                                      : launch_q<ProgFwd, 2, QGTwo>(a, (hipStream_t)stream);
 }
 
 int dmc_x3q_conv_dgrad(const void* dys3, const void* dys1, const void* wpack_t, float* dx, int N, int OH, int OW, int Cin, int Cout,
@@ -871,7 +915,9 @@ int dmc_x3q_conv_dgrad(const void* dys3, const void* dys1, const void* wpack_t, 
     a.N = N; a.H = OH; a.W = OW; a.K = Cout; a.R = Cin; a.M = N * OH * OW;
     a.plane_bytes = (unsigned)a.M * 32u;
     a.pps0 = a.pps1 = Cout / 16;
-    return q_choose_tn(a.M, Cin) == 2 ? launch_q<ProgDgrad, 2>(a, (hipStream_t)stream) : launch_q<ProgDgrad, 1>(a, (hipStream_t)stream);
+    const int var = q_variant(a.M, OW, Cin);
+    return var == 0 ? launch_q<ProgDgrad, 2, QGBig>(a, (hipStream_t)stream) : var == 1 ? launch_q<ProgDgrad, 1, QGBig>(a, (hipStream_t)stream)
+                                                                                        : launch_q<ProgDgrad, 2, QGTwo>(a, (hipStream_t)stream);
 }
 
 int dmc_x3q_conv_wgrad_supported(int N, int OH, int OW, int Cin, int Cout) {

@@ -209,8 +209,9 @@ def test_stride2_block_input_without_slices_is_split_on_the_fly(monkeypatch):
 @pytest.mark.parametrize("shape", [(6, 64, 56, 56, 128), (9, 256, 14, 14, 512), (3, 64, 20, 12, 64), (2, 64, 2, 2, 64)])
 def test_half_size_workgroups_are_bitwise_the_full_size_ones(shape):
     """The TN = 1 variant (128-pixel workgroups of 32 x 32 wave tiles, chosen where 256-pixel tiles would leave a partly
-    filled round of workgroups: option conv_cfg 202 forces it, 201 the full-size one) sums the same products in the same
-    order: forward, both statistics and the data gradient are bitwise equal."""
+    filled round of workgroups: option conv_cfg 202 forces it, 201 the full-size one) and the 4-wave variant that runs two
+    workgroups per CU (203) sum the same products in the same order: forward, both statistics and the data gradient are
+    bitwise equal."""
     n, cin, h, w, cout = shape
     oh, ow = h // 2, w // 2
     L, lib = dmcnet_amd._lib, dmcnet_amd._lib.load()
@@ -223,15 +224,16 @@ def test_half_size_workgroups_are_bitwise_the_full_size_ones(shape):
     before = lib.dmc_get_option(b"conv_cfg")
     out = {}
     try:
-        for cfg in (201, 202):
+        for cfg in (201, 202, 203):
             L.check(lib.dmc_set_option(b"conv_cfg", cfg), "dmc_set_option")
             y3, y1, p3, p1 = ops.x3q_conv_fwd(xq, wf, n, oh, ow, cin, cout, want_stats=True)
             dx = ops.x3q_conv_dgrad(dys3, dys1, wt, n, oh, ow, cin, cout)
             out[cfg] = (y3, y1, dx, p3.sum(0), p1.sum(0), p3.shape[0])
     finally:
         L.check(lib.dmc_set_option(b"conv_cfg", before), "dmc_set_option")
-    a, b = out[201], out[202]
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
-    assert b[5] == (n * oh * ow + 127) // 128 and a[5] == (n * oh * ow + 255) // 256
-    for i in (3, 4):
-        assert float((a[i] - b[i]).abs().max()) <= 1e-12 * float(a[i].abs().max())
+    a, b, c = out[201], out[202], out[203]      # 203: the 4-wave, two-workgroups-per-CU variant (128-pixel tiles, two patch buffers)
+    for o in (b, c):
+        assert torch.equal(a[0], o[0]) and torch.equal(a[1], o[1]) and torch.equal(a[2], o[2])
+        for i in (3, 4):
+            assert float((a[i] - o[i]).abs().max()) <= 1e-12 * float(a[i].abs().max())
+    assert b[5] == (n * oh * ow + 127) // 128 and a[5] == (n * oh * ow + 255) // 256 and c[5] == b[5]
