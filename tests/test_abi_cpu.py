@@ -160,3 +160,78 @@ def test_classifier_conv_entry_points_host_side_without_gpu():
             resnet.RESIDUAL_GRAD_LINK = old
     for a, b in zip(*grads):
         assert torch.equal(a, b)
+
+
+def test_stride2_pair_host_side_without_gpu():
+    """Host-only parts of the round-4 stride-2 block pair (conv_x3q.hip; torchvision BasicBlock conv1 + downsample behind
+    code/dmcnet/model.py:305): which blocks qualify (ops.s2_pair_usable -- asked by the consumer AND by the producer of the
+    block input, which then writes space-to-depth slices and no fp32 tensor), size / capability queries, argument validation
+    before any launch, and the stock-op fallback of such a block on the CPU."""
+    from dmcnet_amd import ops, resnet
+    lib = _lib.load()
+    # capability / sizes: the classifier's three pairs at 120 frames, and shapes the kernels do not cover
+    for n, oh, cin, cout in ((120, 28, 64, 128), (120, 14, 128, 256), (120, 7, 256, 512)):
+        assert lib.dmc_x3q_supported(n, oh, oh, cin, cout) == 1 and lib.dmc_x3q_conv_wgrad_supported(n, oh, oh, cin, cout) == 1
+        assert lib.dmc_x3q_wpack_bytes(cin, cout) == cin * cout * 10 * 6              # nine taps + the shortcut, three bf16 slices
+        assert lib.dmc_x3q_conv_wgrad_bytes(n, oh, oh, cin, cout) > 0
+        m = n * oh * oh
+        assert lib.dmc_x3q_stat_blocks(n, oh, oh, cout) in ((m + 255) // 256, (m + 127) // 128)
+    assert lib.dmc_x3q_supported(2, 14, 14, 48, 64) == 0                               # Cin % 64
+    assert lib.dmc_x3q_supported(2, 14, 300, 64, 64) == 0                              # a 256-pixel tile's patch does not fit the LDS
+    assert lib.dmc_x3q_conv_wgrad_supported(2, 10, 10, 64, 64) == 0                    # no weight-gradient configuration for this grid
+    dummy = torch.zeros(16)
+    p = _lib.ptr(dummy)
+    assert lib.dmc_x3q_conv_fwd(p, p, p, p, None, None, 0, 2, 14, 14, 48, 64, None) != 0 and b"unsupported shape" in lib.dmc_last_error()
+    assert lib.dmc_x3q_conv_fwd(p, p, p, p, p, p, 1, 120, 28, 28, 64, 128, None) != 0 and b"rows" in lib.dmc_last_error()
+    assert lib.dmc_x3q_split(p, p, 1, 7, 8, 16, None) != 0                             # odd height
+    assert lib.dmc_x3q_pack_weights(p, None, p, p, 64, 64, None) != 0
+    # eligibility of a block
+    torch.manual_seed(0)
+    unit = resnet.ResidualUnit("basic", 64, 128, 2).train()
+    ident = resnet.ResidualUnit("basic", 64, 64, 1).train()
+    assert ops.s2_pair_usable((4, 64, 28, 28), unit)
+    assert not ops.s2_pair_usable((4, 64, 28, 28), ident)                              # no downsample branch
+    assert not ops.s2_pair_usable((4, 64, 27, 28), unit)                               # odd height
+    assert not ops.s2_pair_usable((4, 32, 28, 28), unit)                               # channel mismatch
+    with torch.no_grad():
+        assert not ops.s2_pair_usable((4, 64, 28, 28), unit)                           # a training op: autograd must be on
+    unit.downsample[1].eval()
+    assert not ops.s2_pair_usable((4, 64, 28, 28), unit)                               # BatchNorms in mixed modes
+    unit.train()
+    old = ops.X3Q
+    ops.X3Q = False
+    try:
+        assert not ops.s2_pair_usable((4, 64, 28, 28), unit)
+    finally:
+        ops.X3Q = old
+    _lib.check(lib.dmc_set_option(b"conv_arith", 0), "dmc_set_option")
+    try:
+        assert not ops.s2_pair_usable((4, 64, 28, 28), unit)                           # fp32-MFMA arithmetic: no slice tensors
+    finally:
+        _lib.check(lib.dmc_set_option(b"conv_arith", 1), "dmc_set_option")
+    # on the CPU the block runs on the stock modules (no s2d slices are attached, nothing raises)
+    x = torch.randn(2, 64, 8, 8, requires_grad=True)
+    out = unit(x)
+    out.square().mean().backward()
+    assert out.shape == (2, 128, 4, 4) and x.grad is not None and ops.x3q_of(out) is None
+
+
+def test_small_channel_conv_dispatch_host_side_without_gpu():
+    """conv_small.hip (the discriminator's 16- / 32-channel stride-1 3x3 blocks, code/dmcnet_GAN/model.py:254-279) is
+    dispatched INSIDE dmc_conv_nhwc_fwd / _dgrad: the size queries a caller makes first must describe that kernel -- the
+    statistics partials have one row per persistent workgroup, the weight workspace holds the k-padded fragments."""
+    lib = _lib.load()
+    # 16 channels: five k-blocks of 32 (two taps x 16 channels, the last half empty) x 3 slices x 16 rows x 32 x 2 bytes
+    assert lib.dmc_conv_nhwc_wt_bytes(16, 16, 3, 3) == 3 * 5 * 16 * 32 * 2
+    assert lib.dmc_conv_nhwc_wt_bytes(32, 32, 3, 3) == 3 * 9 * 2 * 16 * 32 * 2 == 32 * 32 * 9 * 6
+    assert lib.dmc_conv_nhwc_wt_bytes(16, 32, 3, 3) == 16 * 32 * 9 * 6                 # (not a small-channel shape)
+    tiles16 = 240 * 112 * 7                                                             # 16-pixel row segments
+    assert lib.dmc_conv_nhwc_stat_blocks(240, 112, 112, 16, 16, 3, 1, 1) == min(2048, (tiles16 + 3) // 4)
+    assert lib.dmc_conv_nhwc_stat_blocks(2, 5, 3, 32, 32, 3, 1, 1) == (2 * 5 * 1 + 7) // 8
+    # stride 2 / other channel pairs keep the implicit-GEMM kernels' tile rows
+    assert lib.dmc_conv_nhwc_stat_blocks(240, 112, 112, 16, 32, 3, 2, 1) == (240 * 56 * 56 + 127) // 128
+    _lib.check(lib.dmc_set_option(b"conv_cfg", 301), "dmc_set_option")                 # 301: the small-channel kernel off
+    try:
+        assert lib.dmc_conv_nhwc_stat_blocks(240, 112, 112, 16, 16, 3, 1, 1) == (240 * 112 * 112 + 255) // 256
+    finally:
+        _lib.check(lib.dmc_set_option(b"conv_cfg", 0), "dmc_set_option")
