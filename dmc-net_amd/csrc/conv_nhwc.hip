@@ -2009,7 +2009,11 @@ int dmc_conv_nhwc_stats_final(const double* partials, int nblk, int C, long coun
 // dmc_conv_nhwc_wgrad_bytes() bytes (the split-K partials; unused when one slice suffices).
 size_t dmc_conv_nhwc_wgrad_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
-    if (wgrad_small_ok(Cin, KH, KW, pad)) return (size_t)512 * Cout * 9 * Cin * sizeof(float) + 16;
+    if (wgrad_small_ok(Cin, KH, KW, pad)) {
+        int groups = 512;
+        if (csm_supported(N, H, W, Cin, Cout, KH, KW, stride, pad) && csm_wgrad_groups(N, H, W, Cin) > groups) groups = csm_wgrad_groups(N, H, W, Cin);
+        return (size_t)groups * Cout * 9 * Cin * sizeof(float) + 16;
+    }
     if (wgrad3_ok(Cin, Cout, KH, KW, pad, stride)) {
         const Wgrad3Plan p = wgrad3_plan(N, OH, OW, Cin, Cout, stride);
         return (size_t)(p.groups > 1 ? p.groups : 0) * Cout * KH * KW * Cin * sizeof(float) + 16;
@@ -2034,6 +2038,8 @@ int dmc_conv_nhwc_wgrad(const float* x, const float* dy, float* dw, float* works
     a.stride = stride; a.pad = pad;
     a.OH = (H + 2 * pad - KH) / stride + 1; a.OW = (W + 2 * pad - KW) / stride + 1;
     a.M = N * a.OH * a.OW;
+    if (csm_supported(N, H, W, Cin, Cout, KH, KW, stride, pad) && option(OPT_CONV_CFG) != 302)   // 302: the fp32-MFMA form (A/B runs)
+        return csm_wgrad(x, dy, dw, workspace, N, H, W, Cin, s);
     if (wgrad_small_ok(Cin, KH, KW, pad)) {
         a.part = nullptr; a.per_slice = 0; a.tiles_ci = a.tiles_co = 0;
         if (Cin == 16 && stride == 1) return Cout % 32 == 0 ? launch_wgrad_small<16, 32, 1>(a, dw, workspace, s) : launch_wgrad_small<16, 16, 1>(a, dw, workspace, s);

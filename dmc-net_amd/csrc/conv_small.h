@@ -10,5 +10,8 @@ int csm_stat_blocks(int N, int H, int W, int C);
 size_t csm_wpack_bytes(int C);
 int csm_fwd(const float* x, const float* w, void* wpack, const float* bias, const float* keep, float* y, double* stat_part,
             int stat_blocks, int N, int H, int W, int C, int act, hipStream_t s);
+// weight gradient: workspace >= csm_wgrad_groups() x C x 9 x C floats (dmc_conv_nhwc_wgrad_bytes); dw [C][3][3][C] (OHWI)
+int csm_wgrad_groups(int N, int H, int W, int C);
+int csm_wgrad(const float* x, const float* g, float* dw, float* workspace, int N, int H, int W, int C, hipStream_t s);
 int csm_dgrad(const float* dy, const float* w, void* wpack, float* dx, int N, int H, int W, int C, hipStream_t s);
 }  // namespace dmc

@@ -262,6 +262,205 @@ __global__ __launch_bounds__(Csm<C>::NW * 64) void csm_conv_kernel(CsmArgs a) {
     }
 }
 
+// ---- weight gradient -----------------------------------------------------------------------------------------------------
+// dw[co][tap][ci] = sum over pixels p of g[p][co] * x[p + d(tap)][ci] -- a GEMM over PIXELS (K) with M = co, N = ci per tap, on
+// v_mfma_f32_16x16x32_bf16 in bf16x3 arithmetic.  A k-block = the 32 pixels of TWO 16-pixel row-segment tiles (k-quarters
+// 0, 1 -> tile a, 2, 3 -> tile b).  Per tile pair a wave loads the two 3 x 18-pixel neighbourhoods of x and the two 16-pixel
+// segments of g (range-checked buffer loads: zeros outside the image / beyond the row), splits every 8-channel piece once
+// and parks the slices PIXEL-MAJOR in its mini patch in LDS ([slice][chunk of 16 channels][pixel][16 channels]): both MFMA
+// operands then need "eight consecutive pixels of one channel per lane" -- ds_read_b64_tr_b16 (x3s_common.h) transposes
+// on the way out of LDS, the nine taps are nine pixel offsets into the same patch.  The 9 x (C/16)^2 accumulator tiles
+// stay in registers for the whole launch; partials per workgroup (waves summed in fixed order) and a fixed-order reduction
+// over the workgroups: deterministic, no atomics.  (conv_wgrad_small_kernel, fp32 MFMA: 0.25-0.28 ms per launch at 240 / 120
+// frames, at 0.7 of the fp32-MFMA peak.)
+struct CsmWgArgs {
+    const float* x;        // [M][C]
+    const float* g;        // [M][C] gradient of the convolution output
+    float* part;           // [gridDim.x][C][9][C]
+    int N, H, W;
+    float rH;
+};
+
+template <int C>
+__global__ __launch_bounds__(256, C == 16 ? 3 : 1) void csm_wgrad_kernel(CsmWgArgs a) {
+    constexpr int OC = C / 8, NCH = C / 16, MT = C / 16;
+    constexpr int XPX = 2 * 54, GPX = 2 * 16;                 // pixels of a tile pair's x patches / g segments
+    constexpr int XPL = XPX * 32, GPL = GPX * 32;             // bytes of one (slice, chunk) plane
+    constexpr int XS = NCH * XPL, GS = NCH * GPL;             // ... of one slice
+    constexpr int WB = 3 * (XS + GS);                         // a wave's mini patch: C = 16: 13,440 B, C = 32: 26,880 B
+    constexpr int NPX_ = XPX * OC, NPG = GPX * OC;            // 8-channel pieces: x, g
+    constexpr int NLX = (NPX_ + 63) / 64, NLG = NPG / 64, NPL = NLX + NLG;      // loads per lane: 4 + 1 (C = 16), 7 + 2 (C = 32)
+    static_assert(NPG % 64 == 0, "g pieces fill whole waves");
+    __shared__ __attribute__((aligned(16))) char patch[4][WB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L = lane & 15, kq = lane >> 4;
+    const int segs = (a.W + 15) >> 4;
+    const int ntiles = a.N * a.H * segs;
+    const int npairs = (ntiles + 1) >> 1;
+    const int stride = (int)gridDim.x * 4;
+    const __amdgpu_buffer_rsrc_t srd_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g), 0, 0x7fffffff, 0x00020000);
+    char* const mp = patch[wave];
+    const float rS = 1.0f / (float)segs;
+    auto geom = [&](int tile, int& img, int& yy, int& x0) {
+        int r = (int)((float)tile * rS);
+        r -= (r * segs > tile);
+        r += ((r + 1) * segs <= tile);
+        x0 = (tile - r * segs) * 16;
+        img = (int)((float)r * a.rH);
+        img -= (img * a.H > r);
+        img += ((img + 1) * a.H <= r);
+        yy = r - img * a.H;
+    };
+    // this lane's pieces (loads 0 .. NLX-1: x piece = (tile, patch row, patch column, octet); NLX ..: g piece = (tile, pixel,
+    // octet)), packed: tile | row << 1 | column << 3 | octet << 8; p_lds = byte offset within slice 0
+    int p_geo[NPL], p_lds[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const bool isx = k < NLX;
+        int f = lane + 64 * (isx ? k : k - NLX);
+        if (isx && f >= NPX_) f = 0;                             // idle lanes of the last x load repeat piece 0 (never stored)
+        const int q = f / OC, oct = f % OC;                      // pixel of the pair's patch / segment array
+        const int tile = isx ? q / 54 : q / 16;
+        const int row = isx ? (q % 54) / 18 : 1;                 // g: the tile's own row = patch row 1
+        const int col = isx ? q % 18 : q % 16 + 1;               //    and pixel px = patch column px + 1
+        p_geo[k] = tile | row << 1 | col << 3 | oct << 8;
+        p_lds[k] = (isx ? 0 : 3 * XS) + (oct >> 1) * (isx ? XPL : GPL) + q * 32 + (oct & 1) * 16;
+    }
+    // D pairs in flight per wave (registers): a pair's loads are issued D - 1 pairs of split + MFMA work ahead of their use --
+    // with D = 1 the 16-channel kernel (54 MFMAs per pair) ran at one memory round trip per pair
+    constexpr int D = C == 16 ? 2 : 1;
+    float4 plo[D][NPL], phi[D][NPL];
+    auto load_pair = [&](int pair, float4 (&lo)[NPL], float4 (&hi)[NPL]) {
+        int img[2], yy[2], x0[2];
+        geom(2 * pair, img[0], yy[0], x0[0]);
+        const bool second = 2 * pair + 1 < ntiles;
+        geom(second ? 2 * pair + 1 : 2 * pair, img[1], yy[1], x0[1]);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const int t = p_geo[k] & 1, row = (p_geo[k] >> 1) & 3, col = (p_geo[k] >> 3) & 31, oct = p_geo[k] >> 8;
+            const int iy = (t ? yy[1] : yy[0]) + row - 1, ix = (t ? x0[1] : x0[0]) + col - 1;
+            const bool ok = (t == 0 || second) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const unsigned off = ok ? (unsigned)((((t ? img[1] : img[0]) * a.H + iy) * a.W + ix) * C + 8 * oct) * 4u : 0x80000000u;
+            if (k < NLX) {
+                lo[k] = buf_load16(srd_x, off);
+                hi[k] = buf_load16(srd_x, off + 16u);
+            } else {
+                lo[k] = buf_load16(srd_g, off);
+                hi[k] = buf_load16(srd_g, off + 16u);
+            }
+        }
+    };
+    f32x4 acc[9][MT][MT];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // transposing reads: lane (L, kq) of a 16-lane group hands in pixel 8 (kq & 1) + L / 4 (+ 4) of tile kq >> 1, channels
+    // 4 (L % 4) ..; it receives channel L of the four pixels = eight k-values of operand row L after two reads
+    const int trb = (L & 3) * 8 + (8 * (kq & 1) + (L >> 2)) * 32;
+    const int g_off = 3 * XS + (kq >> 1) * 16 * 32 + trb;                     // g: segment pixel 8 (kq & 1) + L / 4 of tile kq >> 1
+    const int x_off = (kq >> 1) * 54 * 32 + trb;                              // x: patch row 0, column 0 of that tile (+ tap offset below)
+    lds_cptr const LB = (lds_cptr)mp;
+    const int pair0 = (int)blockIdx.x * 4 + wave;
+#pragma unroll
+    for (int h = 0; h < D; ++h)
+        if (pair0 + h * stride < npairs) load_pair(pair0 + h * stride, plo[h], phi[h]);
+#pragma unroll 1
+    for (int pb = pair0; pb < npairs; pb += D * stride) {
+#pragma unroll
+        for (int h = 0; h < D; ++h) {
+            const int pc = pb + h * stride;
+            if (pc >= npairs) break;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                u32x4 s0, s1, s2;
+                split8(plo[h][k], phi[h][k], s0, s1, s2);
+                if (k != NLX - 1 || NPX_ % 64 == 0 || lane + 64 * k < NPX_) {
+                    const int ss = k < NLX ? XS : GS;
+                    *reinterpret_cast<u32x4*>(mp + p_lds[k]) = s0;
+                    *reinterpret_cast<u32x4*>(mp + p_lds[k] + ss) = s1;
+                    *reinterpret_cast<u32x4*>(mp + p_lds[k] + 2 * ss) = s2;
+                }
+            }
+            if (pc + D * stride < npairs) load_pair(pc + D * stride, plo[h], phi[h]);   // into the registers just consumed
+            __builtin_amdgcn_wave_barrier();
+            u32x4 A[MT][3];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int sl = 0; sl < 3; ++sl)
+                    tr_read2(LB + g_off + sl * GS + i * GPL, LB + g_off + sl * GS + i * GPL + 4 * 32, A[i][sl]);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int toff = ((t / 3) * 18 + (t % 3)) * 32;                // patch row dy, column dx of the tap
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    u32x4 B[3];
+#pragma unroll
+                    for (int sl = 0; sl < 3; ++sl)
+                        tr_read2(LB + x_off + toff + sl * XS + j * XPL, LB + x_off + toff + sl * XS + j * XPL + 4 * 32, B[sl]);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        acc[t][i][j] = mfma16(A[i][0], B[2], acc[t][i][j]);
+                        acc[t][i][j] = mfma16(A[i][2], B[0], acc[t][i][j]);
+                        acc[t][i][j] = mfma16(A[i][1], B[1], acc[t][i][j]);
+                        acc[t][i][j] = mfma16(A[i][0], B[1], acc[t][i][j]);
+                        acc[t][i][j] = mfma16(A[i][1], B[0], acc[t][i][j]);
+                        acc[t][i][j] = mfma16(A[i][0], B[0], acc[t][i][j]);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();                 // the next pair's stores follow this pair's reads
+        }
+    }
+    // waves summed in fixed order through LDS (the patches are dead), one partial per workgroup:
+    // lane (L = ci column, kq) holds rows co = 16 i + 4 kq + e of column ci = 16 j + L
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(&patch[0][0]);        // [C][9][C] floats: 9.2 / 36.9 KB
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < MT; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int idx = ((16 * i + 4 * kq + e) * 9 + t) * C + 16 * j + L;
+                            red[idx] = (w == 0 ? 0.f : red[idx]) + acc[t][i][j][e];
+                        }
+        }
+        __syncthreads();
+    }
+    float* out = a.part + (size_t)blockIdx.x * C * 9 * C;
+    for (int i = tid; i < C * 9 * C; i += 256) out[i] = red[i];
+}
+
+// dw = sum over workgroups of the partials, fixed order: 16 group lanes x 16 float4 columns per workgroup (group lane sl sums
+// groups sl, sl + 16, ..; the 16 lane sums are added in lane order)
+__global__ __launch_bounds__(256) void csm_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int ngroup, int numel) {
+    __shared__ float4 red[16][17];
+    const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int i = (int)blockIdx.x * 64 + 4 * o;                    // numel = 9 C^2 is a multiple of 64
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = sl; k < ngroup; k += 16) {
+        const float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * numel + i);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    red[sl][o] = s;
+    __syncthreads();
+    if (sl == 0) {
+        float4 t = red[0][o];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) { const float4 v = red[k][o]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        *reinterpret_cast<float4*>(dw + i) = t;
+    }
+}
+
 // w [Cout][9][Cin] fp32 (OHWI) -> fragment order [3 slices][KB][MT][16 rows][32 k] bf16
 //   forward:        row = co, k-block value (tap, ci) = w[co][tap][ci]
 //   data gradient:  row = ci, k-block value (tap, co) = w[co][8 - tap][ci]          (mirrored taps)
@@ -333,6 +532,26 @@ int csm_fwd(const float* x, const float* w, void* wpack, const float* bias, cons
             int stat_blocks, int N, int H, int W, int C, int act, hipStream_t s) {
     return C == 16 ? csm_launch<16>(x, w, wpack, bias, keep, y, stat_part, stat_blocks, N, H, W, act, 0, s)
                    : csm_launch<32>(x, w, wpack, bias, keep, y, stat_part, stat_blocks, N, H, W, act, 0, s);
+}
+
+int csm_wgrad_groups(int N, int H, int W, int C) {
+    const long pairs = ((long)N * H * ((W + 15) / 16) + 1) / 2;
+    const long cap = C == 16 ? 768 : 256;                  // resident workgroups: 3 / 1 per CU (53.8 / 107.5 KB of LDS)
+    long g = (pairs + 3) / 4;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+int csm_wgrad(const float* x, const float* g, float* dw, float* workspace, int N, int H, int W, int C, hipStream_t s) {
+    CsmWgArgs a;
+    a.x = x; a.g = g; a.part = workspace; a.N = N; a.H = H; a.W = W; a.rH = 1.0f / (float)H;
+    const int groups = csm_wgrad_groups(N, H, W, C);
+    if (C == 16) csm_wgrad_kernel<16><<<groups, 256, 0, s>>>(a);
+    else csm_wgrad_kernel<32><<<groups, 256, 0, s>>>(a);
+    int rc = check_launch("csm_wgrad");
+    if (rc) return rc;
+    const int numel = C * 9 * C;
+    csm_wgrad_reduce_kernel<<<numel / 64, 256, 0, s>>>(workspace, dw, groups, numel);
+    return check_launch("csm_wgrad_reduce");
 }
 
 int csm_dgrad(const float* dy, const float* w, void* wpack, float* dx, int N, int H, int W, int C, hipStream_t s) {
