@@ -288,6 +288,9 @@ def main():
                     help="arithmetic of this package's NHWC convolutions (option conv_arith): 0 = fp32 MFMA, 1 = bf16x3 "
                          "(fp32 operands as three bf16 slices, six bf16 MFMAs per product block, fp32 accumulate: "
                          "fp32-level error at a multiple of the fp32 instruction's rate)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="library kernel-selection option for A/B runs (dmc_set_option), e.g. --option gen_x3=2; recorded in the "
+                         "JSON line's config")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -312,6 +315,9 @@ def main():
     from dmcnet_amd import dataset, ddp, miopen, ops, resnet, train
     resnet.OWN_CONV = bool(args.own_conv)
     dmcnet_amd._lib.check(dmcnet_amd._lib.load().dmc_set_option(b"conv_arith", int(args.conv_arith)), "dmc_set_option")
+    for kv in args.option:
+        name, value = kv.split("=")
+        dmcnet_amd._lib.check(dmcnet_amd._lib.load().dmc_set_option(name.encode(), int(value)), "dmc_set_option %s" % kv)
     if args.miopen_find:
         miopen.enable_find()          # before the first convolution of the process
     if args.config == "i3d":
@@ -471,6 +477,7 @@ def main():
                                    ", batch %d clips/GPU, random-init weights" % args.batch,
                        "global_batch": world * args.batch, "num_class": args.num_class,
                        "parallelism": "dp%d" % world, "final_loss": round(loss, 6),
+                       **({"options": args.option} if args.option else {}),
                        "classifier_convs": (("libdmcnet_hip conv_x3s (3x3 stride 1) + conv_x3q (the stride-2 blocks: 3x3 stride 2 fused with "
                                              "the 1x1 shortcut on space-to-depth slice tensors): every operand pre-split into "
                                              "bf16x3 slice tensors by its producer, " if ops.X3Q else

@@ -26,8 +26,6 @@ using namespace dmc::x3;
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 // 16 bytes through a buffer descriptor: an offset beyond num_records returns zeros -- the zero padding of the convolution
 // costs neither a branch nor a register move (the branchy form spent a quarter of the kernel's instructions on it)
 __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t srd, unsigned voff) {
@@ -52,24 +50,6 @@ template <int C> struct Csm {
     static constexpr int NFRAG = 3 * KB * MT;           // weight fragments (1 KB each)
     static constexpr int NW = C == 16 ? 4 : 8;          // waves per workgroup (C = 32: eight waves share the 54 KB of weights)
 };
-
-__device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f32x4& c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-// eight fp32 values -> three bf16x8 fragments (truncation split, as split3)
-__device__ __forceinline__ void split8(const float4& lo, const float4& hi, u32x4& s0, u32x4& s1, u32x4& s2) {
-    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    unsigned u0[8], u1[8], u2[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) split3(v[e], u0[e], u1[e], u2[e]);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        s0[e] = pack_hi(u0[2 * e + 1], u0[2 * e]);
-        s1[e] = pack_hi(u1[2 * e + 1], u1[2 * e]);
-        s2[e] = pack_hi(u2[2 * e + 1], u2[2 * e]);
-    }
-}
 
 // Tiles are 16-pixel segments of one image row ((W + 15) / 16 per row; the last one of a row may be partial).  The nine taps
 // of a tile touch 3 rows x 18 columns of the input: every lane loads and splits its share of those 54 x C / 8 eight-channel

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #include "dmc_common.h"
+#include "gen_x3.h"
 
 using namespace dmc;
 
@@ -2107,7 +2108,8 @@ int pack(const float* const* w, const float* const* b, float* pk, hipStream_t s)
 
 extern "C" {
 
-size_t dmc_gen_tiny_workspace_bytes(void) { return (size_t)(PACKED_TOTAL + ZERO_PAD) * sizeof(float); }
+// the packed fp32 parameters + zero words, then the bf16x3 weight fragments of gen_x3.hip
+size_t dmc_gen_tiny_workspace_bytes(void) { return (size_t)(PACKED_TOTAL + ZERO_PAD) * sizeof(float) + gen_x3_frag_bytes(); }
 
 size_t dmc_gen_tiny_saved_bytes(int N, int H, int W) {
     return (size_t)N * NFEAT * H * W * sizeof(float);
@@ -2134,12 +2136,22 @@ static int gen_tiny_fwd_impl(const float* mv, const float* res, const float* con
     a.pk = workspace; a.out = out; a.H = H; a.W = W; a.add_mv = add_mv_delta;
     a.mse_flow = nullptr; a.mse_part = nullptr;
     if (fused_wgs) *fused_wgs = 0;
+    int x3mask = option(OPT_GEN_X3);
+    for (int K = 0; K < 3; ++K)
+        if (!gen_x3_supported(K, H, W)) x3mask &= ~(1 << K);
+    if (x3mask && (rc = gen_x3_pack(workspace, workspace + PACKED_TOTAL + ZERO_PAD, s))) return rc;
     const int step = frames_per_pass(N, H, W);
     for (int n0 = 0; n0 < N; n0 += step) {
         const int nn = (N - n0) < step ? (N - n0) : step;
-        if ((rc = launch_layer<0, 0>(a, n0, nn, s))) return rc;
-        if ((rc = launch_layer<0, 1>(a, n0, nn, s))) return rc;
-        if ((rc = launch_layer<0, 2>(a, n0, nn, s))) return rc;
+        // option gen_x3: bit K = hidden layer K on the bf16x3 16x16x32 kernel of gen_x3.hip
+        const size_t HWn = (size_t)H * W;
+        auto x3 = [&](int K) {
+            return gen_x3_layer(K, mv + (size_t)n0 * 2 * HWn, res + (size_t)n0 * 3 * HWn, saved + (size_t)n0 * NFEAT * HWn, workspace,
+                                workspace + PACKED_TOTAL + ZERO_PAD, nn, H, W, s);
+        };
+        if ((rc = ((x3mask >> 0) & 1) ? x3(0) : launch_layer<0, 0>(a, n0, nn, s))) return rc;
+        if ((rc = ((x3mask >> 1) & 1) ? x3(1) : launch_layer<0, 1>(a, n0, nn, s))) return rc;
+        if ((rc = ((x3mask >> 2) & 1) ? x3(2) : launch_layer<0, 2>(a, n0, nn, s))) return rc;
         if ((rc = launch_layer<0, 3>(a, n0, nn, s))) return rc;
         const int fuse45 = option(OPT_GEN_FUSE45), lpath = option(OPT_GEN_LAYER_PATH);
         if (fuse45 && (lpath == 1 || lpath == 3 || lpath == 4 || lpath == 5) && W % 4 == 0 && W <= P_MAXW) {

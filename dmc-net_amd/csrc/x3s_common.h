@@ -56,5 +56,25 @@ __device__ __forceinline__ void tr_read2(lds_cptr p0, lds_cptr p1, u32x4& f) {  
 }
 
 
+// ---- v_mfma_f32_16x16x32_bf16 users (conv_small.hip, gen_x3.hip) -----------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// eight fp32 values -> three bf16x8 fragments (truncation split, as split3)
+__device__ __forceinline__ void split8(const float4& lo, const float4& hi, u32x4& s0, u32x4& s1, u32x4& s2) {
+    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    unsigned u0[8], u1[8], u2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split3(v[e], u0[e], u1[e], u2[e]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        s0[e] = pack_hi(u0[2 * e + 1], u0[2 * e]);
+        s1[e] = pack_hi(u1[2 * e + 1], u1[2 * e]);
+        s2[e] = pack_hi(u2[2 * e + 1], u2[2 * e]);
+    }
+}
+
 }  // namespace x3
 }  // namespace dmc

@@ -47,7 +47,9 @@ const char* dmc_last_error(void);
  * fastest measured path.  Names: "gen_layer_path" (0: VALU layer kernels instead of the matrix-core
  * ones), "gen_gather" (0: push form for the Cout-8 layers), "gen_fuse45" (0: layers 4 and 5 as two
  * launches), "gen_wgrad_path" (0: all-waves-stage weight gradient; 1: fp32 producer/consumer; 2 / 3: bf16x3; 4, the default: bf16x3 with wide LDS reads), "gen_fuse_fwd" / "gen_fuse_bwd"
- * (0: the layer-by-layer forward / data-gradient launches instead of the fused groups).
+ * (0: the layer-by-layer forward / data-gradient launches instead of the fused groups), "gen_x3" (bit K: hidden
+ * layer K of the generator forward, K = 0 .. 2, in bf16x3 arithmetic on the 16x16x32 matrix instruction, gen_x3.hip;
+ * default 2 = layer 1).
  * dmc_set_option returns DMC_E_INVALID for an unknown name; dmc_get_option returns -1 for one. */
 int dmc_set_option(const char* name, int value);
 int dmc_get_option(const char* name);
@@ -65,7 +67,7 @@ int dmc_profile_mark(dmc_stream_t stream);
  * predict_flow.weight/.bias.
  */
 
-/* Bytes of `workspace` the generator entry points need (repacked weights, zero words). */
+/* Bytes of `workspace` the generator entry points need (repacked weights, zero words, bf16x3 weight fragments). */
 size_t dmc_gen_tiny_workspace_bytes(void);
 /* Bytes of the saved-activation buffer for N frames of H x W (28 channels fp32). */
 size_t dmc_gen_tiny_saved_bytes(int N, int H, int W);
