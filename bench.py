@@ -36,17 +36,18 @@ TRAFFIC_JSON = os.path.join("profiles", "r4_gen_traffic.json")
 def measured_traffic(px):
     """HBM bytes per generator-forward call from the PMC counters: collected with rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE (separate passes, calibrated; tools/pmc_traffic.py) on the SAME kernel
-    source -- the JSON records the sha256 of gen_tiny.hip it was measured on and the figure is
-    reported only while that still matches the source in the tree (else null: stale)."""
+    source -- the JSON records the sha256 of gen_tiny.hip + gen_x3.hip it was measured on and the figure is
+    reported only while that still matches the sources in the tree (else null: stale)."""
     import hashlib
     path = os.path.join(ROOT, TRAFFIC_JSON)
     if not os.path.exists(path):
         return None, "no PMC measurement in the tree (%s)" % TRAFFIC_JSON
     rec = json.load(open(path))
-    src = os.path.join(ROOT, "dmc-net_amd", "csrc", "gen_tiny.hip")
-    sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+    csrc = os.path.join(ROOT, "dmc-net_amd", "csrc")
+    both = b"".join(open(os.path.join(csrc, f), "rb").read() for f in ("gen_tiny.hip", "gen_x3.hip"))
+    sha = hashlib.sha256(both).hexdigest()[:16]
     if rec.get("kernel_source_sha16") != sha:
-        return None, "%s was measured on another version of gen_tiny.hip (stale, not reported)" % TRAFFIC_JSON
+        return None, "%s was measured on another version of gen_tiny.hip / gen_x3.hip (stale, not reported)" % TRAFFIC_JSON
     return int(rec["gen_fwd_bytes_per_px"] * px), "%s: %s; kernel source sha16 %s" % (TRAFFIC_JSON, rec["method"], sha)
 
 

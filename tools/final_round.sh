@@ -2,6 +2,10 @@
 # the round's closing measurements in one gpurun call:  tools/final_round.sh <out-subdir-of-gpurun_out>
 O=$1; OUT=$GRAFT_REPO_ROOT/gpurun_out/$O; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
+# HBM traffic of the generator kernels first: bench.py reports roofline.traffic only from a measurement of the sources in the tree
+tools/pmc_gen_traffic.sh $O > /dev/null 2>&1
+cp $OUT/gen_traffic.json profiles/r4_gen_traffic.json; cp $OUT/gen_traffic.csv profiles/r4_gen_traffic.csv
+cd $GRAFT_REPO_ROOT
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python bench.py --config gan --no-cpu-baseline > $OUT/bench_gan.json 2>/dev/null
 python bench.py --config i3d --no-cpu-baseline > $OUT/bench_i3d.json 2>/dev/null

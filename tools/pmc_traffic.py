@@ -42,7 +42,7 @@ def main():
         name = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         print("%s,%.2f,%.2f,%.2f,%.2f,%.1f" % (name, f / 1e6, w / 1e6, f * kr / 1e6, w * kw / 1e6,
                                              (f * kr + w * kw) / px))
-        grp = "fwd" if (("_kernel<0" in k or "_kernel<1" in k) and "gen_layer" in k) or "gen_l45" in k else \
+        grp = "fwd" if (("_kernel<0" in k or "_kernel<1" in k) and "gen_layer" in k) or "gen_l45" in k or "gen_x3_kernel" in k else \
               "bwd" if ("_kernel<2" in k and "gen_layer" in k) or "gen_bwd" in k else None
         if grp:
             tot[grp] += f * kr + w * kw
@@ -53,9 +53,10 @@ def main():
         import hashlib
         import json
         import os
-        src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dmc-net_amd", "csrc", "gen_tiny.hip")
+        csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dmc-net_amd", "csrc")
+        both = b"".join(open(os.path.join(csrc, f), "rb").read() for f in ("gen_tiny.hip", "gen_x3.hip"))   # as bench.py hashes them
         json.dump({"frames": n, "fetch_scale": kr, "write_scale": kw,
-                   "kernel_source_sha16": hashlib.sha256(open(src, "rb").read()).hexdigest()[:16],
+                   "kernel_source_sha16": hashlib.sha256(both).hexdigest()[:16],
                    "gen_fwd_bytes_per_px": tot["fwd"] / px, "gen_bwd_bytes_per_px": tot["bwd"] / px,
                    "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
                              "tools/gen_microbench.py, calibrated on flow_mse kernels of known traffic"},
