@@ -19,9 +19,12 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // parameter repack: PyTorch [Cout][Cin_logical][3][3] -> WF | BF | WB (see dmc_common.h)
 // ------------------------------------------------------------------------------------------
-__global__ void pack_params_kernel(ParamPtrs P, float* __restrict__ pk) {
+__global__ void pack_params_kernel(ParamPtrs P, float* __restrict__ pk, unsigned short* __restrict__ x3_frags) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= PACKED_TOTAL + ZERO_PAD) return;
+    if (i >= PACKED_TOTAL + ZERO_PAD) {          // the bf16x3 weight fragments of gen_x3.hip (forward only: x3_frags != null)
+        if (x3_frags) gen_x3_pack_thread(P, x3_frags, i - (PACKED_TOTAL + ZERO_PAD));
+        return;
+    }
     if (i >= PACKED_TOTAL) {
         pk[i] = 0.f;                         // zero words: source of out-of-image LDS-DMA lanes
     } else if (i < WF_TOTAL) {
@@ -2093,14 +2096,15 @@ int launch_layer(LayerArgs a, int n0, int N, hipStream_t s) {
     return check_launch("gen_layer");
 }
 
-int pack(const float* const* w, const float* const* b, float* pk, hipStream_t s) {
+int pack(const float* const* w, const float* const* b, float* pk, hipStream_t s, unsigned short* x3_frags = nullptr) {
     ParamPtrs P;
     for (int k = 0; k < NL; ++k) {
         if (!w[k] || (b && !b[k])) return fail(DMC_E_INVALID, "null weight/bias pointer %d", k);
         P.w[k] = w[k];
         P.b[k] = b ? b[k] : w[k];   // bias slots are unused by the backward pass
     }
-    pack_params_kernel<<<(PACKED_TOTAL + ZERO_PAD + 255) / 256, 256, 0, s>>>(P, pk);
+    const int threads = PACKED_TOTAL + ZERO_PAD + (x3_frags ? GX_PACK_THREADS : 0);
+    pack_params_kernel<<<(threads + 255) / 256, 256, 0, s>>>(P, pk, x3_frags);
     return check_launch("pack_params");
 }
 
@@ -2129,17 +2133,18 @@ static int gen_tiny_fwd_impl(const float* mv, const float* res, const float* con
         return fail(DMC_E_INVALID, "dmc_gen_tiny_fwd: null pointer");
     if (N <= 0 || H <= 0 || W <= 0) return fail(DMC_E_INVALID, "dmc_gen_tiny_fwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
-    int rc = pack(w, b, workspace, s);
+    int x3mask = option(OPT_GEN_X3);
+    for (int K = 0; K < GX_LAYERS; ++K)
+        if (!gen_x3_supported(K, H, W)) x3mask &= ~(1 << K);
+    x3mask &= (1 << GX_LAYERS) - 1;
+    // one launch packs the fp32 parameter block and (when a layer takes that path) the bf16x3 fragments behind it
+    int rc = pack(w, b, workspace, s, x3mask ? reinterpret_cast<unsigned short*>(workspace + PACKED_TOTAL + ZERO_PAD) : nullptr);
     if (rc) return rc;
     LayerArgs a;
     a.mv = mv; a.res = res; a.feat = saved; a.feat_out = saved; a.gout = nullptr; a.gbuf = nullptr;
     a.pk = workspace; a.out = out; a.H = H; a.W = W; a.add_mv = add_mv_delta;
     a.mse_flow = nullptr; a.mse_part = nullptr;
     if (fused_wgs) *fused_wgs = 0;
-    int x3mask = option(OPT_GEN_X3);
-    for (int K = 0; K < 3; ++K)
-        if (!gen_x3_supported(K, H, W)) x3mask &= ~(1 << K);
-    if (x3mask && (rc = gen_x3_pack(workspace, workspace + PACKED_TOTAL + ZERO_PAD, s))) return rc;
     const int step = frames_per_pass(N, H, W);
     for (int n0 = 0; n0 < N; n0 += step) {
         const int nn = (N - n0) < step ? (N - n0) : step;

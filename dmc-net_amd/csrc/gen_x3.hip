@@ -36,7 +36,6 @@ using namespace dmc::x3;
 
 namespace {
 
-constexpr int GX_LAYERS = 3;          // hidden layers 0, 1, 2 (Cout 8, 8, 6: two row tiles)
 constexpr int GX_RS = 32;             // output rows per strip
 constexpr int GX_SW = 28;             // output columns per strip: 28 + 2 halo pixels = 30 of a half wave's 32 lanes
 constexpr int GX_WAVES = 4;
@@ -48,37 +47,8 @@ template <int K> struct GX {
     static constexpr int RT = 2;
     static constexpr int PS = 16 * NCH + (NCH % 2 == 0 ? 16 : 0);      // pixel stride in bytes: 16, 48, 48
     static constexpr int PL = 34 * PS, RB = 3 * PL;          // slice plane / row buffer of a wave
-    static constexpr int NFRAG = RT * KB * 3;
+    static_assert(RT * KB * 3 == gx_nfrag(K), "fragment table of gen_x3.h");
 };
-__host__ __device__ constexpr int gx_nfrag(int K) { return K == 0 ? GX<0>::NFRAG : K == 1 ? GX<1>::NFRAG : GX<2>::NFRAG; }
-__host__ __device__ constexpr int gx_frag_off(int K) {      // in fragments of 1 KB
-    int o = 0;
-    for (int i = 0; i < K; ++i) o += gx_nfrag(i);
-    return o;
-}
-
-// A fragments: [layer][row tile][k-block][slice][lane][8 bf16]; lane (i, kq): row R = 16 rt + i = (dy, co) = (R / 8, R % 8),
-// k = 8 kq + j of k-block kb = group g = 4 kb + kq = (dx, chunk) = (g / NCH, g % NCH), channel 8 chunk + j
-__global__ __launch_bounds__(256) void gen_x3_pack_kernel(const float* __restrict__ pk, unsigned short* __restrict__ frags) {
-    const int t = blockIdx.x * 256 + threadIdx.x;                    // one (fragment triple, lane, j)
-    int K = 0, base = 0;
-    while (K < GX_LAYERS && t >= (base + gx_nfrag(K) / 3) * 512) { base += gx_nfrag(K) / 3; ++K; }
-    if (K >= GX_LAYERS) return;
-    const int cin = cin_of(K), cout = cout_of(K), nch = (cin + 7) / 8, G = 3 * nch, KB = (G + 3) / 4;
-    const int u = t - base * 512, j = u & 7, lane = (u >> 3) & 63, f = u >> 9;     // f = rt * KB + kb
-    const int kb = f % KB, rt = f / KB;
-    const int R = 16 * rt + (lane & 15), g = 4 * kb + (lane >> 4);
-    const int dy = R >> 3, co = R & 7, dx = g / nch, ci = 8 * (g % nch) + j;
-    float w = 0.f;
-    if (R < 24 && co < cout && g < G && ci < cin) w = pk[wf_off(K) + (ci * 9 + dy * 3 + dx) * cout + co];
-    unsigned u0, u1, u2;
-    split3(w, u0, u1, u2);
-    unsigned short* dst = frags + ((size_t)(gx_frag_off(K) + f * 3) * 64 + lane) * 8 + j;
-    dst[0] = (unsigned short)(u0 >> 16);
-    dst[512] = (unsigned short)(u1 >> 16);
-    dst[1024] = (unsigned short)(u2 >> 16);
-}
-
 struct GenX3Args {
     const float* mv;       // [N][2][H][W]
     const float* res;      // [N][3][H][W]
@@ -273,16 +243,8 @@ int launch_gx(const float* mv, const float* res, float* feat, const float* pk, c
 
 namespace dmc {
 
-size_t gen_x3_frag_bytes() { return (size_t)gx_frag_off(GX_LAYERS) * 1024; }
-
 bool gen_x3_supported(int K, int H, int W) {
     return K >= 0 && K < GX_LAYERS && H > 0 && W > 0 && (long)H * W < (1l << 30);
-}
-
-int gen_x3_pack(const float* pk, void* frags, hipStream_t s) {
-    const int threads = gx_frag_off(GX_LAYERS) / 3 * 512;
-    gen_x3_pack_kernel<<<(threads + 255) / 256, 256, 0, s>>>(pk, static_cast<unsigned short*>(frags));
-    return check_launch("gen_x3_pack");
 }
 
 int gen_x3_layer(int K, const float* mv, const float* res, float* feat, const float* pk, const void* frags, int N, int H, int W,
