@@ -428,6 +428,95 @@ __global__ __launch_bounds__(S3_DG_WAVES * 64) void stem3d_dgrad_kernel(Stem3dDg
     }
 }
 
+// The same computation with FOUR consecutive input rows per wave (h0 .. h0 + 3, h0 a multiple of 4).  With one row per wave
+// every dy row was fetched once per (input row, ky) that uses it -- 12 times on average, 7.4 GB through the L2 for the 64-frame
+// clips, matrix pipe 5 % busy (profiles/r4_pmc_i3d_kernels.csv).  The four rows' windows overlap: the five dy rows
+// oh = h0 / 2 + d, d = -2 .. 2, serve 1 + 3 + 4 + 4 + 2 = 14 (row, ky) pairs (ky = r + 2 - 2 d), so each A fragment is
+// loaded once and multiplied into up to four accumulator sets: 2.8x fewer dy bytes, same MFMAs.  Fold as above, row by row;
+// Q rows are 20 floats apart (16 made the fold's reads 16-way bank conflicts).
+constexpr int S3_QS = 20;
+template <int MTC>
+__global__ __launch_bounds__(S3_DG_WAVES * 64) void stem3d_dgrad4_kernel(Stem3dDgArgs a) {
+    static_assert(MTC >= 1 && MTC <= S3_DG_MT, "compile-time tile count");
+    __shared__ float qlds[S3_DG_WAVES][S3_DG_MT * 16 * S3_QS];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int l15 = lane & 15, kg = lane >> 4;
+    float* Q = qlds[wave];
+    const int hgroups = (a.H + 3) >> 2;
+    const long ngroups = (long)a.N * a.T * hgroups;
+    const long plane = (long)a.T * a.H * a.W;
+    for (long grp = (long)blockIdx.x * S3_DG_WAVES + wave; grp < ngroups; grp += (long)gridDim.x * S3_DG_WAVES) {
+        const int h0 = (int)(grp % hgroups) * 4;
+        const long nt = grp / hgroups;
+        const int t = (int)(nt % a.T);
+        const int n = (int)(nt / a.T);
+        const int nrow = a.H - h0 < 4 ? a.H - h0 : 4;       // rows of this group inside the image
+        s3_f32x4 acc[4][MTC];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int m = 0; m < MTC; ++m) acc[r][m] = s3_f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kz = (t & 1); kz < S3_K; kz += 2) {
+            const int od = (t + 2 - kz) >> 1;
+            if (t + 2 - kz < 0 || od >= a.OD) continue;
+            const bf16_t* wkz = a.wq + (long)kz * S3_K * 16 * S3_CO + l15 * S3_CO + 8 * kg;
+#pragma unroll
+            for (int d = -2; d <= 2; ++d) {
+                const int oh = (h0 >> 1) + d;
+                if (oh < 0 || oh >= a.OH) continue;                // (wave-uniform)
+                const bf16_t* drow = a.dy + (((long)n * a.OD + od) * a.OH + oh) * a.OW * S3_CO + 8 * kg;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    u32x4 af[MTC];
+#pragma unroll
+                    for (int m = 0; m < MTC; ++m) {
+                        int ow = 16 * m + l15;
+                        ow = ow < a.OW ? ow : a.OW - 1;            // clipped rows: valid memory, their Q rows are never read
+                        af[m] = *reinterpret_cast<const u32x4*>(drow + (long)ow * S3_CO + 32 * kb);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ky = r + 2 - 2 * d;              // compile-time
+                        if (ky < 0 || ky >= S3_K) continue;
+                        if (r >= nrow) continue;                   // (wave-uniform)
+                        const u32x4 bf = *reinterpret_cast<const u32x4*>(wkz + ky * 16 * S3_CO + 32 * kb);
+#pragma unroll
+                        for (int m = 0; m < MTC; ++m)
+                            acc[r][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[m]), __builtin_bit_cast(bf16x8, bf), acc[r][m], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r >= nrow) break;
+            // C layout of 16x16: lane (column l15 = j, rows 4 kg + q = ow within the tile)
+#pragma unroll
+            for (int m = 0; m < MTC; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Q[(16 * m + 4 * kg + q) * S3_QS + l15] = acc[r][m][q];
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // fold: dx[w][c] = sum_{kx = w (mod 2)} Q[(w + 2 - kx) / 2][2 kx + c]
+            float* dst = a.dx + ((long)n * 2 * a.T + t) * a.H * a.W + (long)(h0 + r) * a.W;
+            for (int i = lane; i < 2 * a.W; i += 64) {
+                const int c = i / a.W, w = i - c * a.W;
+                float sum = 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kx = (w & 1) + 2 * u;
+                    const int ow2 = w + 2 - kx;
+                    if (kx < S3_K && ow2 >= 0 && (ow2 >> 1) < a.OW) sum += Q[(ow2 >> 1) * S3_QS + 2 * kx + c];
+                }
+                dst[c * plane + w] = sum;
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+}
+
 int s3_wg_groups(long nseg) { return (int)(nseg < 256 ? nseg : 256); }
 
 int s3_blocks(long tiles) {
@@ -532,7 +621,12 @@ int dmc_stem3d_bf16_dgrad(const void* dy, const float* w, float* dx, void* works
     long blocks = (rows + S3_DG_WAVES - 1) / S3_DG_WAVES;
     if (blocks > 2048) blocks = 2048;
     const int mt = (OW + 15) / 16;
-    if (mt == 7) stem3d_dgrad_kernel<7><<<(int)blocks, S3_DG_WAVES * 64, 0, s>>>(a);        // 224-wide frames
+    if (mt == 7 && option(OPT_CONV3D_WGRAD) != 10) {          // 224-wide frames: four input rows per wave (option value 10: one row, A/B)
+        long b4 = ((long)N * T * ((H + 3) / 4) + S3_DG_WAVES - 1) / S3_DG_WAVES;
+        if (b4 > 2048) b4 = 2048;
+        stem3d_dgrad4_kernel<7><<<(int)b4, S3_DG_WAVES * 64, 0, s>>>(a);
+    }
+    else if (mt == 7) stem3d_dgrad_kernel<7><<<(int)blocks, S3_DG_WAVES * 64, 0, s>>>(a);
     else if (mt == 8) stem3d_dgrad_kernel<8><<<(int)blocks, S3_DG_WAVES * 64, 0, s>>>(a);
     else stem3d_dgrad_kernel<0><<<(int)blocks, S3_DG_WAVES * 64, 0, s>>>(a);
     return check_launch("stem3d_dgrad");

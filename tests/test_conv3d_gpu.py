@@ -226,12 +226,13 @@ def test_conv_bn_relu3d_reads_a_concatenation_slice_gradient_in_place():
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("shape", [(2, 2, 8, 32, 24), (1, 2, 4, 18, 70), (1, 2, 16, 64, 64)])
+@pytest.mark.parametrize("shape", [(2, 2, 8, 32, 24), (1, 2, 4, 18, 70), (1, 2, 16, 64, 64), (1, 2, 4, 10, 224), (2, 2, 2, 6, 224)])
 def test_i3d_stem_forward_and_unit_vs_stock(shape):
     """conv3d_1a_7x7 (2 -> 64, 7x7x7, stride 2, TF-"SAME"): dmc_stem3d_bf16_fwd against an fp64 evaluation of the
     stock pad + conv3d on the same bf16-rounded operands; then the whole stem unit (conv -> BatchNorm3d -> ReLU, own
     forward, MIOpen convolution gradients) against the stock unit under bf16 autocast: output and the gradients of
-    the cue, the convolution weight and the BatchNorm parameters."""
+    the cue, the convolution weight and the BatchNorm parameters.  The 224-wide shapes take the data gradient's
+    four-rows-per-wave kernel (row groups that end inside the image)."""
     torch.manual_seed(11)
     unit = i3d.Unit3Dpy(2, 64, (7, 7, 7), (2, 2, 2)).to(DEV).train()
     x = torch.randn(*shape, device=DEV)
