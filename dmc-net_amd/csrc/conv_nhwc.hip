@@ -2040,6 +2040,8 @@ int dmc_conv_nhwc_wgrad(const float* x, const float* dy, float* dw, float* works
     a.M = N * a.OH * a.OW;
     if (csm_supported(N, H, W, Cin, Cout, KH, KW, stride, pad) && option(OPT_CONV_CFG) != 302)   // 302: the fp32-MFMA form (A/B runs)
         return csm_wgrad(x, dy, dw, workspace, N, H, W, Cin, s);
+    if (csm_wgrad_s2_supported(N, H, W, Cin, Cout, KH, KW, stride, pad))
+        return csm_wgrad_s2(x, dy, dw, workspace, N, H, W, Cin, s);
     if (wgrad_small_ok(Cin, KH, KW, pad)) {
         a.part = nullptr; a.per_slice = 0; a.tiles_ci = a.tiles_co = 0;
         if (Cin == 16 && stride == 1) return Cout % 32 == 0 ? launch_wgrad_small<16, 32, 1>(a, dw, workspace, s) : launch_wgrad_small<16, 16, 1>(a, dw, workspace, s);

@@ -441,6 +441,174 @@ __global__ __launch_bounds__(256) void csm_wgrad_reduce_kernel(const float* __re
     }
 }
 
+// ---- weight gradient of the stride-2 blocks (16 -> 32 on 112 x 112 outputs... of 224 x 224 inputs, 32 -> 64) --------------------------
+// dw[co][ky][kx][ci] = sum over output pixels (n, oy, ox) of g[n][oy][ox][co] * x[n][2 oy + ky - 1][2 ox + kx - 1][ci] (3 x 3, stride 2,
+// padding 1, even H and W; Cout = 2 Cin): the same GEMM over pixels as csm_wgrad_kernel, with the stride taken out of the operand
+// reads by the STAGING: of the three input rows 2 oy - 1 .. 2 oy + 1 a tile's patch keeps the even columns Ev[i] = x[2 (ox0 + i)]
+// (16 slots) and the odd columns Od[i] = x[2 (ox0 + i) - 1] (17 slots) apart, so that tap kx = 1 reads Ev[i], kx = 0 reads Od[i] and
+// kx = 2 reads Od[i + 1] for output pixel i -- eight consecutive output pixels are eight consecutive slots, which is what the
+// transposing LDS read wants.  (conv_wgrad_small_kernel<., ., 2>, fp32 MFMA: 0.43 / 0.25 ms per launch for the I3D recipe's 192
+// frames, 0.28 / 0.15 at 240 / 120 frames of config 3.)
+// A WORKGROUP works on one tile pair at a time (k-block = 32 output pixels): all threads load and split the pair's pieces (double-
+// buffered patch, one barrier per pair), and the waves divide the OUTPUT -- Cin 32: wave = (16 output channels, 16 input channels)
+// x all nine taps; Cin 16: wave = (16 output channels, taps 0-4 or 5-8) -- so no wave-level reduction is needed and the
+// per-workgroup partials go straight to the fixed-order reduction.
+struct CsmWg2Args {
+    const float* x;        // [N][H][W][CIN]
+    const float* g;        // [N][H/2][W/2][2 CIN]
+    float* part;           // [gridDim.x][2 CIN][9][CIN]
+    int N, H, W, OH, OW;
+    float rOH;
+};
+
+template <int CIN>
+__global__ __launch_bounds__(CIN == 32 ? 512 : 256) void csm_wgrad_s2_kernel(CsmWg2Args a) {
+    constexpr int COUT = 2 * CIN, NT = CIN == 32 ? 512 : 256;
+    constexpr int OCX = CIN / 8, OCG = COUT / 8;
+    constexpr int XPL = 2 * 99 * 32, GPL = 32 * 32;          // bytes of one (slice, 16-channel chunk) plane: x (two tiles x 99 slots), g (32 pixels)
+    constexpr int XS = (CIN / 16) * XPL, GS = (COUT / 16) * GPL;
+    constexpr int BUF = 3 * (XS + GS);                        // Cin 32: 50,304 B; Cin 16: 25,152 B
+    constexpr int NPX = 2 * 99 * OCX, NPG = 32 * OCG;         // pieces of a pair: x, g
+    constexpr int NLX = (NPX + NT - 1) / NT, NLG = (NPG + NT - 1) / NT, NPL = NLX + NLG;
+    constexpr int NACC = CIN == 32 ? 9 : 5;
+    __shared__ __attribute__((aligned(16))) char lds[2][BUF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L = lane & 15, kq = lane >> 4;
+    const int segs = (a.OW + 15) >> 4;
+    const int ntiles = a.N * a.OH * segs;
+    const int npairs = (ntiles + 1) >> 1;
+    const __amdgpu_buffer_rsrc_t srd_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g), 0, 0x7fffffff, 0x00020000);
+    const float rS = 1.0f / (float)segs;
+    auto geom = [&](int tile, int& img, int& oy, int& ox0) {
+        int r = (int)((float)tile * rS);
+        r -= (r * segs > tile);
+        r += ((r + 1) * segs <= tile);
+        ox0 = (tile - r * segs) * 16;
+        img = (int)((float)r * a.rOH);
+        img -= (img * a.OH > r);
+        img += ((img + 1) * a.OH <= r);
+        oy = r - img * a.OH;
+    };
+    // this thread's pieces: loads 0 .. NLX-1 = x piece (tile, row, slot, octet), NLX .. = g piece (pixel of the pair, octet);
+    // packed tile | row << 1 | slot << 3 | octet << 9 (x) resp. pixel | octet << 9 (g); p_lds = byte offset within slice 0
+    int p_geo[NPL], p_lds[NPL];
+    bool p_on[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const bool isx = k < NLX;
+        const int f = tid + NT * (isx ? k : k - NLX);
+        p_on[k] = f < (isx ? NPX : NPG);
+        const int ff = p_on[k] ? f : 0;
+        if (isx) {
+            const int q = ff / OCX, oct = ff % OCX;             // q = tile * 99 + row * 33 + slot
+            const int tile = q / 99, row = (q % 99) / 33, slot = q % 33;
+            p_geo[k] = tile | row << 1 | slot << 3 | oct << 9;
+            p_lds[k] = (oct >> 1) * XPL + q * 32 + (oct & 1) * 16;
+        } else {
+            const int px = ff / OCG, oct = ff % OCG;
+            p_geo[k] = px | oct << 9;
+            p_lds[k] = 3 * XS + (oct >> 1) * GPL + px * 32 + (oct & 1) * 16;
+        }
+    }
+    float4 plo[NPL], phi[NPL];
+    auto load_pair = [&](int pair) {
+        int img[2], oy[2], ox0[2];
+        geom(2 * pair, img[0], oy[0], ox0[0]);
+        const bool second = 2 * pair + 1 < ntiles;
+        geom(second ? 2 * pair + 1 : 2 * pair, img[1], oy[1], ox0[1]);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            unsigned off = 0x80000000u;
+            if (k < NLX) {
+                const int t = p_geo[k] & 1, row = (p_geo[k] >> 1) & 3, slot = (p_geo[k] >> 3) & 63, oct = p_geo[k] >> 9;
+                const int iy = 2 * (t ? oy[1] : oy[0]) + row - 1;
+                const int ix = slot < 16 ? 2 * ((t ? ox0[1] : ox0[0]) + slot) : 2 * ((t ? ox0[1] : ox0[0]) + slot - 16) - 1;
+                if (p_on[k] && (t == 0 || second) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                    off = (unsigned)((((t ? img[1] : img[0]) * a.H + iy) * a.W + ix) * CIN + 8 * oct) * 4u;
+                plo[k] = buf_load16(srd_x, off);
+                phi[k] = buf_load16(srd_x, off + 16u);
+            } else {
+                const int px = p_geo[k] & 511, oct = p_geo[k] >> 9, t = px >> 4;
+                const int ox = (t ? ox0[1] : ox0[0]) + (px & 15);
+                if (p_on[k] && (t == 0 || second) && ox < a.OW)
+                    off = (unsigned)((((t ? img[1] : img[0]) * a.OH + (t ? oy[1] : oy[0])) * a.OW + ox) * COUT + 8 * oct) * 4u;
+                plo[k] = buf_load16(srd_g, off);
+                phi[k] = buf_load16(srd_g, off + 16u);
+            }
+        }
+    };
+    auto store_pair = [&](int b) {
+        char* const mp = lds[b];
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            u32x4 s0, s1, s2;
+            split8(plo[k], phi[k], s0, s1, s2);
+            if (p_on[k]) {
+                const int ss = k < NLX ? XS : GS;
+                *reinterpret_cast<u32x4*>(mp + p_lds[k]) = s0;
+                *reinterpret_cast<u32x4*>(mp + p_lds[k] + ss) = s1;
+                *reinterpret_cast<u32x4*>(mp + p_lds[k] + 2 * ss) = s2;
+            }
+        }
+    };
+    // this wave's share of dw: output-channel tile cot, input-channel tile cit, taps t0 .. t0 + nt - 1
+    const int cot = CIN == 32 ? (wave & 3) : (wave & 1);
+    const int cit = CIN == 32 ? (wave >> 2) : 0;
+    const int t0 = CIN == 32 ? 0 : (wave >> 1) * 5;
+    const int nt = CIN == 32 ? 9 : ((wave >> 1) ? 4 : 5);
+    f32x4 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // transposing reads (x3s_common.h): lane (L, kq) hands in pixel 8 (kq & 1) + L / 4 (+ 4) of tile kq >> 1, channels 4 (L % 4) ..
+    const int trb = (L & 3) * 8 + (8 * (kq & 1) + (L >> 2)) * 32;
+    const int g_off = 3 * XS + cot * GPL + (kq >> 1) * 16 * 32 + trb;
+    const int x_off = cit * XPL + (kq >> 1) * 99 * 32 + trb;
+    int toff[NACC];                                            // tap (ky, kx): row ky, slot base Od (kx = 0), Ev (1), Od + 1 (2)
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+        const int t = t0 + (i < nt ? i : 0), ky = t / 3, kx = t - 3 * ky;
+        toff[i] = (ky * 33 + (kx == 1 ? 0 : kx == 0 ? 16 : 17)) * 32;
+    }
+
+    int pair = (int)blockIdx.x, it = 0;
+    if (pair < npairs) { load_pair(pair); store_pair(0); }
+    __syncthreads();
+#pragma unroll 1
+    for (; pair < npairs; pair += (int)gridDim.x, ++it) {
+        const int next = pair + (int)gridDim.x;
+        if (next < npairs) load_pair(next);                     // in flight under this pair's MFMAs
+        lds_cptr const LB = (lds_cptr)lds[it & 1];
+        u32x4 A[3];
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) tr_read2(LB + g_off + sl * GS, LB + g_off + sl * GS + 4 * 32, A[sl]);
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) {
+            if (i >= nt) break;                                 // (wave-uniform)
+            u32x4 B[3];
+#pragma unroll
+            for (int sl = 0; sl < 3; ++sl) tr_read2(LB + x_off + toff[i] + sl * XS, LB + x_off + toff[i] + sl * XS + 4 * 32, B[sl]);
+            acc[i] = mfma16(A[0], B[2], acc[i]);
+            acc[i] = mfma16(A[2], B[0], acc[i]);
+            acc[i] = mfma16(A[1], B[1], acc[i]);
+            acc[i] = mfma16(A[0], B[1], acc[i]);
+            acc[i] = mfma16(A[1], B[0], acc[i]);
+            acc[i] = mfma16(A[0], B[0], acc[i]);
+        }
+        if (next < npairs) store_pair((it + 1) & 1);             // the buffer the pair before this one was read from
+        __syncthreads();
+    }
+    // lane (L = ci column, kq) holds rows co = 16 cot + 4 kq + e of column ci = 16 cit + L
+    float* out = a.part + (size_t)blockIdx.x * COUT * 9 * CIN;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+        if (i >= nt) break;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[((16 * cot + 4 * kq + e) * 9 + t0 + i) * CIN + 16 * cit + L] = acc[i][e];
+    }
+}
+
 // w [Cout][9][Cin] fp32 (OHWI) -> fragment order [3 slices][KB][MT][16 rows][32 k] bf16
 //   forward:        row = co, k-block value (tap, ci) = w[co][tap][ci]
 //   data gradient:  row = ci, k-block value (tap, co) = w[co][8 - tap][ci]          (mirrored taps)
@@ -532,6 +700,31 @@ int csm_wgrad(const float* x, const float* g, float* dw, float* workspace, int N
     const int numel = C * 9 * C;
     csm_wgrad_reduce_kernel<<<numel / 64, 256, 0, s>>>(workspace, dw, groups, numel);
     return check_launch("csm_wgrad_reduce");
+}
+
+bool csm_wgrad_s2_supported(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    if (option(OPT_CONV_ARITH) != 1 || option(OPT_CONV_PATH) != 1 || option(OPT_CONV_CFG) == 301 || option(OPT_CONV_CFG) == 302) return false;
+    if ((Cin != 16 && Cin != 32) || Cout != 2 * Cin || KH != 3 || KW != 3 || stride != 2 || pad != 1 || (H & 1) || (W & 1)) return false;
+    return N > 0 && H > 0 && W > 0 && (long)N * H * W < (1L << 24) && (long)N * H * W * Cin * 4 < (1L << 31);
+}
+
+int csm_wgrad_s2_groups(int N, int H, int W, int Cin) {
+    const long pairs = ((long)N * (H / 2) * ((W / 2 + 15) / 16) + 1) / 2;
+    const long cap = Cin == 16 ? 512 : 256;                 // resident workgroups (50 / 101 KB of LDS); <= 512 partials fit the workspace
+    return (int)(pairs < 1 ? 1 : (pairs > cap ? cap : pairs));
+}
+
+int csm_wgrad_s2(const float* x, const float* g, float* dw, float* workspace, int N, int H, int W, int Cin, hipStream_t s) {
+    CsmWg2Args a;
+    a.x = x; a.g = g; a.part = workspace; a.N = N; a.H = H; a.W = W; a.OH = H / 2; a.OW = W / 2; a.rOH = 1.0f / (float)a.OH;
+    const int groups = csm_wgrad_s2_groups(N, H, W, Cin);
+    if (Cin == 16) csm_wgrad_s2_kernel<16><<<groups, 256, 0, s>>>(a);
+    else csm_wgrad_s2_kernel<32><<<groups, 512, 0, s>>>(a);
+    int rc = check_launch("csm_wgrad_s2");
+    if (rc) return rc;
+    const int numel = 2 * Cin * 9 * Cin;
+    csm_wgrad_reduce_kernel<<<numel / 64, 256, 0, s>>>(workspace, dw, groups, numel);
+    return check_launch("csm_wgrad_s2_reduce");
 }
 
 int csm_dgrad(const float* dy, const float* w, void* wpack, float* dx, int N, int H, int W, int C, hipStream_t s) {

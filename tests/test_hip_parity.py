@@ -878,6 +878,10 @@ CONV_CASES = [  # (N, Cin, H, W, Cout, k, stride)
     (1, 32, 5, 3, 32, 3, 1),         # straddle rows and images, a last tile with invalid pixels, a 1 x 1 image
     (2, 16, 1, 1, 16, 3, 1),
     (5, 32, 4, 30, 32, 3, 1),
+    (3, 16, 10, 38, 32, 3, 2),       # the stride-2 small-channel weight gradient (even / odd column staging): a row of 16 + 3 output
+    (1, 32, 6, 4, 64, 3, 2),         # pixels, images smaller than a tile pair, an odd number of tiles
+    (2, 32, 56, 56, 64, 3, 2),
+    (1, 16, 2, 2, 32, 3, 2),
 ]
 
 
