@@ -9,6 +9,7 @@ CPU by tests/golden/g10_i3d_trainer.npz, which the reference's own ``fit`` loop 
 import torch
 import torch.distributed as dist
 
+from . import ops
 from .i3d import i3d_losses
 
 
@@ -187,12 +188,15 @@ class I3DTrainer(object):
         ``old + new`` is formed per parameter exactly as AccumulateGrad would (fp32 addition commutes): bit-identical."""
         params = [p for p in self.net.parameters() if p.requires_grad]
         stash = [p.grad for p in params]
-        if all(t is None for t in stash) or not all(t is None or t.is_cuda for t in stash):
+        if not all(t is None or t.is_cuda for t in stash):
             loss.backward()
             return
         for p in params:
             p.grad = None
-        loss.backward()
+        # no gradient to accumulate into during this pass: weight gradients may run on the side stream (ops._on_wgrad_stream:
+        # the stem's and the serial units' overlap the data-gradient chain down to the generator); joined on exit
+        with ops.wgrad_side_stream():
+            loss.backward()
         old, new = [], []
         for p, t in zip(params, stash):
             if t is None:

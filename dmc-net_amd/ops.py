@@ -1898,6 +1898,11 @@ def maxpool3d_tf(x, kernel, stride):
     return _MaxPool3dTF.apply(x, tuple(int(k) for k in kernel), tuple(int(s) for s in stride))
 
 
+#: weight gradients of the I3D trunk's serial units on the side stream (DMC_UNIT3D_WGRAD_SIDE=0: inside the unit's one call)
+UNIT3D_WGRAD_SIDE = __import__("os").environ.get("DMC_UNIT3D_WGRAD_SIDE", "1") != "0"
+UNIT3D_WGRAD_SIDE_MINW = int(__import__("os").environ.get("DMC_UNIT3D_WGRAD_SIDE_MINW", "56"))
+
+
 class _ConvBnRelu3d(torch.autograd.Function):
     """relu?(BatchNorm3d(conv3d(x, w))) of a Unit3Dpy in training mode (code/dmcnet_I3D/network/i3d.py:390-398) on the
     bf16 kernels: the convolution's epilogue reduces the batch statistics, one streaming pass normalises and rectifies;
@@ -1943,13 +1948,26 @@ class _ConvBnRelu3d(torch.autograd.Function):
         dy = torch.empty_like(y)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device) if ctx.needs_input_grad[1] else None
+        # the weight gradient on the side stream (see _on_wgrad_stream) for the units of the trunk's SERIAL part (the stem's
+        # successors, 56-wide maps): their input gradient heads a dependent chain, nothing reads dw.  Inside the Inception
+        # blocks the branches already overlap on their own streams.
+        side = ctx.needs_input_grad[1] and UNIT3D_WGRAD_SIDE and w >= UNIT3D_WGRAD_SIDE_MINW and WGRAD_STREAM and _WGRAD_SCOPE[0] > 0
+        dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device) if ctx.needs_input_grad[1] and not side else None
         bws = torch.empty(lib.dmc_unit3d_bf16_bwd_workspace_bytes(*geom), dtype=torch.uint8, device=x.device)
         with _span("conv3d_bf16_bwd"):
             _lib.check(lib.dmc_unit3d_bf16_bwd(_lib.ptr(dout), ld, _lib.ptr(x), _lib.ptr(y), _lib.ptr(ws), _lib.ptr(gamma),
                                                _lib.ptr(beta), _lib.ptr(bws), _lib.ptr(dy), _lib.ptr(dx), _lib.ptr(dw),
                                                _lib.ptr(dgamma), _lib.ptr(dbeta), *geom, int(ctx.relu), _stream()),
                        "dmc_unit3d_bf16_bwd")
+        if side:
+            def launch():
+                dw_ = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+                work_ = torch.empty(lib.dmc_conv3d_bf16_wgrad_bytes(*geom), dtype=torch.uint8, device=x.device)
+                _lib.check(lib.dmc_conv3d_bf16_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw_), _lib.ptr(work_), *geom, _stream()),
+                           "dmc_conv3d_bf16_wgrad")
+                return dw_
+            with _span("conv3d_bf16_wgrad"):
+                dw = _on_wgrad_stream(weight, (x, dy), launch)
         if dx is not None and not ctx.x_was_cl3:
             dx = dx.contiguous()
         return dx, dw, dgamma, dbeta, None, None, None, None, None
@@ -2027,12 +2045,14 @@ class _Stem3dBnRelu(torch.autograd.Function):
         t, h, w = xc.shape[2:]
         dx = dw = None
         if ctx.needs_input_grad[1]:
-            dw = torch.empty((64, 2, 7, 7, 7), dtype=torch.float32, device=y.device)
-            work = _floats(lib.dmc_stem3d_bf16_wgrad_workspace_bytes(n, t, h, w), y.device)
-            with _span("stem3d_wgrad"):
-                _lib.check(lib.dmc_stem3d_bf16_wgrad(_lib.ptr(xc), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(work), n, t, h, w, _stream()),
+            def launch():       # nothing below reads dw: on the side stream it runs next to the data gradient and the generator's backward
+                dw_ = torch.empty((64, 2, 7, 7, 7), dtype=torch.float32, device=y.device)
+                work_ = _floats(lib.dmc_stem3d_bf16_wgrad_workspace_bytes(n, t, h, w), y.device)
+                _lib.check(lib.dmc_stem3d_bf16_wgrad(_lib.ptr(xc), _lib.ptr(dy), _lib.ptr(dw_), _lib.ptr(work_), n, t, h, w, _stream()),
                            "dmc_stem3d_bf16_wgrad")
-            dw = dw.to(weight.dtype)
+                return dw_.to(weight.dtype)
+            with _span("stem3d_wgrad"):
+                dw = _on_wgrad_stream(weight, (xc, dy), launch)
         if ctx.needs_input_grad[0] and w <= 256:           # data gradient (2 channels): row GEMM + fold on the matrix cores
             dx = torch.empty((n, 2, t, h, w), dtype=torch.float32, device=y.device)
             work = _floats(lib.dmc_stem3d_bf16_dgrad_workspace_bytes(), y.device)
