@@ -1865,6 +1865,7 @@ int dmc_conv_nhwc_supported(int N, int H, int W, int Cin, int Cout, int KH, int 
 // number of [Cout][2] double partial rows the forward writes when asked for statistics
 int dmc_conv_nhwc_stat_blocks(int N, int H, int W, int Cin, int Cout, int KH, int stride, int pad) {
     if (csm_supported(N, H, W, Cin, Cout, KH, KH, stride, pad)) return csm_stat_blocks(N, H, W, Cin);
+    if (csm_fwd_s2_supported(N, H, W, Cin, Cout, KH, KH, stride, pad)) return csm_fwd_s2_stat_blocks(N, H, W);
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
     const long M = (long)N * OH * OW;
     const int bm = block_pixels(Cin, Cout, M);
@@ -1883,6 +1884,8 @@ int dmc_conv_nhwc_fwd(const float* x, const float* w, void* wpack, const float* 
     // 16- / 32-channel stride-1 3x3 layers (the discriminator's high-resolution blocks): the small-channel bf16x3 kernel
     if (w && wpack && csm_supported(N, H, W, Cin, Cout, KH, KW, stride, pad))
         return csm_fwd(x, w, wpack, bias, keep, y, stat_partials, stat_blocks, N, H, W, Cin, act, (hipStream_t)stream);
+    if (w && wpack && csm_fwd_s2_supported(N, H, W, Cin, Cout, KH, KW, stride, pad))
+        return csm_fwd_s2(x, w, wpack, bias, keep, y, stat_partials, stat_blocks, N, H, W, act, (hipStream_t)stream);
     ConvArgs a;
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.keep = keep; a.stat_part = stat_partials;
     a.stat_blocks = stat_partials ? stat_blocks : -1;
@@ -1928,7 +1931,8 @@ int dmc_conv_nhwc_split(const float* w, void* wpack_f, void* wpack_t, int Cin, i
 // packed-weight workspace of the forward and the data gradient: fp32 transposed weights or three bf16 slices
 size_t dmc_conv_nhwc_wt_bytes(int Cin, int Cout, int KH, int KW) {
     const size_t plain = (size_t)Cin * Cout * KH * KW * 6;
-    const size_t small = (Cin == Cout && (Cin == 16 || Cin == 32) && KH == 3 && KW == 3) ? csm_wpack_bytes(Cin) : 0;   // k padded to 32
+    size_t small = (Cin == Cout && (Cin == 16 || Cin == 32) && KH == 3 && KW == 3) ? csm_wpack_bytes(Cin) : 0;   // k padded to 32
+    if (Cin == 16 && Cout == 32 && KH == 3 && KW == 3) small = csm_fwd_s2_wpack_bytes();
     return plain > small ? plain : small;
 }
 

@@ -242,6 +242,221 @@ __global__ __launch_bounds__(Csm<C>::NW * 64) void csm_conv_kernel(CsmArgs a) {
     }
 }
 
+// ---- forward of the 16 -> 32 stride-2 block ---------------------------------------------------------------------------------
+// csm_conv_kernel's scheme for Conv2d(16, 32, 3, 2, 1) on even-sized maps (the second block of every PatchGAN discriminator,
+// code/dmcnet_GAN/model.py:254-279; conv_nhwc_kernel<256, 16, ...>, fp32 MFMA: 87 us per launch in the I3D recipe): rows = the 32
+// output channels (two row tiles), columns = 16 output pixels of an output row, five k-blocks of two taps x 16 channels.  The
+// tile's patch keeps, per input row 2 oy - 1 .. 2 oy + 1, the even columns Ev[i] = x[2 (ox0 + i)] (16 slots) and the odd columns
+// Od[i] = x[2 (ox0 + i) - 1] (17 slots) apart: tap kx = 1 reads Ev[n], kx = 0 reads Od[n], kx = 2 reads Od[n + 1] for output pixel
+// n -- unit-stride fragment reads as in the stride-1 kernel.
+struct Csm2 {
+    static constexpr int CIN = 16, COUT = 32, KB = 5, MT = 2, NW = 4, NFRAG = 3 * KB * MT;
+};
+
+__global__ __launch_bounds__(256) void csm_pack_s2_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp) {
+    constexpr int total = Csm2::KB * Csm2::MT * 16 * 32;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        int t = i;
+        const int kk = t & 31; t >>= 5;
+        const int row = t & 15; t >>= 4;
+        const int mt = t % Csm2::MT;
+        const int kb = t / Csm2::MT;
+        const int tap = 2 * kb + (kk >> 4), ci = kk & 15, co = mt * 16 + row;
+        float v = 0.f;
+        if (tap < 9) v = w[((size_t)co * 9 + tap) * Csm2::CIN + ci];
+        unsigned u0, u1, u2;
+        split3(v, u0, u1, u2);
+        const size_t e = (size_t)((kk >> 3) * 16 + row) * 8 + (kk & 7);
+        const size_t f = (size_t)(kb * Csm2::MT + mt) * 512;
+        const size_t sl = (size_t)Csm2::KB * Csm2::MT * 512;
+        wp[f + e] = (unsigned short)(u0 >> 16);
+        wp[sl + f + e] = (unsigned short)(u1 >> 16);
+        wp[2 * sl + f + e] = (unsigned short)(u2 >> 16);
+    }
+}
+
+struct Csm2Args {
+    const float* x;        // [N][H][W][16]
+    const void* wp;
+    const float* bias;     // [32] or null
+    const float* keep;     // [N][32] or null
+    float* y;              // [N][H/2][W/2][32]
+    double* stat_part;     // [gridDim.x][32][2] or null
+    int N, H, W, OH, OW, act;
+    float rOH;
+};
+
+__global__ __launch_bounds__(Csm2::NW * 64) void csm_conv_s2_kernel(Csm2Args a) {
+    constexpr int KB = Csm2::KB, MT = Csm2::MT, NW = Csm2::NW, CIN = Csm2::CIN, COUT = Csm2::COUT;
+    constexpr int OC = CIN / 8;
+    constexpr int NPC = 3 * 33 * OC;                          // pieces of a tile's patch: [row][slot: Ev 0..15 | Od 16..32][octet]
+    constexpr int SS = NPC * 16;
+    constexpr int NPL = (NPC + 63) / 64;
+    __shared__ __attribute__((aligned(16))) u32x4 wlds[Csm2::NFRAG * 64];    // 30 KB
+    __shared__ __attribute__((aligned(16))) char patch[NW][3 * SS];
+    __shared__ double red[NW][COUT][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wp);
+    for (int i = tid; i < Csm2::NFRAG * 64; i += NW * 64) wlds[i] = wsrc[i];
+    __syncthreads();
+    float bias_r[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias_r[mt][i] = a.bias ? a.bias[mt * 16 + 4 * kq + i] : 0.f;
+    double ssum[MT][4], ssq[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ssum[mt][i] = ssq[mt][i] = 0.0;
+    const int segs = (a.OW + 15) >> 4;
+    const int ntiles = a.N * a.OH * segs;
+    const int stride = (int)gridDim.x * NW;
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0x7fffffff, 0x00020000);
+    char* const mp = patch[wave];
+    int prow[NPL], pslot[NPL], poct[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int f = lane + 64 * k;
+        prow[k] = f / (33 * OC);
+        pslot[k] = (f / OC) % 33;
+        poct[k] = f % OC;
+    }
+    int boff[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        int tap = 2 * kb + (kq >> 1);
+        tap = tap < 9 ? tap : 8;                               // (tap 9 has zero weights: it re-reads tap 8's finite values)
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const int slot = dx == 1 ? n : dx == 0 ? 16 + n : 17 + n;
+        boff[kb] = ((dy * 33 + slot) * OC + (kq & 1)) * 16;
+    }
+    const float rS = 1.0f / (float)segs;
+    auto geom = [&](int tile, int& img, int& oy, int& ox0) {
+        int r = (int)((float)tile * rS);
+        r -= (r * segs > tile);
+        r += ((r + 1) * segs <= tile);
+        ox0 = (tile - r * segs) * 16;
+        img = (int)((float)r * a.rOH);
+        img -= (img * a.OH > r);
+        img += ((img + 1) * a.OH <= r);
+        oy = r - img * a.OH;
+    };
+    float4 plo[2][NPL], phi[2][NPL];
+    auto load_patch = [&](int tile, float4 (&lo)[NPL], float4 (&hi)[NPL]) {
+        int img, oy, ox0;
+        geom(tile, img, oy, ox0);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const int f = lane + 64 * k;
+            const int iy = 2 * oy + prow[k] - 1;
+            const int ix = pslot[k] < 16 ? 2 * (ox0 + pslot[k]) : 2 * (ox0 + pslot[k] - 16) - 1;
+            const bool ok = f < NPC && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const unsigned off = ok ? (unsigned)(((img * a.H + iy) * a.W + ix) * CIN + 8 * poct[k]) * 4u : 0x80000000u;
+            lo[k] = buf_load16(srd, off);
+            hi[k] = buf_load16(srd, off + 16u);
+        }
+    };
+    const int tile0 = (int)blockIdx.x * NW + wave;
+    if (tile0 < ntiles) load_patch(tile0, plo[0], phi[0]);
+#pragma unroll 1
+    for (int tile = tile0; tile < ntiles; tile += 2 * stride) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int tcur = tile + half * stride;
+            if (tcur >= ntiles) break;
+            asm volatile("" ::: "memory");                   // the weight fragments are re-read from LDS per tile, not hoisted into registers
+            if (tcur + stride < ntiles) load_patch(tcur + stride, plo[half ^ 1], phi[half ^ 1]);
+            int img, oy, ox0;
+            geom(tcur, img, oy, ox0);
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                const int f = lane + 64 * k;
+                u32x4 s0, s1, s2;
+                split8(plo[half][k], phi[half][k], s0, s1, s2);
+                if (f < NPC) {
+                    *reinterpret_cast<u32x4*>(mp + f * 16) = s0;
+                    *reinterpret_cast<u32x4*>(mp + SS + f * 16) = s1;
+                    *reinterpret_cast<u32x4*>(mp + 2 * SS + f * 16) = s2;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            f32x4 acc[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const u32x4 b0 = *reinterpret_cast<const u32x4*>(mp + boff[kb]);
+                const u32x4 b1 = *reinterpret_cast<const u32x4*>(mp + SS + boff[kb]);
+                const u32x4 b2 = *reinterpret_cast<const u32x4*>(mp + 2 * SS + boff[kb]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const u32x4 w0 = wlds[((0 * KB + kb) * MT + mt) * 64 + lane];
+                    const u32x4 w1 = wlds[((1 * KB + kb) * MT + mt) * 64 + lane];
+                    const u32x4 w2 = wlds[((2 * KB + kb) * MT + mt) * 64 + lane];
+                    acc[mt] = mfma16(w0, b2, acc[mt]);
+                    acc[mt] = mfma16(w2, b0, acc[mt]);
+                    acc[mt] = mfma16(w1, b1, acc[mt]);
+                    acc[mt] = mfma16(w0, b1, acc[mt]);
+                    acc[mt] = mfma16(w1, b0, acc[mt]);
+                    acc[mt] = mfma16(w0, b0, acc[mt]);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const bool pvalid = ox0 + n < a.OW;
+            const size_t p = (size_t)(img * a.OH + oy) * a.OW + ox0 + n;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float t = acc[mt][i] + bias_r[mt][i];
+                    if (a.act) t = t > 0.f ? t : 0.2f * t;
+                    v[i] = t;
+                }
+                if (a.keep) {
+                    const float4 k = *reinterpret_cast<const float4*>(a.keep + (size_t)img * COUT + mt * 16 + 4 * kq);
+                    v[0] *= k.x; v[1] *= k.y; v[2] *= k.z; v[3] *= k.w;
+                }
+                if (pvalid) {
+                    *reinterpret_cast<float4*>(a.y + p * COUT + mt * 16 + 4 * kq) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (a.stat_part) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            ssum[mt][i] += (double)v[i];
+                            ssq[mt][i] += (double)v[i] * (double)v[i];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (!a.stat_part) return;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) {
+                ssum[mt][i] += __shfl_xor(ssum[mt][i], m, 64);
+                ssq[mt][i] += __shfl_xor(ssq[mt][i], m, 64);
+            }
+            if (n == 0) {
+                red[wave][mt * 16 + 4 * kq + i][0] = ssum[mt][i];
+                red[wave][mt * 16 + 4 * kq + i][1] = ssq[mt][i];
+            }
+        }
+    __syncthreads();
+    if (tid < 2 * COUT) {
+        const int c = tid >> 1, which = tid & 1;
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[w][c][which];
+        a.stat_part[((size_t)blockIdx.x * COUT + c) * 2 + which] = t;
+    }
+}
+
 // ---- weight gradient -----------------------------------------------------------------------------------------------------
 // dw[co][tap][ci] = sum over pixels p of g[p][co] * x[p + d(tap)][ci] -- a GEMM over PIXELS (K) with M = co, N = ci per tap, on
 // v_mfma_f32_16x16x32_bf16 in bf16x3 arithmetic.  A k-block = the 32 pixels of TWO 16-pixel row-segment tiles (k-quarters
@@ -680,6 +895,35 @@ int csm_fwd(const float* x, const float* w, void* wpack, const float* bias, cons
             int stat_blocks, int N, int H, int W, int C, int act, hipStream_t s) {
     return C == 16 ? csm_launch<16>(x, w, wpack, bias, keep, y, stat_part, stat_blocks, N, H, W, act, 0, s)
                    : csm_launch<32>(x, w, wpack, bias, keep, y, stat_part, stat_blocks, N, H, W, act, 0, s);
+}
+
+bool csm_fwd_s2_supported(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    if (option(OPT_CONV_ARITH) != 1 || option(OPT_CONV_PATH) != 1 || option(OPT_CONV_CFG) == 301 || option(OPT_CONV_CFG) == 303) return false;   // 303: off (A/B)
+    if (Cin != 16 || Cout != 32 || KH != 3 || KW != 3 || stride != 2 || pad != 1 || (H & 1) || (W & 1)) return false;
+    return N > 0 && H > 0 && W > 0 && (long)N * H * W < (1L << 24) && (long)N * H * W * Cin * 4 < (1L << 31);
+}
+
+int csm_fwd_s2_stat_blocks(int N, int H, int W) {
+    const long tiles = (long)N * (H / 2) * ((W / 2 + 15) / 16);
+    long g = (tiles + Csm2::NW - 1) / Csm2::NW;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+size_t csm_fwd_s2_wpack_bytes() { return (size_t)Csm2::NFRAG * 1024; }
+
+int csm_fwd_s2(const float* x, const float* w, void* wpack, const float* bias, const float* keep, float* y, double* stat_part,
+               int stat_blocks, int N, int H, int W, int act, hipStream_t s) {
+    csm_pack_s2_kernel<<<8, 256, 0, s>>>(w, static_cast<unsigned short*>(wpack));
+    int rc = check_launch("csm_pack_s2");
+    if (rc) return rc;
+    Csm2Args a;
+    a.x = x; a.wp = wpack; a.bias = bias; a.keep = keep; a.y = y; a.stat_part = stat_part;
+    a.N = N; a.H = H; a.W = W; a.OH = H / 2; a.OW = W / 2; a.act = act; a.rOH = 1.0f / (float)a.OH;
+    const int grid = csm_fwd_s2_stat_blocks(N, H, W);
+    if (stat_part && stat_blocks != grid)
+        return fail(DMC_E_INVALID, "conv_small: statistics partials have %d rows but this launch writes %d", stat_blocks, grid);
+    csm_conv_s2_kernel<<<grid, Csm2::NW * 64, 0, s>>>(a);
+    return check_launch("csm_conv_s2");
 }
 
 int csm_wgrad_groups(int N, int H, int W, int C) {
