@@ -1945,6 +1945,8 @@ static int conv_dgrad(const float* dy, const float* w, float* wt, const float* a
     hipStream_t s = (hipStream_t)stream;
     if (w && !addend && csm_supported(N, H, W, Cin, Cout, KH, KW, stride, pad))
         return csm_dgrad(dy, w, wt, dx, N, H, W, Cin, s);
+    if (w && !addend && csm_dgrad_s2_supported(N, H, W, Cin, Cout, KH, KW, stride, pad))
+        return csm_dgrad_s2(dy, w, wt, dx, N, H, W, s);
     const int KK = KH * KW;
     const long total = (long)Cin * Cout * KK;
     const bool v3 = use_v3(Cout, Cin);                    // the GEMM contracts over Cout and produces Cin channels

@@ -19,6 +19,10 @@ int csm_fwd_s2_stat_blocks(int N, int H, int W);
 size_t csm_fwd_s2_wpack_bytes();
 int csm_fwd_s2(const float* x, const float* w, void* wpack, const float* bias, const float* keep, float* y, double* stat_part,
                int stat_blocks, int N, int H, int W, int act, hipStream_t s);
+// data gradient of the same block: dx [N][H][W][16] from dy [N][H/2][W/2][32] in ONE launch (all four parity classes)
+bool csm_dgrad_s2_supported(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+size_t csm_dgrad_s2_wpack_bytes();
+int csm_dgrad_s2(const float* dy, const float* w, void* wpack, float* dx, int N, int H, int W, hipStream_t s);
 // weight gradient of the 3 x 3 / stride-2 / padding-1 blocks with Cout = 2 Cin (Cin 16 or 32, even H and W): workspace >= 512 x
 // Cout x 9 x Cin floats (dmc_conv_nhwc_wgrad_bytes); dw [Cout][3][3][Cin] (OHWI)
 bool csm_wgrad_s2_supported(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);

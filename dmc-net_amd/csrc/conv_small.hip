@@ -457,6 +457,149 @@ __global__ __launch_bounds__(Csm2::NW * 64) void csm_conv_s2_kernel(Csm2Args a) 
     }
 }
 
+// ---- data gradient of the 16 -> 32 stride-2 block --------------------------------------------------------------------------------
+// dx[2 oy + py][2 ox + px][ci] = sum over the taps whose stride-2 window reaches that pixel and over co of g[oy'][ox'][co] w[co][tap][ci]:
+// per parity class (py, px) the taps and their output pixels are STATIC -- (0, 0): tap (1, 1) of g(oy, ox); (0, 1): (1, 0) of
+// g(oy, ox + 1), (1, 2) of g(oy, ox); (1, 0): (0, 1) of g(oy + 1, ox), (2, 1) of g(oy, ox); (1, 1): (0, 0) of g(oy + 1, ox + 1), (0, 2) of
+// g(oy + 1, ox), (2, 0) of g(oy, ox + 1), (2, 2) of g(oy, ox) -- nine k-blocks of one tap x 32 output channels into four accumulator
+// tiles, from ONE patch of g (2 rows x 17 pixels): one launch where conv_nhwc.hip ran one fp32-MFMA launch per class, each reading
+// g (4 x 87 us in the I3D recipe).  Tile = 16 positions ox of one row oy = 64 input pixels; rows of the MFMA = the 16 input channels.
+constexpr int CSM2D_TAP[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};      // k-block j: tap ky * 3 + kx
+constexpr int CSM2D_A[9] = {0, 0, 0, 1, 0, 1, 1, 0, 0};        //            row oy + a
+constexpr int CSM2D_B[9] = {0, 1, 0, 0, 0, 1, 0, 1, 0};        //            pixel ox + b
+constexpr int CSM2D_CLS[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};      //            class 2 py + px
+
+__global__ __launch_bounds__(256) void csm_pack_d2_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp) {
+    // fragment (slice, j): lane (row = ci, kq) holds k = 8 kq + e = co: w[co][tap_j][ci]  (w is [32][9][16], OHWI)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 9 * 16 * 32) return;
+    const int kk = i & 31, row = (i >> 5) & 15, j = i >> 9;
+    const float v = w[((size_t)kk * 9 + CSM2D_TAP[j]) * 16 + row];
+    unsigned u0, u1, u2;
+    split3(v, u0, u1, u2);
+    const size_t e = (size_t)((kk >> 3) * 16 + row) * 8 + (kk & 7), f = (size_t)j * 512, sl = (size_t)9 * 512;
+    wp[f + e] = (unsigned short)(u0 >> 16);
+    wp[sl + f + e] = (unsigned short)(u1 >> 16);
+    wp[2 * sl + f + e] = (unsigned short)(u2 >> 16);
+}
+
+struct Csm2dArgs {
+    const float* g;        // [N][OH][OW][32]
+    const void* wp;
+    float* dx;             // [N][2 OH][2 OW][16]
+    int N, OH, OW;
+    float rOH;
+};
+
+__global__ __launch_bounds__(256) void csm_dgrad_s2_kernel(Csm2dArgs a) {
+    constexpr int NW = 4, OCG = 4;                            // 8-channel pieces per g pixel
+    constexpr int NPC = 2 * 17 * OCG;                         // pieces of a tile's patch: [row a][pixel 0 .. 16][octet]
+    constexpr int SS = NPC * 16;
+    constexpr int NPL = (NPC + 63) / 64;
+    __shared__ __attribute__((aligned(16))) u32x4 wlds[27 * 64];             // 27 KB
+    __shared__ __attribute__((aligned(16))) char patch[NW][3 * SS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wp);
+    for (int i = tid; i < 27 * 64; i += NW * 64) wlds[i] = wsrc[i];
+    __syncthreads();
+    const int segs = (a.OW + 15) >> 4;
+    const int ntiles = a.N * a.OH * segs;
+    const int stride = (int)gridDim.x * NW;
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g), 0, 0x7fffffff, 0x00020000);
+    char* const mp = patch[wave];
+    int prow[NPL], ppx[NPL], poct[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int f = lane + 64 * k;
+        prow[k] = f / (17 * OCG);
+        ppx[k] = (f / OCG) % 17;
+        poct[k] = f % OCG;
+    }
+    int boff[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) boff[j] = ((CSM2D_A[j] * 17 + n + CSM2D_B[j]) * OCG + kq) * 16;
+    const float rS = 1.0f / (float)segs;
+    auto geom = [&](int tile, int& img, int& oy, int& ox0) {
+        int r = (int)((float)tile * rS);
+        r -= (r * segs > tile);
+        r += ((r + 1) * segs <= tile);
+        ox0 = (tile - r * segs) * 16;
+        img = (int)((float)r * a.rOH);
+        img -= (img * a.OH > r);
+        img += ((img + 1) * a.OH <= r);
+        oy = r - img * a.OH;
+    };
+    float4 plo[2][NPL], phi[2][NPL];
+    auto load_patch = [&](int tile, float4 (&lo)[NPL], float4 (&hi)[NPL]) {
+        int img, oy, ox0;
+        geom(tile, img, oy, ox0);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const int f = lane + 64 * k;
+            const int gy = oy + prow[k], gx = ox0 + ppx[k];
+            const bool ok = f < NPC && gy < a.OH && gx < a.OW;
+            const unsigned off = ok ? (unsigned)(((img * a.OH + gy) * a.OW + gx) * 32 + 8 * poct[k]) * 4u : 0x80000000u;
+            lo[k] = buf_load16(srd, off);
+            hi[k] = buf_load16(srd, off + 16u);
+        }
+    };
+    const int H = 2 * a.OH, W = 2 * a.OW;
+    const int tile0 = (int)blockIdx.x * NW + wave;
+    if (tile0 < ntiles) load_patch(tile0, plo[0], phi[0]);
+#pragma unroll 1
+    for (int tile = tile0; tile < ntiles; tile += 2 * stride) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int tcur = tile + half * stride;
+            if (tcur >= ntiles) break;
+            asm volatile("" ::: "memory");                   // the weight fragments are re-read from LDS per tile, not hoisted into registers
+            if (tcur + stride < ntiles) load_patch(tcur + stride, plo[half ^ 1], phi[half ^ 1]);
+            int img, oy, ox0;
+            geom(tcur, img, oy, ox0);
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                const int f = lane + 64 * k;
+                u32x4 s0, s1, s2;
+                split8(plo[half][k], phi[half][k], s0, s1, s2);
+                if (f < NPC) {
+                    *reinterpret_cast<u32x4*>(mp + f * 16) = s0;
+                    *reinterpret_cast<u32x4*>(mp + SS + f * 16) = s1;
+                    *reinterpret_cast<u32x4*>(mp + 2 * SS + f * 16) = s2;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            f32x4 acc[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const u32x4 b0 = *reinterpret_cast<const u32x4*>(mp + boff[j]);
+                const u32x4 b1 = *reinterpret_cast<const u32x4*>(mp + SS + boff[j]);
+                const u32x4 b2 = *reinterpret_cast<const u32x4*>(mp + 2 * SS + boff[j]);
+                const u32x4 w0 = wlds[(0 * 9 + j) * 64 + lane], w1 = wlds[(1 * 9 + j) * 64 + lane], w2 = wlds[(2 * 9 + j) * 64 + lane];
+                constexpr int dummy = 0; (void)dummy;
+                f32x4& t = acc[CSM2D_CLS[j]];
+                t = mfma16(w0, b2, t);
+                t = mfma16(w2, b0, t);
+                t = mfma16(w1, b1, t);
+                t = mfma16(w0, b1, t);
+                t = mfma16(w1, b0, t);
+                t = mfma16(w0, b0, t);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // lane holds input channels 4 kq + i of position n: pixel (2 oy + py, 2 (ox0 + n) + px) of class c = 2 py + px
+            if (ox0 + n < a.OW) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const size_t p = ((size_t)(img * H + 2 * oy + (c >> 1)) * W + 2 * (ox0 + n) + (c & 1));
+                    *reinterpret_cast<float4*>(a.dx + p * 16 + 4 * kq) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+                }
+            }
+        }
+    }
+}
+
 // ---- weight gradient -----------------------------------------------------------------------------------------------------
 // dw[co][tap][ci] = sum over pixels p of g[p][co] * x[p + d(tap)][ci] -- a GEMM over PIXELS (K) with M = co, N = ci per tap, on
 // v_mfma_f32_16x16x32_bf16 in bf16x3 arithmetic.  A k-block = the 32 pixels of TWO 16-pixel row-segment tiles (k-quarters
@@ -924,6 +1067,27 @@ int csm_fwd_s2(const float* x, const float* w, void* wpack, const float* bias, c
         return fail(DMC_E_INVALID, "conv_small: statistics partials have %d rows but this launch writes %d", stat_blocks, grid);
     csm_conv_s2_kernel<<<grid, Csm2::NW * 64, 0, s>>>(a);
     return check_launch("csm_conv_s2");
+}
+
+bool csm_dgrad_s2_supported(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    if (option(OPT_CONV_CFG) == 304) return false;          // 304: off (A/B)
+    return csm_fwd_s2_supported(N, H, W, Cin, Cout, KH, KW, stride, pad) && (long)N * (H / 2) * (W / 2) * 32 * 4 < (1L << 31);
+}
+
+size_t csm_dgrad_s2_wpack_bytes() { return (size_t)27 * 1024; }
+
+// dx [N][H][W][16] from dy [N][H/2][W/2][32], w [32][9][16] (OHWI); wpack >= csm_dgrad_s2_wpack_bytes()
+int csm_dgrad_s2(const float* dy, const float* w, void* wpack, float* dx, int N, int H, int W, hipStream_t s) {
+    csm_pack_d2_kernel<<<(9 * 16 * 32 + 255) / 256, 256, 0, s>>>(w, static_cast<unsigned short*>(wpack));
+    int rc = check_launch("csm_pack_d2");
+    if (rc) return rc;
+    Csm2dArgs a;
+    a.g = dy; a.wp = wpack; a.dx = dx; a.N = N; a.OH = H / 2; a.OW = W / 2; a.rOH = 1.0f / (float)a.OH;
+    const long tiles = (long)N * a.OH * ((a.OW + 15) / 16);
+    long g = (tiles + 3) / 4;
+    g = g < 1 ? 1 : (g > 2048 ? 2048 : g);
+    csm_dgrad_s2_kernel<<<(int)g, 256, 0, s>>>(a);
+    return check_launch("csm_dgrad_s2");
 }
 
 int csm_wgrad_groups(int N, int H, int W, int C) {
