@@ -7,7 +7,9 @@
 // 803 KB written per 224x224 frame), so these are direct VALU kernels: one thread per output pixel,
 // all COUT channels in registers, weights through the scalar cache.
 //   forward   x [M,2,H,W] -> z [M,OH,OW,COUT] = keep * lrelu(conv + bias)
-//   dgrad     g [M,OH,OW,COUT] -> dx [M,2,H,W]     (gathers the <= 4 taps whose parity matches)
+//   dgrad     g [M,OH,OW,COUT] -> dx [M,2,H,W]     (gathers the <= 4 taps whose parity matches; an LDS-staged form with one thread per
+//             2 x 2 input pixels and static taps was built and measured SLOWER, 295 vs 254 us at 384 frames: 288 scalar-cache
+//             weights per thread)
 //   wgrad     dw [COUT,2,3,3], db [COUT]: per-workgroup partials over a pixel range, then a
 //             fixed-order reduction (deterministic)
 #include "dmc_common.h"
@@ -53,6 +55,71 @@ __global__ __launch_bounds__(256) void disc_first_fwd_kernel(const float* __rest
 #pragma unroll
         for (int c4 = 0; c4 < COUT / 4; ++c4)
             dst[c4] = make_float4(out[4 * c4], out[4 * c4 + 1], out[4 * c4 + 2], out[4 * c4 + 3]);
+    }
+}
+
+// Forward through LDS (COUT = 16, W % 4 == 0, W <= 512): a workgroup owns FOUR output rows of one frame.  It stages the nine input
+// rows 2 oy0 - 1 .. 2 oy0 + 7 of both planes with coalesced 16-byte loads (zeros outside the image, a zero pad left and right of every
+// row), then a thread = (output pixel, channel quad): its 18 taps are LDS reads shared by the pixel's four lanes, its 72 weights sit in
+// registers, and the 64 lanes of a wave store 1 KB of consecutive NHWC memory.  (One thread per pixel with all 16 channels made
+// every vector access 64-byte strided: 192 us for the I3D recipe's 384 frames against a stream floor of 85.)
+constexpr int DF_ROWS = 4, DF_PAD = 4;
+__global__ __launch_bounds__(256) void disc_first_fwd_lds_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ bias, const float* __restrict__ keep,
+                                                                 float* __restrict__ z, int H, int W, int OH, int OW, int act,
+                                                                 int strips) {
+    extern __shared__ __attribute__((aligned(16))) float df_lds[];          // [2 planes][9 rows][W + 8]
+    const int tid = threadIdx.x;
+    const int n = (int)blockIdx.x / strips, oy0 = ((int)blockIdx.x % strips) * DF_ROWS;
+    const int pitch = W + 2 * DF_PAD;
+    // ---- stage ----
+    const int q_per_row = pitch / 4;                                         // float4 slots per LDS row (pads included)
+    const int nslots = 2 * 9 * q_per_row;
+    for (int i = tid; i < nslots; i += 256) {
+        const int q = i % q_per_row, r = (i / q_per_row) % 9, c = i / (9 * q_per_row);
+        const int iy = 2 * oy0 - 1 + r, ix = 4 * q - DF_PAD;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const float4*>(x + (((size_t)n * 2 + c) * H + iy) * W + ix);
+        *reinterpret_cast<float4*>(df_lds + (c * 9 + r) * pitch + 4 * q) = v;
+    }
+    // ---- this thread's channel quad: weights, bias, keep ----
+    const int c4 = tid & 3;
+    float wr[4][18], br[4], kr[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int co = 4 * c4 + e;
+#pragma unroll
+        for (int t = 0; t < 18; ++t) wr[e][t] = w[co * 18 + t];              // [co][ci][ky][kx]
+        br[e] = bias ? bias[co] : 0.f;
+        kr[e] = keep ? keep[(size_t)n * 16 + co] : 1.f;
+    }
+    __syncthreads();
+    const int items = DF_ROWS * OW * 4;
+    for (int it = tid; it < items; it += 256) {
+        const int ox = (it >> 2) % OW, r = (it >> 2) / OW;
+        const int oy = oy0 + r;
+        if (oy >= OH) break;
+        float acc[4] = {br[0], br[1], br[2], br[3]};
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float* row = df_lds + (ci * 9 + 2 * r + ky) * pitch + DF_PAD + 2 * ox - 1;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float v = row[kx];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = fmaf(v, wr[e][ci * 9 + ky * 3 + kx], acc[e]);
+                }
+            }
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = acc[e];
+            if (act) t = t > 0.f ? t : 0.2f * t;
+            o[e] = t * kr[e];
+        }
+        *reinterpret_cast<float4*>(z + (((size_t)n * OH + oy) * OW + ox) * 16 + 4 * c4) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -210,6 +277,12 @@ int dmc_disc_first_fwd(const float* x, const float* w, const float* bias, const 
     const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
     hipStream_t s = (hipStream_t)stream;
     const int nb = blocks_for((long)M * OH * OW);
+    if (Cout == 16 && W % 4 == 0 && W <= 512 && option(OPT_CONV_CFG) != 305) {          // 305: the one-thread-per-pixel form (A/B)
+        const int strips = (OH + DF_ROWS - 1) / DF_ROWS;
+        const size_t lds = (size_t)2 * 9 * (W + 2 * DF_PAD) * sizeof(float);
+        disc_first_fwd_lds_kernel<<<M * strips, 256, lds, s>>>(x, w, bias, keep, z, H, W, OH, OW, act, strips);
+        return check_launch("disc_first_fwd_lds");
+    }
     if (Cout == 16) disc_first_fwd_kernel<16><<<nb, 256, 0, s>>>(x, w, bias, keep, z, M, H, W, OH, OW, act);
     else disc_first_fwd_kernel<8><<<nb, 256, 0, s>>>(x, w, bias, keep, z, M, H, W, OH, OW, act);
     return check_launch("disc_first_fwd");
