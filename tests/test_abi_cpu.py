@@ -224,12 +224,17 @@ def test_small_channel_conv_dispatch_host_side_without_gpu():
     # 16 channels: five k-blocks of 32 (two taps x 16 channels, the last half empty) x 3 slices x 16 rows x 32 x 2 bytes
     assert lib.dmc_conv_nhwc_wt_bytes(16, 16, 3, 3) == 3 * 5 * 16 * 32 * 2
     assert lib.dmc_conv_nhwc_wt_bytes(32, 32, 3, 3) == 3 * 9 * 2 * 16 * 32 * 2 == 32 * 32 * 9 * 6
-    assert lib.dmc_conv_nhwc_wt_bytes(16, 32, 3, 3) == 16 * 32 * 9 * 6                 # (not a small-channel shape)
+    # 16 -> 32 (the stride-2 block): five k-blocks x two row tiles x 3 slices of 1 KB fragments (forward); the data gradient's 27 fit
+    assert lib.dmc_conv_nhwc_wt_bytes(16, 32, 3, 3) == 3 * 5 * 2 * 1024 >= 16 * 32 * 9 * 6
+    assert lib.dmc_conv_nhwc_wt_bytes(32, 64, 3, 3) == 32 * 64 * 9 * 6                 # (not a small-channel forward shape)
     tiles16 = 240 * 112 * 7                                                             # 16-pixel row segments
     assert lib.dmc_conv_nhwc_stat_blocks(240, 112, 112, 16, 16, 3, 1, 1) == min(2048, (tiles16 + 3) // 4)
     assert lib.dmc_conv_nhwc_stat_blocks(2, 5, 3, 32, 32, 3, 1, 1) == (2 * 5 * 1 + 7) // 8
-    # stride 2 / other channel pairs keep the implicit-GEMM kernels' tile rows
-    assert lib.dmc_conv_nhwc_stat_blocks(240, 112, 112, 16, 32, 3, 2, 1) == (240 * 56 * 56 + 127) // 128
+    # the 16 -> 32 stride-2 block on even maps: one row per persistent workgroup of four waves over the 16-pixel output segments
+    assert lib.dmc_conv_nhwc_stat_blocks(240, 112, 112, 16, 32, 3, 2, 1) == min(2048, (240 * 56 * 4 + 3) // 4)
+    # odd sizes / other channel pairs keep the implicit-GEMM kernels' tile rows
+    assert lib.dmc_conv_nhwc_stat_blocks(2, 13, 11, 16, 32, 3, 2, 1) == (2 * 7 * 6 + 127) // 128
+    assert lib.dmc_conv_nhwc_stat_blocks(240, 56, 56, 32, 64, 3, 2, 1) == (240 * 28 * 28 + 255) // 256
     _lib.check(lib.dmc_set_option(b"conv_cfg", 301), "dmc_set_option")                 # 301: the small-channel kernel off
     try:
         assert lib.dmc_conv_nhwc_stat_blocks(240, 112, 112, 16, 16, 3, 1, 1) == (240 * 112 * 112 + 255) // 256
