@@ -78,7 +78,7 @@ size_t dmc_gen_tiny_saved_bytes(int N, int H, int W);
  * features, physical channel order) -- the later layers read them from it and the backward pass
  * needs them.  Inference callers may release it as soon as the call has been enqueued on a
  * stream-ordered allocator.
- * workspace: dmc_gen_tiny_workspace_bytes() (repacked weights + 256 zero words).
+ * workspace: dmc_gen_tiny_workspace_bytes() (repacked weights + 256 zero words + the bf16x3 weight fragments of gen_x3.hip).
  * add_mv_delta != 0 adds input_mv to the result (gen_flow_or_delta == 1).
  * Any H, W >= 1; W % 4 == 0 takes the vectorised path.
  */
