@@ -531,6 +531,7 @@ struct RingArgs {
     LayerArgs a;
     int tiles_y, ntiles;                              // row bands per frame, tiles in this launch
     int ablate;                                       // measurement only (option gen_ablate): 1 = no transfers, 2 = no epilogue stores
+    int stagger = 0;                                  // gen_wino_kernel: start delay per phase step, in 10 ns ticks (option gen_stagger)
 };
 
 // producer: stage chunk c of tile (n, ty0) -- 4 channels x 10 rows, one 1 KB row per instruction.
@@ -726,7 +727,8 @@ __global__ __launch_bounds__(LTHREADS, HALF ? 4 : 2) void gen_layer_mfma_kernel(
 #pragma unroll 1
     for (int q = 0; q < nitems; ++q) {
         asm volatile("s_barrier" ::: "memory");
-        mfma_chunk<MODE, K, NT, HALF>(acc, lds + slot * P_BUF, wl, c * G::CH, boffq, lane);
+        if (!(ra.ablate & 4) || r < 4)      // ablate 4: one computing wave per SIMD (waves 4 .. 6 only keep the barriers)
+            mfma_chunk<MODE, K, NT, HALF>(acc, lds + slot * P_BUF, wl, c * G::CH, boffq, lane);
         slot = slot + 1 == RING ? 0 : slot + 1;
         if (++c < NCHUNK) continue;
         c = 0;
@@ -803,6 +805,272 @@ __global__ __launch_bounds__(LTHREADS, HALF ? 4 : 2) void gen_layer_mfma_kernel(
         for (int s = 0; s < M_SEGS; ++s)
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[s][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        tile += t_step;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) form of the ring kernel (option gen_wino; hidden layers of the forward and the data-gradient groups).
+//
+// The direct kernels above are bound by the matrix pipe (ablations: `gen_ablate`; one computing wave per SIMD runs the
+// 4x4x1 MFMAs back to back at 8.6 cycles each): 9 multiplications per output value and (cin, cout) pair.  The minimal
+// filtering algorithm F(2x2, 3x3) needs 16 per 2 x 2 OUTPUT BLOCK and pair -- 4 per output value, 2.25x fewer:
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A        d = the block's 4 x 4 input window, g = the 3 x 3 filter
+//     B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
+// In the transformed domain a layer is 16 independent [Cout x Cin] x [Cin x blocks] products -- again v_mfma_f32_4x4x1
+// with "one pixel per lane", the pixel now being a 2 x 2 output block and the K-steps (cin, position): rows = output
+// channels (no push rows, no horizontal-tap epilogue, no exchange between waves), 16 Cin NT MFMAs per 64 blocks = 256
+// pixels where the push form issues 4 x 3 Cin NT' (layer 2: 672 against 1,260 per wave and tile).
+// Same tile (8 rows x W <= 224 pixels = 4 x 112 blocks = 7 consumer waves x 64 lanes), same producer wave, same
+// three-stage ring of LDS-DMA'd channel chunks as gen_layer_mfma_kernel (ring_stage is shared).  Per staged channel a
+// lane reads its block's 4 x 4 window (columns 2 tc - 1 .. 2 tc + 2: the columns left of 0 and right of W - 1 are the
+// 32 pad floats of a 256-float LDS row, zeroed once -- the transfers are EXEC-masked to the image width and never
+// touch them), transforms it with 32 additions (B^T d B has no multiplications) and issues the 16 NT MFMAs; the
+// transformed filters U = G g G^T are computed once per workgroup (in double, rounded once) into LDS as
+// [ci][row tile][4 positions][row-in-tile][4].  Epilogue: A^T M A per output channel (24 additions), bias +
+// LeakyReLU (forward) or LeakyReLU' of the saved feature (data gradient), 8-byte stores (two pixels of a row per lane:
+// 512 contiguous bytes per wave and row).
+// Arithmetic: fp32 throughout; the result differs from the direct form's by the usual Winograd rounding (the transforms
+// add / subtract values of like magnitude: measured <= 3x the direct kernels' distance from an fp64 evaluation,
+// tests/test_gen_wino_gpu.py), not bit for bit.
+// ------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// One staged channel's window: three 8-byte reads per row at constant offsets from one address.  VOLATILE loads: the compiler
+// neither pairs them into ds_read2_b64 (half the LDS rate) nor into dword pairs that need an address register each, and it
+// still counts them in its s_waitcnt bookkeeping.
+typedef const volatile __attribute__((address_space(3))) f32x2* wino_lds_t;
+__device__ __forceinline__ void wino_window(f32x2 (&d)[4][3], const float* p) {
+    const wino_lds_t q = (wino_lds_t)(__attribute__((address_space(3))) void*)(void*)const_cast<float*>(p);
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d[y][k] = q[y * (LTW / 2) + k];
+}
+constexpr int WN_PAD = 4;                          // floats in front of the ring: column -1 of its first row
+template <int MODE, int K>
+struct WinoGeom {
+    using G = MfmaGeom<MODE, K, 0>;
+    static constexpr int CIN = G::CIN, COUT = G::COUT, CH = G::CH, NCHUNK = G::NCHUNK;
+    static constexpr int NT = (COUT + 3) / 4;                     // row tiles = output channels / 4
+    static constexpr int WL = NCHUNK * CH * NT * 64;              // [ci][t][position quad][row-in-tile][4], zero for ci >= CIN
+};
+__host__ __device__ inline bool wino_shape_ok(int H, int W) { return W % 4 == 0 && W <= P_MAXW && W >= 64 && H >= 1; }
+
+template <int MODE, int K>
+__global__ __launch_bounds__(LTHREADS, 2) void gen_wino_kernel(RingArgs ra) {
+    static_assert(MODE == 0 || MODE == 2, "hidden layers of the forward / data-gradient groups");
+    using WG = WinoGeom<MODE, K>;
+    using G = MfmaGeom<MODE, K, 0>;
+    constexpr int CIN = WG::CIN, COUT = WG::COUT, NT = WG::NT, NCHUNK = WG::NCHUNK, CH = WG::CH;
+    constexpr int P_BUF = LCH * RingGeo<0>::PLANE;
+    constexpr int AHEAD = RING - 1;
+    __shared__ __attribute__((aligned(16))) float lds_all[WN_PAD + RING * P_BUF + WG::WL];
+    float* lds = lds_all + WN_PAD;
+    float* wl = lds + RING * P_BUF;
+    const LayerArgs& a = ra.a;
+    const size_t HW = (size_t)a.H * a.W;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int r = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave: 0..6 = consumers, 7 = producer
+    const float* zero = a.pk + PACKED_TOTAL;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds;
+
+    const int nwg = gridDim.x;                                    // XCD-aware tile schedule, as above
+    const int t_begin = nwg % 8 == 0 ? (int)(blockIdx.x % 8) * (nwg / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int t_step = nwg;
+    const int nitems = t_begin < ra.ntiles ? (ra.ntiles - t_begin + nwg - 1) / nwg * NCHUNK : 0;
+    if (nitems == 0) return;
+
+    // transformed filters U[pa][pb] = sum_{dy,dx} G[pa][dy] G[pb][dx] g[dy][dx]
+    const float* wbase = a.pk + (MODE == 2 ? wb_off(K) : wf_off(K));
+    for (int idx = tid; idx < WG::WL; idx += LTHREADS) {
+        const int e = idx & 3, i = (idx >> 2) & 3, pq = (idx >> 4) & 3, t = (idx >> 6) % NT, ci = idx / (64 * NT);
+        const int co = 4 * t + i;
+        double u = 0.0;
+        if (co < COUT && ci < CIN) {
+            const double Gm[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+                    u += Gm[pq][dy] * Gm[e][dx] * (double)wbase[(ci * 9 + dy * 3 + dx) * COUT + co];
+        }
+        wl[idx] = (float)u;
+    }
+    // the pad columns [W, 256) of every ring row (and the four floats in front of the ring) are the zero padding in x
+    {
+        const int padw = LTW - a.W;
+        for (int idx = tid; idx < RING * LCH * P_ROWS * padw; idx += LTHREADS) {
+            const int row = idx / padw, col = a.W + (idx - row * padw);
+            lds[row * LTW + col] = 0.f;
+        }
+        if (tid < WN_PAD) lds_all[tid] = 0.f;
+    }
+    // Staggered start: a tile ends with a burst of stores (COUT planes x 8 rows), and workgroups that run in phase all write
+    // at the same time -- the chip alternates between a read / compute phase and a write phase that drains at the HBM rate with
+    // nothing else in flight (38 us of 116 for layer 0).  Workgroups started (b / 8 mod 8) steps apart keep the mix constant.
+    if (ra.stagger > 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long wait = (unsigned long long)((blockIdx.x >> 3) & 7) * (unsigned)ra.stagger;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(4);
+    }
+    __syncthreads();
+
+    if (r == P_CONS) {
+        // ------------------------------ producer wave (as in gen_layer_mfma_kernel, no epilogue barrier) ------------------------------
+        if (4 * lane >= a.W) return;
+        const unsigned voff = (unsigned)lane * 16;
+#pragma unroll 1
+        for (int pre = 0; pre < AHEAD && pre < nitems; ++pre) {
+            const int tile = t_begin + (pre / NCHUNK) * t_step, n = tile / ra.tiles_y;
+            ring_stage<MODE, K, 0>(a, lds0 + pre * (P_BUF * 4), n, (tile - n * ra.tiles_y) * PT_H, pre % NCHUNK, HW, voff, zero);
+        }
+        int tile = t_begin, c = 0, slot = 0;
+#pragma unroll 1
+        for (int q = 0; q < nitems; ++q) {
+            if (q + 1 < nitems && !(ra.ablate & 1)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(G::CH * P_ROWS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (q + AHEAD < nitems && !(ra.ablate & 1)) {
+                const int c2 = c + AHEAD, tile2 = tile + (c2 / NCHUNK) * t_step, n2 = tile2 / ra.tiles_y;
+                int slot2 = slot + AHEAD; slot2 = slot2 >= RING ? slot2 - RING : slot2;
+                ring_stage<MODE, K, 0>(a, lds0 + (unsigned)slot2 * (P_BUF * 4), n2, (tile2 - n2 * ra.tiles_y) * PT_H,
+                                       c2 % NCHUNK, HW, voff, zero);
+            }
+            slot = slot + 1 == RING ? 0 : slot + 1;
+            if (++c == NCHUNK) { c = 0; tile += t_step; }
+        }
+        return;
+    }
+
+    // ------------------------------ consumer waves ------------------------------
+    // lane = one 2 x 2 output block of the tile: block row tr (0..3), block column tc (0 .. W/2 - 1)
+    const int bx = a.W >> 1;
+    const int t = r * 64 + lane;
+    const bool valid = t < 4 * bx;
+    const int tv = valid ? t : 0;
+    const int tr = tv / bx, tc = tv - tr * bx;
+    // window origin: staged row 2 tr (image row ty0 + 2 tr - 1), column 2 tc - 2: three 8-byte reads per row fetch columns
+    // 2 tc - 2 .. 2 tc + 3 (the window is the middle four): ds_read_b64 moves 256 B per clock without bank conflicts where
+    // dword reads at this two-dword lane stride are 2-way conflicted at 128 B per clock
+    const int wofs = (2 * tr) * LTW + 2 * tc - 2;
+    const float* wl_lane = wl + (lane & 3) * 4;
+    f32x4 acc[16][NT];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) acc[p][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // transformed filters of one (channel, row tile) GROUP = 16 positions = four 16-byte reads; group g + 1 is requested
+    // before the 16 MFMAs of group g (register double buffer), across chunk and tile boundaries too (the table is static)
+    constexpr int NG = CH * NT, PLANE = RingGeo<0>::PLANE;
+    static_assert(NG % 2 == 0, "the buffer parity of a chunk's first group is fixed");
+    float4 wq[2][4];
+    auto load_group = [&](float4 (&w)[4], int g) {
+#pragma unroll
+        for (int pq = 0; pq < 4; ++pq) w[pq] = *reinterpret_cast<const float4*>(wl_lane + (g * 4 + pq) * 16);
+    };
+    load_group(wq[0], 0);
+
+    int tile = t_begin, c = 0, slot = 0;
+#pragma unroll 1
+    for (int q = 0; q < nitems; ++q) {
+        asm volatile("s_barrier" ::: "memory");
+        {
+            const float* buf = lds + slot * P_BUF + wofs;
+            const int cn = c + 1 == NCHUNK ? 0 : c + 1;
+            f32x2 d[4][3];
+            wino_window(d, buf);
+#pragma unroll
+            for (int cc = 0; cc < CH; ++cc) {
+                // B^T d: rows combined, vectorised over the column pairs (v_pk_add_f32; the unused outer halves fall away)
+                f32x2 u[4][3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    u[0][k] = d[0][k] - d[2][k]; u[1][k] = d[1][k] + d[2][k];
+                    u[2][k] = d[2][k] - d[1][k]; u[3][k] = d[1][k] - d[3][k];
+                }
+                if (cc + 1 < CH) wino_window(d, buf + (cc + 1) * PLANE);    // in flight behind this channel's MFMAs
+                // (B^T d) B: columns -1, 0, 1, 2 of a row are u[.][0].y, u[.][1].x, u[.][1].y, u[.][2].x
+                float v[4][4];
+#pragma unroll
+                for (int y = 0; y < 4; ++y) {
+                    v[y][0] = u[y][0].y - u[y][1].y;
+                    v[y][1] = u[y][1].x + u[y][1].y;
+                    v[y][2] = u[y][1].y - u[y][1].x;
+                    v[y][3] = u[y][1].x - u[y][2].x;
+                }
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) {
+                    const int g = cc * NT + tt;
+                    if (g + 1 < NG) load_group(wq[(g + 1) & 1], (c * CH) * NT + g + 1);
+                    else load_group(wq[0], (cn * CH) * NT);
+                    __builtin_amdgcn_sched_barrier(0);           // (the compiler would sink the requests down to their first use)
+                    const float4 (&w)[4] = wq[g & 1];
+#pragma unroll
+                    for (int pq = 0; pq < 4; ++pq) {
+                        acc[4 * pq + 0][tt] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[pq].x, v[pq][0], acc[4 * pq + 0][tt], 0, 0, 0);
+                        acc[4 * pq + 1][tt] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[pq].y, v[pq][1], acc[4 * pq + 1][tt], 0, 0, 0);
+                        acc[4 * pq + 2][tt] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[pq].z, v[pq][2], acc[4 * pq + 2][tt], 0, 0, 0);
+                        acc[4 * pq + 3][tt] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[pq].w, v[pq][3], acc[4 * pq + 3][tt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        slot = slot + 1 == RING ? 0 : slot + 1;
+        if (++c < NCHUNK) continue;
+        c = 0;
+
+        // ---- epilogue: A^T M A per output channel, bias / activation, store ----
+        const int n = tile / ra.tiles_y, ty0 = (tile - n * ra.tiles_y) * PT_H;
+        const int y0 = ty0 + 2 * tr;
+        const bool ok0 = valid && y0 < a.H, ok1 = valid && y0 + 1 < a.H;
+        const size_t pix0 = (size_t)(ok0 ? y0 : 0) * a.W + 2 * tc, pix1 = (size_t)(ok1 ? y0 + 1 : 0) * a.W + 2 * tc;
+        float2 ex0[COUT], ex1[COUT];                 // MODE 2: the saved feature y_K (LeakyReLU'), one batch of loads
+        if (MODE == 2) {
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                const float* fp = a.feat + ((size_t)n * NFEAT + (yoff(K) - NIN) + co) * HW;
+                ex0[co] = *reinterpret_cast<const float2*>(fp + pix0);
+                ex1[co] = *reinterpret_cast<const float2*>(fp + pix1);
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            const int tt = co >> 2, qq = co & 3;
+            float s0[4], s1[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const float m0 = acc[x][tt][qq], m1 = acc[4 + x][tt][qq], m2 = acc[8 + x][tt][qq], m3 = acc[12 + x][tt][qq];
+                s0[x] = (m0 + m1) + m2;
+                s1[x] = (m1 - m2) - m3;
+            }
+            float o[2][2] = {{(s0[0] + s0[1]) + s0[2], (s0[1] - s0[2]) - s0[3]}, {(s1[0] + s1[1]) + s1[2], (s1[1] - s1[2]) - s1[3]}};
+            const float exv[2][2] = {{MODE == 2 ? ex0[co].x : 0.f, MODE == 2 ? ex0[co].y : 0.f},
+                                     {MODE == 2 ? ex1[co].x : 0.f, MODE == 2 ? ex1[co].y : 0.f}};
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    if (MODE == 0) {
+                        o[y][x] += a.pk[bf_off(K) + co];
+                        o[y][x] = o[y][x] > 0.f ? o[y][x] : 0.1f * o[y][x];
+                    } else {
+                        o[y][x] *= exv[y][x] > 0.f ? 1.f : 0.1f;
+                    }
+                }
+            // (ablate 8: the arithmetic without the stores.  Measured and not kept: the results held in registers and stored a few
+            // channels per chunk of the NEXT tile -- no gain without spills, a loss with them: the stores' cost is their HBM
+            // traffic, not the moment of their issue)
+            float* op = (MODE == 0 ? a.feat_out : a.gbuf) + ((size_t)n * NFEAT + (yoff(K) - NIN) + co) * HW;
+            const bool st = !(ra.ablate & 2) && (!(ra.ablate & 8) || o[0][0] == 1.2345678e33f);
+            if (st) {
+                if (ok0) *reinterpret_cast<float2*>(op + pix0) = make_float2(o[0][0], o[0][1]);
+                if (ok1) *reinterpret_cast<float2*>(op + pix1) = make_float2(o[1][0], o[1][1]);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) acc[p][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         tile += t_step;
     }
 }
@@ -2036,6 +2304,20 @@ int launch_layer(LayerArgs a, int n0, int N, hipStream_t s) {
     a.gout = a.gout ? a.gout + (size_t)n0 * 2 * HW : nullptr;
     a.gbuf = a.gbuf ? a.gbuf + (size_t)n0 * NFEAT * HW : nullptr;
     a.out = a.out ? a.out + (size_t)n0 * 2 * HW : nullptr;
+    if constexpr (MODE != 1) {
+        // option gen_wino: bit K = forward hidden layer K, bit 8 + K = data-gradient group K on the Winograd kernel
+        if (((option(OPT_GEN_WINO) >> (MODE == 0 ? K : 8 + K)) & 1) && wino_shape_ok(a.H, a.W)) {
+            RingArgs ra;
+            ra.a = a;
+            ra.tiles_y = (a.H + PT_H - 1) / PT_H;
+            ra.ntiles = ra.tiles_y * N;
+            ra.ablate = option(OPT_GEN_ABLATE);
+            ra.stagger = option(OPT_GEN_STAGGER);
+            const int wgs = ra.ntiles < num_cus() ? ra.ntiles : num_cus();
+            gen_wino_kernel<MODE, K><<<wgs, LTHREADS, 0, s>>>(ra);
+            return check_launch("gen_wino");
+        }
+    }
     const dim3 grid((a.W + LTW - 1) / LTW, (a.H + LTH - 1) / LTH, N);
     // measured per layer (N=120, 224x224): the LDS-DMA + DPP kernel wins where little arithmetic
     // rides on each staged channel (Cout 2: layers 4, 5; gradient groups 2, 3, 4), the
@@ -2137,6 +2419,7 @@ static int gen_tiny_fwd_impl(const float* mv, const float* res, const float* con
     for (int K = 0; K < GX_LAYERS; ++K)
         if (!gen_x3_supported(K, H, W)) x3mask &= ~(1 << K);
     x3mask &= (1 << GX_LAYERS) - 1;
+    if (wino_shape_ok(H, W)) x3mask &= ~option(OPT_GEN_WINO);        // a layer on the Winograd kernel (launch_layer) does not take gen_x3.hip
     // one launch packs the fp32 parameter block and (when a layer takes that path) the bf16x3 fragments behind it
     int rc = pack(w, b, workspace, s, x3mask ? reinterpret_cast<unsigned short*>(workspace + PACKED_TOTAL + ZERO_PAD) : nullptr);
     if (rc) return rc;

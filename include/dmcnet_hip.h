@@ -49,7 +49,12 @@ const char* dmc_last_error(void);
  * launches), "gen_wgrad_path" (0: all-waves-stage weight gradient; 1: fp32 producer/consumer; 2 / 3: bf16x3; 4, the default: bf16x3 with wide LDS reads), "gen_fuse_fwd" / "gen_fuse_bwd"
  * (0: the layer-by-layer forward / data-gradient launches instead of the fused groups), "gen_x3" (bit K: hidden
  * layer K of the generator forward, K = 0 .. 2, in bf16x3 arithmetic on the 16x16x32 matrix instruction, gen_x3.hip;
- * default 2 = layer 1).
+ * default 2 = layer 1), "gen_wino" (bit K: hidden layer K of the generator forward, K = 0 .. 3; bit 8 + K: data-gradient
+ * group K, K = 0 .. 4, on the Winograd F(2x2, 3x3) ring kernel, gen_tiny.hip gen_wino_kernel -- fp32 arithmetic with 2.25x
+ * fewer multiplications, results within rounding of the direct kernels', not bit-identical to them; shapes with W % 4 == 0,
+ * 64 <= W <= 224; a set bit overrides "gen_x3" for that layer; default 770 = layer 1 and gradient groups 0 and 1, the
+ * launches it wins), "gen_ablate" / "conv_ablate" (measurement only: parts of a kernel switched off, results wrong),
+ * "gen_stagger" (measurement only: start delay between workgroups of gen_wino_kernel, 10 ns ticks per step; default 0).
  * dmc_set_option returns DMC_E_INVALID for an unknown name; dmc_get_option returns -1 for one. */
 int dmc_set_option(const char* name, int value);
 int dmc_get_option(const char* name);
