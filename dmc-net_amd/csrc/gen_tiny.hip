@@ -856,7 +856,7 @@ struct WinoGeom {
 };
 __host__ __device__ inline bool wino_shape_ok(int H, int W) { return W % 4 == 0 && W <= P_MAXW && W >= 64 && H >= 1; }
 
-template <int MODE, int K>
+template <int MODE, int K, int DBG = 0>     // DBG (measurement only, option gen_ablate >> 8): 1 no transform, 2 no MFMAs, 3 no window reads, 4 no filter reads
 __global__ __launch_bounds__(LTHREADS, 2) void gen_wino_kernel(RingArgs ra) {
     static_assert(MODE == 0 || MODE == 2, "hidden layers of the forward / data-gradient groups");
     using WG = WinoGeom<MODE, K>;
@@ -978,7 +978,12 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_wino_kernel(RingArgs ra) {
             const float* buf = lds + slot * P_BUF + wofs;
             const int cn = c + 1 == NCHUNK ? 0 : c + 1;
             f32x2 d[4][3];
-            wino_window(d, buf);
+            if (DBG == 3) {
+#pragma unroll
+                for (int y = 0; y < 4; ++y)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) d[y][k] = (f32x2){(float)(lane + y), (float)(k + q)};
+            } else wino_window(d, buf);
 #pragma unroll
             for (int cc = 0; cc < CH; ++cc) {
                 // B^T d: rows combined, vectorised over the column pairs (v_pk_add_f32; the unused outer halves fall away)
@@ -988,7 +993,7 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_wino_kernel(RingArgs ra) {
                     u[0][k] = d[0][k] - d[2][k]; u[1][k] = d[1][k] + d[2][k];
                     u[2][k] = d[2][k] - d[1][k]; u[3][k] = d[1][k] - d[3][k];
                 }
-                if (cc + 1 < CH) wino_window(d, buf + (cc + 1) * PLANE);    // in flight behind this channel's MFMAs
+                if (cc + 1 < CH && DBG != 3) wino_window(d, buf + (cc + 1) * PLANE);    // in flight behind this channel's MFMAs
                 // (B^T d) B: columns -1, 0, 1, 2 of a row are u[.][0].y, u[.][1].x, u[.][1].y, u[.][2].x
                 float v[4][4];
 #pragma unroll
@@ -997,16 +1002,22 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_wino_kernel(RingArgs ra) {
                     v[y][1] = u[y][1].x + u[y][1].y;
                     v[y][2] = u[y][1].y - u[y][1].x;
                     v[y][3] = u[y][1].x - u[y][2].x;
+                    if (DBG == 1) { v[y][0] = d[y][0].y; v[y][1] = d[y][1].x; v[y][2] = d[y][1].y; v[y][3] = d[y][2].x; }
                 }
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
                     const int g = cc * NT + tt;
-                    if (g + 1 < NG) load_group(wq[(g + 1) & 1], (c * CH) * NT + g + 1);
+                    if (DBG == 4) { }
+                    else if (g + 1 < NG) load_group(wq[(g + 1) & 1], (c * CH) * NT + g + 1);
                     else load_group(wq[0], (cn * CH) * NT);
                     __builtin_amdgcn_sched_barrier(0);           // (the compiler would sink the requests down to their first use)
                     const float4 (&w)[4] = wq[g & 1];
 #pragma unroll
                     for (int pq = 0; pq < 4; ++pq) {
+                        if (DBG == 2) {          // the operands stay alive, the matrix pipe idles
+                            asm volatile("" :: "v"(w[pq].x), "v"(w[pq].y), "v"(w[pq].z), "v"(w[pq].w), "v"(v[pq][0]), "v"(v[pq][1]), "v"(v[pq][2]), "v"(v[pq][3]));
+                            continue;
+                        }
                         acc[4 * pq + 0][tt] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[pq].x, v[pq][0], acc[4 * pq + 0][tt], 0, 0, 0);
                         acc[4 * pq + 1][tt] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[pq].y, v[pq][1], acc[4 * pq + 1][tt], 0, 0, 0);
                         acc[4 * pq + 2][tt] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[pq].z, v[pq][2], acc[4 * pq + 2][tt], 0, 0, 0);
@@ -2314,6 +2325,15 @@ int launch_layer(LayerArgs a, int n0, int N, hipStream_t s) {
             ra.ablate = option(OPT_GEN_ABLATE);
             ra.stagger = option(OPT_GEN_STAGGER);
             const int wgs = ra.ntiles < num_cus() ? ra.ntiles : num_cus();
+            const int dbg = ra.ablate >> 8;
+            ra.ablate &= 255;
+            if constexpr ((MODE == 0 && K == 2) || (MODE == 0 && K == 3)) {
+                if (dbg == 1) gen_wino_kernel<MODE, K, 1><<<wgs, LTHREADS, 0, s>>>(ra);
+                else if (dbg == 2) gen_wino_kernel<MODE, K, 2><<<wgs, LTHREADS, 0, s>>>(ra);
+                else if (dbg == 3) gen_wino_kernel<MODE, K, 3><<<wgs, LTHREADS, 0, s>>>(ra);
+                else if (dbg == 4) gen_wino_kernel<MODE, K, 4><<<wgs, LTHREADS, 0, s>>>(ra);
+                else gen_wino_kernel<MODE, K><<<wgs, LTHREADS, 0, s>>>(ra);
+            } else
             gen_wino_kernel<MODE, K><<<wgs, LTHREADS, 0, s>>>(ra);
             return check_launch("gen_wino");
         }

@@ -47,7 +47,8 @@ def test_generator_wino_vs_oracle_and_golden(golden, gen_wino, tag, shape, sd):
 
 @pytest.mark.parametrize("shape", [(1, 5, 1, 1), (1, 5, 3, 5), (2, 5, 8, 64), (1, 5, 9, 68), (2, 5, 64, 260), (1, 5, 8, 4),
                                    (3, 5, 17, 220), (1, 5, 33, 224), (2, 5, 16, 64), (2, 5, 23, 100), (1, 5, 2, 224),
-                                   (1, 5, 40, 228), (2, 5, 65, 128), (1, 5, 1, 224), (1, 5, 7, 112), (1, 5, 96, 96)])
+                                   (1, 5, 40, 228), (2, 5, 65, 128), (1, 5, 1, 224), (1, 5, 7, 112), (1, 5, 96, 96),
+                                   (2, 5, 31, 188)])
 def test_generator_wino_edge_shapes(gen_wino, shape):
     """Tiles that end inside the image (odd and even row counts, one row), widths below 224 (blocks of idle lanes), widths the
     path does not take (no multiple of 4, above 224, below 64: the other kernels run)."""

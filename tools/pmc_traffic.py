@@ -42,8 +42,9 @@ def main():
         name = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         print("%s,%.2f,%.2f,%.2f,%.2f,%.1f" % (name, f / 1e6, w / 1e6, f * kr / 1e6, w * kw / 1e6,
                                              (f * kr + w * kw) / px))
-        grp = "fwd" if (("_kernel<0" in k or "_kernel<1" in k) and "gen_layer" in k) or "gen_l45" in k or "gen_x3_kernel" in k else \
-              "bwd" if ("_kernel<2" in k and "gen_layer" in k) or "gen_bwd" in k else None
+        layer = "gen_layer" in k or "gen_wino" in k          # (template arguments: <MODE, K ...>, MODE 2 = data gradient)
+        grp = "fwd" if (("_kernel<0" in k or "_kernel<1" in k) and layer) or "gen_l45" in k or "gen_x3_kernel" in k else \
+              "bwd" if ("_kernel<2" in k and layer) or "gen_bwd" in k else None
         if grp:
             tot[grp] += f * kr + w * kw
     for g, v in tot.items():
