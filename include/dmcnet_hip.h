@@ -52,8 +52,8 @@ const char* dmc_last_error(void);
  * default 2 = layer 1), "gen_wino" (bit K: hidden layer K of the generator forward, K = 0 .. 3; bit 8 + K: data-gradient
  * group K, K = 0 .. 4, on the Winograd F(2x2, 3x3) ring kernel, gen_tiny.hip gen_wino_kernel -- fp32 arithmetic with 2.25x
  * fewer multiplications, results within rounding of the direct kernels', not bit-identical to them; shapes with W % 4 == 0,
- * 64 <= W <= 224; a set bit overrides "gen_x3" for that layer; default 770 = layer 1 and gradient groups 0 and 1, the
- * launches it wins), "gen_ablate" / "conv_ablate" (measurement only: parts of a kernel switched off, results wrong),
+ * 64 <= W <= 224; a set bit overrides "gen_x3" for that layer; default 768 = gradient groups 0 and 1; layer 1 of the forward
+ * (bit 1) is faster on it too but stays on "gen_x3": DESIGN 4.10), "gen_ablate" / "conv_ablate" (measurement only: parts of a kernel switched off, results wrong),
  * "gen_stagger" (measurement only: start delay between workgroups of gen_wino_kernel, 10 ns ticks per step; default 0).
  * dmc_set_option returns DMC_E_INVALID for an unknown name; dmc_get_option returns -1 for one. */
 int dmc_set_option(const char* name, int value);
