@@ -1044,38 +1044,48 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_wino_kernel(RingArgs ra) {
                 ex1[co] = *reinterpret_cast<const float2*>(fp + pix1);
             }
         }
+        // two output channels at a time: components (2 h, 2 h + 1) of an accumulator are a register pair -> v_pk_add_f32
+        // (the same additions in the same order as one channel at a time: bit-identical)
 #pragma unroll
-        for (int co = 0; co < COUT; ++co) {
-            const int tt = co >> 2, qq = co & 3;
-            float s0[4], s1[4];
+        for (int cp = 0; cp < (COUT + 1) / 2; ++cp) {
+            const int tt = cp >> 1, hh = cp & 1;
+            auto M = [&](int p) { return (f32x2){acc[p][tt][2 * hh], acc[p][tt][2 * hh + 1]}; };
+            f32x2 s0[4], s1[4];
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
-                const float m0 = acc[x][tt][qq], m1 = acc[4 + x][tt][qq], m2 = acc[8 + x][tt][qq], m3 = acc[12 + x][tt][qq];
+                const f32x2 m0 = M(x), m1 = M(4 + x), m2 = M(8 + x), m3 = M(12 + x);
                 s0[x] = (m0 + m1) + m2;
                 s1[x] = (m1 - m2) - m3;
             }
-            float o[2][2] = {{(s0[0] + s0[1]) + s0[2], (s0[1] - s0[2]) - s0[3]}, {(s1[0] + s1[1]) + s1[2], (s1[1] - s1[2]) - s1[3]}};
-            const float exv[2][2] = {{MODE == 2 ? ex0[co].x : 0.f, MODE == 2 ? ex0[co].y : 0.f},
-                                     {MODE == 2 ? ex1[co].x : 0.f, MODE == 2 ? ex1[co].y : 0.f}};
+            const f32x2 t00 = (s0[0] + s0[1]) + s0[2], t01 = (s0[1] - s0[2]) - s0[3];
+            const f32x2 t10 = (s1[0] + s1[1]) + s1[2], t11 = (s1[1] - s1[2]) - s1[3];
 #pragma unroll
-            for (int y = 0; y < 2; ++y)
+            for (int e = 0; e < 2; ++e) {
+                const int co = 2 * cp + e;
+                if (co >= COUT) continue;
+                float o[2][2] = {{t00[e], t01[e]}, {t10[e], t11[e]}};
+                const float exv[2][2] = {{MODE == 2 ? ex0[co].x : 0.f, MODE == 2 ? ex0[co].y : 0.f},
+                                         {MODE == 2 ? ex1[co].x : 0.f, MODE == 2 ? ex1[co].y : 0.f}};
 #pragma unroll
-                for (int x = 0; x < 2; ++x) {
-                    if (MODE == 0) {
-                        o[y][x] += a.pk[bf_off(K) + co];
-                        o[y][x] = o[y][x] > 0.f ? o[y][x] : 0.1f * o[y][x];
-                    } else {
-                        o[y][x] *= exv[y][x] > 0.f ? 1.f : 0.1f;
+                for (int y = 0; y < 2; ++y)
+#pragma unroll
+                    for (int x = 0; x < 2; ++x) {
+                        if (MODE == 0) {
+                            o[y][x] += a.pk[bf_off(K) + co];
+                            o[y][x] = o[y][x] > 0.f ? o[y][x] : 0.1f * o[y][x];
+                        } else {
+                            o[y][x] *= exv[y][x] > 0.f ? 1.f : 0.1f;
+                        }
                     }
+                // (ablate 8: the arithmetic without the stores.  Measured and not kept: the results held in registers and stored a
+                // few channels per chunk of the NEXT tile -- no gain without spills, a loss with them: the stores' cost is their HBM
+                // traffic, not the moment of their issue)
+                float* op = (MODE == 0 ? a.feat_out : a.gbuf) + ((size_t)n * NFEAT + (yoff(K) - NIN) + co) * HW;
+                const bool st = !(ra.ablate & 2) && (!(ra.ablate & 8) || o[0][0] == 1.2345678e33f);
+                if (st) {
+                    if (ok0) *reinterpret_cast<float2*>(op + pix0) = make_float2(o[0][0], o[0][1]);
+                    if (ok1) *reinterpret_cast<float2*>(op + pix1) = make_float2(o[1][0], o[1][1]);
                 }
-            // (ablate 8: the arithmetic without the stores.  Measured and not kept: the results held in registers and stored a few
-            // channels per chunk of the NEXT tile -- no gain without spills, a loss with them: the stores' cost is their HBM
-            // traffic, not the moment of their issue)
-            float* op = (MODE == 0 ? a.feat_out : a.gbuf) + ((size_t)n * NFEAT + (yoff(K) - NIN) + co) * HW;
-            const bool st = !(ra.ablate & 2) && (!(ra.ablate & 8) || o[0][0] == 1.2345678e33f);
-            if (st) {
-                if (ok0) *reinterpret_cast<float2*>(op + pix0) = make_float2(o[0][0], o[0][1]);
-                if (ok1) *reinterpret_cast<float2*>(op + pix1) = make_float2(o[1][0], o[1][1]);
             }
         }
 #pragma unroll
