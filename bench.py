@@ -479,6 +479,9 @@ def main():
                        "global_batch": world * args.batch, "num_class": args.num_class,
                        "parallelism": "dp%d" % world, "final_loss": round(loss, 6),
                        **({"options": args.option} if args.option else {}),
+                       "generator_kernels": ("libdmcnet_hip gen_tiny / gen_x3: fp32 4x4x1-MFMA ring kernels; forward layer mask on gen_x3 (bf16x3) %d; "
+                                             "Winograd F(2x2,3x3) ring kernel mask %#x (bit K: forward layer K, bit 8 + K: data-gradient group K; fp32)"
+                                             % (dmcnet_amd._lib.load().dmc_get_option(b"gen_x3"), dmcnet_amd._lib.load().dmc_get_option(b"gen_wino"))),
                        "classifier_convs": (("libdmcnet_hip conv_x3s (3x3 stride 1) + conv_x3q (the stride-2 blocks: 3x3 stride 2 fused with "
                                              "the 1x1 shortcut on space-to-depth slice tensors): every operand pre-split into "
                                              "bf16x3 slice tensors by its producer, " if ops.X3Q else
