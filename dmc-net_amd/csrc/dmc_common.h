@@ -50,7 +50,7 @@ struct LdsLimit {
 // A/B measurements; the defaults are the fastest measured path.  They are relaxed atomics read
 // once per entry-point call -- the only process-wide state of the library.
 enum Option { OPT_GEN_LAYER_PATH = 0, OPT_GEN_GATHER, OPT_GEN_FUSE45, OPT_GEN_WGRAD_PATH, OPT_GEN_FUSE_FWD,
-              OPT_GEN_FUSE_BWD, OPT_GEN_FRAMES, OPT_CONV_PATH, OPT_CONV_CFG, OPT_CONV_ABLATE, OPT_GEN_ABLATE, OPT_CONV_ARITH, OPT_CONV3D_WGRAD, OPT_GEN_X3, OPT_GEN_WINO, OPT_GEN_STAGGER, OPT_COUNT };
+              OPT_GEN_FUSE_BWD, OPT_GEN_FRAMES, OPT_CONV_PATH, OPT_CONV_CFG, OPT_CONV_ABLATE, OPT_GEN_ABLATE, OPT_CONV_ARITH, OPT_CONV3D_WGRAD, OPT_GEN_X3, OPT_GEN_WINO, OPT_GEN_STAGGER, OPT_GEN_FUSED, OPT_COUNT };
 int option(Option o);
 
 // ---- EstimatorDenseNetTiny geometry (code/dmcnet/model.py:172-194) --------------------------

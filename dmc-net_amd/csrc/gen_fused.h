@@ -1,0 +1,16 @@
+// EstimatorDenseNetTiny forward as ONE launch (gen_fused.hip): interface to gen_tiny.hip.
+#pragma once
+#include "dmc_common.h"
+
+namespace dmc {
+
+// shapes the fused forward serves: any H, W <= 224 (one strip up to 118 columns, two strips above)
+bool gen_fused_supported(int H, int W);
+// upper bound of the per-wave loss partials one launch writes (doubles)
+int gen_fused_max_partials();
+// out = predict_flow(...) [+ mv]; feat ([N][28][H][W], may be null: inference, nothing saved) receives y0 .. y4;
+// flow != null: sum((out - flow)^2) per wave into mse_part[0 .. *nparts)
+int gen_fused_fwd(const float* mv, const float* res, float* feat, float* out, const float* pk, const float* flow,
+                  double* mse_part, int* nparts, int N, int H, int W, int add_mv, hipStream_t s);
+
+}  // namespace dmc

@@ -11,6 +11,7 @@
 
 #include "dmc_common.h"
 #include "gen_x3.h"
+#include "gen_fused.h"
 
 using namespace dmc;
 
@@ -2436,7 +2437,7 @@ size_t dmc_gen_tiny_partials_bytes(int N, int H, int W) {
 }
 
 // flow != null: also reduce sum((out - flow)^2) into mse_part (the fused kernel's epilogue); *fused_wgs receives
-// the number of workgroups that wrote partials, 0 if the shape took a path without the fused epilogue
+// the number of partials written, 0 if the shape took a path without the fused epilogue
 static int gen_tiny_fwd_impl(const float* mv, const float* res, const float* const* w,
                              const float* const* b, float* out, float* saved, float* workspace, int N,
                              int H, int W, int add_mv_delta, const float* flow, double* mse_part, int* fused_wgs,
@@ -2445,6 +2446,14 @@ static int gen_tiny_fwd_impl(const float* mv, const float* res, const float* con
         return fail(DMC_E_INVALID, "dmc_gen_tiny_fwd: null pointer");
     if (N <= 0 || H <= 0 || W <= 0) return fail(DMC_E_INVALID, "dmc_gen_tiny_fwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
+    if (fused_wgs) *fused_wgs = 0;
+    // option gen_fused (default): the whole forward as ONE launch (gen_fused.hip: line-buffered in LDS, layers pipelined
+    // across waves); the layer-by-layer kernels below serve wider images and the A/B options
+    if (option(OPT_GEN_FUSED) && gen_fused_supported(H, W)) {
+        int rc = pack(w, b, workspace, s);
+        if (rc) return rc;
+        return gen_fused_fwd(mv, res, saved, out, workspace, flow, mse_part, fused_wgs, N, H, W, add_mv_delta, s);
+    }
     int x3mask = option(OPT_GEN_X3);
     for (int K = 0; K < GX_LAYERS; ++K)
         if (!gen_x3_supported(K, H, W)) x3mask &= ~(1 << K);
@@ -2485,7 +2494,7 @@ static int gen_tiny_fwd_impl(const float* mv, const float* res, const float* con
             const int wgs = ra.ntiles < num_cus() ? ra.ntiles : num_cus();
             if (flow && mse_part && step >= N) {              // (one pass over all frames: one partial set)
                 ra.a.mse_flow = flow; ra.a.mse_part = mse_part;
-                if (fused_wgs) *fused_wgs = wgs;
+                if (fused_wgs) *fused_wgs = wgs * P_CONS;
             }
             gen_l45_kernel<<<wgs, LTHREADS, 0, s>>>(ra);
             if ((rc = check_launch("gen_l45"))) return rc;
@@ -2505,7 +2514,8 @@ int dmc_gen_tiny_fwd(const float* mv, const float* res, const float* const* w,
 }
 
 size_t dmc_gen_tiny_mse_partials_bytes(void) {
-    const size_t fused = (size_t)num_cus() * P_CONS * sizeof(double), plain = dmc_flow_mse_partials_bytes();
+    const int fparts = num_cus() * P_CONS > gen_fused_max_partials() ? num_cus() * P_CONS : gen_fused_max_partials();
+    const size_t fused = (size_t)fparts * sizeof(double), plain = dmc_flow_mse_partials_bytes();
     return fused > plain ? fused : plain;
 }
 
@@ -2520,8 +2530,7 @@ int dmc_gen_tiny_fwd_mse(const float* mv, const float* res, const float* const* 
     const size_t numel = (size_t)N * 2 * H * W;
     if (wgs == 0)       // this shape took a path without the fused epilogue: the streaming reduction instead
         return dmc_flow_mse_fwd(out, flow, loss_out, static_cast<float*>(mse_partials), numel, stream);
-    gen_mse_final_kernel<<<1, 256, 0, (hipStream_t)stream>>>(static_cast<const double*>(mse_partials), wgs * P_CONS,
-                                                            loss_out, (double)numel);
+    gen_mse_final_kernel<<<1, 256, 0, (hipStream_t)stream>>>(static_cast<const double*>(mse_partials), wgs, loss_out, (double)numel);
     return check_launch("gen_mse_final");
 }
 
