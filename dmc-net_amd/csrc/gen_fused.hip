@@ -73,7 +73,33 @@ struct FusedArgs {
     int H, W, add_mv;
     int nstrips, sw, m;   // strips per frame; strip width in LDS columns; first image column the second strip owns
     int nitems;           // N * nstrips
+#ifdef DMC_MEASURE
+    unsigned long long* prof;     // [gridDim.x][12 waves][4]: busy clocks, total clocks, HW_ID, steps (tools/ubench/gen_fused_prof.hip)
+#endif
 };
+
+#if defined(DMC_MEASURE) && !defined(FZ_NOPROF)
+struct FzProf {
+    unsigned long long busy = 0, t_first = 0, t_mark = 0, steps = 0;
+    __device__ __forceinline__ void begin() { t_mark = __builtin_amdgcn_s_memtime(); if (!t_first) t_first = t_mark; }
+    __device__ __forceinline__ void end() { busy += __builtin_amdgcn_s_memtime() - t_mark; ++steps; }
+    __device__ __forceinline__ void flush(const FusedArgs& a, int wave, int lane) {
+        if (!a.prof || lane) return;
+        unsigned long long* q = a.prof + ((size_t)blockIdx.x * 12 + wave) * 4;
+        q[0] = busy; q[1] = __builtin_amdgcn_s_memtime() - t_first; q[2] = __builtin_amdgcn_s_getreg(4 | (31 << 11)); q[3] = steps;
+    }
+};
+#else
+struct FzProf {
+    __device__ __forceinline__ void begin() {}
+    __device__ __forceinline__ void end() {}
+    __device__ __forceinline__ void flush(const FusedArgs&, int, int) {}
+};
+#endif
+
+// steps per strip: H + 11 (the last output row leaves layer 5 in step H + 10), rounded up to whole phase triples; the
+// extra steps find every row out of range and only meet the barrier
+__device__ __forceinline__ int fz_steps(int H) { return (H + FZ_LAG + 1 + 2) / 3 * 3; }
 
 // one strip of one frame, as a workgroup sees it
 struct Strip {
@@ -81,6 +107,23 @@ struct Strip {
     int c0;               // image column of LDS column 0
     int v0, v1;           // LDS columns [v0, v1) are this strip's to store
 };
+
+// global access = scalar plane base + 32-bit BYTE offset per lane (the form the saddr encodings take: no 64-bit vector adds).
+// The plane base passes through readfirstlane: opaque to the reassociation that would otherwise fold it into per-lane
+// 64-bit adds; the rebuilt pointer is given the global address space explicitly (a generic one would become flat_*).
+typedef __attribute__((address_space(1))) float gfloat;
+__device__ __forceinline__ gfloat* scalar_plane(const float* p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned long long r = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                                 (unsigned)__builtin_amdgcn_readfirstlane((int)u);
+    return (gfloat*)r;
+}
+__device__ __forceinline__ void store_at(float* plane, unsigned byte_off, float v) {
+    *(gfloat*)((__attribute__((address_space(1))) char*)scalar_plane(plane) + byte_off) = v;
+}
+__device__ __forceinline__ float load_at(const float* plane, unsigned byte_off) {
+    return *(const gfloat*)((const __attribute__((address_space(1))) char*)scalar_plane(plane) + byte_off);
+}
 
 __device__ __forceinline__ float dpp_shr0(float cur) {      // lane i <- cur[i-1]; lane 0 <- 0
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cur), 0x138, 0xf, 0xf, false));
@@ -91,34 +134,54 @@ __device__ __forceinline__ float dpp_shl0(float cur) {      // lane i <- cur[i+1
 // end-of-step barrier: LDS traffic drained, global stores left in flight
 __device__ __forceinline__ void step_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int T, int NT, int NA>
-struct TileLoop {
-    static __device__ __forceinline__ void run(f32x4 (&acc)[NT], const float (&a)[NA], float b) {
-        acc[T] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[T / 16], b, acc[T], 4, T % 16, 0);
-        TileLoop<T + 1, NT, NA>::run(acc, a, b);
-    }
-};
-template <int NT, int NA>
-struct TileLoop<NT, NT, NA> {
-    static __device__ __forceinline__ void run(f32x4 (&)[NT], const float (&)[NA], float) {}
-};
-
 // what a wave knows about its pixel half
 struct Half {
     int col;              // LDS column of this lane
+    unsigned ucol;        // the same, unsigned: global accesses take a scalar row base + this 32-bit lane offset
     bool own;             // this lane's column is one the half produces
     bool store;           // ... and one the strip stores to HBM
 };
 
 // ------------------------------------------------------------------------------------------------------------
 // Layer K as a wave sees it: weights and accumulators in registers, one step() per image row.
+//
+// Accumulator rows are (set, dx, co).  Where a set (3 Cout rows) is a whole number of 4-row tiles (Cout 8 and 4) the three
+// sets ROTATE BY RENAMING: in phase J = step mod 3 the set that receives tap dy is physical set (J - dy) mod 3, the step
+// code exists three times and no accumulator ever moves.  Otherwise (Cout 6, 2) the rows stay flat (dy, dx, co) and are
+// shifted by 3 Cout rows with register moves after each step.  A set starts its life with the first MFMA of a step taking
+// a ZERO C operand (whole fresh tiles; the rows of a shared tile are zeroed by the shift), the bias joins in the epilogue.
 // ------------------------------------------------------------------------------------------------------------
 template <int K>
-struct FzLayer {
+struct FzG {
     static constexpr int CIN = cin_of(K), C = cout_of(K), NROW = 9 * C, NT = (NROW + 3) / 4, NA = (NT + 15) / 16;
+    static constexpr bool ROT = (3 * C) % 4 == 0;
+    static constexpr int TPS = 3 * C / 4;              // ROT: tiles per set; flat: whole tiles at the head of set 0
+    static constexpr int OLD = K == 0 ? 0 : yoff(K - 1);   // input channels [0, OLD) were complete a step ago: prefetched across the barrier
+};
+
+template <int K, int J, int T, bool FIRST>
+struct FzTiles {
+    using G = FzG<K>;
+    static __device__ __forceinline__ void run(f32x4 (&acc)[G::NT], const float (&a)[G::NA], float b) {
+        constexpr int dy = G::ROT ? T / G::TPS : 0;
+        constexpr int P = G::ROT ? ((J + 3 - dy) % 3) * G::TPS + T % G::TPS : T;
+        constexpr bool fresh = FIRST && (G::ROT ? dy == 0 : T < G::TPS);
+        if constexpr (fresh) acc[P] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[T / 16], b, (f32x4){0.f, 0.f, 0.f, 0.f}, 4, T % 16, 0);
+        else acc[P] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[T / 16], b, acc[P], 4, T % 16, 0);
+        if constexpr (T + 1 < G::NT) FzTiles<K, J, T + 1, FIRST>::run(acc, a, b);
+    }
+};
+
+template <int K>
+struct FzLayer {
+    using G = FzG<K>;
+    static constexpr int CIN = G::CIN, C = G::C, NROW = G::NROW, NT = G::NT, NA = G::NA, OLD = G::OLD;
     float A[CIN][NA];                 // lane 4 t' + i of A[ci][a]: row 4 (16 a + t') + i = (dy, dx, co) of input channel ci
-    f32x4 acc[NT];                    // flat rows (dy, dx, co); element [r / 4][r % 4], one pixel per lane
+    f32x4 acc[NT];                    // one pixel per lane
+    float b[CIN];                     // the step's B operands (channels [0, OLD) requested before the previous barrier)
+    float bias[C];
     double sq;                        // K == 5: sum of squared differences to the flow target
+    static constexpr bool ROT = G::ROT;
 
     __device__ __forceinline__ void load_weights(const float* __restrict__ pk, int lane) {
 #pragma unroll
@@ -129,81 +192,189 @@ struct FzLayer {
                 const int dy = r / (3 * C), dx = (r / C) % 3, co = r % C;
                 A[ci][a] = r < NROW ? pk[wf_off(K) + (ci * 9 + dy * 3 + dx) * C + co] : 0.f;
             }
-    }
-    // accumulator set dy starts as the bias in its centre-tap rows
-    __device__ __forceinline__ void init_set(const float* __restrict__ pk, int dy) {
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-            for (int co = 0; co < C; ++co) {
-                const int r = dy * 3 * C + dx * C + co;
-                acc[r / 4][r % 4] = dx == 1 ? pk[bf_off(K) + co] : 0.f;
-            }
+        for (int co = 0; co < C; ++co) bias[co] = pk[bf_off(K) + co];
     }
-    __device__ __forceinline__ void reset(const float* __restrict__ pk) {
+    __device__ __forceinline__ void reset() {
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        init_set(pk, 0); init_set(pk, 1); init_set(pk, 2);
     }
-
-    // step t of the strip: consume input row t - 2K, complete output row t - 2K - 1
-    __device__ __forceinline__ void step(const FusedArgs& a, const Strip& st, const Half& h, float* lds, int t) {
-        const int i = t - 2 * K, o = i - 1;
-        const bool emit = o >= 0 && o < a.H;
-        const size_t HW = (size_t)a.H * a.W;
-        // layer 5: the delta input and the flow target of the row it completes, requested ahead of the MFMAs
-        float mvv[2] = {0.f, 0.f}, flw[2] = {0.f, 0.f};
-        if (K == NL - 1 && emit && h.store) {
-            const size_t px = (size_t)o * a.W + st.c0 + h.col;
-#pragma unroll
-            for (int co = 0; co < 2; ++co) {
-                if (a.add_mv) mvv[co] = a.mv[((size_t)st.n * 2 + co) * HW + px];
-                if (a.flow) flw[co] = a.flow[((size_t)st.n * 2 + co) * HW + px];
-            }
-        }
-        if (i >= 0 && i < a.H) {
+    // B operands of input row i, channels [C0, C1)
+    template <int C0, int C1>
+    __device__ __forceinline__ void load_b(const float* lds, int col, int i) {
+        if constexpr (C0 < C1) {
             const float* pg[K + 1];
 #pragma unroll
-            for (int g = 0; g <= K; ++g) pg[g] = lds + fz_base(g) + (i % fz_len(g)) * (fz_planes(g) * FZ_RS) + h.col;
-            float b[CIN];
+            for (int g = fz_group_of(C0); g <= fz_group_of(C1 - 1); ++g)
+                pg[g] = lds + fz_base(g) + (i % fz_len(g)) * (fz_planes(g) * FZ_RS) + col;
 #pragma unroll
-            for (int ci = 0; ci < CIN; ++ci) b[ci] = pg[fz_group_of(ci)][fz_plane_of(ci) * FZ_RS];
-#pragma unroll
-            for (int ci = 0; ci < CIN; ++ci) TileLoop<0, NT, NA>::run(acc, A[ci], b[ci]);
+            for (int ci = C0; ci < C1; ++ci) b[ci] = pg[fz_group_of(ci)][fz_plane_of(ci) * FZ_RS];
         }
-        if (emit) {
-            float* ring = lds + h.col;
-            if constexpr (K < NL - 1) ring += fz_base(K + 1) + (o % fz_len(K + 1)) * (C * FZ_RS);
+    }
+    // requested before the barrier that opens step t: the B operands whose rows are already complete and, for layer 5, the
+    // delta input and the flow target of the row that step completes (a global load takes about a step under load)
+    float mvv[2], flw[2];
+    __device__ __forceinline__ void prefetch(const FusedArgs& a, const Strip& st, const Half& h, const float* lds, int t) {
+        const int i = t - 2 * K, o = i - 1;
+        if (i >= 0 && i < a.H) load_b<0, OLD>(lds, h.col, i);
+        if constexpr (K == NL - 1) {
+            mvv[0] = mvv[1] = flw[0] = flw[1] = 0.f;
+            if (o >= 0 && o < a.H && h.store) {
+                const unsigned hw = (unsigned)(a.H * a.W);
+                const size_t plane = (size_t)st.n * 2 * hw;
+                const unsigned pix = ((unsigned)(o * a.W + st.c0) + h.ucol) * 4u;
 #pragma unroll
-            for (int co = 0; co < C; ++co) {
-                constexpr int S2 = 6 * C;
-                const int r0 = S2 + co, r1 = S2 + C + co, r2 = S2 + 2 * C + co;
-                // (the shifts run with all lanes active; only the stores are masked)
-                float v = acc[r1 / 4][r1 % 4] + dpp_shr0(acc[r0 / 4][r0 % 4]) + dpp_shl0(acc[r2 / 4][r2 % 4]);
-                if constexpr (K < NL - 1) {
-                    v = v > 0.f ? v : 0.1f * v;
-                    if (h.own) ring[co * FZ_RS] = v;
-                    if (h.store && a.feat)
-                        a.feat[((size_t)st.n * NFEAT + (yoff(K) - NIN) + co) * HW + (size_t)o * a.W + st.c0 + h.col] = v;
-                } else {
-                    v += mvv[co];
-                    if (h.store) {
-                        a.out[((size_t)st.n * 2 + co) * HW + (size_t)o * a.W + st.c0 + h.col] = v;
-                        if (a.flow) { const float d = v - flw[co]; sq += (double)d * (double)d; }
-                    }
+                for (int co = 0; co < 2; ++co) {
+                    if (a.add_mv) mvv[co] = load_at(a.mv + plane + co * hw, pix);
+                    if (a.flow) flw[co] = load_at(a.flow + plane + co * hw, pix);
                 }
             }
         }
-        // S_2 <- S_1 <- S_0 <- bias
+    }
+
+    // step t of the strip (phase J = t mod 3 for the rotating layers): consume input row t - 2K, complete output row t - 2K - 1
+    template <int J>
+    __device__ __forceinline__ void step(const FusedArgs& a, const Strip& st, const Half& h, float* lds, int t) {
+        const int i = t - 2 * K, o = i - 1;
+        const bool emit = o >= 0 && o < a.H;
+        if (i >= 0 && i < a.H) {
+            load_b<OLD, CIN>(lds, h.col, i);
+            FzTiles<K, J, 0, true>::run(acc, A[0], b[0]);
 #pragma unroll
-        for (int r = NROW - 1; r >= 3 * C; --r) acc[r / 4][r % 4] = acc[(r - 3 * C) / 4][(r - 3 * C) % 4];
-        init_set(a.pk, 0);
+            for (int ci = 1; ci < CIN; ++ci) FzTiles<K, J, 0, false>::run(acc, A[ci], b[ci]);
+        } else {
+            // nothing enters the fresh set: it is zero
+#pragma unroll
+            for (int j = 0; j < G::TPS; ++j) acc[(G::ROT ? (J % 3) * G::TPS : 0) + j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (emit) {
+            constexpr int S2 = G::ROT ? ((J + 1) % 3) * 3 * C : 6 * C;            // the set that has seen all three taps
+            float v[C];
+#pragma unroll
+            for (int co = 0; co < C; ++co) {
+                const int r0 = S2 + co, r1 = S2 + C + co, r2 = S2 + 2 * C + co;
+                // (the shifts run with all lanes active; only the stores are masked)
+                v[co] = acc[r1 / 4][r1 % 4] + dpp_shr0(acc[r0 / 4][r0 % 4]);
+                v[co] += dpp_shl0(acc[r2 / 4][r2 % 4]);
+                v[co] += bias[co];
+                if constexpr (K < NL - 1) v[co] = fmaxf(v[co], 0.1f * v[co]);     // LeakyReLU(0.1)
+                else v[co] += mvv[co];
+            }
+            // (uniform row pointers: the stores take a scalar base and one 32-bit lane offset)
+            // (scalar plane bases that do not change with the step + one 32-bit lane offset that does)
+            const unsigned hw = (unsigned)(a.H * a.W), pix = ((unsigned)(o * a.W + st.c0) + h.ucol) * 4u;
+            if constexpr (K < NL - 1) {
+                if (h.own) {
+                    float* ring = lds + fz_base(K + 1) + (o % fz_len(K + 1)) * (C * FZ_RS) + h.col;
+#pragma unroll
+                    for (int co = 0; co < C; ++co) ring[co * FZ_RS] = v[co];
+                }
+                if (h.store && a.feat) {
+                    float* plane = a.feat + ((size_t)st.n * NFEAT + (yoff(K) - NIN)) * hw;
+#pragma unroll
+                    for (int co = 0; co < C; ++co) store_at(plane + co * hw, pix, v[co]);
+                }
+            } else if (h.store) {
+                float* plane = a.out + (size_t)st.n * 2 * hw;
+#pragma unroll
+                for (int co = 0; co < C; ++co) {
+                    store_at(plane + co * hw, pix, v[co]);
+                    if (a.flow) { const float d = v[co] - flw[co]; sq += (double)d * (double)d; }
+                }
+            }
+        }
+        if constexpr (!G::ROT) {
+            // S_2 <- S_1 <- S_0; the rows of set 0 that share a tile with set 1 restart at zero
+#pragma unroll
+            for (int r = NROW - 1; r >= 3 * C; --r) acc[r / 4][r % 4] = acc[(r - 3 * C) / 4][(r - 3 * C) % 4];
+#pragma unroll
+            for (int r = 4 * G::TPS; r < 3 * C; ++r) acc[r / 4][r % 4] = 0.f;
+        }
+        prefetch(a, st, h, lds, t + 1);
+    }
+};
+
+// Layer 0 (5 -> 8) with GATHERED vertical taps: K = (ci, dy), rows (dx, co) = 6 tiles -- the same 90 MFMAs as the push form
+// with 24 accumulator registers instead of 72 and nothing to rotate, so that it can share a wave with another layer.
+// Output row t - 1 reads input rows t - 2 .. t (the row the staging wave delivered before this step's opening barrier).
+template <>
+struct FzLayer<0> {
+    static constexpr int CIN = NIN, C = 8, NT = 6;
+    static constexpr bool ROT = false;
+    float A[CIN * 3];                 // lane 4 t + i of A[ci * 3 + dy]: row 4 t + i = (dx, co)
+    f32x4 acc[NT];
+    float bias[C];
+    double sq;
+
+    __device__ __forceinline__ void load_weights(const float* __restrict__ pk, int lane) {
+#pragma unroll
+        for (int q = 0; q < CIN * 3; ++q) {
+            const int r = lane, dx = r / C, co = r % C;
+            A[q] = r < 3 * C ? pk[wf_off(0) + ((q / 3) * 9 + (q % 3) * 3 + dx) * C + co] : 0.f;
+        }
+#pragma unroll
+        for (int co = 0; co < C; ++co) bias[co] = pk[bf_off(0) + co];
+    }
+    __device__ __forceinline__ void reset() {}
+    __device__ __forceinline__ void prefetch(const FusedArgs&, const Strip&, const Half&, const float*, int) {}
+
+    template <int T, bool FRESH>
+    __device__ __forceinline__ void tiles(float a, float b) {
+        if constexpr (FRESH) acc[T] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, (f32x4){0.f, 0.f, 0.f, 0.f}, 4, T, 0);
+        else acc[T] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc[T], 4, T, 0);
+        if constexpr (T + 1 < NT) tiles<T + 1, FRESH>(a, b);
+    }
+    template <int DY, bool FRESH>
+    __device__ __forceinline__ void tap_row(const float (&b)[3][CIN]) {
+        tiles<0, FRESH>(A[DY], b[DY][0]);
+#pragma unroll
+        for (int ci = 1; ci < CIN; ++ci) tiles<0, false>(A[ci * 3 + DY], b[DY][ci]);
+    }
+    template <int J>
+    __device__ __forceinline__ void step(const FusedArgs& a, const Strip& st, const Half& h, float* lds, int t) {
+        const int o = t - 1;
+        if (o < 0 || o >= a.H) return;
+        // all fifteen operands first (a row outside the image is read from the nearest one inside and not used)
+        float b[3][CIN];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            int r = o + dy - 1;
+            r = r < 0 ? 0 : r >= a.H ? a.H - 1 : r;
+            const float* p = lds + fz_base(0) + (r % fz_len(0)) * (NIN * FZ_RS) + h.col;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) b[dy][ci] = p[ci * FZ_RS];
+        }
+        __builtin_amdgcn_sched_barrier(0);           // (the compiler otherwise sinks each read to its MFMA, one exposed LDS latency per pair)
+        tap_row<1, true>(b);
+        if (o >= 1) tap_row<0, false>(b);
+        if (o + 1 < a.H) tap_row<2, false>(b);
+        float v[C];
+#pragma unroll
+        for (int co = 0; co < C; ++co) {
+            const int r0 = co, r1 = C + co, r2 = 2 * C + co;
+            v[co] = acc[r1 / 4][r1 % 4] + dpp_shr0(acc[r0 / 4][r0 % 4]);
+            v[co] += dpp_shl0(acc[r2 / 4][r2 % 4]);
+            v[co] += bias[co];
+            v[co] = fmaxf(v[co], 0.1f * v[co]);
+        }
+        if (h.own) {
+            float* ring = lds + fz_base(1) + (o % fz_len(1)) * (C * FZ_RS) + h.col;
+#pragma unroll
+            for (int co = 0; co < C; ++co) ring[co * FZ_RS] = v[co];
+        }
+        if (h.store && a.feat) {
+            const unsigned hw = (unsigned)(a.H * a.W), pix = ((unsigned)(o * a.W + st.c0) + h.ucol) * 4u;
+            float* plane = a.feat + (size_t)st.n * NFEAT * hw;
+#pragma unroll
+            for (int co = 0; co < C; ++co) store_at(plane + co * hw, pix, v[co]);
+        }
     }
 };
 
 __device__ __forceinline__ Strip strip_of(const FusedArgs& a, int item) {
     Strip st;
-    st.n = item / a.nstrips;
+    // (readfirstlane: the division runs on the vector unit; everything derived from the frame index should be scalar again)
+    st.n = __builtin_amdgcn_readfirstlane(item / a.nstrips);
     const int s = item - st.n * a.nstrips;
     if (a.nstrips == 1) { st.c0 = 0; st.v0 = 0; st.v1 = a.W; }
     else if (s == 0) { st.c0 = 0; st.v0 = 0; st.v1 = a.m; }
@@ -218,34 +389,55 @@ __device__ __forceinline__ Half half_of(const FusedArgs& a, const Strip& st, int
     Half h;
     h.col = hf == 0 ? lane : a.sw - 62 + lane;
     if (a.sw <= 62 && hf == 1) h.col = lane;                 // (idle half: reads valid LDS, produces nothing)
+    h.ucol = (unsigned)h.col;
     h.own = hf == 0 ? h.col < ha : (a.sw > 62 && h.col >= ha && h.col < a.sw);
     h.store = h.own && h.col >= st.v0 && h.col < st.v1;
     return h;
 }
 
-// a wave that runs layer KA (and, when KB >= 0, layer KB after it) on pixel half hf
+// a wave that runs layer KA on pixel half hf (and, when KB >= 0, layer KB on half hfb after it)
 template <int KA, int KB>
-__device__ __forceinline__ void run_layers(const FusedArgs& a, float* lds, int hf, int lane) {
+__device__ __forceinline__ void run_layers(const FusedArgs& a, float* lds, int hf, int hfb, int lane, int wave) {
+    FzProf prof;
     FzLayer<KA> la;
     FzLayer<(KB >= 0 ? KB : 0)> lb;
     la.load_weights(a.pk, lane);
     la.sq = 0.0;
     if (KB >= 0) { lb.load_weights(a.pk, lane); lb.sq = 0.0; }
-    const int steps = a.H + FZ_LAG + 1;
+    const int steps = fz_steps(a.H);
 #pragma unroll 1
     for (int item = blockIdx.x; item < a.nitems; item += gridDim.x) {
         const Strip st = strip_of(a, item);
-        const Half h = half_of(a, st, hf, lane);
-        la.reset(a.pk);
-        if (KB >= 0) lb.reset(a.pk);
+        const Half h = half_of(a, st, hf, lane), hb = half_of(a, st, hfb, lane);
+        la.reset();
+        if (KB >= 0) lb.reset();
         step_barrier();                                        // input row 0 is staged
+        la.prefetch(a, st, h, lds, 0);
+        if (KB >= 0) lb.prefetch(a, st, hb, lds, 0);
+        if constexpr (KB < 0 && FzLayer<KA>::ROT) {
+            // a rotating layer: three steps per trip, one per phase (straight-line code: the accumulators never meet a phi)
 #pragma unroll 1
-        for (int t = 0; t < steps; ++t) {
-            la.step(a, st, h, lds, t);
-            if (KB >= 0) lb.step(a, st, h, lds, t);
-            step_barrier();
+            for (int t = 0; t < steps; t += 3) {
+                prof.begin(); la.template step<0>(a, st, h, lds, t); prof.end();
+                step_barrier();
+                prof.begin(); la.template step<1>(a, st, h, lds, t + 1); prof.end();
+                step_barrier();
+                prof.begin(); la.template step<2>(a, st, h, lds, t + 2); prof.end();
+                step_barrier();
+            }
+        } else {
+            static_assert(KB < 0 || (!FzLayer<KA>::ROT && !FzLayer<(KB >= 0 ? KB : 0)>::ROT), "a rotating layer has its wave to itself");
+#pragma unroll 1
+            for (int t = 0; t < steps; ++t) {
+                prof.begin();
+                la.template step<0>(a, st, h, lds, t);
+                if (KB >= 0) lb.template step<0>(a, st, hb, lds, t);
+                prof.end();
+                step_barrier();
+            }
         }
     }
+    prof.flush(a, wave, lane);
     if (KA == NL - 1 && a.flow) {
         double s = la.sq;
 #pragma unroll
@@ -254,13 +446,15 @@ __device__ __forceinline__ void run_layers(const FusedArgs& a, float* lds, int h
     }
 }
 
-// the staging wave: input row t + 1 of the five input planes -> ring group 0, during step t
-__device__ __forceinline__ void run_loader(const FusedArgs& a, float* lds, int lane) {
-    const int steps = a.H + FZ_LAG + 1;
+// the staging wave: input row t + 1 of the five input planes -> ring group 0 during step t; its global loads were issued
+// a step earlier (the values wait in registers across the barrier)
+__device__ __forceinline__ void run_loader(const FusedArgs& a, float* lds, int lane, int wave) {
+    FzProf prof;
+    const int steps = fz_steps(a.H);
     const size_t HW = (size_t)a.H * a.W;
-    auto stage = [&](const Strip& st, int row) {
+    float v[NIN][2];
+    auto request = [&](const Strip& st, int row) {
         if (row >= a.H) return;
-        float v[NIN][2];
 #pragma unroll
         for (int p = 0; p < NIN; ++p) {
             const float* src = (p < 2 ? a.mv + ((size_t)st.n * 2 + p) * HW : a.res + ((size_t)st.n * 3 + (p - 2)) * HW) +
@@ -271,6 +465,9 @@ __device__ __forceinline__ void run_loader(const FusedArgs& a, float* lds, int l
                 v[p][q] = col < a.sw ? src[col] : 0.f;
             }
         }
+    };
+    auto park = [&](int row) {
+        if (row >= a.H) return;
         float* dst = lds + fz_base(0) + (row % fz_len(0)) * (NIN * FZ_RS);
 #pragma unroll
         for (int p = 0; p < NIN; ++p)
@@ -283,14 +480,20 @@ __device__ __forceinline__ void run_loader(const FusedArgs& a, float* lds, int l
 #pragma unroll 1
     for (int item = blockIdx.x; item < a.nitems; item += gridDim.x) {
         const Strip st = strip_of(a, item);
-        stage(st, 0);
+        request(st, 0);
+        park(0);
+        request(st, 1);
         step_barrier();
 #pragma unroll 1
         for (int t = 0; t < steps; ++t) {
-            stage(st, t + 1);
+            prof.begin();
+            park(t + 1);
+            request(st, t + 2);
+            prof.end();
             step_barrier();
         }
     }
+    prof.flush(a, wave, lane);
 }
 
 __global__ __launch_bounds__(FZ_THREADS) void gen_fused_kernel(FusedArgs a) {
@@ -299,20 +502,17 @@ __global__ __launch_bounds__(FZ_THREADS) void gen_fused_kernel(FusedArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int i = threadIdx.x; i < FZ_LDS; i += FZ_THREADS) lds[i] = 0.f;      // (columns >= the strip width stay zero)
     __syncthreads();
-    // wave w runs on SIMD w % 4: MFMAs per step and SIMD 588 (layer 2 twice) / 576 / 623 / 575
+    // waves w, w + 4, w + 8 share a SIMD (measured: HW_ID of tools/ubench/gen_fused_prof.hip).  Cost of a wave's step = 8 clocks per
+    // MFMA + 4 per other vector instruction (they do not overlap); per SIMD: layer 2 twice + staging / 3, 3, 4 / 1, 1, 4 / 5, 5, 0 + 0
     switch (wave) {
-        case 0: run_layers<2, -1>(a, lds, 0, lane); break;
-        case 4: run_layers<2, -1>(a, lds, 1, lane); break;
-        case 8: run_loader(a, lds, lane); break;
-        case 1: run_layers<3, -1>(a, lds, 0, lane); break;
-        case 5: run_layers<3, -1>(a, lds, 1, lane); break;
-        case 9: run_layers<0, -1>(a, lds, 0, lane); break;
-        case 2: run_layers<1, -1>(a, lds, 0, lane); break;
-        case 6: run_layers<1, -1>(a, lds, 1, lane); break;
-        case 10: run_layers<4, -1>(a, lds, 0, lane); break;
-        case 3: run_layers<5, -1>(a, lds, 0, lane); break;
-        case 7: run_layers<5, -1>(a, lds, 1, lane); break;
-        default: run_layers<4, 0>(a, lds, 1, lane); break;
+        case 0: case 4: run_layers<2, -1>(a, lds, wave >> 2, 0, lane, wave); break;
+        case 8: run_loader(a, lds, lane, wave); break;
+        case 1: case 5: run_layers<3, -1>(a, lds, wave >> 2, 0, lane, wave); break;
+        case 9: run_layers<4, -1>(a, lds, 0, 0, lane, wave); break;
+        case 2: case 6: run_layers<1, -1>(a, lds, wave >> 2, 0, lane, wave); break;
+        case 10: run_layers<4, -1>(a, lds, 1, 0, lane, wave); break;
+        case 3: case 7: run_layers<5, -1>(a, lds, wave >> 2, 0, lane, wave); break;
+        default: run_layers<0, 0>(a, lds, 0, 1, lane, wave); break;       // layer 0, both halves
     }
 }
 
@@ -328,6 +528,10 @@ int fz_num_cus() {
 }
 
 }  // namespace
+
+#ifdef DMC_MEASURE
+static unsigned long long* g_fz_prof = nullptr;      // measurement builds only (tools/ubench/gen_fused_prof.hip sets it)
+#endif
 
 namespace dmc {
 
@@ -346,6 +550,9 @@ int gen_fused_fwd(const float* mv, const float* res, float* feat, float* out, co
     if (W <= FZ_MAXSW) { a.nstrips = 1; a.sw = W; a.m = W; }
     else { a.nstrips = 2; a.m = (W + 1) / 2; a.sw = a.m + FZ_HALO; }
     a.nitems = N * a.nstrips;
+#ifdef DMC_MEASURE
+    a.prof = g_fz_prof;
+#endif
     const int wgs = a.nitems < fz_num_cus() ? a.nitems : fz_num_cus();
     if (nparts) *nparts = a.flow ? 2 * wgs : 0;
     gen_fused_kernel<<<wgs, FZ_THREADS, 0, s>>>(a);
