@@ -74,6 +74,7 @@ struct FusedArgs {
     int nstrips, sw, m;   // strips per frame; strip width in LDS columns; first image column the second strip owns
     int nitems;           // N * nstrips
 #ifdef DMC_MEASURE
+    int feat_one_frame;           // every frame's features land in frame 0's planes (isolates the cost of the store INSTRUCTIONS from HBM write traffic)
     unsigned long long* prof;     // [gridDim.x][12 waves][4]: busy clocks, total clocks, HW_ID, steps (tools/ubench/gen_fused_prof.hip)
 #endif
 };
@@ -95,6 +96,12 @@ struct FzProf {
     __device__ __forceinline__ void end() {}
     __device__ __forceinline__ void flush(const FusedArgs&, int, int) {}
 };
+#endif
+
+#ifdef DMC_MEASURE
+__device__ __forceinline__ int fz_feat_frame(const FusedArgs& a, int n) { return a.feat_one_frame ? 0 : n; }
+#else
+__device__ __forceinline__ int fz_feat_frame(const FusedArgs&, int n) { return n; }
 #endif
 
 // steps per strip: H + 11 (the last output row leaves layer 5 in step H + 10), rounded up to whole phase triples; the
@@ -270,7 +277,7 @@ struct FzLayer {
                     for (int co = 0; co < C; ++co) ring[co * FZ_RS] = v[co];
                 }
                 if (h.store && a.feat) {
-                    float* plane = a.feat + ((size_t)st.n * NFEAT + (yoff(K) - NIN)) * hw;
+                    float* plane = a.feat + ((size_t)fz_feat_frame(a, st.n) * NFEAT + (yoff(K) - NIN)) * hw;
 #pragma unroll
                     for (int co = 0; co < C; ++co) store_at(plane + co * hw, pix, v[co]);
                 }
@@ -364,7 +371,7 @@ struct FzLayer<0> {
         }
         if (h.store && a.feat) {
             const unsigned hw = (unsigned)(a.H * a.W), pix = ((unsigned)(o * a.W + st.c0) + h.ucol) * 4u;
-            float* plane = a.feat + (size_t)st.n * NFEAT * hw;
+            float* plane = a.feat + (size_t)fz_feat_frame(a, st.n) * NFEAT * hw;
 #pragma unroll
             for (int co = 0; co < C; ++co) store_at(plane + co * hw, pix, v[co]);
         }
@@ -447,35 +454,35 @@ __device__ __forceinline__ void run_layers(const FusedArgs& a, float* lds, int h
 }
 
 // the staging wave: input row t + 1 of the five input planes -> ring group 0 during step t; its global loads were issued
-// a step earlier (the values wait in registers across the barrier)
+// a step earlier (the values wait in registers across the barrier).  Branch-free: lanes beyond the strip re-read its last
+// column and do not write.
 __device__ __forceinline__ void run_loader(const FusedArgs& a, float* lds, int lane, int wave) {
     FzProf prof;
     const int steps = fz_steps(a.H);
-    const size_t HW = (size_t)a.H * a.W;
+    const unsigned hw = (unsigned)(a.H * a.W);
     float v[NIN][2];
+    const unsigned c[2] = {(unsigned)min(lane, a.sw - 1) * 4u, (unsigned)min(lane + 64, a.sw - 1) * 4u};
     auto request = [&](const Strip& st, int row) {
         if (row >= a.H) return;
+        const unsigned rowoff = (unsigned)(row * a.W + st.c0) * 4u;
 #pragma unroll
         for (int p = 0; p < NIN; ++p) {
-            const float* src = (p < 2 ? a.mv + ((size_t)st.n * 2 + p) * HW : a.res + ((size_t)st.n * 3 + (p - 2)) * HW) +
-                               (size_t)row * a.W + st.c0;
+            const float* plane = p < 2 ? a.mv + ((size_t)st.n * 2 + p) * hw : a.res + ((size_t)st.n * 3 + (p - 2)) * hw;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int col = lane + 64 * q;
-                v[p][q] = col < a.sw ? src[col] : 0.f;
-            }
+            for (int q = 0; q < 2; ++q) v[p][q] = load_at(plane, rowoff + c[q]);
         }
     };
     auto park = [&](int row) {
         if (row >= a.H) return;
-        float* dst = lds + fz_base(0) + (row % fz_len(0)) * (NIN * FZ_RS);
+        float* dst = lds + fz_base(0) + (row % fz_len(0)) * (NIN * FZ_RS) + lane;
+        if (lane < a.sw) {
 #pragma unroll
-        for (int p = 0; p < NIN; ++p)
+            for (int p = 0; p < NIN; ++p) dst[p * FZ_RS] = v[p][0];
+        }
+        if (lane + 64 < a.sw) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int col = lane + 64 * q;
-                if (col < a.sw) dst[p * FZ_RS + col] = v[p][q];
-            }
+            for (int p = 0; p < NIN; ++p) dst[p * FZ_RS + 64] = v[p][1];
+        }
     };
 #pragma unroll 1
     for (int item = blockIdx.x; item < a.nitems; item += gridDim.x) {
@@ -530,6 +537,7 @@ int fz_num_cus() {
 }  // namespace
 
 #ifdef DMC_MEASURE
+static int g_fz_feat_one_frame = 0;
 static unsigned long long* g_fz_prof = nullptr;      // measurement builds only (tools/ubench/gen_fused_prof.hip sets it)
 #endif
 
@@ -552,6 +560,7 @@ int gen_fused_fwd(const float* mv, const float* res, float* feat, float* out, co
     a.nitems = N * a.nstrips;
 #ifdef DMC_MEASURE
     a.prof = g_fz_prof;
+    a.feat_one_frame = g_fz_feat_one_frame;
 #endif
     const int wgs = a.nitems < fz_num_cus() ? a.nitems : fz_num_cus();
     if (nparts) *nparts = a.flow ? 2 * wgs : 0;

@@ -13,6 +13,16 @@ import dmcnet_amd
 from tests.test_hip_parity import CASES, DEV, checksum, rel_err, rnd, tiny_pair
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def layerwise_forward():
+    """These tests select kernels of the layer-by-layer forward: the fused one-launch forward (option gen_fused, the default) off."""
+    lib = dmcnet_amd._lib.load()
+    before = lib.dmc_get_option(b"gen_fused")
+    dmcnet_amd._lib.check(lib.dmc_set_option(b"gen_fused", 0), "dmc_set_option")
+    yield
+    dmcnet_amd._lib.check(lib.dmc_set_option(b"gen_fused", before), "dmc_set_option")
 FWD, BWD, ALL = 0x0F, 0x1F00, 0x1F0F
 
 

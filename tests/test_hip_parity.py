@@ -1047,6 +1047,8 @@ def test_generator_half_tile_variant_is_bit_identical():
     224 x 224 and an edge shape."""
     lib = dmcnet_amd._lib.load()
     before = lib.dmc_get_option(b"gen_layer_path")
+    fused_before = lib.dmc_get_option(b"gen_fused")
+    dmcnet_amd._lib.check(lib.dmc_set_option(b"gen_fused", 0), "dmc_set_option")       # (the layer-by-layer forward is what the option selects within)
     try:
         for (n, h, w) in ((5, 224, 224), (2, 70, 92)):
             torch.manual_seed(3)
@@ -1065,3 +1067,4 @@ def test_generator_half_tile_variant_is_bit_identical():
                     assert torch.equal(a, b)
     finally:
         dmcnet_amd._lib.check(lib.dmc_set_option(b"gen_layer_path", before), "dmc_set_option")
+        dmcnet_amd._lib.check(lib.dmc_set_option(b"gen_fused", fused_before), "dmc_set_option")

@@ -8,7 +8,8 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 120, H = argc > 2 ? atoi(argv[2]) : 224, W = argc > 3 ? atoi(argv[3]) : 224;
-    const int save = argc > 4 ? atoi(argv[4]) : 1;
+    const int save = argc > 4 ? atoi(argv[4]) : 1;      // 0: nothing saved; 1: features saved; 2: saved, every frame into frame 0's planes
+    g_fz_feat_one_frame = save == 2;
     const size_t HW = (size_t)H * W;
     float *mv, *res, *feat, *out, *pk, *flow; double* part;
     CK(hipMalloc(&mv, N * 2 * HW * 4)); CK(hipMalloc(&res, N * 3 * HW * 4)); CK(hipMalloc(&feat, N * NFEAT * HW * 4));
