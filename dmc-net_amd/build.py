@@ -22,8 +22,17 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=False):
-    """Compile every HIP source into dmc-net_amd/libdmcnet_hip.so; returns the path."""
+MEASURE_LIB = os.path.join(PKG, "libdmcnet_hip_measure.so")
+
+
+def build_library(force=False, verbose=False, measure=False):
+    """Compile every HIP source into dmc-net_amd/libdmcnet_hip.so; returns the path.
+
+    measure=True: the -DDMC_MEASURE build (libdmcnet_hip_measure.so) -- the only one in which the options "gen_ablate",
+    "conv_ablate" and "gen_stagger" (parts of a kernel switched off, results wrong) exist.  tools/ load it through
+    DMC_HIP_LIB; the package never does."""
+    if measure:
+        return _build_measure(verbose)
     if not force and not _stale():
         return LIB
     objs = []
@@ -48,5 +57,22 @@ def build_library(force=False, verbose=False):
     return LIB
 
 
+def _build_measure(verbose):
+    objs = []
+    for src in SOURCES:
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(CSRC, "measure_" + src.replace(".hip", ".o"))
+        objs.append(obj)
+        deps = [path, os.path.abspath(__file__)] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+        if os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
+            continue
+        cmd = [HIPCC] + FLAGS + ["-DDMC_MEASURE", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", MEASURE_LIB] + objs)
+    return MEASURE_LIB
+
+
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv, verbose=True))
+    print(build_library(force="--force" in sys.argv, verbose=True, measure="--measure" in sys.argv))

@@ -555,7 +555,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv2_kernel(ConvArgs a) {
             // remaining groups; nothing is issued, or waited for, in front of the step's first MFMA).  A
             // dedicated producer wave was measured too: its ~40 transfers per step serialise on one wave's
             // issue (60-100 cycles each) and the consumers wait at the barrier (0.29 -> 0.46 ms for layer1)
-            if (more && !(a.ablate & 1)) {
+            if (more && !(DMC_ABL(a.ablate) & 1)) {
 #pragma unroll
                 for (int j = g * ND / 4; j < (g + 1) * ND / 4; ++j) issue_one(j, buf ^ 1);
             }
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3_kernel(ConvArgs a) {
     using ISKIP = std::integral_constant<int, (NMF >= 12 ? 4 : 2)>;
 
     const int T_steps = a.ntaps * (a.Cin >> 5);
-    const bool dma_on = !(a.ablate & 1);
+    const bool dma_on = !(DMC_ABL(a.ablate) & 1);
     if (T_steps == 0) {                                    // a parity class of a strided data gradient without taps: zeros
         conv_tile_epilogue<BM, BN, WM, WN, TM, TN>(a, acc, lds3, m0, co0, wm, wn, l31, khalf, tid);
         return;
@@ -1768,8 +1768,9 @@ int launch_cfg3(const ConvArgs& a, hipStream_t s) {
     if (attr != hipSuccess) return fail(DMC_E_LAUNCH, "conv3: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
     dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN);
     if (int rc = stat_rows_ok(a, grid.x)) return rc;
+#ifdef DMC_MEASURE
     if constexpr (BM == 128 && BN == 128 && WM == 4 && WN == 2) {       // ablation variants of ONE configuration (measurement only)
-        const int abl = a.ablate & 12;
+        const int abl = DMC_ABL(a.ablate) & 12;
         if (abl) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_kernel<BM, BN, WM, WN, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_kernel<BM, BN, WM, WN, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -1780,6 +1781,7 @@ int launch_cfg3(const ConvArgs& a, hipStream_t s) {
             return check_launch("conv3 (ablation)");
         }
     }
+#endif
     conv3_kernel<BM, BN, WM, WN><<<grid, WM * WN * 64, lds_bytes, s>>>(a);
     return check_launch("conv3");
 }

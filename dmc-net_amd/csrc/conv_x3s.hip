@@ -278,7 +278,7 @@ __global__ __launch_bounds__(WM * WN * 64) void x3s_conv_kernel(X3Args a) {
         }
         __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
     };
-    const bool dma_on = !(a.ablate & 64);
+    const bool dma_on = !(DMC_ABL(a.ablate) & 64);
     // One step = tap row q of chunk c (operands in patch buffer pbuf / weight buffer wbuf).  On entry FA holds the
     // fragments of its first tap.  The loop is software-pipelined over taps -- tap t + 1's fragments are read behind tap
     // t's MFMAs -- and the step's barrier stands in front of its LAST tap's MFMAs: by then every fragment of the step is
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(WM * WN * 64) void x3s_conv_kernel(X3Args a) {
         load_frags(pbufc, wbufc, std::integral_constant<int, 3 * q + 2>{}, FA);
         mfma_frags(FB, T1{}, nothing);
         interleave();
-        if (a.ablate & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (DMC_ABL(a.ablate) & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's transfers for step s + 1 have landed
         __builtin_amdgcn_s_barrier();                                  // ... everyone's; step s's buffers are dead
         // the patch slice whose buffer the barrier released: q = 0, 1: slice q + 1 of chunk c + 1; q = 2: slice 0 of chunk c + 2
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(WM * WN * 64) void x3s_conv_kernel(X3Args a) {
     load_frags(I0{}, I0{}, Q0{}, F0);
     // chunk pairs (K % 32 == 0): patch buffers 0, 1; weight buffers alternate per step: 0 1 0 | 1 0 1
 #pragma unroll 1
-    for (int c = 0; c < ((a.ablate & 256) ? 0 : nchunk); c += 2) {
+    for (int c = 0; c < ((DMC_ABL(a.ablate) & 256) ? 0 : nchunk); c += 2) {
         step(I0{}, I0{}, Q0{}, F0, F1, c);
         step(I0{}, I1{}, Q1{}, F1, F0, c);
         step(I0{}, I0{}, Q2{}, F0, F1, c);
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(WM * WN * 64) void x3s_conv_kernel(X3Args a) {
                     *reinterpret_cast<float4*>(etile + (32 * i + l31) * EP + (32 * j + 8 * g + 4 * khalf) * 4) = v;
                 }
         }
-        if (!(a.ablate & 128)) {
+        if (!(DMC_ABL(a.ablate) & 128)) {
 #pragma unroll
             for (int it = 0; it < 8 * TM; ++it) {
                 const int prow = 4 * it + (lane >> 4);
@@ -577,7 +577,7 @@ int run_x3s(const void* xs, const void* wp, const float* addend, float* y, doubl
         a.bnb_relu = bnb->relu; a.bnb_part = bnb->part;
     }
     a.ablate = option(OPT_CONV_ABLATE);
-    if (a.ablate & 32) a.stat_part = nullptr;
+    if (DMC_ABL(a.ablate) & 32) a.stat_part = nullptr;
     switch (cfg) {
         case 0: return launch_x3s<8, 1, 608>(a, s);
         case 1: return launch_x3s<4, 1, 320>(a, s);

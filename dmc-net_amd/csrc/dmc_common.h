@@ -52,6 +52,17 @@ struct LdsLimit {
 enum Option { OPT_GEN_LAYER_PATH = 0, OPT_GEN_GATHER, OPT_GEN_FUSE45, OPT_GEN_WGRAD_PATH, OPT_GEN_FUSE_FWD,
               OPT_GEN_FUSE_BWD, OPT_GEN_FRAMES, OPT_CONV_PATH, OPT_CONV_CFG, OPT_CONV_ABLATE, OPT_GEN_ABLATE, OPT_CONV_ARITH, OPT_CONV3D_WGRAD, OPT_GEN_X3, OPT_GEN_WINO, OPT_GEN_STAGGER, OPT_GEN_FUSED, OPT_COUNT };
 int option(Option o);
+// Measurement-only options ("gen_ablate", "conv_ablate", "gen_stagger": parts of a kernel switched off, RESULTS WRONG) exist only
+// in a -DDMC_MEASURE build (dmc-net_amd/build.py --measure -> libdmcnet_hip_measure.so, which tools/ load through DMC_HIP_LIB):
+// the product library refuses to set them, reads them as 0, and DMC_ABL() folds every ablated path out of its kernels.
+#ifdef DMC_MEASURE
+#define DMC_ABL(x) (x)
+constexpr bool MEASURE_BUILD = true;
+#else
+#define DMC_ABL(x) 0
+constexpr bool MEASURE_BUILD = false;
+#endif
+constexpr bool measure_only(int o) { return o == OPT_GEN_ABLATE || o == OPT_CONV_ABLATE || o == OPT_GEN_STAGGER; }
 
 // ---- EstimatorDenseNetTiny geometry (code/dmcnet/model.py:172-194) --------------------------
 // Physical channel order used by every kernel: [mv0 mv1 r0 r1 r2 | y0(8) | y1(8) | y2(6) | y3(4)

@@ -690,9 +690,9 @@ __global__ __launch_bounds__(LTHREADS, HALF ? 4 : 2) void gen_layer_mfma_kernel(
 #pragma unroll 1
         for (int q = 0; q < nitems; ++q) {
             // chunk q has landed (only chunk q+1 may still be in flight); consumers are done with q-1
-            if (AHEAD == 2 && q + 1 < nitems && !(ra.ablate & 1)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(G::CH * RingGeo<HALF>::SROWS) : "memory");
+            if (AHEAD == 2 && q + 1 < nitems && !(DMC_ABL(ra.ablate) & 1)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(G::CH * RingGeo<HALF>::SROWS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            if (q + AHEAD < nitems && !(ra.ablate & 1)) {
+            if (q + AHEAD < nitems && !(DMC_ABL(ra.ablate) & 1)) {
                 const int c2 = c + AHEAD, tile2 = tile + (c2 / NCHUNK) * t_step, n2 = tile2 / ra.tiles_y;
                 int slot2 = slot + AHEAD; slot2 = slot2 >= RING ? slot2 - RING : slot2;
                 ring_stage<MODE, K, HALF>(a, lds0 + (unsigned)slot2 * (P_BUF * 4), n2, (tile2 - n2 * ra.tiles_y) * PT_H,
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(LTHREADS, HALF ? 4 : 2) void gen_layer_mfma_kernel(
 #pragma unroll 1
     for (int q = 0; q < nitems; ++q) {
         asm volatile("s_barrier" ::: "memory");
-        if (!(ra.ablate & 4) || r < 4)      // ablate 4: one computing wave per SIMD (waves 4 .. 6 only keep the barriers)
+        if (!(DMC_ABL(ra.ablate) & 4) || r < 4)      // ablate 4: one computing wave per SIMD (waves 4 .. 6 only keep the barriers)
             mfma_chunk<MODE, K, NT, HALF>(acc, lds + slot * P_BUF, wl, c * G::CH, boffq, lane);
         slot = slot + 1 == RING ? 0 : slot + 1;
         if (++c < NCHUNK) continue;
@@ -793,9 +793,9 @@ __global__ __launch_bounds__(LTHREADS, HALF ? 4 : 2) void gen_layer_mfma_kernel(
                 }
             }
             if constexpr (HALF == 1) {
-                if (inside && !(ra.ablate & 2))
+                if (inside && !(DMC_ABL(ra.ablate) & 2))
                     *reinterpret_cast<float2*>(a.feat_out + ((size_t)n * NFEAT + (yoff(K) - NIN) + co) * HW + pix) = make_float2(v[0], v[1]);
-            } else if (inside && !(ra.ablate & 2)) {
+            } else if (inside && !(DMC_ABL(ra.ablate) & 2)) {
                 const float4 o = make_float4(v[0], v[1], v[2], v[3]);
                 if (MODE == 0) *reinterpret_cast<float4*>(a.feat_out + ((size_t)n * NFEAT + (yoff(K) - NIN) + co) * HW + pix) = o;
                 else if (MODE == 1) *reinterpret_cast<float4*>(a.out + ((size_t)n * 2 + co) * HW + pix) = o;
@@ -909,7 +909,7 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_wino_kernel(RingArgs ra) {
     // Staggered start: a tile ends with a burst of stores (COUT planes x 8 rows), and workgroups that run in phase all write
     // at the same time -- the chip alternates between a read / compute phase and a write phase that drains at the HBM rate with
     // nothing else in flight (38 us of 116 for layer 0).  Workgroups started (b / 8 mod 8) steps apart keep the mix constant.
-    if (ra.stagger > 0) {
+    if (DMC_ABL(ra.stagger) > 0) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         const unsigned long long wait = (unsigned long long)((blockIdx.x >> 3) & 7) * (unsigned)ra.stagger;
         while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(4);
@@ -928,9 +928,9 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_wino_kernel(RingArgs ra) {
         int tile = t_begin, c = 0, slot = 0;
 #pragma unroll 1
         for (int q = 0; q < nitems; ++q) {
-            if (q + 1 < nitems && !(ra.ablate & 1)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(G::CH * P_ROWS) : "memory");
+            if (q + 1 < nitems && !(DMC_ABL(ra.ablate) & 1)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(G::CH * P_ROWS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            if (q + AHEAD < nitems && !(ra.ablate & 1)) {
+            if (q + AHEAD < nitems && !(DMC_ABL(ra.ablate) & 1)) {
                 const int c2 = c + AHEAD, tile2 = tile + (c2 / NCHUNK) * t_step, n2 = tile2 / ra.tiles_y;
                 int slot2 = slot + AHEAD; slot2 = slot2 >= RING ? slot2 - RING : slot2;
                 ring_stage<MODE, K, 0>(a, lds0 + (unsigned)slot2 * (P_BUF * 4), n2, (tile2 - n2 * ra.tiles_y) * PT_H,
@@ -1082,7 +1082,7 @@ __global__ __launch_bounds__(LTHREADS, 2) void gen_wino_kernel(RingArgs ra) {
                 // few channels per chunk of the NEXT tile -- no gain without spills, a loss with them: the stores' cost is their HBM
                 // traffic, not the moment of their issue)
                 float* op = (MODE == 0 ? a.feat_out : a.gbuf) + ((size_t)n * NFEAT + (yoff(K) - NIN) + co) * HW;
-                const bool st = !(ra.ablate & 2) && (!(ra.ablate & 8) || o[0][0] == 1.2345678e33f);
+                const bool st = !(DMC_ABL(ra.ablate) & 2) && (!(DMC_ABL(ra.ablate) & 8) || o[0][0] == 1.2345678e33f);
                 if (st) {
                     if (ok0) *reinterpret_cast<float2*>(op + pix0) = make_float2(o[0][0], o[0][1]);
                     if (ok1) *reinterpret_cast<float2*>(op + pix1) = make_float2(o[1][0], o[1][1]);
@@ -2338,6 +2338,7 @@ int launch_layer(LayerArgs a, int n0, int N, hipStream_t s) {
             const int wgs = ra.ntiles < num_cus() ? ra.ntiles : num_cus();
             const int dbg = ra.ablate >> 8;
             ra.ablate &= 255;
+#ifdef DMC_MEASURE
             if constexpr ((MODE == 0 && K == 2) || (MODE == 0 && K == 3)) {
                 if (dbg == 1) gen_wino_kernel<MODE, K, 1><<<wgs, LTHREADS, 0, s>>>(ra);
                 else if (dbg == 2) gen_wino_kernel<MODE, K, 2><<<wgs, LTHREADS, 0, s>>>(ra);
@@ -2345,7 +2346,9 @@ int launch_layer(LayerArgs a, int n0, int N, hipStream_t s) {
                 else if (dbg == 4) gen_wino_kernel<MODE, K, 4><<<wgs, LTHREADS, 0, s>>>(ra);
                 else gen_wino_kernel<MODE, K><<<wgs, LTHREADS, 0, s>>>(ra);
             } else
+#endif
             gen_wino_kernel<MODE, K><<<wgs, LTHREADS, 0, s>>>(ra);
+            (void)dbg;
             return check_launch("gen_wino");
         }
     }

@@ -155,7 +155,7 @@ int option_index(const char* name) {
 }  // namespace
 
 namespace dmc {
-int option(Option o) { return g_options[o].load(std::memory_order_relaxed); }
+int option(Option o) { return !MEASURE_BUILD && measure_only(o) ? 0 : g_options[o].load(std::memory_order_relaxed); }
 }  // namespace dmc
 
 // Empty kernel with a recognisable name: bench.py brackets its timed region with it so that a
@@ -211,12 +211,14 @@ int dmc_version(void) { return 200; }   // 0.2.0
 int dmc_set_option(const char* name, int value) {
     const int i = option_index(name);
     if (i < 0) return fail(DMC_E_INVALID, "dmc_set_option: unknown option '%s'", name ? name : "(null)");
+    if (!MEASURE_BUILD && measure_only(i))
+        return fail(DMC_E_INVALID, "dmc_set_option: '%s' switches parts of a kernel off (results wrong) and exists only in the -DDMC_MEASURE build", name);
     g_options[i].store(value, std::memory_order_relaxed);
     return DMC_OK;
 }
 int dmc_get_option(const char* name) {
     const int i = option_index(name);
-    return i < 0 ? -1 : g_options[i].load(std::memory_order_relaxed);
+    return i < 0 ? -1 : (!MEASURE_BUILD && measure_only(i)) ? 0 : g_options[i].load(std::memory_order_relaxed);
 }
 const char* dmc_last_error(void) { return err_buf(); }
 

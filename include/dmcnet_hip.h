@@ -43,8 +43,10 @@ typedef void* dmc_stream_t; /* hipStream_t */
 int dmc_version(void);
 /* Text of the last error on this host thread ("" if none). */
 const char* dmc_last_error(void);
-/* Kernel-selection options for A/B measurements (tools/, bench.py); every default is 1 = the
- * fastest measured path.  Names: "gen_layer_path" (0: VALU layer kernels instead of the matrix-core
+/* Kernel-selection options for A/B measurements (tools/, bench.py); every default is the
+ * fastest measured path.  Names: "gen_fused" (1, the default: the generator forward as ONE launch, gen_fused.hip -- strips
+ * of <= 118 columns walked row by row, features line-buffered in LDS, the six layers pipelined across the waves of a
+ * workgroup; any H, W <= 224; 0: the layer-by-layer kernels below, which also serve wider images), "gen_layer_path" (0: VALU layer kernels instead of the matrix-core
  * ones), "gen_gather" (0: push form for the Cout-8 layers), "gen_fuse45" (0: layers 4 and 5 as two
  * launches), "gen_wgrad_path" (0: all-waves-stage weight gradient; 1: fp32 producer/consumer; 2 / 3: bf16x3; 4, the default: bf16x3 with wide LDS reads), "gen_fuse_fwd" / "gen_fuse_bwd"
  * (0: the layer-by-layer forward / data-gradient launches instead of the fused groups), "gen_x3" (bit K: hidden
@@ -53,8 +55,10 @@ const char* dmc_last_error(void);
  * group K, K = 0 .. 4, on the Winograd F(2x2, 3x3) ring kernel, gen_tiny.hip gen_wino_kernel -- fp32 arithmetic with 2.25x
  * fewer multiplications, results within rounding of the direct kernels', not bit-identical to them; shapes with W % 4 == 0,
  * 64 <= W <= 224; a set bit overrides "gen_x3" for that layer; default 768 = gradient groups 0 and 1; layer 1 of the forward
- * (bit 1) is faster on it too but stays on "gen_x3": DESIGN 4.10), "gen_ablate" / "conv_ablate" (measurement only: parts of a kernel switched off, results wrong),
- * "gen_stagger" (measurement only: start delay between workgroups of gen_wino_kernel, 10 ns ticks per step; default 0).
+ * (bit 1) is faster on it too but stays on "gen_x3": DESIGN 4.10), "gen_ablate" / "conv_ablate" (parts of a kernel switched off, results wrong) and
+ * "gen_stagger" (start delay between workgroups of gen_wino_kernel, 10 ns ticks per step): MEASUREMENT BUILD ONLY
+ * (-DDMC_MEASURE, dmc-net_amd/build.py --measure -> libdmcnet_hip_measure.so): in the product library dmc_set_option refuses
+ * them (DMC_E_INVALID), they read 0 and the ablated paths are not compiled into its kernels.
  * dmc_set_option returns DMC_E_INVALID for an unknown name; dmc_get_option returns -1 for one. */
 int dmc_set_option(const char* name, int value);
 int dmc_get_option(const char* name);

@@ -130,7 +130,13 @@ def test_classifier_conv_entry_points_host_side_without_gpu():
     # generator kernel selection: layer 1 on gen_x3.hip, data-gradient groups 0 and 1 on the Winograd ring kernel;
     # the measurement-only options are off
     assert lib.dmc_get_option(b"gen_x3") == 2 and lib.dmc_get_option(b"gen_wino") == 0x300
-    assert lib.dmc_get_option(b"gen_ablate") == 0 and lib.dmc_get_option(b"gen_stagger") == 0 and lib.dmc_get_option(b"conv_ablate") == 0
+    assert lib.dmc_get_option(b"gen_fused") == 1                 # the one-launch forward (csrc/gen_fused.hip)
+    # the options that switch parts of a kernel off (results wrong) exist only in the -DDMC_MEASURE build: the product library
+    # refuses to set them and reads them as 0 -- no option value can make it compute something else than the reference
+    for name in (b"gen_ablate", b"gen_stagger", b"conv_ablate"):
+        assert lib.dmc_get_option(name) == 0
+        assert lib.dmc_set_option(name, 1) != 0 and b"DMC_MEASURE" in lib.dmc_last_error()
+        assert lib.dmc_get_option(name) == 0
     assert lib.dmc_get_option(b"no_such_option") == -1 and lib.dmc_set_option(b"no_such_option", 1) != 0
     for cin, cout, want in [(64, 64, 1), (64, 128, 1), (512, 512, 1), (256, 64, 1), (3, 64, 0), (16, 32, 0), (96, 64, 0)]:
         assert lib.dmc_conv_nhwc_presplit_supported(cin, cout) == want, (cin, cout)

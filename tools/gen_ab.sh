@@ -2,6 +2,8 @@
 # per-kernel times of the generator micro-benchmark under option sets:  tools/gen_ab.sh <out-subdir> "opt=v opt=v" "..." ...
 O=$1; shift; OUT=$GRAFT_REPO_ROOT/gpurun_out/$O; mkdir -p $OUT
 R=$GRAFT_REPO_ROOT
+# option sets that name gen_ablate / conv_ablate / gen_stagger need the measurement build (python dmc-net_amd/build.py --measure):
+case "$*" in *ablate*|*stagger*) export DMC_HIP_LIB=$R/dmc-net_amd/libdmcnet_hip_measure.so;; esac
 cd /tmp && export TMPDIR=/tmp
 i=0
 for m in "$@"; do
