@@ -30,13 +30,13 @@ GEN_FLOP_PER_PX = 9108         # 4,554 MAC, SURVEY.md 8(d)
 GEN_BYTES_PER_PX = 28          # read 5 ch + write 2 ch fp32 (fused, inference-style)
 
 HP = dict(lr=0.01, weight_decay=1e-4, lr_cls_mult=0.01, lr_mse_mult=1.0)
-TRAFFIC_JSON = os.path.join("profiles", "r4_gen_traffic.json")
+TRAFFIC_JSON = os.path.join("profiles", "r5_gen_traffic.json")
 
 
 def measured_traffic(px):
     """HBM bytes per generator-forward call from the PMC counters: collected with rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE (separate passes, calibrated; tools/pmc_traffic.py) on the SAME kernel
-    source -- the JSON records the sha256 of gen_tiny.hip + gen_x3.hip it was measured on and the figure is
+    source -- the JSON records the sha256 of gen_tiny.hip + gen_x3.hip + gen_fused.hip it was measured on and the figure is
     reported only while that still matches the sources in the tree (else null: stale)."""
     import hashlib
     path = os.path.join(ROOT, TRAFFIC_JSON)
@@ -44,10 +44,10 @@ def measured_traffic(px):
         return None, "no PMC measurement in the tree (%s)" % TRAFFIC_JSON
     rec = json.load(open(path))
     csrc = os.path.join(ROOT, "dmc-net_amd", "csrc")
-    both = b"".join(open(os.path.join(csrc, f), "rb").read() for f in ("gen_tiny.hip", "gen_x3.hip"))
+    both = b"".join(open(os.path.join(csrc, f), "rb").read() for f in ("gen_tiny.hip", "gen_x3.hip", "gen_fused.hip"))
     sha = hashlib.sha256(both).hexdigest()[:16]
     if rec.get("kernel_source_sha16") != sha:
-        return None, "%s was measured on another version of gen_tiny.hip / gen_x3.hip (stale, not reported)" % TRAFFIC_JSON
+        return None, "%s was measured on another version of gen_tiny.hip / gen_x3.hip / gen_fused.hip (stale, not reported)" % TRAFFIC_JSON
     return int(rec["gen_fwd_bytes_per_px"] * px), "%s: %s; kernel source sha16 %s" % (TRAFFIC_JSON, rec["method"], sha)
 
 
@@ -479,9 +479,11 @@ def main():
                        "global_batch": world * args.batch, "num_class": args.num_class,
                        "parallelism": "dp%d" % world, "final_loss": round(loss, 6),
                        **({"options": args.option} if args.option else {}),
-                       "generator_kernels": ("libdmcnet_hip gen_tiny / gen_x3: fp32 4x4x1-MFMA ring kernels; forward layer mask on gen_x3 (bf16x3) %d; "
-                                             "Winograd F(2x2,3x3) ring kernel mask %#x (bit K: forward layer K, bit 8 + K: data-gradient group K; fp32)"
-                                             % (dmcnet_amd._lib.load().dmc_get_option(b"gen_x3"), dmcnet_amd._lib.load().dmc_get_option(b"gen_wino"))),
+                       "generator_kernels": (("libdmcnet_hip gen_fused: the forward as ONE launch (fp32 4x4x1 MFMA, features line-buffered in LDS, "
+                                              "layers pipelined across waves); " if dmcnet_amd._lib.load().dmc_get_option(b"gen_fused") else
+                                              "libdmcnet_hip gen_tiny / gen_x3 layer-by-layer forward (gen_x3 mask %d); " % dmcnet_amd._lib.load().dmc_get_option(b"gen_x3")) +
+                                             "backward: gen_tiny ring kernels, Winograd F(2x2,3x3) mask %#x (bit 8 + K: data-gradient group K; fp32)"
+                                             % dmcnet_amd._lib.load().dmc_get_option(b"gen_wino")),
                        "classifier_convs": (("libdmcnet_hip conv_x3s (3x3 stride 1) + conv_x3q (the stride-2 blocks: 3x3 stride 2 fused with "
                                              "the 1x1 shortcut on space-to-depth slice tensors): every operand pre-split into "
                                              "bf16x3 slice tensors by its producer, " if ops.X3Q else

@@ -43,7 +43,7 @@ def main():
         print("%s,%.2f,%.2f,%.2f,%.2f,%.1f" % (name, f / 1e6, w / 1e6, f * kr / 1e6, w * kw / 1e6,
                                              (f * kr + w * kw) / px))
         layer = "gen_layer" in k or "gen_wino" in k          # (template arguments: <MODE, K ...>, MODE 2 = data gradient)
-        grp = "fwd" if (("_kernel<0" in k or "_kernel<1" in k) and layer) or "gen_l45" in k or "gen_x3_kernel" in k else \
+        grp = "fwd" if (("_kernel<0" in k or "_kernel<1" in k) and layer) or "gen_l45" in k or "gen_x3_kernel" in k or "gen_fused_kernel" in k else \
               "bwd" if ("_kernel<2" in k and layer) or "gen_bwd" in k else None
         if grp:
             tot[grp] += f * kr + w * kw
@@ -55,7 +55,7 @@ def main():
         import json
         import os
         csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dmc-net_amd", "csrc")
-        both = b"".join(open(os.path.join(csrc, f), "rb").read() for f in ("gen_tiny.hip", "gen_x3.hip"))   # as bench.py hashes them
+        both = b"".join(open(os.path.join(csrc, f), "rb").read() for f in ("gen_tiny.hip", "gen_x3.hip", "gen_fused.hip"))   # as bench.py hashes them
         json.dump({"frames": n, "fetch_scale": kr, "write_scale": kw,
                    "kernel_source_sha16": hashlib.sha256(both).hexdigest()[:16],
                    "gen_fwd_bytes_per_px": tot["fwd"] / px, "gen_bwd_bytes_per_px": tot["bwd"] / px,
