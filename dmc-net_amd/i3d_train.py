@@ -176,7 +176,10 @@ class I3DTrainer(object):
         if self.iter_size != 1:
             grads = [p.grad for g in opt.param_groups for p in g["params"]]
             if all(t is not None and t.is_cuda for t in grads):
-                torch._foreach_div_(grads, self.iter_size)      # the same divisions, a few multi-tensor launches
+                # ``t /= python_scalar`` on a CUDA tensor is lowered to a multiplication by the reciprocal (the division
+                # kernel's CPU-scalar path); the multi-tensor form reproduces exactly that for every iter_size, not only
+                # for powers of two
+                torch._foreach_mul_(grads, 1.0 / self.iter_size)
             else:
                 for t in grads:
                     t /= self.iter_size
@@ -191,12 +194,21 @@ class I3DTrainer(object):
         if not all(t is None or t.is_cuda for t in stash):
             loss.backward()
             return
+        # (a post-accumulate hook -- ddp.GradBucketReducer -- would see the fresh micro-batch gradient instead of the window's sum)
+        assert not any(getattr(p, "_post_accumulate_grad_hooks", None) for p in params), \
+            "I3DTrainer accumulates outside autograd: post-accumulate gradient hooks would see partial gradients"
         for p in params:
             p.grad = None
         # no gradient to accumulate into during this pass: weight gradients may run on the side stream (ops._on_wgrad_stream:
         # the stem's and the serial units' overlap the data-gradient chain down to the generator); joined on exit
-        with ops.wgrad_side_stream():
-            loss.backward()
+        try:
+            with ops.wgrad_side_stream():
+                loss.backward()
+        except BaseException:
+            # a failed pass (out of memory, a DMC_E_* from a kernel) must not lose the window's accumulated gradients
+            for p, t in zip(params, stash):
+                p.grad = t
+            raise
         old, new = [], []
         for p, t in zip(params, stash):
             if t is None:

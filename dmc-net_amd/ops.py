@@ -962,6 +962,7 @@ _WGRAD_PENDING = [False]
 _WGRAD_SCOPE = [0]
 _WGRAD_COUNT = [0]            # launches that went to the side stream (diagnostics / tests)
 _WGRAD_SEEN = set()           # id() of the weights whose gradient went to the side stream since the last join
+_WGRAD_MAIN = set()           # id() of the weights forced to the main stream for the REST of this backward pass (seen twice)
 
 
 class wgrad_side_stream(object):
@@ -971,11 +972,13 @@ class wgrad_side_stream(object):
     def __enter__(self):
         _WGRAD_SCOPE[0] += 1
         _WGRAD_SEEN.clear()
+        _WGRAD_MAIN.clear()
         return self
 
     def __exit__(self, *exc):
         _WGRAD_SCOPE[0] -= 1
         join_wgrad_stream()
+        _WGRAD_MAIN.clear()
         return False
 
 
@@ -1003,8 +1006,14 @@ def _wgrad_side_ok(weight):
     # a weight used TWICE in one backward pass (a shared convolution, a module called twice): the engine sums the two
     # gradients on the main stream -- in its input buffer or in AccumulateGrad -- believing the main stream produced the
     # first one.  The second sighting therefore re-joins (the first gradient is complete on the main stream) and stays there.
+    # The mid-pass join forgets which gradients are in flight (_WGRAD_SEEN), so the weight is remembered separately for the
+    # rest of the pass: a THIRD use (a module called three times, a discriminator applied to real, fake and an interpolate)
+    # must stay on the main stream too -- its gradient is summed into the same buffer.
+    if id(weight) in _WGRAD_MAIN:
+        return False
     if id(weight) in _WGRAD_SEEN:
         join_wgrad_stream()
+        _WGRAD_MAIN.add(id(weight))
         return False
     # C++-level gradient hooks (torch's DistributedDataParallel reducer) read the gradient on the main stream the moment it
     # is accumulated and are not visible from Python: with a process group up, only parameters that carry THIS package's

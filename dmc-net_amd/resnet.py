@@ -32,6 +32,9 @@ def _bn_act(bn, x, residual=None, relu=True):
 # DMC_OWN_CONV=0 switch it off.
 import os as _os
 OWN_CONV = _os.environ.get("DMC_OWN_CONV", "1") != "0"
+#: True: the last unit of layer1 / layer2 / layer3 also writes its fp32 result (by default the stride-2 block that follows reads
+#: bf16x3 slices only and the fp32 memory of that tensor stays unwritten: nothing but this package's ops may read it)
+KEEP_F32_OUTPUTS = _os.environ.get("DMC_KEEP_F32_OUTPUTS", "0") == "1"
 # identity-shortcut blocks: residual gradient added in the first convolution's data-gradient epilogue (ops.ResidualGradLink)
 RESIDUAL_GRAD_LINK = _os.environ.get("DMC_RESIDUAL_GRAD_LINK", "1") != "0"
 
@@ -112,6 +115,12 @@ class ResidualUnit(nn.Module):
         self.next_identity = [False] # ... and whether that unit has an identity shortcut
         self.next_unit = [None]      # ... and the unit itself when it has a downsample branch (stride-2 pair path)
 
+    def _next_unit(self):
+        """The next unit when ITS input may exist as slices only (stride-2 pair path): then this unit's fp32 result is never
+        written.  Not when someone else may read that result -- a forward hook on this unit, or KEEP_F32_OUTPUTS (feature taps,
+        hooks on the enclosing Sequential, callers that do not go through ResNet.forward)."""
+        return None if (KEEP_F32_OUTPUTS or self._forward_hooks) else self.next_unit[0]
+
     def forward(self, x):
         link = None
         if self.downsample is None:
@@ -125,7 +134,7 @@ class ResidualUnit(nn.Module):
                                               _same_bn_mode(self.bn1, self.bn2))
             return _conv_bn_act(self.conv2, self.bn2, y, residual=shortcut, next_conv=self.next_conv[0],
                                 bn_link="block" if (self.next_identity[0] and RESIDUAL_GRAD_LINK) else None,
-                                next_unit=self.next_unit[0])
+                                next_unit=self._next_unit())
         else:
             shortcut = _conv_bn_act(self.downsample[0], self.downsample[1], x, relu=False)
         # conv1's result is read by conv2 alone: slices only when conv2 takes the pre-split path
@@ -136,7 +145,7 @@ class ResidualUnit(nn.Module):
         if self.kind == "basic":
             return _conv_bn_act(self.conv2, self.bn2, y, residual=shortcut, link=link, next_conv=self.next_conv[0],
                                 bn_link="block" if (self.next_identity[0] and RESIDUAL_GRAD_LINK) else None,
-                                next_unit=self.next_unit[0])
+                                next_unit=self._next_unit())
         y = _conv_bn_act(self.conv2, self.bn2, y, next_conv=self.conv3, only_consumer=True, next_bn=self.bn3)
         return _conv_bn_act(self.conv3, self.bn3, y, residual=shortcut, link=link, next_conv=self.next_conv[0])
 

@@ -551,6 +551,39 @@ def test_side_stream_with_a_weight_used_twice_in_one_backward(monkeypatch):
         assert torch.equal(w1, w0) and torch.equal(x1, x0)
 
 
+def test_side_stream_with_a_weight_used_three_times_in_one_backward(monkeypatch):
+    """The same convolution applied THREE times: the second sighting re-joins the streams (which forgets what was in flight);
+    the third must still stay on the main stream -- its gradient is summed into the buffer the first two share.  Bitwise the
+    one-stream result, repeatedly, and exactly one launch leaves the main stream."""
+    monkeypatch.setattr(resnet, "OWN_CONV", True)
+    torch.manual_seed(14)
+    conv = torch.nn.Conv2d(64, 64, 3, 1, 1, bias=False).to(DEV).to(memory_format=CL)
+    bns = [torch.nn.BatchNorm2d(64).to(DEV).train() for _ in range(3)]
+    x = rnd(521, (24, 64, 56, 56)).to(DEV).contiguous(memory_format=CL)
+
+    def run(side):
+        monkeypatch.setattr(ops, "WGRAD_STREAM", side)
+        for m in [conv] + bns:
+            m.zero_grad(set_to_none=True)
+        xin = x.clone().requires_grad_(True)
+        y = resnet._conv_bn_act(conv, bns[0], xin, next_conv=conv)
+        y = resnet._conv_bn_act(conv, bns[1], y, next_conv=conv)
+        z = resnet._conv_bn_act(conv, bns[2], y)
+        n0 = ops._WGRAD_COUNT[0]
+        with ops.wgrad_side_stream():
+            z.square().mean().backward()
+        torch.cuda.synchronize()
+        return conv.weight.grad.clone(), xin.grad.clone(), ops._WGRAD_COUNT[0] - n0
+
+    w0, x0, n_main = run(False)
+    assert n_main == 0
+    for _ in range(3):
+        w1, x1, n_side = run(True)
+        assert n_side == 1                                   # the first sighting only
+        assert torch.equal(w1, w0) and torch.equal(x1, x0)
+    assert not ops._WGRAD_MAIN                               # cleared when the pass ends
+
+
 @pytest.mark.parametrize("case", [(6, 64, 14, 14, 128), (37, 64, 14, 14, 64), (5, 128, 7, 7, 64), (42, 64, 14, 14, 512)])
 def test_x3s_two_workgroups_per_cu_configuration(case):
     """Tile configuration 4 of the pre-split convolutions (128-pixel tiles, 4 waves, a patch of <= 224 pixels: 79,872 B of
