@@ -337,6 +337,17 @@ def main():
     # when N ranks share one GPU) would otherwise dominate
     replicas = os.environ.get("DMC_BENCH_REPLICAS") == "1"
     reducer = ddp.for_model(model) if (world > 1 and not replicas) else None
+    # DMC_BENCH_STUB_ALLREDUCE=1 (test hook, same tool): the reducer runs in full -- post-accumulate hooks, bucket copies,
+    # side-stream joins, waits -- but the collective itself returns at once (a completed Work): what the N > 1 path costs the
+    # HOST without the host-memory transport of gloo, which an RCCL run does not have.  Gradients are NOT exchanged.
+    if reducer is not None and os.environ.get("DMC_BENCH_STUB_ALLREDUCE") == "1":
+        class _DoneWork(object):
+            def wait(self, *a, **k):
+                return True
+
+            def is_completed(self):
+                return True
+        ddp.dist.all_reduce = lambda *a, **k: _DoneWork()
     if gan:
         stepper = train.GanTrainStep(model, S, 1.0, 1.0, 0.01, 10.0, lr_d_mult=1.0, reducer=reducer, **HP)
     else:

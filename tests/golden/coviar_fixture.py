@@ -74,3 +74,4 @@ CASES = [("test0", False, 0, 0, 0, False), ("test1", False, 1, 0, 1, False),
          ("train_s3", True, 1, 3, 0, True), ("train_s4", True, 0, 4, 0, True),
          ("train_s5", True, 1, 5, 0, True), ("train_s8", True, 1, 8, 0, True)]
 CROP = 48
+DS16_CROPS = (48, 40)      # flow_ds_factor = 16 cases: whole blocks / ragged blocks (zero-padded by block_reduce)

@@ -9,9 +9,13 @@ The reference's dataset.py / transforms.py are imported as they are (stub ``cv2`
 the removed alias), ``coviar.load`` is the seeded stand-in of tests/golden/coviar_fixture.py and the
 flow frames are the files that module writes.  Transforms: the reference's own ``GroupCenterCrop``
 and ``GroupRandomHorizontalFlip`` (pure numpy; ``GroupScale`` / ``GroupMultiScaleCrop`` call
-cv2.resize, which is absent).  Stored: the reference's 4-tuple per case, ``flow_ds_factor = 0``.
-NOT pinned: ``flow_ds_factor = 16`` -- skimage's ``block_reduce`` is absent; that one function stays
-restated from its documentation.
+cv2.resize, which is absent).  Stored: the reference's 4-tuple per case, ``flow_ds_factor = 0``
+(g9_dataset_item.npz) and ``flow_ds_factor = 16`` (g9_dataset_item_ds16.npz: BASELINE config 2's setting).
+For the second file the reference's own lines around the blockify call (dataset.py:229-246: which tensor is reduced, the
+``repeat`` back, the crop to the input size, its place BEFORE /255 and the normalisation) run as they are; only
+``skimage.measure.block_reduce`` itself -- absent from this image -- is a numpy stand-in written from its documentation
+(pad with ``cval = 0`` to whole blocks, apply ``func`` over every block).  Crops of 48 (whole 16 x 16 blocks) and 40
+(the ragged, zero-padded path).
 """
 import os
 import random
@@ -26,6 +30,17 @@ sys.path.insert(0, ROOT)
 
 from tests.golden import coviar_fixture as CF            # noqa: E402
 from tests.golden.make_golden import import_ref, install_stubs   # noqa: E402
+
+
+def block_reduce_standin(image, block_size, func=np.sum, cval=0):
+    """skimage.measure.block_reduce as documented: the image is padded with ``cval`` where it is not a whole number of blocks,
+    then ``func`` is applied over each block's axes."""
+    pad = [(0, (-s) % b) for s, b in zip(image.shape, block_size)]
+    image = np.pad(image, pad, mode="constant", constant_values=cval)
+    shape = []
+    for s, b in zip(image.shape, block_size):
+        shape += [s // b, b]
+    return func(image.reshape(shape), axis=tuple(range(1, 2 * image.ndim, 2)))
 
 
 def main():
@@ -50,6 +65,23 @@ def main():
             out[tag + "_label"] = np.int64(label)
             print(tag, tuple(flow.shape), tuple(mv.shape), tuple(res.shape), label, float(mv.mean()))
     np.savez_compressed(os.path.join(HERE, "g9_dataset_item.npz"), **out)
+    # flow_ds_factor = 16 through the reference's own __getitem__ (block_reduce: the stand-in above)
+    ref_ds.block_reduce = block_reduce_standin
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        data_root, flow_root, lst = CF.write_dataset(tmp)
+        for tag, is_train, minmax, seed, index, with_flip in CF.CASES:
+            for crop in CF.DS16_CROPS:
+                ts = [ref_tf.GroupCenterCrop(crop)] + ([ref_tf.GroupRandomHorizontalFlip()] if with_flip else [])
+                ds = ref_ds.CoviarDataSet(data_root, flow_root, "hmdb51", lst, "mv", 1, 16, False, Compose(ts), 3,
+                                          is_train, True, 12, mv_minmaxnorm=minmax)
+                random.seed(seed)
+                flow, mv, res, label = ds[index]
+                key = "%s_c%d" % (tag, crop)
+                out[key + "_flow"], out[key + "_mv"], out[key + "_res"] = flow.numpy(), mv.numpy(), res.numpy()
+                out[key + "_label"] = np.int64(label)
+                print(key, tuple(flow.shape), flow.dtype, label, float(flow.mean()))
+    np.savez_compressed(os.path.join(HERE, "g9_dataset_item_ds16.npz"), **out)
 
 
 if __name__ == "__main__":

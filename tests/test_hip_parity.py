@@ -731,6 +731,30 @@ def test_device_prep_matches_reference_getitem(golden, tmp_path, monkeypatch):
             assert torch.equal(got[0].cpu(), torch.from_numpy(g[tag + key])), (tag, key)
 
 
+def test_device_prep_flow_ds_factor_16_matches_reference_getitem(golden, tmp_path, monkeypatch):
+    """The same with flow_ds_factor = 16 (BASELINE config 2's setting): DevicePrep's one-pass blockify on the device against the
+    reference's __getitem__ (golden g9_dataset_item_ds16; code/dmcnet/dataset.py:229-246), whole and ragged blocks, bit for bit."""
+    import random
+    import sys
+    from dmcnet_amd import dataset, transforms
+    from tests.golden import coviar_fixture as CF
+    monkeypatch.setitem(sys.modules, "coviar", CF.coviar_module())
+    data_root, flow_root, lst = CF.write_dataset(str(tmp_path))
+    g = golden("g9_dataset_item_ds16")
+    prep = dataset.DevicePrep(DEV, flow_ds_factor=16)
+    for tag, is_train, minmax, seed, index, with_flip in CF.CASES:
+        for crop in CF.DS16_CROPS:
+            ts = [transforms.GroupCenterCrop(crop)] + ([transforms.GroupRandomHorizontalFlip()] if with_flip else [])
+            ds = dataset.CoviarDataSet(data_root, flow_root, "hmdb51", lst, "mv", 1, 16, False, transforms.Compose(ts),
+                                       3, is_train, True, 12, mv_minmaxnorm=minmax)
+            key = "%s_c%d" % (tag, crop)
+            random.seed(seed)
+            flow, mv, res, label = prep(dataset.collate_raw([ds.raw_item(index)]))
+            assert int(label[0]) == int(g[key + "_label"])
+            for got, k in ((flow, "_flow"), (mv, "_mv"), (res, "_res")):
+                assert torch.equal(got[0].cpu(), torch.from_numpy(g[key + k])), (key, k)
+
+
 def test_i3d_forward_vs_reference_golden(golden):
     """BASELINE config 5: I3D trunk over the per-frame HIP generator, eval mode, against the
     reference's own i3d.py (golden G8); bf16-autocast trunk sanity."""

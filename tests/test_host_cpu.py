@@ -453,7 +453,7 @@ def test_dataset_item_bit_exact_vs_reference_getitem(golden, tmp_path, monkeypat
     was run on the seeded stand-in of tests/golden/coviar_fixture.py (golden G9,
     tests/golden/make_golden_dataset.py); this dataset must return the same 4-tuple bit for bit --
     sampling, RNG call order, the MV scaling, clipping, crop, flip with x negation, /255 and
-    normalisation.  (flow_ds_factor = 16 stays unpinned: skimage is absent, blockify is restated.)"""
+    normalisation.  (flow_ds_factor = 16: the next test.)"""
     from tests.golden import coviar_fixture as CF
     g = golden("g9_dataset_item")
     flips = 0
@@ -477,6 +477,36 @@ def test_dataset_item_bit_exact_vs_reference_getitem(golden, tmp_path, monkeypat
         back = dataset.to_tensors(np.transpose(np.array(crop), (0, 3, 1, 2)), 0)
         assert torch.equal(back[1], mv) and torch.equal(back[0], flow) and torch.equal(back[2], res)
     assert 0 < flips < sum(1 for c in CF.CASES if c[5])      # both flip outcomes are covered
+
+
+def test_dataset_item_flow_ds_factor_16_vs_reference_getitem(golden, tmp_path, monkeypatch):
+    """The flow_ds_factor = 16 leg of the contract (BASELINE config 2's setting; code/dmcnet/dataset.py:229-246) against the
+    reference's own __getitem__ (golden g9_dataset_item_ds16: the reference's lines around the blockify call ran as they are,
+    block_reduce itself -- skimage is absent -- as a numpy stand-in written from its documentation,
+    tests/golden/make_golden_dataset.py): whole 16 x 16 blocks (crop 48) and ragged, zero-padded ones (crop 40), bit for bit;
+    the GPU-side plan (raw item -> apply_plan -> to_tensors) likewise."""
+    import sys
+    from tests.golden import coviar_fixture as CF
+    g = golden("g9_dataset_item_ds16")
+    monkeypatch.setitem(sys.modules, "coviar", CF.coviar_module())
+    data_root, flow_root, lst = CF.write_dataset(str(tmp_path))
+    for tag, is_train, minmax, seed, index, with_flip in CF.CASES:
+        for crop in CF.DS16_CROPS:
+            ts = [transforms.GroupCenterCrop(crop)] + ([transforms.GroupRandomHorizontalFlip()] if with_flip else [])
+            ds = dataset.CoviarDataSet(data_root, flow_root, "hmdb51", lst, "mv", 1, 16, False, transforms.Compose(ts),
+                                       3, is_train, True, 12, mv_minmaxnorm=minmax)
+            key = "%s_c%d" % (tag, crop)
+            random.seed(seed)
+            flow, mv, res, label = ds[index]
+            assert label == int(g[key + "_label"])
+            assert torch.equal(flow, torch.from_numpy(g[key + "_flow"])), key
+            assert torch.equal(mv, torch.from_numpy(g[key + "_mv"])), key
+            assert torch.equal(res, torch.from_numpy(g[key + "_res"])), key
+            random.seed(seed)
+            frames, box, out, flip, _ = ds.raw_item(index)
+            cropd = [transforms.apply_plan(f, box, out, flip) for f in frames]
+            back = dataset.to_tensors(np.transpose(np.array(cropd), (0, 3, 1, 2)), 16)
+            assert torch.equal(back[0], flow) and torch.equal(back[1], mv) and torch.equal(back[2], res), key
 
 
 def test_geometry_plan_matches_applied_transforms():
