@@ -13,4 +13,7 @@ int gen_fused_max_partials();
 int gen_fused_fwd(const float* mv, const float* res, float* feat, float* out, const float* pk, const float* flow,
                   double* mse_part, int* nparts, int N, int H, int W, int add_mv, hipStream_t s);
 
+// g_0 .. g_4 (gbuf, [N][28][H][W]) = the data gradient of every feature group from dL/dout and the saved features, one launch
+int gen_fused_bwd_data(const float* gout, const float* feat, float* gbuf, const float* pk, int N, int H, int W, hipStream_t s);
+
 }  // namespace dmc

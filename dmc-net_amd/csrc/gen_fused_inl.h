@@ -28,6 +28,12 @@ __device__ __forceinline__ gfloat* scalar_plane(const float* p) {
                                  (unsigned)__builtin_amdgcn_readfirstlane((int)u);
     return (gfloat*)r;
 }
+// (the same pointer, scalar, for inline assembly operands)
+__device__ __forceinline__ const float* scalar_plane_generic(const float* p) {
+    const unsigned long long u = (unsigned long long)p;
+    return (const float*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                          (unsigned)__builtin_amdgcn_readfirstlane((int)u));
+}
 __device__ __forceinline__ void store_at(float* plane, unsigned byte_off, float v) {
     *(gfloat*)((__attribute__((address_space(1))) char*)scalar_plane(plane) + byte_off) = v;
 }

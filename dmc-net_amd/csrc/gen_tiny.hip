@@ -2452,7 +2452,7 @@ static int gen_tiny_fwd_impl(const float* mv, const float* res, const float* con
     if (fused_wgs) *fused_wgs = 0;
     // option gen_fused (default): the whole forward as ONE launch (gen_fused.hip: line-buffered in LDS, layers pipelined
     // across waves); the layer-by-layer kernels below serve wider images and the A/B options
-    if (option(OPT_GEN_FUSED) && gen_fused_supported(H, W)) {
+    if ((option(OPT_GEN_FUSED) & 1) && gen_fused_supported(H, W)) {
         int rc = pack(w, b, workspace, s);
         if (rc) return rc;
         return gen_fused_fwd(mv, res, saved, out, workspace, flow, mse_part, fused_wgs, N, H, W, add_mv_delta, s);
@@ -2557,7 +2557,10 @@ int dmc_gen_tiny_bwd(const float* mv, const float* res, const float* const* w, c
     la.pk = workspace; la.out = nullptr; la.H = H; la.W = W; la.add_mv = 0;
     la.mse_flow = nullptr; la.mse_part = nullptr;
     const int step = frames_per_pass(N, H, W);
-    for (int n0 = 0; n0 < N; n0 += step) {
+    // option gen_fused bit 1 (default): the five data-gradient groups as ONE launch (gen_fused_bwd.hip)
+    const bool fused_data = (option(OPT_GEN_FUSED) & 2) && gen_fused_supported(H, W);
+    if (fused_data && (rc = gen_fused_bwd_data(grad_out, saved, gbuf, workspace, N, H, W, s))) return rc;
+    for (int n0 = 0; n0 < N && !fused_data; n0 += step) {
         const int nn = (N - n0) < step ? (N - n0) : step;
         if ((rc = launch_layer<2, 4>(la, n0, nn, s))) return rc;
         if ((rc = launch_layer<2, 3>(la, n0, nn, s))) return rc;

@@ -44,9 +44,11 @@ int dmc_version(void);
 /* Text of the last error on this host thread ("" if none). */
 const char* dmc_last_error(void);
 /* Kernel-selection options for A/B measurements (tools/, bench.py); every default is the
- * fastest measured path.  Names: "gen_fused" (1, the default: the generator forward as ONE launch, gen_fused.hip -- strips
+ * fastest measured path.  Names: "gen_fused" (bit 0, set by default: the generator forward as ONE launch, gen_fused.hip -- strips
  * of <= 118 columns walked row by row, features line-buffered in LDS, the six layers pipelined across the waves of a
- * workgroup; any H, W <= 224; 0: the layer-by-layer kernels below, which also serve wider images), "gen_layer_path" (0: VALU layer kernels instead of the matrix-core
+ * workgroup; any H, W <= 224; clear: the layer-by-layer kernels below, which also serve wider images.  Bit 1, opt-in: the
+ * five data-gradient groups as ONE launch, gen_fused_bwd.hip -- same scheme, global memory touched by a staging and a
+ * storing wave only; measured slower than the five layer launches at 120 frames), "gen_layer_path" (0: VALU layer kernels instead of the matrix-core
  * ones), "gen_gather" (0: push form for the Cout-8 layers), "gen_fuse45" (0: layers 4 and 5 as two
  * launches), "gen_wgrad_path" (0: all-waves-stage weight gradient; 1: fp32 producer/consumer; 2 / 3: bf16x3; 4, the default: bf16x3 with wide LDS reads), "gen_fuse_fwd" / "gen_fuse_bwd"
  * (0: the layer-by-layer forward / data-gradient launches instead of the fused groups), "gen_x3" (bit K: hidden

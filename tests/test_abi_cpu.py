@@ -130,7 +130,7 @@ def test_classifier_conv_entry_points_host_side_without_gpu():
     # generator kernel selection: layer 1 on gen_x3.hip, data-gradient groups 0 and 1 on the Winograd ring kernel;
     # the measurement-only options are off
     assert lib.dmc_get_option(b"gen_x3") == 2 and lib.dmc_get_option(b"gen_wino") == 0x300
-    assert lib.dmc_get_option(b"gen_fused") == 1                 # the one-launch forward (csrc/gen_fused.hip)
+    assert lib.dmc_get_option(b"gen_fused") == 1                 # bit 0: the one-launch forward (csrc/gen_fused.hip); bit 1 (opt-in): the one-launch data gradient (gen_fused_bwd.hip)
     # the options that switch parts of a kernel off (results wrong) exist only in the -DDMC_MEASURE build: the product library
     # refuses to set them and reads them as 0 -- no option value can make it compute something else than the reference
     for name in (b"gen_ablate", b"gen_stagger", b"conv_ablate"):

@@ -1,4 +1,5 @@
-"""EstimatorDenseNetTiny forward as ONE launch (csrc/gen_fused.hip; option gen_fused = 1, the default): strips of <= 118 columns
+"""EstimatorDenseNetTiny forward as ONE launch (csrc/gen_fused.hip; option gen_fused bit 0, the default) and its data gradient as
+ONE launch (gen_fused_bwd.hip; bit 1, opt-in: measured slower than the five layer launches): strips of <= 118 columns
 walked row by row, six layers pipelined across the waves of a workgroup.  The oracle / golden cases of tests/test_hip_parity.py
 run on it by default; here: the shapes its geometry cares about (one strip with one or two pixel halves, two strips with even
 and odd widths, images shorter than the pipeline, more strips than workgroups), the saved features the backward reads, the
@@ -24,7 +25,7 @@ def _set(name, value):
 
 
 def test_fused_forward_is_the_default():
-    assert dmcnet_amd._lib.load().dmc_get_option(b"gen_fused") == 1
+    assert dmcnet_amd._lib.load().dmc_get_option(b"gen_fused") == 1      # bit 0: forward (default), bit 1: data gradient (opt-in)
 
 
 # widths: <= 62 one pixel half; 63 .. 118 two halves of one strip; 119 .. 224 two strips (odd widths: unequal strips);
@@ -32,8 +33,10 @@ def test_fused_forward_is_the_default():
 @pytest.mark.parametrize("shape", [(1, 5, 1, 1), (2, 5, 2, 3), (1, 5, 5, 62), (1, 5, 7, 63), (2, 5, 9, 64), (1, 5, 12, 117),
                                    (1, 5, 13, 118), (1, 5, 11, 119), (2, 5, 10, 120), (1, 5, 8, 121), (1, 5, 17, 223),
                                    (2, 5, 30, 224), (1, 5, 3, 224), (1, 5, 1, 224), (1, 5, 26, 180), (1, 5, 6, 225)])
-@pytest.mark.parametrize("delta", [False, True])
-def test_fused_forward_edge_shapes(shape, delta):
+@pytest.mark.parametrize("delta,fused", [(False, 1), (True, 1), (True, 3)])
+def test_fused_forward_edge_shapes(shape, delta, fused, request):
+    before = _set(b"gen_fused", fused)                 # 3: the one-launch data gradient too
+    request.addfinalizer(lambda: _set(b"gen_fused", before))
     o, m = tiny_pair(12)
     x = rnd(7, shape)
     yo = o(x) + (x[:, :2] if delta else 0)
@@ -72,7 +75,7 @@ def test_fused_forward_saved_features_and_second_witness():
     y64 = o64.predict_flow(xin) + mv.double()
     ws, bs = m._params()
     got = {}
-    for fused in (1, 0):
+    for fused in (3, 0):
         before = _set(b"gen_fused", fused)
         try:
             with torch.enable_grad():
@@ -82,11 +85,11 @@ def test_fused_forward_saved_features_and_second_witness():
         finally:
             _set(b"gen_fused", before)
     f64 = torch.cat(feats64, 1)                                  # physical order: y0 | y1 | y2 | y3 | y4
-    e_f, e_l = rel_err(got[1][1], f64), rel_err(got[0][1], f64)
+    e_f, e_l = rel_err(got[3][1], f64), rel_err(got[0][1], f64)
     assert e_f <= max(2 * e_l, 1e-6), (e_f, e_l)
-    e_f, e_l = rel_err(got[1][0], y64), rel_err(got[0][0], y64)
+    e_f, e_l = rel_err(got[3][0], y64), rel_err(got[0][0], y64)
     assert e_f <= max(2 * e_l, 1e-6), (e_f, e_l)
-    assert rel_err(got[1][0], got[0][0]) < 2e-6 and rel_err(got[1][1], got[0][1]) < 2e-6
+    assert rel_err(got[3][0], got[0][0]) < 2e-6 and rel_err(got[3][1], got[0][1]) < 2e-6
 
 
 def test_fused_forward_full_frames_vs_fp64_and_determinism():
@@ -103,7 +106,7 @@ def test_fused_forward_full_frames_vs_fp64_and_determinism():
         y64 = o64(x.double()) + mv.double()
     loss64 = float(((y64 - flow.double()) ** 2).mean())
     runs = {}
-    for fused in (1, 1, 0):
+    for fused in (3, 3, 0):
         before = _set(b"gen_fused", fused)
         try:
             m.zero_grad()
@@ -115,7 +118,7 @@ def test_fused_forward_full_frames_vs_fp64_and_determinism():
             runs.setdefault(fused, []).append((y.detach().clone(), [p.grad.clone() for p in m.parameters()], float(loss), saved))
         finally:
             _set(b"gen_fused", before)
-    a, b = runs[1]
+    a, b = runs[3]
     assert torch.equal(a[0], b[0]) and a[2] == b[2] and torch.equal(a[3], b[3])
     for ga, gb in zip(a[1], b[1]):
         assert torch.equal(ga, gb)

@@ -193,7 +193,7 @@ def _generic_case(seed, frames):
 GENERIC_CASES = [(23, 24), (24, 24), (25, 24), (26, 24), (27, 24), (23, 120)]
 
 
-@pytest.mark.parametrize("backward_mask", [0x300, 0x1F00], ids=["default", "every_group_winograd"])
+@pytest.mark.parametrize("backward_mask", [0x300, 0x1F00, -1], ids=["default", "every_group_winograd", "one_launch_data_gradient"])
 @pytest.mark.parametrize("seed,frames", GENERIC_CASES)
 def test_generator_full_batch_generic_weights(seed, frames, backward_mask):
     """224 x 224 frames with GENERIC weights (mixed-sign pre-activations in every tile), conditioned on the run's own LeakyReLU
@@ -209,14 +209,18 @@ def test_generator_full_batch_generic_weights(seed, frames, backward_mask):
         pytest.skip("the 120-frame batch runs once, on the default selection")
     o, o64, m, x, r = _generic_case(seed, frames)
     lib = dmcnet_amd._lib.load()
-    before = lib.dmc_get_option(b"gen_wino")
-    dmcnet_amd._lib.check(lib.dmc_set_option(b"gen_wino", backward_mask), "dmc_set_option")
+    before, fused_before = lib.dmc_get_option(b"gen_wino"), lib.dmc_get_option(b"gen_fused")
+    if backward_mask < 0:          # the five data-gradient groups as one launch (csrc/gen_fused_bwd.hip, option gen_fused bit 1)
+        dmcnet_amd._lib.check(lib.dmc_set_option(b"gen_fused", 3), "dmc_set_option")
+    else:
+        dmcnet_amd._lib.check(lib.dmc_set_option(b"gen_wino", backward_mask), "dmc_set_option")
     try:
         y = m.forward_mv_res(x[:, :2].contiguous().to(DEV), x[:, 2:].contiguous().to(DEV), add_mv=True)
         saved = y.grad_fn.saved_tensors[2].view(frames, 28, 224, 224)
         (y * r.to(DEV)).sum().backward()
     finally:
         dmcnet_amd._lib.check(lib.dmc_set_option(b"gen_wino", before), "dmc_set_option")
+        dmcnet_amd._lib.check(lib.dmc_set_option(b"gen_fused", fused_before), "dmc_set_option")
     rep = conditioned_report(o, o64, x, r, y.detach(), [p.grad for p in m.parameters()], saved)
     print("seed %d, %d frames: sign disagreements with fp64: device %d, oracle %d; output error %.2e (oracle %.2e)"
           % (seed, frames, rep["flips_hip"], rep["flips_ref"], rep["e_out_hip"], rep["e_out_ref"]))
