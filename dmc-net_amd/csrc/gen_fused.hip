@@ -68,7 +68,8 @@ struct FusedArgs {
     double* mse_part;     // [gridDim.x * 2]
     int H, W, add_mv;
     int nstrips, sw, m;   // strips per frame; strip width in LDS columns; first image column the second strip owns
-    int nitems;           // N * nstrips
+    int vsplit, vhalo;    // row bands per strip; rows a band recomputes above / below
+    int nitems;           // N * nstrips * vsplit
 #ifdef DMC_MEASURE
     int feat_one_frame;           // every frame's features land in frame 0's planes (isolates the cost of the store INSTRUCTIONS from HBM write traffic)
     unsigned long long* prof;     // [gridDim.x][12 waves][4]: busy clocks, total clocks, HW_ID, steps (tools/ubench/gen_fused_prof.hip)
@@ -100,8 +101,8 @@ __device__ __forceinline__ int fz_feat_frame(const FusedArgs& a, int n) { return
 __device__ __forceinline__ int fz_feat_frame(const FusedArgs&, int n) { return n; }
 #endif
 
-// steps per strip: H + 11 (the last output row leaves layer 5 in step H + 10), rounded up to whole phase triples; the
-// extra steps find every row out of range and only meet the barrier
+// steps per work item of H window rows: H + 11 (the last output row leaves layer 5 in step H + 10), rounded up to whole phase
+// triples; the extra steps find every row out of range and only meet the barrier
 __device__ __forceinline__ int fz_steps(int H) { return (H + FZ_LAG + 1 + 2) / 3 * 3; }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -178,10 +179,10 @@ struct FzLayer {
     float mvv[2], flw[2];
     __device__ __forceinline__ void prefetch(const FusedArgs& a, const Strip& st, const Half& h, const float* lds, int t) {
         const int i = t - 2 * K, o = i - 1;
-        if (i >= 0 && i < a.H) load_b<0, OLD>(lds, h.col, i);
+        if (i >= st.w0 && i < st.w1) load_b<0, OLD>(lds, h.col, i);
         if constexpr (K == NL - 1) {
             mvv[0] = mvv[1] = flw[0] = flw[1] = 0.f;
-            if (o >= 0 && o < a.H && h.store) {
+            if (o >= st.s0 && o < st.s1 && h.store) {
                 const unsigned hw = (unsigned)(a.H * a.W);
                 const size_t plane = (size_t)st.n * 2 * hw;
                 const unsigned pix = ((unsigned)(o * a.W + st.c0) + h.ucol) * 4u;
@@ -198,8 +199,8 @@ struct FzLayer {
     template <int J>
     __device__ __forceinline__ void step(const FusedArgs& a, const Strip& st, const Half& h, float* lds, int t) {
         const int i = t - 2 * K, o = i - 1;
-        const bool emit = o >= 0 && o < a.H;
-        if (i >= 0 && i < a.H) {
+        const bool emit = o >= st.w0 && o < st.w1, keep = o >= st.s0 && o < st.s1;      // complete a row of the window / one the item stores
+        if (i >= st.w0 && i < st.w1) {
             load_b<OLD, CIN>(lds, h.col, i);
             FzTiles<K, J, 0, true>::run(acc, A[0], b[0]);
 #pragma unroll
@@ -231,12 +232,12 @@ struct FzLayer {
 #pragma unroll
                     for (int co = 0; co < C; ++co) ring[co * FZ_RS] = v[co];
                 }
-                if (h.store && a.feat) {
+                if (h.store && keep && a.feat) {
                     float* plane = a.feat + ((size_t)fz_feat_frame(a, st.n) * NFEAT + (yoff(K) - NIN)) * hw;
 #pragma unroll
                     for (int co = 0; co < C; ++co) store_at(plane + co * hw, pix, v[co]);
                 }
-            } else if (h.store) {
+            } else if (h.store && keep) {
                 float* plane = a.out + (size_t)st.n * 2 * hw;
 #pragma unroll
                 for (int co = 0; co < C; ++co) {
@@ -295,21 +296,21 @@ struct FzLayer<0> {
     template <int J>
     __device__ __forceinline__ void step(const FusedArgs& a, const Strip& st, const Half& h, float* lds, int t) {
         const int o = t - 1;
-        if (o < 0 || o >= a.H) return;
+        if (o < st.w0 || o >= st.w1) return;
         // all fifteen operands first (a row outside the image is read from the nearest one inside and not used)
         float b[3][CIN];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
             int r = o + dy - 1;
-            r = r < 0 ? 0 : r >= a.H ? a.H - 1 : r;
+            r = r < st.w0 ? st.w0 : r >= st.w1 ? st.w1 - 1 : r;
             const float* p = lds + fz_base(0) + (r % fz_len(0)) * (NIN * FZ_RS) + h.col;
 #pragma unroll
             for (int ci = 0; ci < CIN; ++ci) b[dy][ci] = p[ci * FZ_RS];
         }
         __builtin_amdgcn_sched_barrier(0);           // (the compiler otherwise sinks each read to its MFMA, one exposed LDS latency per pair)
         tap_row<1, true>(b);
-        if (o >= 1) tap_row<0, false>(b);
-        if (o + 1 < a.H) tap_row<2, false>(b);
+        if (o - 1 >= st.w0) tap_row<0, false>(b);
+        if (o + 1 < st.w1) tap_row<2, false>(b);
         float v[C];
 #pragma unroll
         for (int co = 0; co < C; ++co) {
@@ -324,7 +325,7 @@ struct FzLayer<0> {
 #pragma unroll
             for (int co = 0; co < C; ++co) ring[co * FZ_RS] = v[co];
         }
-        if (h.store && a.feat) {
+        if (h.store && o >= st.s0 && o < st.s1 && a.feat) {
             const unsigned hw = (unsigned)(a.H * a.W), pix = ((unsigned)(o * a.W + st.c0) + h.ucol) * 4u;
             float* plane = a.feat + (size_t)fz_feat_frame(a, st.n) * NFEAT * hw;
 #pragma unroll
@@ -342,20 +343,20 @@ __device__ __forceinline__ void run_layers(const FusedArgs& a, float* lds, int h
     la.load_weights(a.pk, lane);
     la.sq = 0.0;
     if (KB >= 0) { lb.load_weights(a.pk, lane); lb.sq = 0.0; }
-    const int steps = fz_steps(a.H);
 #pragma unroll 1
     for (int item = blockIdx.x; item < a.nitems; item += gridDim.x) {
         const Strip st = strip_of(a, item);
         const Half h = half_of(a, st, hf, lane), hb = half_of(a, st, hfb, lane);
+        const int t0 = st.w0, steps = fz_steps(st.w1 - st.w0);        // step t0 + k consumes the window's row k in layer 0
         la.reset();
         if (KB >= 0) lb.reset();
-        step_barrier();                                        // input row 0 is staged
-        la.prefetch(a, st, h, lds, 0);
-        if (KB >= 0) lb.prefetch(a, st, hb, lds, 0);
+        step_barrier();                                        // the window's first input row is staged
+        la.prefetch(a, st, h, lds, t0);
+        if (KB >= 0) lb.prefetch(a, st, hb, lds, t0);
         if constexpr (KB < 0 && FzLayer<KA>::ROT) {
             // a rotating layer: three steps per trip, one per phase (straight-line code: the accumulators never meet a phi)
 #pragma unroll 1
-            for (int t = 0; t < steps; t += 3) {
+            for (int t = t0; t < t0 + steps; t += 3) {
                 prof.begin(); la.template step<0>(a, st, h, lds, t); prof.end();
                 step_barrier();
                 prof.begin(); la.template step<1>(a, st, h, lds, t + 1); prof.end();
@@ -366,7 +367,7 @@ __device__ __forceinline__ void run_layers(const FusedArgs& a, float* lds, int h
         } else {
             static_assert(KB < 0 || (!FzLayer<KA>::ROT && !FzLayer<(KB >= 0 ? KB : 0)>::ROT), "a rotating layer has its wave to itself");
 #pragma unroll 1
-            for (int t = 0; t < steps; ++t) {
+            for (int t = t0; t < t0 + steps; ++t) {
                 prof.begin();
                 la.template step<0>(a, st, h, lds, t);
                 if (KB >= 0) lb.template step<0>(a, st, hb, lds, t);
@@ -389,12 +390,11 @@ __device__ __forceinline__ void run_layers(const FusedArgs& a, float* lds, int h
 // column and do not write.
 __device__ __forceinline__ void run_loader(const FusedArgs& a, float* lds, int lane, int wave) {
     FzProf prof;
-    const int steps = fz_steps(a.H);
     const unsigned hw = (unsigned)(a.H * a.W);
     float v[NIN][2];
     const unsigned c[2] = {(unsigned)min(lane, a.sw - 1) * 4u, (unsigned)min(lane + 64, a.sw - 1) * 4u};
     auto request = [&](const Strip& st, int row) {
-        if (row >= a.H) return;
+        if (row >= st.w1) return;
         const unsigned rowoff = (unsigned)(row * a.W + st.c0) * 4u;
 #pragma unroll
         for (int p = 0; p < NIN; ++p) {
@@ -403,8 +403,8 @@ __device__ __forceinline__ void run_loader(const FusedArgs& a, float* lds, int l
             for (int q = 0; q < 2; ++q) v[p][q] = load_at(plane, rowoff + c[q]);
         }
     };
-    auto park = [&](int row) {
-        if (row >= a.H) return;
+    auto park = [&](const Strip& st, int row) {
+        if (row >= st.w1) return;
         float* dst = lds + fz_base(0) + (row % fz_len(0)) * (NIN * FZ_RS) + lane;
         if (lane < a.sw) {
 #pragma unroll
@@ -418,14 +418,15 @@ __device__ __forceinline__ void run_loader(const FusedArgs& a, float* lds, int l
 #pragma unroll 1
     for (int item = blockIdx.x; item < a.nitems; item += gridDim.x) {
         const Strip st = strip_of(a, item);
-        request(st, 0);
-        park(0);
-        request(st, 1);
+        const int t0 = st.w0, steps = fz_steps(st.w1 - st.w0);
+        request(st, t0);
+        park(st, t0);
+        request(st, t0 + 1);
         step_barrier();
 #pragma unroll 1
-        for (int t = 0; t < steps; ++t) {
+        for (int t = t0; t < t0 + steps; ++t) {
             prof.begin();
-            park(t + 1);
+            park(st, t + 1);
             request(st, t + 2);
             prof.end();
             step_barrier();
@@ -475,9 +476,10 @@ int gen_fused_fwd(const float* mv, const float* res, float* feat, float* out, co
     a.flow = flow && mse_part ? flow : nullptr;
     a.mse_part = mse_part;
     a.H = H; a.W = W; a.add_mv = add_mv;
-    const StripGeo geo = strip_geo(W, FZ_HALO);
+    const StripGeo geo = strip_geo(N, H, W, FZ_HALO, FZ_LAG);
     a.nstrips = geo.nstrips; a.sw = geo.sw; a.m = geo.m;
-    a.nitems = N * a.nstrips;
+    a.vsplit = geo.vsplit; a.vhalo = FZ_HALO;
+    a.nitems = N * a.nstrips * a.vsplit;
 #ifdef DMC_MEASURE
     a.prof = g_fz_prof;
     a.feat_one_frame = g_fz_feat_one_frame;

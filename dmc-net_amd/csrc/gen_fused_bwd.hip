@@ -82,6 +82,7 @@ struct BwdArgs {
     const float* pk;      // packed parameters (WB block)
     int H, W;
     int nstrips, sw, m, nitems;
+    int vsplit, vhalo;    // (row bands: not used by this kernel -- 1, 0)
 };
 
 __device__ __forceinline__ int bz_steps(int H) { return (H + BZ_LAG + 1 + 2) / 3 * 3; }
@@ -385,8 +386,9 @@ int gen_fused_bwd_data(const float* gout, const float* feat, float* gbuf, const 
     if (!gen_fused_supported(H, W)) return fail(DMC_E_INVALID, "gen_fused_bwd_data: shape %d x %d not served", H, W);
     BwdArgs a;
     a.gout = gout; a.feat = feat; a.gbuf = gbuf; a.pk = pk; a.H = H; a.W = W;
-    const StripGeo geo = strip_geo(W, BZ_HALO);
+    const StripGeo geo = strip_geo(N, H, W, BZ_HALO, BZ_LAG);
     a.nstrips = geo.nstrips; a.sw = geo.sw; a.m = geo.m;
+    a.vsplit = 1; a.vhalo = 0;
     a.nitems = N * a.nstrips;
     const int wgs = a.nitems < fz_num_cus() ? a.nitems : fz_num_cus();
     gen_fused_bwd_kernel<<<wgs, BZ_THREADS, 0, s>>>(a);

@@ -16,6 +16,8 @@ struct Strip {
     int n;                // frame
     int c0;               // image column of LDS column 0
     int v0, v1;           // LDS columns [v0, v1) are this strip's to store
+    int w0, w1;           // image rows [w0, w1): the rows this work item sees (everything outside counts as zero padding)
+    int s0, s1;           // image rows [s0, s1) are this item's to store (the window = these + the halo rows inside the image)
 };
 
 // global access = scalar plane base + 32-bit BYTE offset per lane (the form the saddr encodings take: no 64-bit vector adds).
@@ -58,15 +60,24 @@ struct Half {
     bool store;           // ... and one the strip stores to HBM
 };
 
+// item -> (frame, strip, vertical part).  A frame's strips may be cut into a.vsplit row bands (more, shorter work items when
+// frames x strips does not fill the CUs in whole rounds); a band recomputes a.vhalo rows of every layer above and below
+// (where the image continues) exactly as a strip recomputes halo columns.
 template <typename Args>
 __device__ __forceinline__ Strip strip_of(const Args& a, int item) {
     Strip st;
-    // (readfirstlane: the division runs on the vector unit; everything derived from the frame index should be scalar again)
-    st.n = __builtin_amdgcn_readfirstlane(item / a.nstrips);
-    const int s = item - st.n * a.nstrips;
+    // (readfirstlane: the divisions run on the vector unit; everything derived from the item should be scalar again)
+    const int fs = __builtin_amdgcn_readfirstlane(item / a.vsplit), vp = item - fs * a.vsplit;
+    st.n = __builtin_amdgcn_readfirstlane(fs / a.nstrips);
+    const int s = fs - st.n * a.nstrips;
     if (a.nstrips == 1) { st.c0 = 0; st.v0 = 0; st.v1 = a.W; }
     else if (s == 0) { st.c0 = 0; st.v0 = 0; st.v1 = a.m; }
     else { st.c0 = a.W - a.sw; st.v0 = a.sw - (a.W - a.m); st.v1 = a.sw; }
+    const int rp = (a.H + a.vsplit - 1) / a.vsplit;
+    st.s0 = vp * rp;
+    st.s1 = min(a.H, st.s0 + rp);
+    st.w0 = max(0, st.s0 - a.vhalo);
+    st.w1 = min(a.H, st.s1 + a.vhalo);
     return st;
 }
 
@@ -97,11 +108,20 @@ inline int fz_num_cus() {
 
 
 // strip geometry of a launch: one strip up to FZ_MAXSW columns, else two strips with `halo` recomputed columns on the interior side
-struct StripGeo { int nstrips, sw, m; };
-inline StripGeo strip_geo(int W, int halo) {
+struct StripGeo { int nstrips, sw, m, vsplit; };
+// vsplit: the number of row bands per strip that minimises (rounds of workgroups) x (steps of a band); `lag` = pipeline depth in steps
+inline StripGeo strip_geo(int N, int H, int W, int halo, int lag) {
     StripGeo g;
     if (W <= FZ_MAXSW) { g.nstrips = 1; g.sw = W; g.m = W; }
     else { g.nstrips = 2; g.m = (W + 1) / 2; g.sw = g.m + halo; }
+    long best = -1;
+    g.vsplit = 1;
+    for (int vs = 1; vs <= 4 && (vs == 1 || (H + vs - 1) / vs >= 4 * halo); ++vs) {
+        const long items = (long)N * g.nstrips * vs, rounds = (items + fz_num_cus() - 1) / fz_num_cus();
+        const int rows = (H + vs - 1) / vs + (vs > 1 ? 2 * halo : 0);
+        const long cost = rounds * ((rows + lag + 1 + 2) / 3 * 3);
+        if (best < 0 || cost < best) { best = cost; g.vsplit = vs; }
+    }
     return g;
 }
 
