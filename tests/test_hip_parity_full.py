@@ -189,12 +189,13 @@ def _generic_case(seed, frames):
     return o, copy.deepcopy(o).double(), m, x, r
 
 
-# (seed, frames): the five data seeds of tools/gen_flip_lottery.py at 24 frames each, and the full 120-frame batch once
-GENERIC_CASES = [(23, 24), (24, 24), (25, 24), (26, 24), (27, 24), (23, 120)]
+# (seed, frames, backward selection): the five data seeds of tools/gen_flip_lottery.py at 16 frames each for the default backward and
+# for every data-gradient group on the Winograd kernel (mask 0x1F00); the one-launch data gradient (-1) on two seeds; the full
+# 120-frame batch once.  (16 frames = 0.8 M pixels per seed: the CPU side -- one fp32 and three fp64 passes -- sets the run time.)
+GENERIC_CASES = ([(s, 16, m) for s in (23, 24, 25, 26, 27) for m in (0x300, 0x1F00)] + [(23, 16, -1), (24, 16, -1), (23, 120, 0x300)])
 
 
-@pytest.mark.parametrize("backward_mask", [0x300, 0x1F00, -1], ids=["default", "every_group_winograd", "one_launch_data_gradient"])
-@pytest.mark.parametrize("seed,frames", GENERIC_CASES)
+@pytest.mark.parametrize("seed,frames,backward_mask", GENERIC_CASES)
 def test_generator_full_batch_generic_weights(seed, frames, backward_mask):
     """224 x 224 frames with GENERIC weights (mixed-sign pre-activations in every tile), conditioned on the run's own LeakyReLU
     branches (tests/gen_conditioned.py): every parameter gradient of the device run is compared with the fp64 backward whose
@@ -205,8 +206,6 @@ def test_generator_full_batch_generic_weights(seed, frames, backward_mask):
     included: profiles/r4_gen_wino.txt.)  Runs for the default kernel selection and with every data-gradient group on the
     Winograd kernel; the forward is the fused one-launch kernel (csrc/gen_fused.hip)."""
     from tests.gen_conditioned import conditioned_report
-    if backward_mask != 0x300 and frames == 120:
-        pytest.skip("the 120-frame batch runs once, on the default selection")
     o, o64, m, x, r = _generic_case(seed, frames)
     lib = dmcnet_amd._lib.load()
     before, fused_before = lib.dmc_get_option(b"gen_wino"), lib.dmc_get_option(b"gen_fused")

@@ -48,8 +48,11 @@ def _oracle(num_class, gan, seed, dtype):
     return o, opts
 
 
-def run(kind="dmcnet", steps=20, batch=8, num_class=51, seed=700, log=None, fp64=False):
-    """Returns a list of per-step dicts: {"ref": {...}, "got": {...}, "rel": {...}, "cos": float}; with ``fp64`` also the
+def run(kind="dmcnet", steps=20, batch=8, num_class=51, seed=700, log=None, fp64=False, resync=False):
+    """``resync``: before every step the device model is given the ORACLE's current weights and buffers, so every step is a
+    one-step comparison from an identical state along the trajectory the oracle takes (losses and logits depend on the
+    weights only; the optimizer update itself is pinned by the golden G4 steps) -- no chaotic amplification in it.
+    Returns a list of per-step dicts: {"ref": {...}, "got": {...}, "rel": {...}, "cos": float}; with ``fp64`` also the
     same trajectory of the oracle in DOUBLE precision ("f64") and the gaps of both fp32 runs to it ("rel64_hip", "rel64_ref"):
     how far two fp32 evaluations of the same recipe drift apart by themselves."""
     gan = kind == "gan"
@@ -68,6 +71,8 @@ def run(kind="dmcnet", steps=20, batch=8, num_class=51, seed=700, log=None, fp64
         b = O.synthetic_batch(seed=seed + 1 + i, batch=batch, num_segments=3, num_class=num_class,
                               flow_ds_factor=0 if gan else 16)
         b64 = tuple(t.double() if t.is_floating_point() else t for t in b)
+        if resync and i > 0:
+            m.load_state_dict(o.state_dict())
         t0 = time.time()
         r64 = None
         if gan:
