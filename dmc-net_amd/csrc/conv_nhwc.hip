@@ -2018,8 +2018,10 @@ int dmc_conv_nhwc_stats_final(const double* partials, int nblk, int C, long coun
 size_t dmc_conv_nhwc_wgrad_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     if (wgrad_small_ok(Cin, KH, KW, pad)) {
+        // sized for whichever kernel the launch may pick: the choice depends on process-wide options (conv_arith, conv_cfg) that can
+        // differ between this call and the launch, the group count of the small-channel kernel only on the shape -- take the larger
         int groups = 512;
-        if (csm_supported(N, H, W, Cin, Cout, KH, KW, stride, pad) && csm_wgrad_groups(N, H, W, Cin) > groups) groups = csm_wgrad_groups(N, H, W, Cin);
+        if (csm_wgrad_groups(N, H, W, Cin) > groups) groups = csm_wgrad_groups(N, H, W, Cin);
         return (size_t)groups * Cout * 9 * Cin * sizeof(float) + 16;
     }
     if (wgrad3_ok(Cin, Cout, KH, KW, pad, stride)) {
