@@ -8,9 +8,9 @@ namespace dmc {
 bool gen_fused_supported(int H, int W);
 // upper bound of the per-wave loss partials one launch writes (doubles)
 int gen_fused_max_partials();
-// out = predict_flow(...) [+ mv]; feat ([N][28][H][W], may be null: inference, nothing saved) receives y0 .. y4;
+// prm: the six weights [Cout][Cin][3][3] and six biases as PyTorch holds them (no repack).  out = predict_flow(...) [+ mv]; feat ([N][28][H][W], may be null: inference, nothing saved) receives y0 .. y4;
 // flow != null: sum((out - flow)^2) per wave into mse_part[0 .. *nparts)
-int gen_fused_fwd(const float* mv, const float* res, float* feat, float* out, const float* pk, const float* flow,
+int gen_fused_fwd(const float* mv, const float* res, float* feat, float* out, const ParamPtrs& prm, const float* flow,
                   double* mse_part, int* nparts, int N, int H, int W, int add_mv, hipStream_t s);
 
 // g_0 .. g_4 (gbuf, [N][28][H][W]) = the data gradient of every feature group from dL/dout and the saved features, one launch

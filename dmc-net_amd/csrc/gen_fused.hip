@@ -20,7 +20,8 @@
 //     18/20: 1,181 MFMAs per 64 pixels against 1,266 with gathered vertical taps.
 //   * The weights live in REGISTERS for the whole launch: with cbsz = 4 the MFMA broadcasts the A values of block `abid`
 //     to all 16 blocks, so ONE register holds the 4-row A operands of 16 row tiles (lane 4 t + i = row i of tile t) and
-//     layer k needs Cin ceil(NT / 16) of them (10 / 26 / 21 / 27 / 31 / 33).  No weight traffic at all.
+//     layer k needs Cin ceil(NT / 16) of them (10 / 26 / 21 / 27 / 31 / 33), read once per wave straight from the twelve PyTorch
+//     parameter tensors (the reference's prepend channel order is mapped on the fly: no repack launch).  No weight traffic at all.
 //   * Layer k consumes input row t - 2k in step t and completes output row t - 2k - 1, which layer k + 1 consumes in step
 //     t + 1: every value read in a step was written in an EARLIER step, so the layers run CONCURRENTLY on different waves
 //     with one barrier per step.  Ring of group g (g = 0: the 5 input planes; g = 1 .. 5: y0 .. y4) holds rows
@@ -63,7 +64,7 @@ struct FusedArgs {
     const float* res;     // [N,3,H,W]
     float* feat;          // [N,28,H,W] or null
     float* out;           // [N,2,H,W]
-    const float* pk;      // packed parameters (dmc_common.h)
+    ParamPtrs prm;        // the twelve parameter tensors as PyTorch holds them (w[k]: [Cout][Cin_logical][3][3]): read once per wave
     const float* flow;    // [N,2,H,W] or null
     double* mse_part;     // [gridDim.x * 2]
     int H, W, add_mv;
@@ -146,17 +147,18 @@ struct FzLayer {
     double sq;                        // K == 5: sum of squared differences to the flow target
     static constexpr bool ROT = G::ROT;
 
-    __device__ __forceinline__ void load_weights(const float* __restrict__ pk, int lane) {
+    __device__ __forceinline__ void load_weights(const ParamPtrs& prm, int lane) {
 #pragma unroll
         for (int ci = 0; ci < CIN; ++ci)
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
                 const int r = 4 * (16 * a + (lane >> 2)) + (lane & 3);
                 const int dy = r / (3 * C), dx = (r / C) % 3, co = r % C;
-                A[ci][a] = r < NROW ? pk[wf_off(K) + (ci * 9 + dy * 3 + dx) * C + co] : 0.f;
+                // (physical channel ci of this kernel = logical channel logical_of(K, ci) of the reference's prepend order)
+                A[ci][a] = r < NROW ? prm.w[K][(co * CIN + logical_of(K, ci)) * 9 + dy * 3 + dx] : 0.f;
             }
 #pragma unroll
-        for (int co = 0; co < C; ++co) bias[co] = pk[bf_off(K) + co];
+        for (int co = 0; co < C; ++co) bias[co] = prm.b[K][co];
     }
     __device__ __forceinline__ void reset() {
 #pragma unroll
@@ -269,14 +271,14 @@ struct FzLayer<0> {
     float bias[C];
     double sq;
 
-    __device__ __forceinline__ void load_weights(const float* __restrict__ pk, int lane) {
+    __device__ __forceinline__ void load_weights(const ParamPtrs& prm, int lane) {
 #pragma unroll
         for (int q = 0; q < CIN * 3; ++q) {
             const int r = lane, dx = r / C, co = r % C;
-            A[q] = r < 3 * C ? pk[wf_off(0) + ((q / 3) * 9 + (q % 3) * 3 + dx) * C + co] : 0.f;
+            A[q] = r < 3 * C ? prm.w[0][(co * CIN + logical_of(0, q / 3)) * 9 + (q % 3) * 3 + dx] : 0.f;
         }
 #pragma unroll
-        for (int co = 0; co < C; ++co) bias[co] = pk[bf_off(0) + co];
+        for (int co = 0; co < C; ++co) bias[co] = prm.b[0][co];
     }
     __device__ __forceinline__ void reset() {}
     __device__ __forceinline__ void prefetch(const FusedArgs&, const Strip&, const Half&, const float*, int) {}
@@ -340,9 +342,9 @@ __device__ __forceinline__ void run_layers(const FusedArgs& a, float* lds, int h
     FzProf prof;
     FzLayer<KA> la;
     FzLayer<(KB >= 0 ? KB : 0)> lb;
-    la.load_weights(a.pk, lane);
+    la.load_weights(a.prm, lane);
     la.sq = 0.0;
-    if (KB >= 0) { lb.load_weights(a.pk, lane); lb.sq = 0.0; }
+    if (KB >= 0) { lb.load_weights(a.prm, lane); lb.sq = 0.0; }
 #pragma unroll 1
     for (int item = blockIdx.x; item < a.nitems; item += gridDim.x) {
         const Strip st = strip_of(a, item);
@@ -468,11 +470,11 @@ bool gen_fused_supported(int H, int W) { return H >= 1 && W >= 1 && W <= 2 * (FZ
 
 int gen_fused_max_partials() { return 2 * fz_num_cus(); }
 
-int gen_fused_fwd(const float* mv, const float* res, float* feat, float* out, const float* pk, const float* flow,
+int gen_fused_fwd(const float* mv, const float* res, float* feat, float* out, const ParamPtrs& prm, const float* flow,
                   double* mse_part, int* nparts, int N, int H, int W, int add_mv, hipStream_t s) {
     if (!gen_fused_supported(H, W)) return fail(DMC_E_INVALID, "gen_fused_fwd: shape %d x %d not served", H, W);
     FusedArgs a;
-    a.mv = mv; a.res = res; a.feat = feat; a.out = out; a.pk = pk;
+    a.mv = mv; a.res = res; a.feat = feat; a.out = out; a.prm = prm;
     a.flow = flow && mse_part ? flow : nullptr;
     a.mse_part = mse_part;
     a.H = H; a.W = W; a.add_mv = add_mv;

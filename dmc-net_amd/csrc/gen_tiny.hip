@@ -2445,17 +2445,25 @@ static int gen_tiny_fwd_impl(const float* mv, const float* res, const float* con
                              const float* const* b, float* out, float* saved, float* workspace, int N,
                              int H, int W, int add_mv_delta, const float* flow, double* mse_part, int* fused_wgs,
                              dmc_stream_t stream) {
-    if (!mv || !res || !w || !b || !out || !saved || !workspace)
+    if (!mv || !res || !w || !b || !out || !workspace)
         return fail(DMC_E_INVALID, "dmc_gen_tiny_fwd: null pointer");
+    // saved == NULL (inference: nothing kept for a backward pass) is served by the one-launch forward only -- the layer-by-layer
+    // kernels pass the features from launch to launch THROUGH that buffer
+    if (!saved && !((option(OPT_GEN_FUSED) & 1) && N > 0 && H > 0 && W > 0 && gen_fused_supported(H, W)))
+        return fail(DMC_E_INVALID, "dmc_gen_tiny_fwd: saved == NULL needs the fused forward (option gen_fused bit 0, W <= 224)");
     if (N <= 0 || H <= 0 || W <= 0) return fail(DMC_E_INVALID, "dmc_gen_tiny_fwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
     if (fused_wgs) *fused_wgs = 0;
     // option gen_fused (default): the whole forward as ONE launch (gen_fused.hip: line-buffered in LDS, layers pipelined
     // across waves); the layer-by-layer kernels below serve wider images and the A/B options
     if ((option(OPT_GEN_FUSED) & 1) && gen_fused_supported(H, W)) {
-        int rc = pack(w, b, workspace, s);
-        if (rc) return rc;
-        return gen_fused_fwd(mv, res, saved, out, workspace, flow, mse_part, fused_wgs, N, H, W, add_mv_delta, s);
+        ParamPtrs P;                                 // (read in place: the one-launch forward needs no repacked parameter block)
+        for (int k = 0; k < NL; ++k) {
+            if (!w[k] || !b[k]) return fail(DMC_E_INVALID, "null weight/bias pointer %d", k);
+            P.w[k] = w[k];
+            P.b[k] = b[k];
+        }
+        return gen_fused_fwd(mv, res, saved, out, P, flow, mse_part, fused_wgs, N, H, W, add_mv_delta, s);
     }
     int x3mask = option(OPT_GEN_X3);
     for (int K = 0; K < GX_LAYERS; ++K)

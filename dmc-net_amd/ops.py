@@ -108,13 +108,17 @@ class _GenTiny(torch.autograd.Function):
         ws, bs = [p.contiguous() for p in params[:6]], [p.contiguous() for p in params[6:]]
         n, _, h, w = mv.shape
         out = torch.empty((n, 2, h, w), dtype=torch.float32, device=mv.device)
-        saved = _floats(lib.dmc_gen_tiny_saved_bytes(n, h, w), mv.device)
+        # inference (no parameter wants a gradient): the one-launch forward keeps no features -- 8 instead of 120 B/px written
+        keep = any(ctx.needs_input_grad[3:]) or not ((lib.dmc_get_option(b"gen_fused") & 1) and w <= 224)
+        saved = _floats(lib.dmc_gen_tiny_saved_bytes(n, h, w), mv.device) if keep else None
         work = _floats(lib.dmc_gen_tiny_workspace_bytes(), mv.device)
         with _span("gen_tiny_fwd"):
             _lib.check(lib.dmc_gen_tiny_fwd(_lib.ptr(mv), _lib.ptr(res), _lib.ptr_array(ws),
-                                            _lib.ptr_array(bs), _lib.ptr(out), _lib.ptr(saved),
+                                            _lib.ptr_array(bs), _lib.ptr(out), _lib.ptr(saved) if keep else None,
                                             _lib.ptr(work), n, h, w, int(add_mv), _stream()),
                        "dmc_gen_tiny_fwd")
+        if not keep:
+            return out
         ctx.save_for_backward(mv, res, saved, *ws)
         ctx.bias_like = [(b.shape, b.dtype) for b in bs]
         return out

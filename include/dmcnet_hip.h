@@ -85,10 +85,10 @@ size_t dmc_gen_tiny_saved_bytes(int N, int H, int W);
 
 /*
  * Forward.  mv [N,2,H,W], res [N,3,H,W] -> out [N,2,H,W].
- * saved: REQUIRED buffer of dmc_gen_tiny_saved_bytes(); it receives y0..y4 (the post-LeakyReLU
- * features, physical channel order) -- the later layers read them from it and the backward pass
- * needs them.  Inference callers may release it as soon as the call has been enqueued on a
- * stream-ordered allocator.
+ * saved: buffer of dmc_gen_tiny_saved_bytes(); it receives y0..y4 (the post-LeakyReLU features, physical channel order) for
+ * the backward pass.  NULL = inference (nothing is kept: the forward then writes 8 instead of 120 bytes per pixel): accepted
+ * when the one-launch forward serves the shape (option "gen_fused" bit 0, W <= 224), DMC_E_INVALID otherwise -- the
+ * layer-by-layer kernels pass the features from launch to launch through this buffer.
  * workspace: dmc_gen_tiny_workspace_bytes() (repacked weights + 256 zero words + the bf16x3 weight fragments of gen_x3.hip).
  * add_mv_delta != 0 adds input_mv to the result (gen_flow_or_delta == 1).
  * Any H, W >= 1; W % 4 == 0 takes the vectorised path.

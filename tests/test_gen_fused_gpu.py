@@ -129,3 +129,29 @@ def test_fused_forward_full_frames_vs_fp64_and_determinism():
     assert rep["flips_hip"] <= 4 * rep["flips_ref"] + 16, rep
     for k, (e_hip, e_ref) in rep["params"].items():
         assert e_hip <= max(2 * e_ref, 2e-6), (k, e_hip, e_ref)
+
+
+def test_fused_forward_inference_keeps_no_features():
+    """Under no_grad the op passes saved = NULL: the one-launch forward writes the output only (8 instead of 120 B/px) -- the
+    result is bit for bit the training-mode one; the layer-by-layer kernels, which pass features from launch to launch through
+    that buffer, refuse a NULL one at the C ABI."""
+    import ctypes
+    _, m = tiny_pair(21)
+    mv, res = rnd(31, (3, 2, 50, 224)).to(DEV), rnd(32, (3, 3, 50, 224)).to(DEV)
+    y_train = m.forward_mv_res(mv, res, add_mv=True)
+    assert y_train.grad_fn is not None
+    with torch.no_grad():
+        y_eval = m.forward_mv_res(mv, res, add_mv=True)
+    assert y_eval.grad_fn is None and torch.equal(y_eval, y_train.detach())
+    L, lib = dmcnet_amd._lib, dmcnet_amd._lib.load()
+    ws, bs = m._params()
+    ws, bs = [w.detach().contiguous() for w in ws], [b.detach().contiguous() for b in bs]
+    out = torch.empty_like(y_eval)
+    work = torch.empty(lib.dmc_gen_tiny_workspace_bytes() // 4, device=DEV)
+    before = _set(b"gen_fused", 0)
+    try:
+        rc = lib.dmc_gen_tiny_fwd(L.ptr(mv), L.ptr(res), L.ptr_array(ws), L.ptr_array(bs), L.ptr(out), ctypes.c_void_p(0), L.ptr(work),
+                                  3, 50, 224, 1, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc != 0 and b"saved == NULL" in lib.dmc_last_error()
+    finally:
+        _set(b"gen_fused", before)

@@ -23,12 +23,14 @@ int main(int argc, char** argv) {
     std::vector<float> hp(PACKED_TOTAL + ZERO_PAD);
     for (auto& v : hp) v = (rand() % 2001 - 1000) * 1e-4f;
     CK(hipMemcpy(pk, hp.data(), hp.size() * 4, hipMemcpyHostToDevice));
+    ParamPtrs P;
+    { int off = 0; for (int k = 0; k < NL; ++k) { P.w[k] = pk + off; off += cin_of(k) * 9 * cout_of(k); } for (int k = 0; k < NL; ++k) { P.b[k] = pk + off; off += cout_of(k); } }
     int nparts = 0;
-    for (int i = 0; i < 3; ++i) if (gen_fused_fwd(mv, res, save ? feat : nullptr, out, pk, flow, part, &nparts, N, H, W, 1, 0)) { printf("launch failed\n"); return 1; }
+    for (int i = 0; i < 3; ++i) if (gen_fused_fwd(mv, res, save ? feat : nullptr, out, P, flow, part, &nparts, N, H, W, 1, 0)) { printf("launch failed\n"); return 1; }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int R = 20;
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < R; ++i) gen_fused_fwd(mv, res, save ? feat : nullptr, out, pk, flow, part, &nparts, N, H, W, 1, 0);
+    for (int i = 0; i < R; ++i) gen_fused_fwd(mv, res, save ? feat : nullptr, out, P, flow, part, &nparts, N, H, W, 1, 0);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double px = (double)N * HW;
@@ -37,7 +39,7 @@ int main(int argc, char** argv) {
     const int wgs = nparts / 2;
     unsigned long long* prof; CK(hipMalloc(&prof, (size_t)wgs * 12 * 4 * 8)); CK(hipMemset(prof, 0, (size_t)wgs * 12 * 4 * 8));
     g_fz_prof = prof;
-    gen_fused_fwd(mv, res, save ? feat : nullptr, out, pk, flow, part, &nparts, N, H, W, 1, 0);
+    gen_fused_fwd(mv, res, save ? feat : nullptr, out, P, flow, part, &nparts, N, H, W, 1, 0);
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> hq((size_t)wgs * 12 * 4);
     CK(hipMemcpy(hq.data(), prof, hq.size() * 8, hipMemcpyDeviceToHost));
