@@ -7,7 +7,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libdmcnet_hip.so")
-SOURCES = ["gen_tiny.hip", "gen_x3.hip", "gen_fused.hip", "gen_fused_bwd.hip", "losses.hip", "disc_tail.hip", "bn_act.hip", "prepare.hip", "stem.hip", "conv_nhwc.hip", "conv_small.hip", "conv_x3s.hip", "conv_x3q.hip", "disc_first.hip", "conv3d_bf16.hip", "pool3d_bf16.hip", "bn3d_bf16.hip", "stem3d_bf16.hip", "unit3d.hip"]
+SOURCES = ["gen_tiny.hip", "gen_x3.hip", "gen_fused.hip", "gen_fused_bwd.hip", "gen_wgrad.hip", "losses.hip", "disc_tail.hip", "bn_act.hip", "prepare.hip", "stem.hip", "conv_nhwc.hip", "conv_small.hip", "conv_x3s.hip", "conv_x3q.hip", "disc_first.hip", "conv3d_bf16.hip", "pool3d_bf16.hip", "bn3d_bf16.hip", "stem3d_bf16.hip", "unit3d.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function"]
@@ -42,7 +42,7 @@ def build_library(force=False, verbose=False, measure=False):
             continue
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(obj)
-        hdrs = [os.path.join(CSRC, "dmc_common.h"), os.path.join(CSRC, "x3s_common.h"), os.path.join(CSRC, "conv_small.h"), os.path.join(CSRC, "gen_x3.h"), os.path.join(CSRC, "gen_fused.h"), os.path.join(CSRC, "gen_fused_inl.h"), os.path.join(ROOT, "include", "dmcnet_hip.h"),
+        hdrs = [os.path.join(CSRC, "dmc_common.h"), os.path.join(CSRC, "x3s_common.h"), os.path.join(CSRC, "conv_small.h"), os.path.join(CSRC, "gen_x3.h"), os.path.join(CSRC, "gen_fused.h"), os.path.join(CSRC, "gen_fused_inl.h"), os.path.join(CSRC, "gen_wgrad.h"), os.path.join(ROOT, "include", "dmcnet_hip.h"),
                 os.path.abspath(__file__)]
         if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in [path] + hdrs):
             continue                              # object newer than its source and the shared headers

@@ -12,6 +12,7 @@
 #include "dmc_common.h"
 #include "gen_x3.h"
 #include "gen_fused.h"
+#include "gen_wgrad.h"
 
 using namespace dmc;
 
@@ -1704,6 +1705,7 @@ constexpr int NT_A = 9, NT_B = 19, NT_ALL = NT_A + NT_B;   // accumulator tiles 
 constexpr int WPART = NT_ALL * 256;                    // floats per workgroup partial
 constexpr int NT3_A = 10, NT3_B = 21, WPART3 = (NT3_A + NT3_B) * 256;   // layout of the shared-window bf16x3 kernel (below)
 constexpr int WPART_MAX = WPART3;
+static_assert(WR_WPART == WPART3 && WR_NA == NT3_A, "gen_wgrad.hip writes the shared-window partial size");
 constexpr int WGRAD_MAX_GROUPS = 256;
 constexpr int BIAS_COL = 297;
 
@@ -2263,9 +2265,13 @@ __global__ void gen_bwd_weight_reduce_kernel(const float* __restrict__ partials,
     int nt = col >> 4, jj = col & 15;
     int slot, row;
     const int na = layout3 ? NT3_A : NT_A, wpart = layout3 ? WPART3 : WPART;
-    if (layout3) {                    // shared-window layout: column tile 3 gt + dx, column g & 15 with g = 3 p + dy; bias: g = 99, dx = 0
+    if (layout3 == 1) {               // shared-window layout: column tile 3 gt + dx, column g & 15 with g = 3 p + dy; bias: g = 99, dx = 0
         const int g = col == BIAS_COL ? 99 : 3 * p + tap / 3, dxi = col == BIAS_COL ? 0 : tap % 3;
         nt = 3 * (g >> 4) + dxi; jj = g & 15;
+    } else if (layout3 == 2) {        // gen_wgrad.hip: g = 33 dy + p; bias: g = 99, dx = 1; tile A holds gt = 0, 2, 4 in slots 3 (gt / 2) + dx
+        const int g = col == BIAS_COL ? 99 : 33 * (tap / 3) + p, dxi = col == BIAS_COL ? 1 : tap % 3;
+        nt = 3 * (g >> 4) + dxi; jj = g & 15;
+        if (k < 2 && col != BIAS_COL) nt = 3 * (g >> 5) + dxi;
     }
     if (k < 2) {                      // tile A: g0 rows 0..7, g1 rows 8..15
         row = k * 8 + co;
@@ -2581,12 +2587,16 @@ int dmc_gen_tiny_bwd(const float* mv, const float* res, const float* const* w, c
     a.mv = mv; a.res = res; a.feat = saved; a.gout = grad_out; a.gbuf = gbuf; a.partials = partials;
     a.N = N; a.H = H; a.W = W;
     a.tiles_x = (W + WT_W - 1) / WT_W;
-    const int groups = wgrad_groups(N, H, W);
+    int groups = wgrad_groups(N, H, W);
     const int wpath = option(OPT_GEN_WGRAD_PATH);
-    const bool layout3 = W % 4 == 0 && (wpath == 3 || wpath == 4);
-    if (W % 4 == 0 && wpath >= 1 && wpath <= 4) {
+    const bool rs = wpath == 5 && gen_wgrad_rs_supported(H, W);            // row-sliding kernel (gen_wgrad.hip)
+    const int layout3 = rs ? 2 : (W % 4 == 0 && wpath >= 3) ? 1 : 0;
+    if (rs) {
+        groups = gen_wgrad_rs_groups(N, H, W, groups);
+        if ((rc = gen_wgrad_rs(mv, res, saved, grad_out, gbuf, workspace + PACKED_TOTAL, partials, N, H, W, groups, s))) return rc;
+    } else if (W % 4 == 0 && wpath >= 1) {
         a.tiles_y = (H + PW_H - 1) / PW_H;
-        if (wpath == 4) gen_bwd_weight_pc_kernel<3><<<groups, 512, 0, s>>>(a);
+        if (wpath >= 4) gen_bwd_weight_pc_kernel<3><<<groups, 512, 0, s>>>(a);
         else if (wpath == 3) gen_bwd_weight_pc_kernel<2><<<groups, 512, 0, s>>>(a);
         else if (wpath == 2) gen_bwd_weight_pc_kernel<1><<<groups, 512, 0, s>>>(a);
         else gen_bwd_weight_pc_kernel<0><<<groups, 512, 0, s>>>(a);
@@ -2599,7 +2609,7 @@ int dmc_gen_tiny_bwd(const float* mv, const float* res, const float* const* w, c
     const int wpart = layout3 ? WPART3 : WPART;
     gen_bwd_weight_reduce1_kernel<<<dim3(wpart / 256, RED_CHUNKS), 256, 0, s>>>(partials, groups, wpart);
     if ((rc = check_launch("gen_bwd_weight_reduce1"))) return rc;
-    gen_bwd_weight_reduce_kernel<<<(NPARAM + 127) / 128, 128, 0, s>>>(partials, groups, G, layout3 ? 1 : 0);
+    gen_bwd_weight_reduce_kernel<<<(NPARAM + 127) / 128, 128, 0, s>>>(partials, groups, G, layout3);
     return check_launch("gen_bwd_weight_reduce");
 }
 
