@@ -5,22 +5,25 @@
 //
 // gen_bwd_weight_pc_kernel<3> splits every fp32 operand into its three bf16 slices IN the consumer waves: the window of a (ci, dy)
 // column is split by the three tile rows that use it, 4.8 vector instructions per MFMA next to 16 matrix clocks, two waves per SIMD:
-// 0.41 matrix-pipe busy.  Here every value is split ONCE, by four splitter waves, into bf16-slice rings in LDS; the eight consumer
+// 0.41 matrix-pipe busy.  Here every value is split ONCE, by eight splitter waves, into bf16-slice rings in LDS; the eight consumer
 // waves read ready 16-byte fragments and issue MFMAs:
 //
 //   * a workgroup walks down a 32-column strip two image rows per step (position); the X ring holds 6 rows x 3 slices x 34 planes
 //     (33 inputs + a plane of ones for the bias column), the G ring the same for 32 gradient planes (30 + two zero rows);
-//   * the three horizontal taps share ONE aligned B fragment (the strip's own 32 columns of an input row, no column halo): the
-//     K slots of tap dx are the gradient pixels x + 1 - dx, so it is the A fragment that shifts -- aligned for dx = 1, and for
-//     dx = 0 / 2 formed with v_alignbit from the aligned 16 bytes + one edge dword (pixels 8 kq - 1 and 8 kq + 8, the E ring);
+//   * the K slots of a tap are chosen so that only LEFT neighbours are needed: dx = 1 pairs aligned fragments; dx = 0 pairs the
+//     aligned gradient fragment with the input fragment shifted one pixel left; dx = 2 the gradient fragment shifted one pixel left
+//     with the aligned input fragment.  A shifted fragment = v_alignbit over the aligned 16 bytes + one edge halfword (pixel
+//     8 kq - 1, the E rings).  The edge of kq = 0 is the last pixel of the strip to the left: the workgroup took that strip in its
+//     previous segment and kept its last column (3 slices x 63 planes x 30 rows of halfwords), so NO halo column is ever loaded --
+//     an earlier form of this kernel fetched 16-byte halo chunks and with them whole 128-byte lines: 2.8 GB for 1.5;
 //   * columns are dy-major (g = 33 dy + ci): a 16-lane column tile reads 16 consecutive planes of ONE row -- conflict-free
 //     ds_read_b128 at a plane pitch of 24 dwords (tools/ubench/wgrad_lds_banks.py);
 //   * consumer wave = (row of the pair, accumulator tiles): tile A (layers 0, 1: inputs < 13 -> column tiles gt = 0, 2, 4) +
 //     its bias | tile B gt 0, 1 | tile B gt 2, 3, 4 | tile B gt 5, 6 -- 93 / 90 / 93 / 90 MFMAs per step on the four SIMDs;
-//   * the splitters load three positions ahead into registers (saddr loads, one array per wave-instruction), split (22 vector
-//     instructions per 4 pixels) and write b64 pairs; one barrier per position;
-//   * work = the global sequence of (frame, strip, row pair) steps cut into equal contiguous ranges, one per workgroup (a range
-//     that starts inside a strip pays one extra position for the row above): all CUs end together.
+//   * the splitters load three positions ahead into registers, split (18 vector instructions per 4 pixels) and write b64 pairs;
+//     one barrier per position; they run at priority 2 (they are the pole of a position, the consumers' MFMAs fill in);
+//   * work = segments (frame, band of <= 14 row pairs, strip), strips of a band consecutive; each workgroup takes a contiguous range
+//     of them.  A range that starts at a strip > 0 reads that strip's left column from memory once (prologue).
 //
 // Deterministic: fixed ranges, fixed summation order.  Partial layout: gen_wgrad.h.
 #include "gen_wgrad.h"
@@ -39,19 +42,27 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int WR_THREADS = 1024;                                       // 8 consumer + 8 splitter waves
 constexpr int SW = 32;                                                  // strip width = one MFMA k-block per image row
-// rings, in dwords (a dword = two horizontally adjacent pixels of one bf16 slice)
-constexpr int XP = 24, XPL = 34, XSL = XPL * XP, XROW = 3 * XSL + 8, XRING = 6 * XROW;      // 16 dwords used per plane row
-constexpr int GP = XP, GSL = XSL, GROW = XROW, GRING = XRING;           // the gradient ring: the same geometry (32 of the 34 planes used)
-constexpr int ESL = 128, EROW = 3 * ESL, ERING = 6 * EROW;              // [M tile][kq][row of the tile]: lo16 = pixel 8 kq + 8, hi16 = 8 kq - 1
-constexpr int WR_LDS = XRING + GRING + ERING;
-static_assert(WR_LDS * 4 <= 160 * 1024, "LDS");
-static_assert(WR_WPART <= XRING, "the final reduction reuses the X ring");
 #ifndef WR_PRIO
 #define WR_PRIO 2
 #endif
 #ifndef WR_BAND
 #define WR_BAND 14                                                      // row pairs per band
 #endif
+// rings, in dwords (a dword = two horizontally adjacent pixels of one bf16 slice)
+constexpr int XP = 24, XPL = 34, XSL = XPL * XP, XROW = 3 * XSL + 8, XRING = 6 * XROW;      // 16 dwords used per plane row
+constexpr int GP = XP, GSL = XSL, GROW = XROW, GRING = XRING;           // the gradient ring: the same geometry (32 of the 34 planes used)
+// edge rings: 8 bytes per (row, plane, kq) = the three slices' halfwords of pixel 8 kq - 1 (+ pad): one b64 write, one b64 read.
+// Gradient planes: [M tile][kq][row of the tile] (the lane order of an A fragment); input planes: [kq][48] (the 16 lanes of a
+// column tile = 16 consecutive planes)
+constexpr int EROW = 2 * 192, ERING = 6 * EROW;
+constexpr int EG0 = XRING + GRING, EX0 = EG0 + ERING;
+// last column of the strip to the left, the same 8-byte entries: [input / gradient][34 planes][32 rows of the segment]
+constexpr int CROWS = 32, CKIND = 2 * XPL * CROWS;                     // (dwords)
+constexpr int C0 = EX0 + ERING;
+constexpr int WR_LDS = C0 + 2 * CKIND;
+static_assert(WR_LDS * 4 <= 160 * 1024, "LDS");
+static_assert(WR_WPART <= XRING, "the final reduction reuses the X ring");
+static_assert(2 * WR_BAND + 2 <= CROWS, "rows of a segment in the left-column cache");
 constexpr unsigned ONE_PAIR = 0x3F803F80u;                              // two bf16 ones
 
 struct WrArgs {
@@ -64,7 +75,7 @@ struct WrArgs {
     float* partials;
     int N, H, W, nstr, HS;          // strips per frame, steps (row pairs) per strip
     int BS, nb;                     // row pairs per band, bands
-    int T, groups;                  // steps in all, workgroups
+    int S, groups;                  // segments in all, workgroups
     unsigned long long* prof;       // (-DWR_PROF harness: [group][16 waves][busy, total] clocks)
 };
 
@@ -90,68 +101,57 @@ struct WrProf {
 #endif
 #define WR_BARRIER(prof) do { (prof).end(); step_barrier(); (prof).begin(); } while (0)
 
-// ---- the positions of one workgroup: [PRE] STEP STEP ... per segment ------------------------------------------------------------
-// The steps of a frame are ordered (row band, strip, row pair): a workgroup finishes a band of BS row pairs in one strip, then takes
-// the same band of the next strip.  The 16-byte edge chunks of the gradient rows pull the neighbouring strip's whole 128-byte line;
-// that line is the next segment's own data (and the previous segment's), BS positions away: close enough for the Infinity Cache
-// to serve every line's second and third use (strip-major order -- 112 positions between them -- fetched 2.8 GB for 1.5).
+// ---- the positions of one workgroup: PRE STEP STEP ... per segment --------------------------------------------------------------
+// Segment = (frame, band, strip), in this order: a workgroup finishes a band of <= BS row pairs in one strip, then takes the same
+// band of the strip to its right.  PRE brings input rows 2 i - 1, 2 i of the segment's first row pair i; STEP i brings input rows
+// 2 i + 1, 2 i + 2 and gradient rows 2 i, 2 i + 1.
 struct Sched {
-    int t, i, n, strip, band, end;      // step index, row pair in the strip, frame, strip, band, first row pair past this segment
+    int seg, n, band, strip, i, end, pos;   // segment, its frame / band / strip, row pair, first row pair past the segment, position in it (PRE = 0)
     bool pre;
     __device__ __forceinline__ static int seg_len(const WrArgs& a, int band) { return band == a.nb - 1 ? a.HS - band * a.BS : a.BS; }
-    // (segment number, offset in the segment) of step t
-    __device__ __forceinline__ static int locate(const WrArgs& a, int t, int& n, int& band, int& strip, int& off) {
-        const int FS = a.nstr * a.HS;
-        n = t / FS;
-        const int u = t - n * FS;
-        band = u / (a.nstr * a.BS);
-        band = band < a.nb - 1 ? band : a.nb - 1;
-        const int v = u - band * a.nstr * a.BS, L = seg_len(a, band);
-        strip = v / L;
-        off = v - strip * L;
-        return (n * a.nb + band) * a.nstr + strip;
+    __device__ __forceinline__ void init(const WrArgs& a, int s0) {
+        seg = s0;
+        n = __builtin_amdgcn_readfirstlane(s0 / (a.nb * a.nstr));
+        const int r = s0 - n * a.nb * a.nstr;
+        band = __builtin_amdgcn_readfirstlane(r / a.nstr);
+        strip = r - band * a.nstr;
+        i = band * a.BS; end = i + seg_len(a, band);
+        pre = true; pos = 0;
     }
-    __device__ __forceinline__ void init(const WrArgs& a, int t0) {
-        int n_, band_, strip_, off_;
-        locate(a, t0, n_, band_, strip_, off_);
-        t = t0;
-        n = __builtin_amdgcn_readfirstlane(n_); band = __builtin_amdgcn_readfirstlane(band_);
-        strip = __builtin_amdgcn_readfirstlane(strip_);
-        i = band * a.BS + __builtin_amdgcn_readfirstlane(off_);
-        end = band * a.BS + seg_len(a, band);
-        pre = true;
+    __device__ __forceinline__ void next_segment(const WrArgs& a) {
+        ++seg;
+        if (++strip == a.nstr) {
+            strip = 0;
+            if (++band == a.nb) { band = 0; ++n; }
+        }
+        i = band * a.BS; end = i + seg_len(a, band);
+        pre = true; pos = 0;
     }
     __device__ __forceinline__ void advance(const WrArgs& a) {
-        if (pre) { pre = false; return; }
-        ++t; ++i;
-        if (i == end) {
-            pre = true;
-            if (++strip == a.nstr) {
-                strip = 0;
-                if (++band == a.nb) { band = 0; ++n; }
-            }
-            i = band * a.BS;
-            end = i + seg_len(a, band);
-        }
+        if (pre) { pre = false; pos = 1; return; }
+        ++i; ++pos;
+        if (i == end) next_segment(a);
     }
 };
 
 // ---- splitter ------------------------------------------------------------------------------------------------------------------
 // A task = one 16-byte chunk (4 pixels of one plane and row) of a position: 2 rows x 33 input planes x 8 chunks, then 2 rows x 30
-// gradient planes x 10 chunks (columns tx0 - 4 .. tx0 + 35: the edge pixels of the shifted fragments) = 1,128 tasks on 8 waves x
-// 2 slots (+ a third slot on two of the waves).  Everything that tells the arrays apart is per-lane data (64-bit plane base, bytes
-// per frame), so the code has no branches on it; a chunk outside the image -- and every gradient chunk of a PRE position -- is read
-// from a.zero: zeros arrive, no masking afterwards.  Per position and task: 6 vector instructions to issue the load (the validity
-// of a lane is a scalar mask: four row classes x a column mask kept per strip), 18 to split, 3 + 3 LDS writes.
-constexpr int NSPLIT = 8, NTASK = 2 * 33 * 8 + 2 * 30 * 10;
+// gradient planes x 8 chunks = 1,008 tasks = two per lane of the 8 waves.  Everything that tells the arrays apart is per-lane data
+// (64-bit plane base, bytes per frame), so the code has no branches on it; a chunk outside the image -- and every gradient chunk of
+// a PRE position -- is read from a.zero: zeros arrive, no masking afterwards.  Per position and task: 6 vector instructions to
+// issue the load (the validity of a lane is a scalar mask: four row classes x a column mask kept per strip), 18 to split, 3 LDS
+// writes of pairs + 3 halfword writes of the edge pixel (odd chunks; chunk 7: into the left-column cache, and from it to kq = 0).
+constexpr int NSPLIT = 8, NS = 2, NTASK = 2 * 33 * 8 + 2 * 30 * 8;
+static_assert(NTASK <= NSPLIT * 64 * NS, "tasks per position");
 struct Task {
     unsigned long long base;   // its plane in frame 0
     unsigned fbytes;           // bytes per frame of its array
-    unsigned voff;             // ((rowp + (input plane ? 1 : 0)) * W + 4 c) * 4: byte offset from (gradient row 0 of the pair, column tx0), wrapping
+    unsigned voff;             // ((rowp + (input plane ? 1 : 0)) * W + 4 c) * 4: byte offset from (gradient row 0 of the pair, column tx0)
     unsigned lds;              // dword offset of the chunk's first pair in ring slot 0, slice 0
-    int eh;                    // halfword index of this chunk's edge pixel in the E ring (slot 0, slice 0), or -1
+    int eh;                    // odd chunks: dword index of the edge entry this chunk supplies (ring slot 0), else -1
+    int ch;                    // chunk 7: dword index of (its plane, row 0 of the pair) in the left-column cache, else -1
     int c4;                    // image column of the chunk relative to tx0
-    int flags;                 // bit 0 rowp, 1 live, 2 writes its pairs, 3 edge pixel = element 3 (else element 0), 4 gradient plane
+    int flags;                 // bit 0 rowp, 1 live, 4 gradient plane
 };
 
 __device__ __forceinline__ Task make_task(const WrArgs& a, int t) {
@@ -159,9 +159,9 @@ __device__ __forceinline__ Task make_task(const WrArgs& a, int t) {
     const unsigned HW = (unsigned)a.H * (unsigned)a.W;
     const bool isx = t < 528, live = t < NTASK;
     const int u = isx ? t : live ? t - 528 : 0;
-    const int chunks = isx ? 8 : 10, per_row = isx ? 264 : 300;
+    const int per_row = isx ? 264 : 240;
     const int rowp = u / per_row, rem = u - rowp * per_row;
-    const int P = rem / chunks, c = rem - P * chunks - (isx ? 0 : 1);   // P: plane in its ring
+    const int P = rem >> 3, c = rem & 7;                               // P: plane in its ring
     const float* arr;
     int pl, chan;
     if (isx) {
@@ -174,19 +174,16 @@ __device__ __forceinline__ Task make_task(const WrArgs& a, int t) {
     }
     s.base = (unsigned long long)arr + (unsigned long long)pl * HW * 4ull;
     s.fbytes = (unsigned)chan * HW * 4u;
-    s.c4 = 4 * c;
+    s.c4 = live ? 4 * c : (1 << 28);                                    // (an idle lane: never inside the image)
     s.voff = (unsigned)(((rowp + (isx ? 1 : 0)) * a.W + 4 * c) * 4);
-    const bool main = live && c >= 0 && c < 8;
-    s.lds = (unsigned)((isx ? 0 : XRING) + rowp * XROW + P * XP + 2 * (main ? c : 0));
-    s.eh = -1;
-    int el3 = 0;
-    if (!isx && live) {
-        int kq = -1, half = 0;
-        if (c == -1 || c == 1 || c == 3 || c == 5) { kq = (c + 1) / 2; half = 1; el3 = 1; }
-        else if (c == 2 || c == 4 || c == 6 || c == 8) { kq = c / 2 - 1; half = 0; }
-        if (kq >= 0) s.eh = 2 * (2 * XRING + rowp * EROW + (P >> 4) * 64 + kq * 16 + (P & 15)) + half;
+    s.lds = (unsigned)((isx ? 0 : XRING) + rowp * XROW + P * XP + 2 * c);
+    s.eh = -1; s.ch = -1;
+    if (live && (c & 1)) {
+        const int kq = c == 7 ? 0 : (c + 1) / 2;                        // chunk 7 hands on the cached left neighbour of kq = 0
+        s.eh = isx ? EX0 + rowp * EROW + 2 * (kq * 48 + P) : EG0 + rowp * EROW + 2 * ((P >> 4) * 64 + kq * 16 + (P & 15));
+        if (c == 7) s.ch = C0 + (isx ? 0 : CKIND) + 2 * (P * CROWS + rowp);
     }
-    s.flags = rowp | (live ? 2 : 0) | (main ? 4 : 0) | (el3 ? 8 : 0) | (isx ? 0 : 16);
+    s.flags = rowp | (live ? 2 : 0) | (isx ? 0 : 16);
     return s;
 }
 
@@ -198,41 +195,26 @@ __device__ __forceinline__ unsigned sel_mask(unsigned if0, unsigned if1, mask_t 
     return r;
 }
 
-template <int RING>
-__device__ __forceinline__ void commit_task(const Task& s, f32x4 v, unsigned* lds) {
+// the three bf16 slices of four pixels, as 16-bit values in the high halves
+struct Split4 { unsigned u[3][4]; };
+__device__ __forceinline__ Split4 split4(f32x4 v) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    unsigned u[3][4];
+    Split4 r;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {                                       // (pairs: the subtractions become v_pk_add_f32)
         const f32x2 x = {v[2 * h], v[2 * h + 1]};
-        u[0][2 * h] = __float_as_uint(x.x); u[0][2 * h + 1] = __float_as_uint(x.y);
-        const f32x2 t0 = {__uint_as_float(u[0][2 * h] & 0xffff0000u), __uint_as_float(u[0][2 * h + 1] & 0xffff0000u)};
+        r.u[0][2 * h] = __float_as_uint(x.x); r.u[0][2 * h + 1] = __float_as_uint(x.y);
+        const f32x2 t0 = {__uint_as_float(r.u[0][2 * h] & 0xffff0000u), __uint_as_float(r.u[0][2 * h + 1] & 0xffff0000u)};
         const f32x2 r1 = x - t0;
-        u[1][2 * h] = __float_as_uint(r1.x); u[1][2 * h + 1] = __float_as_uint(r1.y);
-        const f32x2 t1 = {__uint_as_float(u[1][2 * h] & 0xffff0000u), __uint_as_float(u[1][2 * h + 1] & 0xffff0000u)};
+        r.u[1][2 * h] = __float_as_uint(r1.x); r.u[1][2 * h + 1] = __float_as_uint(r1.y);
+        const f32x2 t1 = {__uint_as_float(r.u[1][2 * h] & 0xffff0000u), __uint_as_float(r.u[1][2 * h + 1] & 0xffff0000u)};
         const f32x2 r2 = r1 - t1;
-        u[2][2 * h] = __float_as_uint(r2.x); u[2][2 * h + 1] = __float_as_uint(r2.y);
+        r.u[2][2 * h] = __float_as_uint(r2.x); r.u[2][2 * h + 1] = __float_as_uint(r2.y);
     }
-    if (s.flags & 4) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            u32x2 w;
-            w.x = __builtin_amdgcn_perm(u[q][1], u[q][0], 0x07060302u);
-            w.y = __builtin_amdgcn_perm(u[q][3], u[q][2], 0x07060302u);
-            *reinterpret_cast<u32x2*>(lds + s.lds + RING * 2 * XROW + q * XSL) = w;
-        }
-    }
-    if (s.eh >= 0) {
-        unsigned short* e16 = reinterpret_cast<unsigned short*>(lds);
-        const bool el3 = s.flags & 8;
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-            e16[s.eh + 2 * (RING * 2 * EROW + q * ESL)] = (unsigned short)((el3 ? u[q][3] : u[q][0]) >> 16);
-    }
+    return r;
 }
 
-template <int NS>
-__device__ __forceinline__ void run_splitter(const WrArgs& a, unsigned* lds, int sw, int lane, int t0, int iters) {
+__device__ __forceinline__ void run_splitter(const WrArgs& a, unsigned* lds, int sw, int lane, int s0, int iters) {
     Task tk[NS];
     mask_t mrow[NS][4], mcol[NS];            // lanes of (input row 0, input row 1, gradient row 0, gradient row 1); lanes whose column is inside
     unsigned long long fp[NS];               // the task's plane in the current frame
@@ -244,8 +226,8 @@ __device__ __forceinline__ void run_splitter(const WrArgs& a, unsigned* lds, int
         for (int c = 0; c < 4; ++c) mrow[s][c] = __builtin_amdgcn_ballot_w64((tk[s].flags & 2) && cls == c);
         mcol[s] = 0; fp[s] = 0;
     }
-    Sched is;
-    is.init(a, t0);
+    Sched is, cs;
+    is.init(a, s0); cs.init(a, s0);
     int cur_n = -1, cur_strip = -1;
     struct Stage { f32x4 r[NS]; } st[3];
     // (loads are issued at every position, also past the end of the range, so that the number in flight is the same everywhere:
@@ -280,19 +262,49 @@ __device__ __forceinline__ void run_splitter(const WrArgs& a, unsigned* lds, int
         }
         is.advance(a);
     };
+    // ridx2 = 2 x (position in the segment) = the cache row of the pair's row 0; border: strip 0 (pixel tx0 - 1 is outside the
+    // image).  Order: the cache reads of both tasks first (their latency passes under the splits), pairs and own edge pixels, then chunk 7's hand-over: cached left
+    // neighbour -> edge of kq = 0, own last pixel -> cache
     auto commit = [&](const Stage& g, auto ringc) {
         constexpr int RING = decltype(ringc)::value;
-#ifdef WR_NO_GSPLIT               // (harness: what the splitters cost without the gradient planes' share -- results wrong)
-        commit_task<RING>(tk[0], g.r[0], lds);
-        if (g.r[NS - 1].x == 12345.f) commit_task<RING>(tk[NS - 1], g.r[NS - 1], lds);
-#else
+        const int ridx2 = 2 * cs.pos;
+        const bool border = cs.strip == 0;
+        u32x2 cached[NS], last[NS];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) commit_task<RING>(tk[s], g.r[s], lds);
-#endif
+        for (int s = 0; s < NS; ++s) {
+            cached[s] = (u32x2){0u, 0u};
+            if (tk[s].ch >= 0) cached[s] = *reinterpret_cast<const u32x2*>(lds + tk[s].ch + 2 * ridx2);
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const Split4 sp = split4(g.r[s]);
+            if (tk[s].flags & 2) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    u32x2 w;
+                    w.x = __builtin_amdgcn_perm(sp.u[q][1], sp.u[q][0], 0x07060302u);
+                    w.y = __builtin_amdgcn_perm(sp.u[q][3], sp.u[q][2], 0x07060302u);
+                    *reinterpret_cast<u32x2*>(lds + tk[s].lds + RING * 2 * XROW + q * XSL) = w;
+                }
+            }
+            last[s].x = __builtin_amdgcn_perm(sp.u[1][3], sp.u[0][3], 0x07060302u);   // the last pixel's slices 0 | 1
+            last[s].y = sp.u[2][3] >> 16;                                              // slice 2
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (tk[s].eh >= 0) {
+                const bool c7 = tk[s].ch >= 0;
+                u32x2 e = last[s];
+                if (c7) e = border ? (u32x2){0u, 0u} : cached[s];
+                *reinterpret_cast<u32x2*>(lds + tk[s].eh + RING * 2 * EROW) = e;
+                if (c7) *reinterpret_cast<u32x2*>(lds + tk[s].ch + 2 * ridx2) = last[s];
+            }
+        }
+        cs.advance(a);
     };
     WrProf prof;
-    // the splitters are the pole of a position (0.94 busy against 0.45-0.6 of the consumers, tools/ubench/gen_wgrad_time.hip -DWR_PROF):
-    // their vector instructions go first, the consumers' MFMAs fill in (0.709 -> 0.650 ms)
+    // the splitters are the pole of a position (tools/ubench/gen_wgrad_time.hip -DWR_PROF): their vector instructions go first,
+    // the consumers' MFMAs fill in
     __builtin_amdgcn_s_setprio(WR_PRIO);
     issue(st[0]);
     issue(st[1]);
@@ -334,12 +346,22 @@ struct Cons {
     static constexpr int slot(int w, int dx) { return M_ == 0 ? 3 * w + dx : WR_NA + 3 * gt(w) + dx; }
 };
 
+// fragment of the pixels one to the left: dword k = (pixel 2 k - 1, pixel 2 k) of the lane's eight; e's high half = the pixel before them
+__device__ __forceinline__ u32x4 shift_left1(u32x4 d, unsigned e) {
+    u32x4 r;
+    r[0] = __builtin_amdgcn_alignbit(d[0], e, 16);
+    r[1] = __builtin_amdgcn_alignbit(d[1], d[0], 16);
+    r[2] = __builtin_amdgcn_alignbit(d[2], d[1], 16);
+    r[3] = __builtin_amdgcn_alignbit(d[3], d[2], 16);
+    return r;
+}
+
 template <typename C>
-__device__ __forceinline__ void run_consumer(const WrArgs& a, unsigned* lds, int wave_id, int lane, int t0, int P, int iters, f32x4 (&acc)[10]) {
+__device__ __forceinline__ void run_consumer(const WrArgs& a, unsigned* lds, int wave_id, int lane, int s0, int P, int iters, f32x4 (&acc)[10]) {
     const int k = (wave_id >> 1) & 1;
     const int j = lane & 15, kq = lane >> 4;
-    // window offsets per phase (the row slot of a lane depends on its dy and wraps in the ring of 6)
-    unsigned offx[3][C::NW];
+    // window / edge offsets per phase (the row slot of a lane depends on its dy and wraps in the ring of 6)
+    unsigned offx[3][C::NW], offex[3][C::NW];
 #pragma unroll
     for (int w = 0; w < C::NW; ++w) {
         int g = 16 * C::gt(w) + j;
@@ -349,42 +371,43 @@ __device__ __forceinline__ void run_consumer(const WrArgs& a, unsigned* lds, int
         for (int ph = 0; ph < 3; ++ph) {
             const int rs = (2 * ((ph + 2) % 3) + k + dy) % 6;
             offx[ph][w] = (unsigned)(rs * XROW + ci * XP + 4 * kq);
+            offex[ph][w] = (unsigned)(EX0 + rs * EROW + 2 * (kq * 48 + ci));
         }
     }
     const unsigned offg = (unsigned)(XRING + k * GROW + (16 * C::M + j) * GP + 4 * kq);
-    const unsigned offe = (unsigned)(XRING + GRING + k * EROW + C::M * 64 + lane);
+    const unsigned offeg = (unsigned)(EG0 + k * EROW + 2 * (C::M * 64 + lane));
 #pragma unroll
     for (int t = 0; t < 10; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     Sched cs;
-    cs.init(a, t0);
+    cs.init(a, s0);
     auto work = [&](auto phc) {
         constexpr int PH = decltype(phc)::value;
-        Frag3 am, a0, ap;                      // gradient pixels x - 1 (tap dx = 2), x (dx = 1), x + 1 (dx = 0)
+        Frag3 a0, am;                          // gradient pixels x (taps dx = 0, 1) and x - 1 (dx = 2)
+        {
+            const u32x2 e = *reinterpret_cast<const u32x2*>(lds + offeg + PH * 2 * EROW);   // halfwords: slice 0 | 1, 2
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const u32x4 d = *reinterpret_cast<const u32x4*>(lds + offg + PH * 2 * GROW + s * GSL);
-            const unsigned e = lds[offe + PH * 2 * EROW + s * ESL];
-            a0.s[s] = d;
-            ap.s[s][0] = __builtin_amdgcn_alignbit(d[1], d[0], 16);
-            ap.s[s][1] = __builtin_amdgcn_alignbit(d[2], d[1], 16);
-            ap.s[s][2] = __builtin_amdgcn_alignbit(d[3], d[2], 16);
-            ap.s[s][3] = __builtin_amdgcn_alignbit(e, d[3], 16);
-            am.s[s][0] = __builtin_amdgcn_alignbit(d[0], e, 16);
-            am.s[s][1] = __builtin_amdgcn_alignbit(d[1], d[0], 16);
-            am.s[s][2] = __builtin_amdgcn_alignbit(d[2], d[1], 16);
-            am.s[s][3] = __builtin_amdgcn_alignbit(d[3], d[2], 16);
+            for (int s = 0; s < 3; ++s) {
+                const u32x4 d = *reinterpret_cast<const u32x4*>(lds + offg + PH * 2 * GROW + s * GSL);
+                a0.s[s] = d;
+                am.s[s] = shift_left1(d, s == 0 ? e.x << 16 : s == 1 ? e.x : e.y << 16);
+            }
         }
-#ifdef WR_NO_MFMA                 // (the kernel without its consumers' LDS reads and MFMAs)
+#ifdef WR_NO_MFMA                 // (the kernel without its consumers' window reads and MFMAs)
         if (a.N > 0) return;
 #endif
 #pragma unroll
         for (int w = 0; w < C::NW; ++w) {
-            Frag3 b;
+            Frag3 b0, bm;                      // input pixels x (dx = 1, 2) and x - 1 (dx = 0)
+            const u32x2 e = *reinterpret_cast<const u32x2*>(lds + offex[PH][w]);
 #pragma unroll
-            for (int s = 0; s < 3; ++s) b.s[s] = *reinterpret_cast<const u32x4*>(lds + offx[PH][w] + s * XSL);
-            acc[3 * w + 0] = mfma_x3(ap, b, acc[3 * w + 0]);
-            acc[3 * w + 1] = mfma_x3(a0, b, acc[3 * w + 1]);
-            acc[3 * w + 2] = mfma_x3(am, b, acc[3 * w + 2]);
+            for (int s = 0; s < 3; ++s) {
+                const u32x4 d = *reinterpret_cast<const u32x4*>(lds + offx[PH][w] + s * XSL);
+                b0.s[s] = d;
+                bm.s[s] = shift_left1(d, s == 0 ? e.x << 16 : s == 1 ? e.x : e.y << 16);
+            }
+            acc[3 * w + 0] = mfma_x3(a0, bm, acc[3 * w + 0]);            // sum g[x] in[x - 1]
+            acc[3 * w + 1] = mfma_x3(a0, b0, acc[3 * w + 1]);            // sum g[x] in[x]
+            acc[3 * w + 2] = mfma_x3(am, b0, acc[3 * w + 2]);            // sum g[x - 1] in[x]
         }
         if constexpr (C::ONES) {               // bias of tile A: the aligned fragment against ones (slices 1, 2 of one are zero)
             const u32x4 one = (u32x4){ONE_PAIR, ONE_PAIR, ONE_PAIR, ONE_PAIR};
@@ -443,18 +466,43 @@ __device__ __forceinline__ void reduce_pair(const WrArgs& a, unsigned* lds, int 
     }
 }
 
+// the left column of a range's first segment (strip > 0), from memory: pixel tx0 - 1 of the 63 planes x the rows of the segment
+__device__ __forceinline__ void cold_fill(const WrArgs& a, unsigned* lds, const Sched& sg) {
+    const size_t HW = (size_t)a.H * a.W;
+    const int col = sg.strip * SW - 1;
+    for (int idx = threadIdx.x; idx < 63 * CROWS; idx += WR_THREADS) {
+        const int Pl = idx / CROWS, ridx = idx - Pl * CROWS;
+        const bool isx = Pl < 33;
+        const int P = isx ? Pl : Pl - 33;
+        const int row = 2 * sg.i + ridx - (isx ? 1 : 2);                // (input rows count from 2 i - 1, gradient rows from 2 i - 2)
+        const float* pl = isx ? (P < 2 ? a.mv + ((size_t)sg.n * 2 + P) * HW : P < 5 ? a.res + ((size_t)sg.n * 3 + (P - 2)) * HW
+                                                                                   : a.feat + ((size_t)sg.n * NFEAT + (P - 5)) * HW)
+                              : (P < NFEAT ? a.gbuf + ((size_t)sg.n * NFEAT + P) * HW : a.gout + ((size_t)sg.n * 2 + (P - NFEAT)) * HW);
+        const float v = row >= 0 && row < a.H ? pl[(size_t)row * a.W + col] : 0.f;
+        const unsigned u0 = __float_as_uint(v);
+        const float r1 = v - __uint_as_float(u0 & 0xffff0000u);
+        const unsigned u1 = __float_as_uint(r1);
+        const unsigned u2 = __float_as_uint(r1 - __uint_as_float(u1 & 0xffff0000u));
+        const int e = C0 + (isx ? 0 : CKIND) + 2 * (P * CROWS + ridx);
+        lds[e] = (u0 >> 16) | (u1 & 0xffff0000u);
+        lds[e + 1] = u2 >> 16;
+    }
+}
+
 __global__ __launch_bounds__(WR_THREADS) void gen_wgrad_rs_kernel(WrArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned lds[WR_LDS];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int b = blockIdx.x;
-    const int t0 = (int)((long)b * a.T / a.groups), t1 = (int)((long)(b + 1) * a.T / a.groups);
-    int P;                                                                 // steps + one PRE per segment
-    {
-        int n_, b_, s_, o_;
-        P = __builtin_amdgcn_readfirstlane((t1 - t0) + Sched::locate(a, t1 - 1, n_, b_, s_, o_) - Sched::locate(a, t0, n_, b_, s_, o_) + 1);
-    }
-    // constant planes: ones (X plane 33), zero gradient rows 30, 31 and their edge dwords
+    const int s0 = (int)((long)b * a.S / a.groups), s1 = (int)((long)(b + 1) * a.S / a.groups);
+    Sched sg;
+    sg.init(a, s0);
+    const Sched first = sg;
+    int P = 0;                                                             // positions: one PRE + the steps of every segment
+    for (; sg.seg < s1; sg.next_segment(a)) P += 1 + (sg.end - sg.i);
+    // edge rings and left-column cache: zero (gradient rows 30, 31 and the ones plane never get an edge); constant planes: ones
+    // (X plane 33), zero gradient planes 30, 31
+    for (int i = EG0 + threadIdx.x; i < WR_LDS; i += WR_THREADS) lds[i] = 0u;
     for (int i = threadIdx.x; i < 6 * 3 * XP; i += WR_THREADS) {
         const int row = i / (3 * XP), s = (i / XP) % 3, d = i % XP;
         lds[row * XROW + s * XSL + 33 * XP + d] = s == 0 ? ONE_PAIR : 0u;
@@ -463,20 +511,17 @@ __global__ __launch_bounds__(WR_THREADS) void gen_wgrad_rs_kernel(WrArgs a) {
         const int row = i / (3 * 2 * GP), s = (i / (2 * GP)) % 3, d = i % (2 * GP);
         lds[XRING + row * GROW + s * GSL + 30 * GP + d] = 0u;
     }
-    for (int i = threadIdx.x; i < 6 * 3 * 8; i += WR_THREADS) {
-        const int rs = i / 8, kq = (i >> 1) & 3, r = 14 + (i & 1);
-        lds[XRING + GRING + rs * ESL + 64 + kq * 16 + r] = 0u;
-    }
+    __syncthreads();
+    if (first.strip > 0) cold_fill(a, lds, first);
     __syncthreads();
     f32x4 acc[10];
     const int k = (wave >> 1) & 1;
     const int iters = (P + 3) / 3;                                         // positions 0 .. P in whole triples
-    if (wave >= 8 + 2) run_splitter<2>(a, lds, wave - 8, lane, t0, iters);
-    else if (wave >= 8) run_splitter<3>(a, lds, wave - 8, lane, t0, iters);   // (tasks 1,024 .. 1,127)
-    else if (wave == 0 || wave == 2) run_consumer<ConsA>(a, lds, wave, lane, t0, P, iters, acc);
-    else if (wave == 1 || wave == 3) run_consumer<ConsC>(a, lds, wave, lane, t0, P, iters, acc);
-    else if (wave == 4 || wave == 6) run_consumer<ConsB>(a, lds, wave, lane, t0, P, iters, acc);
-    else run_consumer<ConsD>(a, lds, wave, lane, t0, P, iters, acc);
+    if (wave >= 8) run_splitter(a, lds, wave - 8, lane, s0, iters);
+    else if (wave == 0 || wave == 2) run_consumer<ConsA>(a, lds, wave, lane, s0, P, iters, acc);
+    else if (wave == 1 || wave == 3) run_consumer<ConsC>(a, lds, wave, lane, s0, P, iters, acc);
+    else if (wave == 4 || wave == 6) run_consumer<ConsB>(a, lds, wave, lane, s0, P, iters, acc);
+    else run_consumer<ConsD>(a, lds, wave, lane, s0, P, iters, acc);
     __syncthreads();                                                       // rings are free: the X ring becomes the scratch
     if (wave == 0 || wave == 2) reduce_pair<ConsA>(a, lds, k, lane, acc);
     else if (wave == 1 || wave == 3) reduce_pair<ConsC>(a, lds, k, lane, acc);
@@ -492,10 +537,23 @@ unsigned long long* g_wr_prof = nullptr;
 #endif
 bool gen_wgrad_rs_supported(int H, int W) { return W % 4 == 0 && H >= 2 && (long)H * W * NFEAT * 4 < (1l << 31); }
 
+namespace {
+struct Geo { int nstr, HS, BS, nb; long S; };
+Geo geo_of(int N, int H, int W) {
+    Geo g;
+    g.nstr = (W + SW - 1) / SW;
+    g.HS = (H + 1) / 2;
+    g.BS = g.HS < WR_BAND ? g.HS : WR_BAND;
+    g.nb = (g.HS + g.BS - 1) / g.BS;
+    g.S = (long)N * g.nb * g.nstr;
+    return g;
+}
+}  // namespace
+
 int gen_wgrad_rs_groups(int N, int H, int W, int max_groups) {
-    const long T = (long)N * ((W + SW - 1) / SW) * ((H + 1) / 2);
+    const long S = geo_of(N, H, W).S;
     const long g = fz_num_cus() < max_groups ? fz_num_cus() : max_groups;
-    return (int)(T < g ? T : g);
+    return (int)(S < g ? S : g);
 }
 
 int gen_wgrad_rs(const float* mv, const float* res, const float* feat, const float* gout, const float* gbuf, const float* zero,
@@ -503,13 +561,10 @@ int gen_wgrad_rs(const float* mv, const float* res, const float* feat, const flo
     WrArgs a;
     a.mv = mv; a.res = res; a.feat = feat; a.gout = gout; a.gbuf = gbuf; a.zero = zero; a.partials = partials;
     a.N = N; a.H = H; a.W = W;
-    a.nstr = (W + SW - 1) / SW;
-    a.HS = (H + 1) / 2;
-    const long T = (long)N * a.nstr * a.HS;
-    if (T >= (1l << 31) || groups < 1 || groups > T) return fail(DMC_E_INVALID, "gen_wgrad_rs: bad shape");
-    a.T = (int)T; a.groups = groups;
-    a.BS = a.HS < WR_BAND ? a.HS : WR_BAND;
-    a.nb = (a.HS + a.BS - 1) / a.BS;
+    const Geo g = geo_of(N, H, W);
+    a.nstr = g.nstr; a.HS = g.HS; a.BS = g.BS; a.nb = g.nb;
+    if (g.S >= (1l << 31) || groups < 1 || groups > g.S) return fail(DMC_E_INVALID, "gen_wgrad_rs: bad shape");
+    a.S = (int)g.S; a.groups = groups;
     a.prof = nullptr;
 #ifdef WR_PROF
     a.prof = g_wr_prof;

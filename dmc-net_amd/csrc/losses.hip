@@ -144,7 +144,7 @@ __global__ __launch_bounds__(1024) void consensus_ce_kernel(const float* __restr
 
 const char* const OPTION_NAMES[OPT_COUNT] = {"gen_layer_path", "gen_gather", "gen_fuse45", "gen_wgrad_path",
                                              "gen_fuse_fwd", "gen_fuse_bwd", "gen_frames", "conv_path", "conv_cfg", "conv_ablate", "gen_ablate", "conv_arith", "conv3d_wgrad", "gen_x3", "gen_wino", "gen_stagger", "gen_fused"};
-std::atomic<int> g_options[OPT_COUNT] = {{1}, {1}, {1}, {4}, {1}, {1}, {0}, {1}, {0}, {0}, {0}, {1}, {2}, {2}, {768}, {0}, {1}};
+std::atomic<int> g_options[OPT_COUNT] = {{1}, {1}, {1}, {5}, {1}, {1}, {0}, {1}, {0}, {0}, {0}, {1}, {2}, {2}, {768}, {0}, {1}};
 int option_index(const char* name) {
     if (!name) return -1;
     for (int i = 0; i < OPT_COUNT; ++i)

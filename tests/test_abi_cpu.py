@@ -126,7 +126,7 @@ def test_classifier_conv_entry_points_host_side_without_gpu():
     code/dmcnet/model.py:305) run on the stock ops on the CPU with the residual-gradient link switched on or off."""
     from dmcnet_amd import resnet
     lib = _lib.load()
-    assert lib.dmc_get_option(b"conv_arith") == 1 and lib.dmc_get_option(b"gen_wgrad_path") == 4
+    assert lib.dmc_get_option(b"conv_arith") == 1 and lib.dmc_get_option(b"gen_wgrad_path") == 5
     # generator kernel selection: layer 1 on gen_x3.hip, data-gradient groups 0 and 1 on the Winograd ring kernel (DESIGN 4.10);
     # the measurement-only options are off
     assert lib.dmc_get_option(b"gen_x3") == 2 and lib.dmc_get_option(b"gen_wino") == 0x300

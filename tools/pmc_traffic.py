@@ -44,7 +44,7 @@ def main():
                                              (f * kr + w * kw) / px))
         layer = "gen_layer" in k or "gen_wino" in k          # (template arguments: <MODE, K ...>, MODE 2 = data gradient)
         grp = "fwd" if (("_kernel<0" in k or "_kernel<1" in k) and layer) or "gen_l45" in k or "gen_x3_kernel" in k or "gen_fused_kernel" in k else \
-              "bwd" if ("_kernel<2" in k and layer) or "gen_bwd" in k else None
+              "bwd" if ("_kernel<2" in k and layer) or "gen_bwd" in k or "gen_wgrad" in k else None
         if grp:
             tot[grp] += f * kr + w * kw
     for g, v in tot.items():

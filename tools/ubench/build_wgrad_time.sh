@@ -11,4 +11,3 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-value -I .
 /opt/rocm/bin/hipcc $F -DWR_PRIO=2 gen_wgrad_time.hip -o bin/gen_wgrad_time_prio 2>&1 | grep -E "error" -A5 | head
 /opt/rocm/bin/hipcc $F -DWR_PRIO=2 -DWR_NO_LOAD gen_wgrad_time.hip -o bin/gen_wgrad_time_prio_noload 2>&1 | grep -E "error" -A5 | head
 ls bin/gen_wgrad_time*
-for b in 7 28 112; do /opt/rocm/bin/hipcc $F -DWR_BAND=$b gen_wgrad_time.hip -o bin/gen_wgrad_time_band$b 2>&1 | grep -E "error" -A5 | head; done
