@@ -50,7 +50,7 @@ const char* dmc_last_error(void);
  * five data-gradient groups as ONE launch, gen_fused_bwd.hip -- same scheme, global memory touched by a staging and a
  * storing wave only; measured slower than the five layer launches at 120 frames), "gen_layer_path" (0: VALU layer kernels instead of the matrix-core
  * ones), "gen_gather" (0: push form for the Cout-8 layers), "gen_fuse45" (0: layers 4 and 5 as two
- * launches), "gen_wgrad_path" (0: all-waves-stage weight gradient; 1: fp32 producer/consumer; 2 / 3: bf16x3; 4, the default: bf16x3 with wide LDS reads), "gen_fuse_fwd" / "gen_fuse_bwd"
+ * launches), "gen_wgrad_path" (0: all-waves-stage weight gradient; 1: fp32 producer/consumer; 2 / 3: bf16x3; 4: bf16x3 tile kernel with wide LDS reads; 5, the default: the row-sliding kernel of gen_wgrad.hip, operands split once into LDS -- W % 4 == 0, else path 4's rules), "gen_fuse_fwd" / "gen_fuse_bwd"
  * (0: the layer-by-layer forward / data-gradient launches instead of the fused groups), "gen_x3" (bit K: hidden
  * layer K of the generator forward, K = 0 .. 2, in bf16x3 arithmetic on the 16x16x32 matrix instruction, gen_x3.hip;
  * default 2 = layer 1), "gen_wino" (bit K: hidden layer K of the generator forward, K = 0 .. 3; bit 8 + K: data-gradient
