@@ -421,6 +421,9 @@ __device__ __forceinline__ void run_consumer(const WrArgs& a, unsigned* lds, int
     // position p computes what the splitters committed at position p - 1 (ring slot (p - 1) % 3); 3 * iters >= P + 1 positions
     WrProf prof;
     prof.begin();
+#ifdef WR_CPRIO                   // (harness: a static priority for the second-dispatched consumer waves)
+    if (wave_id >= 4) __builtin_amdgcn_s_setprio(WR_CPRIO);
+#endif
     for (int p = 0; p < 3 * iters; p += 3) {
         if (p >= 1 && p <= P && !cs.pre) work(std::integral_constant<int, 2>{});
         if (p >= 1) cs.advance(a);
