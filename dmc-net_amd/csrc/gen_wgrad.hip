@@ -52,12 +52,15 @@ constexpr int SW = 32;                                                  // strip
 constexpr int XP = 24, XPL = 34, XSL = XPL * XP, XROW = 3 * XSL + 8, XRING = 6 * XROW;      // 16 dwords used per plane row
 constexpr int GP = XP, GSL = XSL, GROW = XROW, GRING = XRING;           // the gradient ring: the same geometry (32 of the 34 planes used)
 // edge rings: 8 bytes per (row, plane, kq) = the three slices' halfwords of pixel 8 kq - 1 (+ pad): one b64 write, one b64 read.
-// Gradient planes: [M tile][kq][row of the tile] (the lane order of an A fragment); input planes: [kq][48] (the 16 lanes of a
+// Gradient planes: [M tile][kq][row of the tile] (the lane order of an A fragment); input planes: [kq][plane] (the 16 lanes of a
 // column tile = 16 consecutive planes)
 constexpr int EROW = 2 * 192, ERING = 6 * EROW;
+// first entry of the input planes' kq block: 0, 48, 104, 152 -- a read (lanes of kq 0, 1 or 2, 3 together) wants the two blocks 32
+// dwords apart mod 64, a write (the four kq of one plane together) wants them on different banks mod 32: 2-way at best
+__host__ __device__ constexpr int ex_kq(int kq) { return kq * 48 + (kq >> 1) * 8; }
 constexpr int EG0 = XRING + GRING, EX0 = EG0 + ERING;
 // last column of the strip to the left, the same 8-byte entries: [input / gradient][34 planes][32 rows of the segment]
-constexpr int CROWS = 32, CKIND = 2 * XPL * CROWS;                     // (dwords)
+constexpr int CROWS = 32, CPITCH = 33, CKIND = 2 * XPL * CPITCH;       // (dwords; 33 entries per plane: planes two apart on different banks)
 constexpr int C0 = EX0 + ERING;
 constexpr int WR_LDS = C0 + 2 * CKIND;
 static_assert(WR_LDS * 4 <= 160 * 1024, "LDS");
@@ -159,9 +162,14 @@ __device__ __forceinline__ Task make_task(const WrArgs& a, int t) {
     const unsigned HW = (unsigned)a.H * (unsigned)a.W;
     const bool isx = t < 528, live = t < NTASK;
     const int u = isx ? t : live ? t - 528 : 0;
-    const int per_row = isx ? 264 : 240;
-    const int rowp = u / per_row, rem = u - rowp * per_row;
-    const int P = rem >> 3, c = rem & 7;                               // P: plane in its ring
+    // groups of 8 lanes = the chunks of one (row, plane); a 16-lane group of ds_write_b64 = two of them.  At the plane pitch of 24 dwords
+    // neighbouring planes overlap in 8 of the 32 write banks (2-way: SQ_LDS_BANK_CONFLICT 0.43 of the LDS cycles); planes two apart
+    // do not: within every four (row, plane) groups the middle two swap places
+    const int planes = isx ? 33 : 30, ngroups = 2 * planes;
+    int gi = u >> 3;
+    const int c = u & 7;
+    if ((gi | 3) < ngroups) gi = (gi & ~3) | (((gi & 1) << 1) | ((gi >> 1) & 1));
+    const int rowp = gi / planes, P = gi - rowp * planes;             // P: plane in its ring
     const float* arr;
     int pl, chan;
     if (isx) {
@@ -180,8 +188,8 @@ __device__ __forceinline__ Task make_task(const WrArgs& a, int t) {
     s.eh = -1; s.ch = -1;
     if (live && (c & 1)) {
         const int kq = c == 7 ? 0 : (c + 1) / 2;                        // chunk 7 hands on the cached left neighbour of kq = 0
-        s.eh = isx ? EX0 + rowp * EROW + 2 * (kq * 48 + P) : EG0 + rowp * EROW + 2 * ((P >> 4) * 64 + kq * 16 + (P & 15));
-        if (c == 7) s.ch = C0 + (isx ? 0 : CKIND) + 2 * (P * CROWS + rowp);
+        s.eh = isx ? EX0 + rowp * EROW + 2 * (ex_kq(kq) + P) : EG0 + rowp * EROW + 2 * ((P >> 4) * 64 + kq * 16 + (P & 15));
+        if (c == 7) s.ch = C0 + (isx ? 0 : CKIND) + 2 * (P * CPITCH + rowp);
     }
     s.flags = rowp | (live ? 2 : 0) | (isx ? 0 : 16);
     return s;
@@ -371,7 +379,7 @@ __device__ __forceinline__ void run_consumer(const WrArgs& a, unsigned* lds, int
         for (int ph = 0; ph < 3; ++ph) {
             const int rs = (2 * ((ph + 2) % 3) + k + dy) % 6;
             offx[ph][w] = (unsigned)(rs * XROW + ci * XP + 4 * kq);
-            offex[ph][w] = (unsigned)(EX0 + rs * EROW + 2 * (kq * 48 + ci));
+            offex[ph][w] = (unsigned)(EX0 + rs * EROW + 2 * (ex_kq(kq) + ci));
         }
     }
     const unsigned offg = (unsigned)(XRING + k * GROW + (16 * C::M + j) * GP + 4 * kq);
@@ -486,7 +494,7 @@ __device__ __forceinline__ void cold_fill(const WrArgs& a, unsigned* lds, const 
         const float r1 = v - __uint_as_float(u0 & 0xffff0000u);
         const unsigned u1 = __float_as_uint(r1);
         const unsigned u2 = __float_as_uint(r1 - __uint_as_float(u1 & 0xffff0000u));
-        const int e = C0 + (isx ? 0 : CKIND) + 2 * (P * CROWS + ridx);
+        const int e = C0 + (isx ? 0 : CKIND) + 2 * (P * CPITCH + ridx);
         lds[e] = (u0 >> 16) | (u1 & 0xffff0000u);
         lds[e + 1] = u2 >> 16;
     }
