@@ -14,7 +14,7 @@
 //     aligned gradient fragment with the input fragment shifted one pixel left; dx = 2 the gradient fragment shifted one pixel left
 //     with the aligned input fragment.  A shifted fragment = v_alignbit over the aligned 16 bytes + one edge halfword (pixel
 //     8 kq - 1, the E rings).  The edge of kq = 0 is the last pixel of the strip to the left: the workgroup took that strip in its
-//     previous segment and kept its last column (3 slices x 63 planes x 30 rows of halfwords), so NO halo column is ever loaded --
+//     previous segment and kept its last column (63 planes x 30 rows of 8-byte entries), so NO halo column is ever loaded --
 //     an earlier form of this kernel fetched 16-byte halo chunks and with them whole 128-byte lines: 2.8 GB for 1.5;
 //   * columns are dy-major (g = 33 dy + ci): a 16-lane column tile reads 16 consecutive planes of ONE row -- conflict-free
 //     ds_read_b128 at a plane pitch of 24 dwords (tools/ubench/wgrad_lds_banks.py);
@@ -142,8 +142,9 @@ struct Sched {
 // gradient planes x 8 chunks = 1,008 tasks = two per lane of the 8 waves.  Everything that tells the arrays apart is per-lane data
 // (64-bit plane base, bytes per frame), so the code has no branches on it; a chunk outside the image -- and every gradient chunk of
 // a PRE position -- is read from a.zero: zeros arrive, no masking afterwards.  Per position and task: 6 vector instructions to
-// issue the load (the validity of a lane is a scalar mask: four row classes x a column mask kept per strip), 18 to split, 3 LDS
-// writes of pairs + 3 halfword writes of the edge pixel (odd chunks; chunk 7: into the left-column cache, and from it to kq = 0).
+// issue the load (the validity of a lane is a scalar mask: four row classes x a column mask kept per strip), 18 to split, 3 b64
+// writes of pairs + one 8-byte edge entry (odd chunks: the chunk's last pixel; chunk 7: the cached left neighbour to kq = 0 and
+// its own last pixel into the cache).
 constexpr int NSPLIT = 8, NS = 2, NTASK = 2 * 33 * 8 + 2 * 30 * 8;
 static_assert(NTASK <= NSPLIT * 64 * NS, "tasks per position");
 struct Task {
@@ -271,8 +272,8 @@ __device__ __forceinline__ void run_splitter(const WrArgs& a, unsigned* lds, int
         is.advance(a);
     };
     // ridx2 = 2 x (position in the segment) = the cache row of the pair's row 0; border: strip 0 (pixel tx0 - 1 is outside the
-    // image).  Order: the cache reads of both tasks first (their latency passes under the splits), pairs and own edge pixels, then chunk 7's hand-over: cached left
-    // neighbour -> edge of kq = 0, own last pixel -> cache
+    // image).  Order: the cache reads of both tasks first (their latency passes under the splits), the pairs, then the edge
+    // entries -- chunk 7's hand-over: cached left neighbour -> edge of kq = 0, own last pixel -> cache
     auto commit = [&](const Stage& g, auto ringc) {
         constexpr int RING = decltype(ringc)::value;
         const int ridx2 = 2 * cs.pos;
