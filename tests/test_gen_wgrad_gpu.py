@@ -1,8 +1,10 @@
-"""EstimatorDenseNetTiny weight gradient, row-sliding form (csrc/gen_wgrad.hip; option gen_wgrad_path = 5): every operand split
-into its bf16 slices once, into LDS rings a workgroup walks down 32-column strips two rows at a time.  Against the CPU oracle,
-against the tile kernel (gen_wgrad_path = 4: the same bf16x3 products in another summation order) and against an fp64
-evaluation, on the shapes its geometry cares about: odd heights (a last row pair with one row), widths that are not whole strips,
-images of one or two rows, more workgroups than steps, ranges that start inside a strip; bitwise determinism.
+"""EstimatorDenseNetTiny weight gradient, row-sliding form (csrc/gen_wgrad.hip; option gen_wgrad_path = 5, the default): every operand
+split into its bf16 slices once, into LDS rings a workgroup walks down 32-column strips two rows at a time; only left neighbours
+are needed (the strip's left column comes from the previous segment's cache, or from memory where a workgroup's range begins).
+Against the CPU oracle, against the tile kernel (gen_wgrad_path = 4: the same bf16x3 products in another summation order) and
+against an fp64 evaluation, on the shapes its geometry cares about: odd heights (a last row pair with one row), widths that are not
+whole strips, images of two rows, more segments than workgroups and fewer, several bands per strip (heights above 28), ranges that
+begin at a strip > 0 (the cold fill of the left-column cache); bitwise determinism.
 Reference semantics: autograd of code/dmcnet/model.py:187-194."""
 import copy
 
@@ -50,8 +52,8 @@ def test_row_sliding_wgrad_vs_oracle_and_tile_kernel(shape):
 
 
 def test_row_sliding_wgrad_full_frames_fp64_and_determinism():
-    """Eight full 224 x 224 frames (each workgroup's range starts inside a strip): as close to fp64 as the tile kernel, twice
-    the same bits."""
+    """Eight full 224 x 224 frames (448 segments on 256 workgroups: one or two each, most ranges begin at a strip > 0): as close to
+    fp64 as the tile kernel, twice the same bits."""
     o, m = tiny_pair(14)
     x, r = rnd(21, (8, 5, 224, 224)), rnd(22, (8, 2, 224, 224))
     o64 = copy.deepcopy(o).double()
