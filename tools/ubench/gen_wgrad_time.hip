@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
         CK(hipDeviceSynchronize());
         std::vector<unsigned long long> hp((size_t)groups * 32);
         CK(hipMemcpy(hp.data(), dp, hp.size() * 8, hipMemcpyDeviceToHost));
-        printf("wave: busy / total clocks (s_memtime, 100 MHz ticks), mean over groups\n");
+        printf("wave: busy / total clocks (s_memtime), mean over groups\n");
         for (int w = 0; w < 16; ++w) {
             double b = 0, tt = 0;
             for (int g = 0; g < groups; ++g) { b += hp[((size_t)g * 16 + w) * 2]; tt += hp[((size_t)g * 16 + w) * 2 + 1]; }
