@@ -38,23 +38,25 @@ constexpr int S3_CO = 64, S3_K = 7, S3_KB = 49, S3_WAVES = 8;
 constexpr int S3_WLDS = S3_KB * S3_CO * 16 * 2;           // 100,352 bytes
 
 // x fp32 [N][2][T][H][W] -> xq [N][Tp][Hp][Wp] dwords, dword = (bf16 channel 0) | (bf16 channel 1) << 16, zero borders
+// (one padded row (n, zz, yy) per workgroup iteration, threads along xx: the row's coordinates are wave-uniform 32-bit divisions;
+// a flat 64-bit index per element cost three 64-bit divisions each -- 291 us for a 44 MB volume)
 __global__ __launch_bounds__(256) void stem3d_prep_kernel(const float* __restrict__ x, unsigned* __restrict__ xq, int N, int T, int H,
                                                           int W, int Tp, int Hp, int Wp) {
-    const long total = (long)N * Tp * Hp * Wp;
+    const int rows = N * Tp * Hp;
     const long plane = (long)T * H * W;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int xx = (int)(i % Wp);
-        long r = i / Wp;
-        const int yy = (int)(r % Hp); r /= Hp;
-        const int zz = (int)(r % Tp);
-        const int n = (int)(r / Tp);
-        const int t = zz - 2, h = yy - 2, w = xx - 2;
-        unsigned v = 0;
-        if (t >= 0 && t < T && h >= 0 && h < H && w >= 0 && w < W) {
-            const long o = ((long)n * 2) * plane + ((long)t * H + h) * W + w;
-            v = f2bf(x[o]) | (f2bf(x[o + plane]) << 16);
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+        const int yy = r % Hp, q = r / Hp;
+        const int zz = q % Tp, n = q / Tp;
+        const int t = zz - 2, h = yy - 2;
+        const bool row_in = t >= 0 && t < T && h >= 0 && h < H;
+        const float* src = x + ((long)n * 2) * plane + ((long)t * H + h) * W;
+        unsigned* dst = xq + (long)r * Wp;
+        for (int xx = threadIdx.x; xx < Wp; xx += 256) {
+            const int w = xx - 2;
+            unsigned v = 0;
+            if (row_in && w >= 0 && w < W) v = f2bf(src[w]) | (f2bf(src[w + plane]) << 16);
+            dst[xx] = v;
         }
-        xq[i] = v;
     }
 }
 
@@ -312,15 +314,26 @@ __global__ __launch_bounds__(256) void stem3d_wgrad_kernel(Stem3dWgArgs a) {
 }
 
 // dw [64][2][7][7][7] = sum over workgroups of part[g][kb * 16 + 2 kx + c][co], fixed order
+// (thread = (used partial row, co) with co fastest: a wave reads 256 contiguous bytes of every partial.  Indexed by the OUTPUT element,
+// co slowest, every lane of a wave read its own line, and one load at a time was in flight per thread: 267 us per launch for 52 MB of
+// partials; the sums and their order are the same)
 __global__ __launch_bounds__(256) void stem3d_wgrad_reduce_kernel(const float* __restrict__ part, int groups, float* __restrict__ dw) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= S3_CO * 686) return;
-    const int co = i / 686, rem = i - co * 686, c = rem / 343, t = rem - c * 343;
-    const int kb = t / 7, kx = t - kb * 7;
-    const size_t off = (size_t)(kb * 16 + 2 * kx + c) * S3_CO + co;
+    const int co = i & (S3_CO - 1), rj = i / S3_CO;         // rj = kb * 14 + (2 kx + c)
+    const int kb = rj / 14, j = rj - kb * 14, kx = j >> 1, c = j & 1;
+    const size_t off = (size_t)(kb * 16 + j) * S3_CO + co;
     float s = 0.f;
-    for (int g = 0; g < groups; ++g) s += part[(size_t)g * S3_ROWS * S3_CO + off];
-    dw[i] = s;
+    int g = 0;
+    for (; g + 16 <= groups; g += 16) {                      // 16 loads in flight, added in group order (172 workgroups: latency-bound)
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = part[(size_t)(g + k) * S3_ROWS * S3_CO + off];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += v[k];
+    }
+    for (; g < groups; ++g) s += part[(size_t)g * S3_ROWS * S3_CO + off];
+    dw[(size_t)co * 686 + c * 343 + kb * 7 + kx] = s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -550,7 +563,7 @@ int dmc_stem3d_bf16_fwd(const float* x, const float* w, void* workspace, void* y
     unsigned* xq = (unsigned*)workspace;
     bf16_t* wp = (bf16_t*)((char*)workspace + (size_t)N * Tp * Hp * Wp * 4);
     const long total = (long)N * Tp * Hp * Wp;
-    stem3d_prep_kernel<<<(int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256), 256, 0, s>>>(x, xq, N, T, H, W, Tp, Hp, Wp);
+    stem3d_prep_kernel<<<(int)(total / Wp > 16384 ? 16384 : total / Wp), 256, 0, s>>>(x, xq, N, T, H, W, Tp, Hp, Wp);
     int rc = check_launch("stem3d_prep");
     if (rc) return rc;
     stem3d_pack_w_kernel<<<(S3_KB * S3_CO * 16 + 255) / 256, 256, 0, s>>>(w, wp);
@@ -583,7 +596,7 @@ int dmc_stem3d_bf16_wgrad(const float* x, const void* dy, float* dw, void* works
     unsigned* xq = (unsigned*)workspace;
     float* part = (float*)((char*)workspace + (((size_t)N * Tp * Hp * Wp * 4 + 63) / 64) * 64);
     const long total = (long)N * Tp * Hp * Wp;
-    stem3d_prep_kernel<<<(int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256), 256, 0, s>>>(x, xq, N, T, H, W, Tp, Hp, Wp);
+    stem3d_prep_kernel<<<(int)(total / Wp > 16384 ? 16384 : total / Wp), 256, 0, s>>>(x, xq, N, T, H, W, Tp, Hp, Wp);
     int rc = check_launch("stem3d_prep");
     if (rc) return rc;
     Stem3dWgArgs a;
