@@ -141,6 +141,13 @@ SIGNATURES = {
     "dmc_maxpool3d_tf_out_shape": (_I, [_I] * 10 + [_P] * 3),
     "dmc_maxpool3d_tf_bf16_fwd": (_I, [_P] * 3 + [_I] * 11 + [_P]),
     "dmc_maxpool3d_tf_bf16_bwd": (_I, [_P] * 3 + [_I] * 11 + [_P]),
+    "dmc_mv_owner_bytes": (_Z, [_I, _I, _I]),
+    "dmc_mv_accu_init": (_I, [_P, _I, _I, _P]),
+    "dmc_mv_rasterise": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _P]),
+    "dmc_mv_accumulate": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I, _P]),
+    "dmc_mv_from_accu": (_I, [_P, _P, _I, _I, _P]),
+    "dmc_residual": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
+    "dmc_mv_gop_batch": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
 }
 
 _lib = None

@@ -1,0 +1,268 @@
+// Post-decode motion-vector / residual extraction: the three integer loops of the reference's
+// data loader, code/dmcnet/data_loader/coviar_data_loader.c:71-175, on arrays the decoder hands over.
+//
+// The reference walks the AVMotionVector list in order and writes the pixels of every block; where blocks overlap the
+// LATER vector wins.  On the device that order becomes a per-pixel "owner": every (vector, block pixel) pair that passes
+// the reference's four bounds tests does atomicMax(owner[pixel], vector index) -- the maximum of a set does not depend
+// on the order of the updates, so the result is the sequential loop's, bit for bit.  A second pass reads each pixel's
+// owner and does what the reference's innermost statement does for it.
+//
+// A whole accumulated chain needs no ping-pong between frames: accu_t[p] = accu_{t-1}[p + (src - dst) of p's owner in
+// frame t] (or accu_{t-1}[p] when no vector covers p; :101-105 reads accu_src_old, writes accu_src, and :125-127 copies
+// back), and accu_0 is the identity (:311-318) -- so accu_T[p] is the position reached by walking p back through the
+// owner maps of frames T, T-1, ..., 1.  dmc_mv_gop_batch builds the owner maps of every frame of every chain in one
+// launch and walks every pixel back in a second one.
+#include "dmc_common.h"
+
+namespace {
+
+using namespace dmc;
+
+// AVMotionVector (libavutil/motion_vector.h, public ABI): int32 source @0, uint8 w @4, h @5, int16 src_x @6, src_y @8,
+// dst_x @10, dst_y @12, uint64 flags @16 [, int32 motion_x @24, motion_y @28, uint16 motion_scale @32].  sizeof = 24
+// before libavutil 55.63 and 40 since; the caller passes its own sizeof.
+struct MvRec {
+    int w, h, sx, sy, dx, dy, source;
+};
+__device__ __forceinline__ MvRec load_mv(const unsigned char* __restrict__ mvs, int stride, int i) {
+    const unsigned char* p = mvs + (size_t)i * stride;
+    MvRec r;
+    r.source = *reinterpret_cast<const int*>(p);
+    r.w = p[4];
+    r.h = p[5];
+    r.sx = *reinterpret_cast<const short*>(p + 6);
+    r.sy = *reinterpret_cast<const short*>(p + 8);
+    r.dx = *reinterpret_cast<const short*>(p + 10);
+    r.dy = *reinterpret_cast<const short*>(p + 12);
+    return r;
+}
+
+// One wave per vector; lanes over the block's pixels.  frame_off [n_frames + 1]: vector index ranges per frame (the
+// owner plane of frame f is owner + f * H * W, row-major [y][x]).  The loop bounds are the reference's
+// (-1 * w / 2 .. w / 2: C integer division, so an odd w covers 2 * (w / 2) columns), :91-92.
+__global__ __launch_bounds__(256) void mv_owner_kernel(const unsigned char* __restrict__ mvs, int stride,
+                                                       const int* __restrict__ frame_off, int n_frames, int n_mv,
+                                                       int* __restrict__ owner, int H, int W, int* __restrict__ bad_source) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_mv) return;
+    const MvRec m = load_mv(mvs, stride, i);
+    if (m.source != -1 && bad_source != nullptr && lane == 0) atomicAdd(bad_source, 1);   // the reference asserts, :86
+    if (m.dx - m.sx == 0 && m.dy - m.sy == 0) return;                                       // :88
+    int f = 0;
+    if (frame_off != nullptr) {                       // last f with frame_off[f] <= i
+        int lo = 0, hi = n_frames;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (frame_off[mid] <= i) lo = mid; else hi = mid;
+        }
+        f = lo;
+    }
+    int* __restrict__ plane = owner + (size_t)f * H * W;
+    const int hw = m.w / 2, hh = m.h / 2;
+    const int bw = 2 * hw, npx = bw * 2 * hh;
+    for (int q = lane; q < npx; q += 64) {
+        const int oy = q / bw - hh, ox = q % bw - hw;
+        const int pdx = m.dx + ox, pdy = m.dy + oy, psx = m.sx + ox, psy = m.sy + oy;
+        if (pdy >= 0 && pdy < H && pdx >= 0 && pdx < W && psy >= 0 && psy < H && psx >= 0 && psx < W)   // :100-103
+            atomicMax(plane + pdy * W + pdx, i);
+    }
+}
+
+// non-accumulating branch, :111-113: covered pixels get (dst - src) of their owner, the others keep what mv_out holds
+__global__ __launch_bounds__(256) void mv_rasterise_kernel(const unsigned char* __restrict__ mvs, int stride,
+                                                           const int* __restrict__ owner, int* __restrict__ mv_out, int H, int W) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= H * W) return;
+    const int o = owner[p];
+    if (o < 0) return;
+    const MvRec m = load_mv(mvs, stride, o);
+    reinterpret_cast<int2*>(mv_out)[p] = make_int2(m.dx - m.sx, m.dy - m.sy);
+}
+
+// accumulating branch, :105-110, one frame: accu_new[dst] = accu_old[src] for covered pixels, accu_old[dst] for the
+// rest (the reference gets that from :125-127's copy).  Both in the reference's [x][y][2] layout.
+__global__ __launch_bounds__(256) void mv_accumulate_kernel(const unsigned char* __restrict__ mvs, int stride,
+                                                            const int* __restrict__ owner, const int* __restrict__ accu_old,
+                                                            int* __restrict__ accu_new, int H, int W) {
+    // threads run along y (the contiguous index of the accumulator); the owner read is the strided one
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= H * W) return;
+    const int x = q / H, y = q % H;
+    const int o = owner[y * W + x];
+    int sx = x, sy = y;
+    if (o >= 0) {
+        const MvRec m = load_mv(mvs, stride, o);
+        sx = x + m.sx - m.dx;
+        sy = y + m.sy - m.dy;
+    }
+    reinterpret_cast<int2*>(accu_new)[q] = reinterpret_cast<const int2*>(accu_old)[sx * H + sy];
+}
+
+__global__ __launch_bounds__(256) void accu_init_kernel(int* __restrict__ accu, int H, int W) {   // :311-318
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= H * W) return;
+    reinterpret_cast<int2*>(accu)[q] = make_int2(q / H, q % H);
+}
+
+__global__ __launch_bounds__(256) void mv_from_accu_kernel(const int* __restrict__ accu, int* __restrict__ mv_out, int H, int W) {
+    const int p = blockIdx.x * 256 + threadIdx.x;   // :130-139
+    if (p >= H * W) return;
+    const int y = p / W, x = p % W;
+    const int2 a = reinterpret_cast<const int2*>(accu)[x * H + y];
+    reinterpret_cast<int2*>(mv_out)[p] = make_int2(x - a.x, y - a.y);
+}
+
+// :141-175.  src from the accumulator (accumulate) or x - mv (not); the reference reads bgr[0] at the source position
+// and bgr[1] at the pixel itself.
+__global__ __launch_bounds__(256) void residual_kernel(const unsigned char* __restrict__ ref, const unsigned char* __restrict__ cur,
+                                                       const int* __restrict__ accu, const int* __restrict__ mv,
+                                                       int* __restrict__ res, int H, int W) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= H * W) return;
+    const int y = p / W, x = p % W;
+    int sx, sy;
+    if (accu != nullptr) {
+        const int2 a = reinterpret_cast<const int2*>(accu)[x * H + y];
+        sx = a.x;
+        sy = a.y;
+    } else {
+        const int2 v = reinterpret_cast<const int2*>(mv)[p];
+        sx = x - v.x;
+        sy = y - v.y;
+    }
+    const int ls = (sy * W + sx) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) res[p * 3 + c] = (int)cur[p * 3 + c] - (int)ref[ls + c];
+}
+
+// Whole batch: one thread per (chain, pixel) walks back through the chain's owner planes.  chain_off [n_chains + 1]
+// indexes frames; emit [n_chains] (nullable = all 1): 0 leaves the chain's outputs untouched (the reference's
+// `cur_pos > 0` / `if (sd)` gates, :128 and :363).
+__global__ __launch_bounds__(256) void gop_trace_kernel(const unsigned char* __restrict__ mvs, int stride, const int* __restrict__ chain_off,
+                                                        const int* __restrict__ emit, const int* __restrict__ owner,
+                                                        const unsigned char* __restrict__ ref, const unsigned char* __restrict__ cur,
+                                                        int* __restrict__ accu_out, int* __restrict__ mv_out, int* __restrict__ res_out,
+                                                        int H, int W) {
+    const int c = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= H * W) return;
+    if (emit != nullptr && emit[c] == 0) return;
+    const int x0 = p % W, y0 = p / W;
+    int x = x0, y = y0;
+    const int f0 = chain_off[c], f1 = chain_off[c + 1];
+    const size_t hw = (size_t)H * W;
+    for (int f = f1 - 1; f >= f0; --f) {
+        const int o = owner[f * hw + (size_t)y * W + x];
+        if (o >= 0) {
+            const MvRec m = load_mv(mvs, stride, o);
+            x += m.sx - m.dx;
+            y += m.sy - m.dy;
+        }
+    }
+    if (accu_out != nullptr) reinterpret_cast<int2*>(accu_out + (size_t)c * hw * 2)[x0 * H + y0] = make_int2(x, y);
+    if (mv_out != nullptr) reinterpret_cast<int2*>(mv_out + (size_t)c * hw * 2)[p] = make_int2(x0 - x, y0 - y);
+    if (res_out != nullptr) {
+        const unsigned char* __restrict__ r = ref + (size_t)c * hw * 3 + ((size_t)y * W + x) * 3;
+        const unsigned char* __restrict__ k = cur + (size_t)c * hw * 3 + (size_t)p * 3;
+        int* __restrict__ out = res_out + (size_t)c * hw * 3 + (size_t)p * 3;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) out[ch] = (int)k[ch] - (int)r[ch];
+    }
+}
+
+int check_dims(const char* who, int H, int W, int stride) {
+    if (H <= 0 || W <= 0 || (long)H * W > (1l << 28)) return fail(DMC_E_INVALID, "%s: bad frame size %d x %d", who, H, W);
+    if (stride < 14 || (stride & 1)) return fail(DMC_E_INVALID, "%s: mv_stride %d is not a sizeof(AVMotionVector) (24 or 40)", who, stride);
+    return DMC_OK;
+}
+
+int owner_pass(const char* who, const void* mvs, int stride, const int* frame_off, int n_frames, int n_mv, int* owner, int H, int W,
+               int* bad_source, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(owner, 0xFF, (size_t)n_frames * H * W * sizeof(int), s);   // -1 everywhere
+    if (e != hipSuccess) return fail(DMC_E_LAUNCH, "%s: hipMemsetAsync: %s", who, hipGetErrorString(e));
+    if (n_mv > 0) {
+        mv_owner_kernel<<<(n_mv + 3) / 4, 256, 0, s>>>(static_cast<const unsigned char*>(mvs), stride, frame_off, n_frames, n_mv,
+                                                        owner, H, W, bad_source);
+        return check_launch(who);
+    }
+    return DMC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dmc_mv_owner_bytes(int n_frames, int H, int W) {
+    if (n_frames <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)n_frames * H * W * sizeof(int);
+}
+
+int dmc_mv_accu_init(int32_t* accu, int H, int W, dmc_stream_t stream) {
+    if (accu == nullptr) return fail(DMC_E_INVALID, "dmc_mv_accu_init: null pointer");
+    if (int rc = check_dims("dmc_mv_accu_init", H, W, 24)) return rc;
+    accu_init_kernel<<<(H * W + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(accu, H, W);
+    return check_launch("dmc_mv_accu_init");
+}
+
+int dmc_mv_rasterise(const void* mvs, int mv_stride, int n_mv, int32_t* owner_ws, int32_t* mv_out, int32_t* bad_source, int H,
+                     int W, dmc_stream_t stream) {
+    if (owner_ws == nullptr || mv_out == nullptr || (n_mv > 0 && mvs == nullptr) || n_mv < 0)
+        return fail(DMC_E_INVALID, "dmc_mv_rasterise: null pointer or negative count");
+    if (int rc = check_dims("dmc_mv_rasterise", H, W, mv_stride)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = owner_pass("dmc_mv_rasterise", mvs, mv_stride, nullptr, 1, n_mv, owner_ws, H, W, bad_source, s)) return rc;
+    if (n_mv == 0) return DMC_OK;
+    mv_rasterise_kernel<<<(H * W + 255) / 256, 256, 0, s>>>(static_cast<const unsigned char*>(mvs), mv_stride, owner_ws, mv_out, H, W);
+    return check_launch("dmc_mv_rasterise");
+}
+
+int dmc_mv_accumulate(const void* mvs, int mv_stride, int n_mv, int32_t* owner_ws, const int32_t* accu_old, int32_t* accu_new,
+                      int32_t* bad_source, int H, int W, dmc_stream_t stream) {
+    if (owner_ws == nullptr || accu_old == nullptr || accu_new == nullptr || accu_old == accu_new || (n_mv > 0 && mvs == nullptr) ||
+        n_mv < 0)
+        return fail(DMC_E_INVALID, "dmc_mv_accumulate: null pointer, negative count, or accu_old == accu_new");
+    if (int rc = check_dims("dmc_mv_accumulate", H, W, mv_stride)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = owner_pass("dmc_mv_accumulate", mvs, mv_stride, nullptr, 1, n_mv, owner_ws, H, W, bad_source, s)) return rc;
+    mv_accumulate_kernel<<<(H * W + 255) / 256, 256, 0, s>>>(static_cast<const unsigned char*>(mvs), mv_stride, owner_ws, accu_old,
+                                                             accu_new, H, W);
+    return check_launch("dmc_mv_accumulate");
+}
+
+int dmc_mv_from_accu(const int32_t* accu, int32_t* mv_out, int H, int W, dmc_stream_t stream) {
+    if (accu == nullptr || mv_out == nullptr) return fail(DMC_E_INVALID, "dmc_mv_from_accu: null pointer");
+    if (int rc = check_dims("dmc_mv_from_accu", H, W, 24)) return rc;
+    mv_from_accu_kernel<<<(H * W + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(accu, mv_out, H, W);
+    return check_launch("dmc_mv_from_accu");
+}
+
+int dmc_residual(const uint8_t* bgr_ref, const uint8_t* bgr_cur, const int32_t* accu, const int32_t* mv, int32_t* res, int H, int W,
+                 dmc_stream_t stream) {
+    if (bgr_ref == nullptr || bgr_cur == nullptr || res == nullptr || ((accu == nullptr) == (mv == nullptr)))
+        return fail(DMC_E_INVALID, "dmc_residual: null pointer, or not exactly one of accu / mv given");
+    if (int rc = check_dims("dmc_residual", H, W, 24)) return rc;
+    residual_kernel<<<(H * W + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(bgr_ref, bgr_cur, accu, mv, res, H, W);
+    return check_launch("dmc_residual");
+}
+
+int dmc_mv_gop_batch(const void* mvs, int mv_stride, int n_mv, const int32_t* frame_off, int n_frames, const int32_t* chain_off,
+                     int n_chains, const int32_t* emit, int32_t* owner_ws, const uint8_t* bgr_ref, const uint8_t* bgr_cur,
+                     int32_t* accu_out, int32_t* mv_out, int32_t* res_out, int32_t* bad_source, int H, int W, dmc_stream_t stream) {
+    if (n_chains <= 0 || n_frames < 0 || n_mv < 0 || chain_off == nullptr || (n_frames > 0 && (frame_off == nullptr || owner_ws == nullptr)) ||
+        (n_mv > 0 && mvs == nullptr))
+        return fail(DMC_E_INVALID, "dmc_mv_gop_batch: null pointer or bad count");
+    if (res_out != nullptr && (bgr_ref == nullptr || bgr_cur == nullptr))
+        return fail(DMC_E_INVALID, "dmc_mv_gop_batch: res_out needs bgr_ref and bgr_cur");
+    if (n_chains > 65535) return fail(DMC_E_INVALID, "dmc_mv_gop_batch: at most 65535 chains per call");
+    if (int rc = check_dims("dmc_mv_gop_batch", H, W, mv_stride)) return rc;
+    if ((size_t)n_frames * H * W > (size_t)1 << 40) return fail(DMC_E_INVALID, "dmc_mv_gop_batch: owner maps too large");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n_frames > 0)
+        if (int rc = owner_pass("dmc_mv_gop_batch", mvs, mv_stride, frame_off, n_frames, n_mv, owner_ws, H, W, bad_source, s)) return rc;
+    gop_trace_kernel<<<dim3((H * W + 255) / 256, n_chains), 256, 0, s>>>(static_cast<const unsigned char*>(mvs), mv_stride, chain_off, emit,
+                                                                         owner_ws, bgr_ref, bgr_cur, accu_out, mv_out, res_out, H, W);
+    return check_launch("dmc_mv_gop_batch");
+}
+
+}  // extern "C"

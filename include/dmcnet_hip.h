@@ -616,6 +616,50 @@ int dmc_stem3d_bf16_wgrad(const float* x, const void* dy, float* dw, void* works
 size_t dmc_stem3d_bf16_dgrad_workspace_bytes(void);
 int dmc_stem3d_bf16_dgrad(const void* dy, const float* w, float* dx, void* workspace, int N, int T, int H, int W, dmc_stream_t stream);
 
+/* ---- Post-decode motion-vector / residual extraction ---------------------------------------
+ * Replaces the integer loops of create_and_load_mv_residual(), code/dmcnet/data_loader/coviar_data_loader.c:71-175, and
+ * the accumulator set-up of decode_video(), :306-319, on arrays the decoder hands over (the bitstream decode itself is
+ * FFmpeg's and stays on the host).  `mvs`: DEVICE copy of the frame's AV_FRAME_DATA_MOTION_VECTORS side data, an array
+ * of AVMotionVector (libavutil/motion_vector.h, public ABI: int32 source @0, uint8 w @4, h @5, int16 src_x @6, src_y @8,
+ * dst_x @10, dst_y @12), `mv_stride` = the caller's sizeof(AVMotionVector) (24 before libavutil 55.63, 40 since).
+ * Accumulators use the reference's TRANSPOSED layout, accu[x * H * 2 + y * 2 + c] (:107-108); MV planes are int32
+ * [H][W][2] and residuals int32 [H][W][3] as its numpy arrays (:292-309); BGR frames uint8 [H][W][3].
+ * Overlapping blocks: the LATER vector of the list wins, as in the sequential loop (realised as a per-pixel atomicMax of
+ * the vector index into owner_ws, int32 [H][W]: order-independent, bit-exact).  Vectors with zero displacement are
+ * skipped (:88); a (block pixel) is written only when destination AND source are inside the frame (:100-103).
+ * bad_source (nullable): device int32 incremented once per vector whose `source` is not -1 (the reference asserts, :86).
+ *
+ *   dmc_mv_accu_init   :311-318  accu = identity (x, y)
+ *   dmc_mv_rasterise   :88-121, `accumulate == 0` branch: covered pixels of mv_out get (dst - src); the others keep
+ *                      their value (the reference's array is zero-initialised once, :292-298)
+ *   dmc_mv_accumulate  :88-127, `accumulate != 0` branch, ONE frame: accu_new[dst] = accu_old[src] where covered,
+ *                      accu_old[dst] elsewhere (the reference's two buffers + memcpy; here the caller swaps the pointers)
+ *   dmc_mv_from_accu   :130-139  mv_out[y][x] = (x, y) - accu[x][y]
+ *   dmc_residual       :141-175  res[y][x][c] = bgr_cur[y][x][c] - bgr_ref[src_y][src_x][c], src from `accu`
+ *                      (accumulate) or (x, y) - `mv` (not): pass exactly one of the two
+ *   dmc_mv_gop_batch   a BATCH of accumulated chains in two launches: chain c owns the frames chain_off[c] ..
+ *                      chain_off[c + 1] - 1 (in decode order), frame f the vectors frame_off[f] .. frame_off[f + 1] - 1
+ *                      (device int32 arrays of n_chains + 1 / n_frames + 1 entries; owner_ws of dmc_mv_owner_bytes(n_frames,
+ *                      H, W)).  Every pixel is walked back through its chain's owner maps -- the same values as n calls of
+ *                      dmc_mv_accumulate from the identity -- and whichever of accu_out [n_chains][W][H][2], mv_out
+ *                      [n_chains][H][W][2], res_out [n_chains][H][W][3] (bgr_ref / bgr_cur [n_chains][H][W][3]) is non-NULL
+ *                      is written.  emit (nullable, device int32 [n_chains]): 0 = leave that chain's outputs untouched (the
+ *                      reference's `cur_pos > 0` and `if (sd)` gates, :128, :363).  A one-frame chain is also the
+ *                      non-accumulating case (mv = dst - src of the owner, 0 elsewhere).
+ */
+size_t dmc_mv_owner_bytes(int n_frames, int H, int W);
+int dmc_mv_accu_init(int32_t* accu, int H, int W, dmc_stream_t stream);
+int dmc_mv_rasterise(const void* mvs, int mv_stride, int n_mv, int32_t* owner_ws, int32_t* mv_out, int32_t* bad_source, int H,
+                     int W, dmc_stream_t stream);
+int dmc_mv_accumulate(const void* mvs, int mv_stride, int n_mv, int32_t* owner_ws, const int32_t* accu_old, int32_t* accu_new,
+                      int32_t* bad_source, int H, int W, dmc_stream_t stream);
+int dmc_mv_from_accu(const int32_t* accu, int32_t* mv_out, int H, int W, dmc_stream_t stream);
+int dmc_residual(const uint8_t* bgr_ref, const uint8_t* bgr_cur, const int32_t* accu, const int32_t* mv, int32_t* res, int H, int W,
+                 dmc_stream_t stream);
+int dmc_mv_gop_batch(const void* mvs, int mv_stride, int n_mv, const int32_t* frame_off, int n_frames, const int32_t* chain_off,
+                     int n_chains, const int32_t* emit, int32_t* owner_ws, const uint8_t* bgr_ref, const uint8_t* bgr_cur,
+                     int32_t* accu_out, int32_t* mv_out, int32_t* res_out, int32_t* bad_source, int H, int W, dmc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
