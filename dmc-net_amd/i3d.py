@@ -227,15 +227,20 @@ def i3d_losses(net, data, target, stage=None, detach=False):
 
     As written in the reference: channels [:5] feed the generator and channels [5:7] are the flow
     target, although its loader packs [flow2, mv2, res3] -- kept, not "fixed".
-    Returns (logits, [loss_cls, mse] or [loss_cls, mse, loss_adv])."""
+    Returns (logits, [loss_cls, mse] or [loss_cls, mse, loss_adv]).
+
+    The three reductions run on this package's kernels (csrc/losses.hip: ``ops.consensus_ce`` with one segment =
+    ``CrossEntropyLoss``, ``ops.flow_mse`` = ``MSELoss``), the MSE over the frame-major memory the generator wrote (the
+    mean does not depend on the order; no [b,2,T,H,W] copy of the cue is made).  CUDA tensors only -- pinned by golden G11."""
     output, flow = net(data[:, :5], node="flow+logit", detach=detach)
-    losses = [F.cross_entropy(output, target), F.mse_loss(flow, data[:, 5:7])]
+    t = flow.size(2)
+    h, w = flow.shape[-2:]
+    fake = flow.transpose(1, 2).reshape(-1, 2, h, w)             # the generator's own [b*T,2,H,W] output, no copy
+    real = data[:, 5:7].transpose(1, 2).reshape(-1, 2, h, w)
+    losses = [ops.consensus_ce(output, target, 1)[0], ops.flow_mse(fake, real)]
     if stage is not None:
-        t = flow.size(2)
-        h, w = flow.shape[-2:]
         valid = torch.ones(target.numel() * t, dtype=torch.int64, device=target.device)
-        fake = torch.zeros_like(valid)
-        d_in = torch.cat((flow.transpose(1, 2).reshape(-1, 2, h, w),
-                          data[:, 5:7].transpose(1, 2).reshape(-1, 2, h, w)), 0)
-        losses.append(F.cross_entropy(net(d_in, node="D"), torch.cat((fake, valid), 0)))
+        fake_lbl = torch.zeros_like(valid)
+        validity = net(torch.cat((fake, real), 0), node="D")        # fake first, then real (:153-155)
+        losses.append(ops.consensus_ce(validity, torch.cat((fake_lbl, valid), 0), 1)[0])
     return output, losses

@@ -136,7 +136,10 @@ class I3DTrainer(object):
     counterpart of the nn.DataParallel wrap at code/dmcnet_I3D/train_model.py:120."""
 
     def __init__(self, net, optimizers, lr_scheduler, lr_scheduler2=None, lr_scheduler3=None, adv=1.0,
-                 iter_size=1, epoch_thre=1, detach=False, group=None):
+                 iter_size=1, epoch_thre=1, detach=False, group=None, losses_fn=None):
+        #: the loss assembly (``i3d.i3d_losses``: this package's HIP reductions, CUDA tensors only); the CPU policy tests
+        #: pass the oracle's restatement of the same reference lines
+        self.losses_fn = i3d_losses if losses_fn is None else losses_fn
         self.net, self.adv, self.iter_size = net, adv, iter_size
         self.epoch_thre, self.detach, self.group = epoch_thre, detach, group
         self.optimizer = optimizers["optimizer"]
@@ -235,7 +238,7 @@ class I3DTrainer(object):
         if joint:
             # (fit() never forwards its ``detach`` flag to the network, :355,:414-416: the classifier always
             # sees the undetached cue; ``detach`` only zeroes the trunk's stage-1 learning rate below)
-            out, losses = i3d_losses(net, data, target, stage="D" if gan else None, detach=False)
+            out, losses = self.losses_fn(net, data, target, stage="D" if gan else None, detach=False)
         else:
             out = net(data)
             losses = [torch.nn.functional.cross_entropy(out, target)]

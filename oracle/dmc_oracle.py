@@ -603,3 +603,24 @@ def seeded_dropout_masks(seed, disc, n):
         g = torch.Generator().manual_seed((seed * 7919 + zlib.crc32(name.encode())) % (2 ** 31))
         masks[name] = (torch.rand((n, c), generator=g) < 0.75).float() / 0.75
     return masks
+
+
+def i3d_losses(net, data, target, stage=None, detach=False):
+    """Training-mode loss assembly of the I3D variant, code/dmcnet_I3D/train/model.py:135-188 (``static_model.forward``,
+    'flow+logit' node) on stock torch CPU ops; pinned by golden G11 (tests/golden/make_golden_i3d_train.py runs the
+    reference's own method).  ``net(x, node=..., detach=...)`` is any network with the reference I3D's call contract;
+    ``data`` [b,7,T,H,W]: channels [:5] feed the generator, [5:7] are the flow target (:145,:176); with a stage the T axis
+    is folded into the batch for the discriminator, generated frames first then the real ones, targets 0 then 1 (:146-156).
+    Returns (logits, [loss, mse] or [loss, mse, loss_adv])."""
+    output, flow = net(data[:, :5], node="flow+logit", detach=detach)
+    losses = [F.cross_entropy(output, target), F.mse_loss(flow, data[:, 5:7])]
+    if stage is not None:
+        t = flow.size(2)
+        h, w = 224, 224                                               # "manually set", :151-152
+        valid = torch.cat([torch.ones_like(target)] * t, 0)
+        fake = torch.cat([torch.zeros_like(target)] * t, 0)
+        d_in = torch.cat((torch.reshape(torch.transpose(flow, 1, 2), (-1, 2, h, w)),
+                          torch.reshape(torch.transpose(data[:, 5:7], 1, 2), (-1, 2, h, w))), 0)
+        losses.append(F.cross_entropy(net(d_in, node="D"), torch.cat((fake, valid), 0)))
+    return output, losses
+

@@ -780,6 +780,53 @@ def test_i3d_forward_vs_reference_golden(golden):
     assert rel_err(lb, g["logits"]) < 5e-2            # bf16 trunk: loose sanity only
 
 
+def _g11_run(g, detach, trunk_dtype):
+    from dmcnet_amd import i3d
+    c = eval(str(g["cfg"]))
+    net = i3d.I3D(c["num_classes"], modality="flow+mp4", dropout_prob=0, arch_estimator="DenseNetTiny", arch_d="Discriminator")
+    assert list(net.state_dict().keys()) == g["keys"].tolist()
+    O.seeded_state_fill(net, seed=c["seed_net"])
+    net.to(DEV).train()
+    net.trunk_dtype = trunk_dtype
+    data = rnd(c["seed_data"], (1, 7, c["frames"], 224, 224)).to(DEV)
+    net.discriminator.forced_masks = {k: v.to(DEV) for k, v in O.seeded_dropout_masks(c["seed_masks"], net.discriminator, 2 * c["frames"]).items()}
+    logits, losses = i3d.i3d_losses(net, data, torch.tensor([c["label"]], device=DEV), stage=1, detach=detach)
+    sum(losses).backward()
+    return net, logits, losses
+
+
+@pytest.mark.parametrize("tag,detach", [("nodetach", False), ("detach", True)])
+def test_i3d_training_losses_vs_reference_golden(golden, tag, detach):
+    """G11 (the reference's own static_model.forward in TRAINING mode, code/dmcnet_I3D/train/model.py:135-188, around its own
+    I3D): ``i3d.i3d_losses`` -- per-frame HIP generator, the three reductions on csrc/losses.hip, HIP discriminator --
+    with an fp32 trunk: losses and logits to 1e-4, the twelve named gradients to 2e-3 of their largest entry (fp32 sums
+    over 16 x 224 x 224 positions in another order than the CPU's); then the bf16 trunk (BASELINE config 5's setting)
+    against this fp32 run: generator / discriminator losses unchanged to 1e-5 (they do not pass the trunk), the
+    classification loss and the trunk gradients at bf16's resolution."""
+    from tests.test_oracle_golden import g11_compare
+    g = golden("g11_i3d_train")
+    net, logits, losses = _g11_run(g, detach, None)
+    worst = g11_compare(g, tag, logits, losses, dict(net.named_parameters()), 1e-4, 1e-4, 2e-3)
+    print("G11 fp32 trunk", tag, {k: "%.1e" % v for k, v in worst.items()})
+    sd = net.state_dict()
+    assert rel_err(sd["conv3d_1a_7x7.batch3d.running_mean"], g[tag + "_stem_running_mean"]) < 1e-4
+    assert rel_err(sd["conv3d_1a_7x7.batch3d.running_var"], g[tag + "_stem_running_var"]) < 1e-4
+    net16, logits16, losses16 = _g11_run(g, detach, torch.bfloat16)
+    assert abs(float(losses16[1]) - float(losses[1])) <= 1e-5 * float(losses[1])
+    assert abs(float(losses16[2]) - float(losses[2])) <= 1e-5 * float(losses[2])
+    assert abs(float(losses16[0]) - float(losses[0])) <= 2e-2 * float(losses[0])
+    assert rel_err(logits16, logits) < 5e-2
+    p32, p16 = dict(net.named_parameters()), dict(net16.named_parameters())
+    rep = {}
+    for k in g["grad_names"].tolist():
+        rep[k] = float((p16[k].grad - p32[k].grad).norm() / p32[k].grad.norm())
+        bar = 1e-5 if k.startswith("discriminator") else 0.15
+        if detach and k.startswith("gen_flow_model"):
+            bar = 1e-5                                        # detached cue: no gradient reaches the generator through the trunk
+        assert rep[k] <= bar, (k, rep[k])
+    print("G11 bf16 trunk vs fp32", tag, {k: "%.1e" % v for k, v in rep.items()})
+
+
 def test_i3d_train_step_phases():
     from dmcnet_amd import i3d
     torch.manual_seed(0)

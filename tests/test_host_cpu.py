@@ -546,7 +546,8 @@ def _make_i3d_trainer(c, net, group=None):
     opts = IT.make_optimizers(net, c["lr_base"], c["lr_base2"], optim="adam", adv=c["adv"])
     mk = lambda base: IT.MultiFactorScheduler(list(c["sched_steps"]), base_lr=base, factor=c["lr_factor"])
     tr = IT.I3DTrainer(net, opts, mk(c["lr_base"]), mk(c["lr_base2"]), mk(c["lr_d"]), adv=c["adv"],
-                       iter_size=c["iter_size"], epoch_thre=c["epoch_thre"], detach=c["detach"], group=group)
+                       iter_size=c["iter_size"], epoch_thre=c["epoch_thre"], detach=c["detach"], group=group,
+                       losses_fn=O.i3d_losses)      # the package's own assembly is HIP-only; same reference lines, restated on CPU ops
     return tr, opts
 
 
