@@ -63,24 +63,33 @@ def flow_frame_number(gop_index, gop_pos, gop_size=None):
     return gop_index * (GOP_SIZE if gop_size is None else gop_size) + gop_pos + 1
 
 
-def blockify(flow, factor):
-    """Mean over factor x factor blocks (ragged edges zero-padded, as skimage's block_reduce),
-    repeated back to the input size.  ``flow`` [..., H, W] numpy."""
+def blockify(flow, factor, upsample_interp=False):
+    """Mean over factor x factor blocks (ragged edges zero-padded, as skimage's block_reduce), brought back to the
+    input size by repetition or, ``upsample_interp``, by the reference's linear interpolation along one axis after the
+    other (code/dmcnet/dataset.py:236-246: ``scipy.interpolate.interp1d`` between ``linspace(0, 1, n_blocks)`` and
+    ``linspace(0, 1, n_blocks * factor)`` -- the block means sit at the END points of the axis, not at block centres; kept
+    as written).  ``flow`` [..., H, W] numpy."""
     h, w = flow.shape[-2:]
     ph, pw = (-h) % factor, (-w) % factor
     pad = [(0, 0)] * (flow.ndim - 2) + [(0, ph), (0, pw)]
     x = np.pad(flow.astype(np.float64), pad)
     lead = x.shape[:-2]
     x = x.reshape(lead + ((h + ph) // factor, factor, (w + pw) // factor, factor)).mean(axis=(-3, -1))
-    return x.repeat(factor, axis=-2).repeat(factor, axis=-1)[..., :h, :w]
+    if not upsample_interp:
+        return x.repeat(factor, axis=-2).repeat(factor, axis=-1)[..., :h, :w]
+    from scipy import interpolate
+    for axis in (-2, -1):
+        n = x.shape[axis]
+        x = interpolate.interp1d(np.linspace(0, 1, n), x, kind="linear", axis=axis)(np.linspace(0, 1, n * factor))
+    return x[..., :h, :w]
 
 
-def to_tensors(frames, flow_ds_factor=0):
+def to_tensors(frames, flow_ds_factor=0, upsample_interp=False):
     """``frames`` [S,7,H,W] (uint8 or int) = [flow2, mv2, res3] -> the reference's
     (input_flow, input_mv, input_residual) fp32 tensors for representation 'mv'."""
     flow, mv, res = frames[:, 0:2], frames[:, 2:4], frames[:, 4:]
     if flow_ds_factor != 0:
-        flow = blockify(flow, flow_ds_factor)
+        flow = blockify(flow, flow_ds_factor, upsample_interp)
     std = torch.tensor(_STD, dtype=torch.float32).reshape(1, 3, 1, 1)
     f = torch.from_numpy(np.ascontiguousarray(flow)).float() / 255.0
     m = torch.from_numpy(np.ascontiguousarray(mv)).float() / 255.0
@@ -167,8 +176,6 @@ class CoviarDataSet(data.Dataset):
         self._transform, self._num_segments, self._is_train = transform, num_segments, is_train
         self._accumulate, self._mv_minmaxnorm, self._viz = accumulate, mv_minmaxnorm, viz
         self._flow_folder = flow_folder
-        if upsample_interp:
-            raise NotImplementedError("upsample_interp=True is not used by any shipped recipe")
         self._video_list = []
         self._load_list(video_list)
 
@@ -227,7 +234,7 @@ class CoviarDataSet(data.Dataset):
     def __getitem__(self, index):
         frames, label = self._load_frames(index)
         frames = np.transpose(np.array(self._transform(frames)), (0, 3, 1, 2))
-        flow, mv, res = to_tensors(frames, self._flow_ds_factor)
+        flow, mv, res = to_tensors(frames, self._flow_ds_factor, bool(self._upsample_interp))
         return flow, mv, res, label
 
     def raw_item(self, index):

@@ -70,6 +70,30 @@ class GroupScale(object):
         return [resize_bilinear(im, self.size, self.size) for im in group]
 
 
+class GroupOverSample(object):
+    """The 10-crop test-time transform (code/dmcnet/transforms.py:77-114, used by code/dmcnet/test.py:96-99 for
+    ``--test-crops 10``): [optional GroupScale,] then for each of the five fixed offsets (four corners + centre,
+    ``fill_fix_offset(False, ...)``) and each frame: the crop, then its mirror image with the x components of flow and MV
+    negated around 128 -- 10 x len(group) frames, offset-major, crop before flip."""
+
+    def __init__(self, crop_size, scale_size=None):
+        self.crop_size = (crop_size, crop_size) if isinstance(crop_size, int) else crop_size
+        self.scale_worker = GroupScale(scale_size) if scale_size is not None else None
+
+    def __call__(self, group):
+        if self.scale_worker is not None:
+            group = self.scale_worker(group)
+        a, b = group[0].shape[:2]
+        ca, cb = self.crop_size
+        out = []
+        for oa, ob in GroupMultiScaleCrop.fill_fix_offset(False, a, b, ca, cb):
+            for im in group:
+                crop = im[oa:oa + ca, ob:ob + cb]
+                out.append(crop)
+                out.append(flip_with_x_negation(crop))
+        return out
+
+
 class GroupRandomHorizontalFlip(object):
     def __call__(self, group, is_mv_or_flow=False):
         if random.random() < 0.5:

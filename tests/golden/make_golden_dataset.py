@@ -82,6 +82,30 @@ def main():
                 out[key + "_label"] = np.int64(label)
                 print(key, tuple(flow.shape), flow.dtype, label, float(flow.mean()))
     np.savez_compressed(os.path.join(HERE, "g9_dataset_item_ds16.npz"), **out)
+    # round 6: the 10-crop test transform (the reference's own GroupOverSample, transforms.py:77-114, without its optional
+    # cv2 GroupScale) and upsample_interp=True (dataset.py:236-246: the reference's own scipy interp1d lines; block_reduce:
+    # the stand-in above), both through the reference's __getitem__
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        data_root, flow_root, lst = CF.write_dataset(tmp)
+        for tag, is_train, minmax, seed, index, _with_flip in (CF.CASES[0], CF.CASES[2]):
+            ds = ref_ds.CoviarDataSet(data_root, flow_root, "hmdb51", lst, "mv", 1, 0, False,
+                                      Compose([ref_tf.GroupOverSample(CF.CROP, None)]), 3, is_train, True, 12, mv_minmaxnorm=minmax)
+            random.seed(seed)
+            flow, mv, res, label = ds[index]
+            assert flow.shape[0] == 30
+            key = tag + "_over"
+            out[key + "_flow"], out[key + "_mv"], out[key + "_res"] = flow.numpy(), mv.numpy(), res.numpy()
+            out[key + "_label"] = np.int64(label)
+            for crop in CF.DS16_CROPS:
+                ds = ref_ds.CoviarDataSet(data_root, flow_root, "hmdb51", lst, "mv", 1, 16, True,
+                                          Compose([ref_tf.GroupCenterCrop(crop)]), 3, is_train, True, 12, mv_minmaxnorm=minmax)
+                random.seed(seed)
+                flow, mv, res, label = ds[index]
+                key = "%s_interp_c%d" % (tag, crop)
+                out[key + "_flow"], out[key + "_label"] = flow.numpy(), np.int64(label)
+                print(key, tuple(flow.shape), flow.dtype, float(flow.mean()), float(flow.std()))
+    np.savez_compressed(os.path.join(HERE, "g9_dataset_item_extra.npz"), **out)
 
 
 if __name__ == "__main__":

@@ -637,6 +637,30 @@ def test_eval_path_25_segments_vs_oracle():
     assert len(out) == 1 and out[0][1] == 7 and acc in (0.0, 100.0)
 
 
+def test_eval_path_ten_crops_vs_oracle():
+    """The ``--test-crops 10`` leg of test.py (code/dmcnet/test.py:96-99,139-150): frames through the 10-crop transform
+    (transforms.GroupOverSample: 5 offsets x (crop, mirrored crop)), 3 segments x 10 crops per video scored and averaged."""
+    from dmcnet_amd import dataset, evaluate, transforms
+    o, m = _product(False, 65)
+    o.eval(); m.eval()
+    rs = np.random.RandomState(66)
+    over = transforms.GroupOverSample(224, None)
+    mvs, ress, flows = [], [], []
+    for _ in range(2):                                            # two videos, 3 segments each, decoded at 256 x 256
+        clip = dataset.synthetic_clip_u8(rs, 3, size=256)                              # [S,7,H,W] uint8
+        frames = over([np.transpose(f, (1, 2, 0)) for f in clip])                    # 30 HWC crops, segment order inside each offset
+        assert len(frames) == 30
+        flow, mv, res = dataset.to_tensors(np.transpose(np.array(frames), (0, 3, 1, 2)), 0)
+        mvs.append(mv); ress.append(res); flows.append(flow)
+    mv, res = torch.stack(mvs), torch.stack(ress)                # [2, 30, C, 224, 224]
+    with torch.no_grad():
+        ref = o(mv, res)[0].view(2, 30, 51).mean(1).numpy()
+    got = evaluate.forward_video(m, mv.to(DEV), res.to(DEV), 3, 10)
+    assert got.shape == (2, 51) and rel_err(torch.from_numpy(got), ref) < 1e-4
+    out, acc = evaluate.evaluate(m, [(torch.stack(flows), mv, res, torch.tensor([4, 9]))], 3, 10, DEV)
+    assert len(out) == 2 and [x[1] for x in out] == [4, 9] and 0.0 <= acc <= 100.0
+
+
 def test_eval_and_validate_run_no_stock_convolution(monkeypatch):
     """Forward-only paths (evaluate.forward_video = code/dmcnet/test.py:139-198, driver.validate = validate() of
     code/dmcnet/train.py): every convolution of the classifier runs on this package's kernels with the BatchNorm's running

@@ -509,6 +509,41 @@ def test_dataset_item_flow_ds_factor_16_vs_reference_getitem(golden, tmp_path, m
             assert torch.equal(back[0], flow) and torch.equal(back[1], mv) and torch.equal(back[2], res), key
 
 
+def test_ten_crop_and_upsample_interp_vs_reference_getitem(golden, tmp_path, monkeypatch):
+    """Round 6: the 10-crop test transform (GroupOverSample, code/dmcnet/transforms.py:77-114 -- five offsets x (crop, mirrored
+    crop with negated x components), offset-major) and ``upsample_interp=True`` (code/dmcnet/dataset.py:236-246: block means
+    interpolated linearly with scipy's interp1d, one axis after the other) against the reference's own __getitem__ with its
+    own transform / its own interp1d lines (golden g9_dataset_item_extra), bit for bit."""
+    import sys
+    from tests.golden import coviar_fixture as CF
+    g = golden("g9_dataset_item_extra")
+    monkeypatch.setitem(sys.modules, "coviar", CF.coviar_module())
+    data_root, flow_root, lst = CF.write_dataset(str(tmp_path))
+    for tag, is_train, minmax, seed, index, _ in (CF.CASES[0], CF.CASES[2]):
+        ds = dataset.CoviarDataSet(data_root, flow_root, "hmdb51", lst, "mv", 1, 0, False,
+                                   transforms.Compose([transforms.GroupOverSample(CF.CROP, None)]), 3, is_train, True, 12,
+                                   mv_minmaxnorm=minmax)
+        random.seed(seed)
+        flow, mv, res, label = ds[index]
+        key = tag + "_over"
+        assert tuple(flow.shape) == (30, 2, CF.CROP, CF.CROP) and label == int(g[key + "_label"])
+        assert torch.equal(flow, torch.from_numpy(g[key + "_flow"])) and torch.equal(mv, torch.from_numpy(g[key + "_mv"]))
+        assert torch.equal(res, torch.from_numpy(g[key + "_res"]))
+        for crop in CF.DS16_CROPS:
+            ds = dataset.CoviarDataSet(data_root, flow_root, "hmdb51", lst, "mv", 1, 16, True,
+                                       transforms.Compose([transforms.GroupCenterCrop(crop)]), 3, is_train, True, 12,
+                                       mv_minmaxnorm=minmax)
+            random.seed(seed)
+            flow, _, _, label = ds[index]
+            key = "%s_interp_c%d" % (tag, crop)
+            assert label == int(g[key + "_label"]) and torch.equal(flow, torch.from_numpy(g[key + "_flow"])), key
+    # with the optional scale step: 5 offsets x 2 x frames, every crop of the requested size, flips are mirror images
+    frames = [np.random.RandomState(i).randint(0, 256, (64, 80, 7)).astype(np.uint8) for i in range(2)]
+    out = transforms.GroupOverSample(48, 56)(frames)
+    assert len(out) == 20 and all(o.shape == (48, 48, 7) for o in out)
+    assert np.array_equal(out[1][:, ::-1, 1], out[0][:, :, 1]) and np.array_equal(256 - out[1][:, ::-1, 0], out[0][:, :, 0])
+
+
 def test_geometry_plan_matches_applied_transforms():
     """plan + (crop, resize, flip) == applying the Compose, for the reference's train and val pipelines."""
     rs = np.random.RandomState(5)
