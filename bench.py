@@ -179,6 +179,22 @@ def classifier_conv_roofline(conv_spans, n_frames, conv_arith, hw=224):
     return out
 
 
+def add_rank_spread(comm, world, dev, ms_per_step, exposed_ms, host_clean_ms):
+    """The per-rank part of the ``comm`` object (every --config prints the same keys): step time, exposed wait and clean host
+    cost of every rank, the host cores they share, the device."""
+    mine = torch.tensor([ms_per_step, exposed_ms or 0.0, host_clean_ms], device=dev, dtype=torch.float64)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    comm["ms_per_step_by_rank"] = [round(float(t[0]), 3) for t in every]
+    comm["ms_per_step_rank_min"] = round(min(float(t[0]) for t in every), 3)
+    comm["ms_per_step_rank_max"] = round(max(float(t[0]) for t in every), 3)
+    comm["exposed_wait_ms_per_step_rank_max"] = round(max(float(t[1]) for t in every), 4)
+    comm["host_clean_ms_per_step_by_rank"] = [round(float(t[2]), 3) for t in every]
+    comm["host_cores_usable"] = usable_cores()
+    comm["device_of_rank0"] = torch.cuda.get_device_name(dev)
+    return comm
+
+
 def bench_i3d(args, rank, world, dev):
     """BASELINE config 5: I3D over the per-frame DMC generator; micro-batch of 3 clips x T frames,
     trunk under bf16 autocast, generator fp32; D and G phases alternate (iter_size 1)."""
@@ -219,7 +235,7 @@ def bench_i3d(args, rank, world, dev):
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = elapsed_rank = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -236,6 +252,9 @@ def bench_i3d(args, rank, world, dev):
         clean.append((time.perf_counter() - t1) * 1e3)
     torch.cuda.synchronize()
     host_clean_ms = sorted(clean)[len(clean) // 2]
+    comm = {"backend": None, "world_size": 1, "note": "single process: no gradient exchange"}
+    if world > 1:
+        comm = add_rank_spread(trainer.comm_summary(), world, dev, elapsed_rank / args.steps * 1e3, None, host_clean_ms)
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -257,7 +276,9 @@ def bench_i3d(args, rank, world, dev):
         "roofline": {"kernel": "dmc_gen_tiny_fwd (%d frames)" % (b * args.clip_length), "bound": "mfma",
                      "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": None, "launch_ms": round(fwd_ms, 4)},
-        "kernels_ms": {k: round(v[0], 4) for k, v in spans.items()}}))
+        "kernels_ms": {k: round(v[0], 4) for k, v in spans.items()}, "comm": comm}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -340,7 +361,13 @@ def main():
     # DMC_BENCH_STUB_ALLREDUCE=1 (test hook, same tool): the reducer runs in full -- post-accumulate hooks, bucket copies,
     # side-stream joins, waits -- but the collective itself returns at once (a completed Work): what the N > 1 path costs the
     # HOST without the host-memory transport of gloo, which an RCCL run does not have.  Gradients are NOT exchanged.
+    stubbed = False
     if reducer is not None and os.environ.get("DMC_BENCH_STUB_ALLREDUCE") == "1":
+        if os.environ.get("DMC_BENCH_TEST_HOOKS") != "1":
+            raise SystemExit("DMC_BENCH_STUB_ALLREDUCE=1 disables the gradient exchange: a measurement hook of tools/host_contention.sh, "
+                             "refused unless DMC_BENCH_TEST_HOOKS=1 is set as well")
+        stubbed = True
+
         class _DoneWork(object):
             def wait(self, *a, **k):
                 return True
@@ -445,16 +472,9 @@ def main():
         comm = reducer.comm_summary() if reducer is not None else {
             "backend": dist.get_backend(), "world_size": world, "exposed_wait_ms_per_step": None,
             "note": "DMC_BENCH_REPLICAS=1: independent replicas, no gradient exchange (host-contention measurement)"}
-        mine = torch.tensor([elapsed / args.steps * 1e3, comm["exposed_wait_ms_per_step"] or 0.0, host_clean_ms], device=dev, dtype=torch.float64)
-        every = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(every, mine)
-        comm["ms_per_step_by_rank"] = [round(float(t[0]), 3) for t in every]
-        comm["ms_per_step_rank_min"] = round(min(float(t[0]) for t in every), 3)
-        comm["ms_per_step_rank_max"] = round(max(float(t[0]) for t in every), 3)
-        comm["exposed_wait_ms_per_step_rank_max"] = round(max(float(t[1]) for t in every), 4)
-        comm["host_clean_ms_per_step_by_rank"] = [round(float(t[2]), 3) for t in every]
-        comm["host_cores_usable"] = usable_cores()
-        comm["device_of_rank0"] = torch.cuda.get_device_name(dev)
+        if stubbed:
+            comm["allreduce"] = "stubbed"          # DMC_BENCH_STUB_ALLREDUCE: NO gradients were exchanged in this run
+        add_rank_spread(comm, world, dev, elapsed / args.steps * 1e3, comm["exposed_wait_ms_per_step"], host_clean_ms)
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -488,7 +508,8 @@ def main():
                                     "generator, delta mode, MSE x10") +
                                    ", batch %d clips/GPU, random-init weights" % args.batch,
                        "global_batch": world * args.batch, "num_class": args.num_class,
-                       "parallelism": "dp%d" % world, "final_loss": round(loss, 6),
+                       "parallelism": "dp%d" % world + (" (all-reduce STUBBED: gradients not exchanged)" if stubbed else ""),
+                       "final_loss": round(loss, 6),
                        **({"options": args.option} if args.option else {}),
                        "generator_kernels": (("libdmcnet_hip gen_fused: the forward as ONE launch (fp32 4x4x1 MFMA, features line-buffered in LDS, "
                                               "layers pipelined across waves); " if dmcnet_amd._lib.load().dmc_get_option(b"gen_fused") else

@@ -53,10 +53,14 @@ def param_sets_of(model, tags=SET_TAGS):
 
 
 class GradBucketReducer(object):
-    def __init__(self, params, bucket_bytes=16 << 20, group=None, broadcast_from=0):
+    def __init__(self, params, bucket_bytes=16 << 20, group=None, broadcast_from=0, state=None):
         """``params``: either parameters in forward order (one set), or a list of
         ``(name, [parameters])`` sets (see :func:`param_sets_of`).  Within a set buckets are filled
-        in reverse, the order in which backward produces gradients; no bucket spans two sets."""
+        in reverse, the order in which backward produces gradients; no bucket spans two sets.
+        ``state``: further tensors that must start out equal on every rank and are broadcast with the
+        parameters -- frozen parameters and BUFFERS (BatchNorm running statistics, ``num_batches_tracked``):
+        a ``--resume`` on rank 0 alone, or any per-rank difference at construction, would otherwise diverge
+        silently (:func:`for_model` passes them)."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         params = list(params)
@@ -96,8 +100,13 @@ class GradBucketReducer(object):
         self._wait_host_s = 0.0
         self._finished_steps = 0
         if self.world > 1 and broadcast_from is not None:
-            for p in self.params:
-                dist.broadcast(p.data, src=broadcast_from, group=group)
+            seen, todo = set(), []
+            for t in list(self.params) + [p for _, ps in sets for p in ps] + list(state or []):
+                t = t.data if isinstance(t, torch.nn.Parameter) else t
+                if id(t) not in seen and t.numel():
+                    seen.add(id(t))
+                    todo.append(t)
+            broadcast_coalesced(todo, broadcast_from, group)
 
     def _close(self, plist, name):
         total = sum(p.numel() for p in plist)
@@ -246,7 +255,33 @@ class GradBucketReducer(object):
             h.remove()
 
 
+def broadcast_coalesced(tensors, src=0, group=None, chunk_bytes=64 << 20):
+    """Broadcast ``tensors`` from ``src`` in place with one collective per (dtype, <= chunk_bytes) flat buffer instead of
+    one per tensor (a ResNet-18 + generator + discriminator has ~250 parameters and buffers)."""
+    by_type = {}
+    for t in tensors:
+        by_type.setdefault((t.dtype, t.device), []).append(t)
+    for (_dtype, _dev), ts in by_type.items():
+        i = 0
+        while i < len(ts):
+            j, size = i, 0
+            while j < len(ts) and (j == i or size + ts[j].numel() * ts[j].element_size() <= chunk_bytes):
+                size += ts[j].numel() * ts[j].element_size()
+                j += 1
+            part = ts[i:j]
+            flat = torch.cat([t.contiguous().reshape(-1) for t in part])        # logical (row-major) order
+            dist.broadcast(flat, src=src, group=group)
+            off = 0
+            for t in part:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view(t.shape))      # copy_ keeps t's own strides (channels_last stays channels_last)
+                off += n
+            i = j
+
+
 def for_model(model, bucket_bytes=16 << 20, group=None, broadcast_from=0):
-    """The reducer every driver uses: one bucket set per optimizer of the reference."""
+    """The reducer every driver uses: one bucket set per optimizer of the reference; every parameter (trainable or
+    frozen) and every buffer of ``model`` starts out as rank ``broadcast_from``'s."""
+    state = [p for p in model.parameters()] + [b for b in model.buffers()]
     return GradBucketReducer(param_sets_of(model), bucket_bytes=bucket_bytes, group=group,
-                             broadcast_from=broadcast_from)
+                             broadcast_from=broadcast_from, state=state)

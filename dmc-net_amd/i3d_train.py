@@ -155,9 +155,9 @@ class I3DTrainer(object):
             if o is not None:
                 o.zero_grad()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        if self.world > 1:
-            for p in net.parameters():
-                dist.broadcast(p.data, src=0, group=group)
+        if self.world > 1:       # parameters AND buffers (BatchNorm running statistics) start out as rank 0's
+            from .ddp import broadcast_coalesced
+            broadcast_coalesced([p.data for p in net.parameters()] + [b for b in net.buffers() if b.numel()], 0, group)
         self.exchanged = []          # [(optimizer attribute, bytes)] of the last stepping micro-batch
 
     # ---------------------------------------------------------------------------------------
@@ -170,10 +170,25 @@ class I3DTrainer(object):
         flat = torch.cat([t.reshape(-1) for t in grads])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         flat.div_(self.world)
-        off = 0
+        # one multi-tensor copy back instead of one small launch per gradient (102 for the trunk)
+        views, off = [], 0
         for t in grads:
-            t.copy_(flat[off:off + t.numel()].view_as(t))
+            views.append(flat[off:off + t.numel()].view_as(t))
             off += t.numel()
+        torch._foreach_copy_(grads, views)
+
+    def comm_summary(self):
+        """The ``comm`` object of ``bench.py --gpus N --config i3d`` (same keys as ddp.GradBucketReducer.comm_summary where
+        they apply): which communicator, and what the LAST stepping micro-batch exchanged per optimizer.  The exchange is one
+        blocking all-reduce per stepping optimizer after the window's last backward (the recipe's iter_size 32 amortises it
+        over 32 micro-batches), so all of it is exposed."""
+        by_set = {}
+        for name, nbytes in self.exchanged:
+            by_set[name] = by_set.get(name, 0) + nbytes
+        return {"backend": dist.get_backend(self.group) if dist.is_initialized() else None, "world_size": self.world,
+                "reduce_op": "sum, then / world", "last_step_bytes_by_set": by_set,
+                "last_step_launched_from": ["after backward (blocking)"] if self.exchanged else [],
+                "exposed_wait_ms_per_step": None}
 
     def _scale(self, opt):
         if self.iter_size != 1:

@@ -98,7 +98,7 @@ class _GenTiny(torch.autograd.Function):
     """EstimatorDenseNetTiny(cat(mv, res)) [+ mv]; reference code/dmcnet/model.py:187-194,341-346."""
 
     @staticmethod
-    def forward(ctx, mv, res, add_mv, *params):
+    def forward(ctx, mv, res, add_mv, grad_mode, *params):
         lib = _lib.load()
         _need_cuda(mv, res, *params)
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
@@ -108,8 +108,10 @@ class _GenTiny(torch.autograd.Function):
         ws, bs = [p.contiguous() for p in params[:6]], [p.contiguous() for p in params[6:]]
         n, _, h, w = mv.shape
         out = torch.empty((n, 2, h, w), dtype=torch.float32, device=mv.device)
-        # inference (no parameter wants a gradient): the one-launch forward keeps no features -- 8 instead of 120 B/px written
-        keep = any(ctx.needs_input_grad[3:]) or not ((lib.dmc_get_option(b"gen_fused") & 1) and w <= 224)
+        # inference (no parameter wants a gradient, or torch.no_grad()): the one-launch forward keeps no features -- 8 instead
+        # of 120 B/px written.  needs_input_grad reflects the tensors' requires_grad only, NOT the grad mode (it reads True
+        # under no_grad, and torch.is_grad_enabled() is always False in here): the caller passes the mode, `grad_mode`.
+        keep = (grad_mode and any(ctx.needs_input_grad[4:])) or not ((lib.dmc_get_option(b"gen_fused") & 1) and w <= 224)
         saved = _floats(lib.dmc_gen_tiny_saved_bytes(n, h, w), mv.device) if keep else None
         work = _floats(lib.dmc_gen_tiny_workspace_bytes(), mv.device)
         with _span("gen_tiny_fwd"):
@@ -141,7 +143,7 @@ class _GenTiny(torch.autograd.Function):
                                             _lib.ptr_array(dbs), _lib.ptr(gbuf), _lib.ptr(partials),
                                             _lib.ptr(work), n, h, w, _stream()),
                        "dmc_gen_tiny_bwd")
-        return (None, None, None) + tuple(dws) + tuple(dbs)
+        return (None, None, None, None) + tuple(dws) + tuple(dbs)
 
 
 class _GenTinyMSE(torch.autograd.Function):
@@ -212,7 +214,7 @@ def gen_tiny_mse(mv, res, flow, weights, biases, add_mv=False):
 
 def gen_tiny(mv, res, weights, biases, add_mv=False):
     """mv [N,2,H,W], res [N,3,H,W], 6 weights + 6 biases (reference layout) -> [N,2,H,W]."""
-    return _GenTiny.apply(mv, res, bool(add_mv), *weights, *biases)
+    return _GenTiny.apply(mv, res, bool(add_mv), torch.is_grad_enabled(), *weights, *biases)
 
 
 class _FlowMSE(torch.autograd.Function):
@@ -965,7 +967,7 @@ _WGRAD_STREAMS = {}
 _WGRAD_PENDING = [False]
 _WGRAD_SCOPE = [0]
 _WGRAD_COUNT = [0]            # launches that went to the side stream (diagnostics / tests)
-_WGRAD_SEEN = set()           # id() of the weights whose gradient went to the side stream since the last join
+_WGRAD_SEEN = set()           # id() of EVERY weight whose gradient went to the side stream in this backward pass (cleared per pass, not per join)
 _WGRAD_MAIN = set()           # id() of the weights forced to the main stream for the REST of this backward pass (seen twice)
 
 
@@ -982,6 +984,7 @@ class wgrad_side_stream(object):
     def __exit__(self, *exc):
         _WGRAD_SCOPE[0] -= 1
         join_wgrad_stream()
+        _WGRAD_SEEN.clear()
         _WGRAD_MAIN.clear()
         return False
 
@@ -994,8 +997,10 @@ def _wgrad_stream(device):
 
 
 def join_wgrad_stream():
-    """The current stream waits for the weight gradients launched on the side stream (no-op when none are pending)."""
-    _WGRAD_SEEN.clear()
+    """The current stream waits for the weight gradients launched on the side stream (no-op when none are pending).
+    _WGRAD_SEEN survives: a mid-pass join (a shared weight's second use, a gradient bucket being read) completes the gradients
+    in flight but a weight B that produced one before it may still be used AGAIN later in the pass -- its second gradient
+    must then be produced on the main stream, where the engine sums the two."""
     if _WGRAD_PENDING[0]:
         cur = torch.cuda.current_stream()
         for st in _WGRAD_STREAMS.values():
@@ -1010,13 +1015,14 @@ def _wgrad_side_ok(weight):
     # a weight used TWICE in one backward pass (a shared convolution, a module called twice): the engine sums the two
     # gradients on the main stream -- in its input buffer or in AccumulateGrad -- believing the main stream produced the
     # first one.  The second sighting therefore re-joins (the first gradient is complete on the main stream) and stays there.
-    # The mid-pass join forgets which gradients are in flight (_WGRAD_SEEN), so the weight is remembered separately for the
-    # rest of the pass: a THIRD use (a module called three times, a discriminator applied to real, fake and an interpolate)
-    # must stay on the main stream too -- its gradient is summed into the same buffer.
+    # _WGRAD_SEEN is per PASS (cleared by the scope, not by a join): with two shared weights A and B used alternately, A's
+    # second use joins mid-pass; B's second use afterwards must still be recognised.  Any further use (a module called three
+    # times, a discriminator applied to real, fake and an interpolate) stays on the main stream too -- its gradient is
+    # summed into the same buffer.
     if id(weight) in _WGRAD_MAIN:
         return False
     if id(weight) in _WGRAD_SEEN:
-        join_wgrad_stream()
+        join_wgrad_stream()                     # no-op when an earlier join already completed the first gradient
         _WGRAD_MAIN.add(id(weight))
         return False
     # C++-level gradient hooks (torch's DistributedDataParallel reducer) read the gradient on the main stream the moment it

@@ -8,7 +8,8 @@ masks (forward hooks, as G3 does) so that the run is reproducible.
 
 Stored: the three losses, the logits, the generated cue's checksum / a slice, gradients of (loss + mse + loss_adv) for named
 parameters (whole when <= 8192 values, else every stride-th value + a checksum) of the generator, the trunk, the classifier head and the discriminator, and the stem BatchNorm's running
-statistics after the forward -- for `detach` False and True.  ``.cuda()`` is a no-op here (no GPU in the build container).
+statistics after the forward -- for `detach` False and True -- and the same gradients from an fp64 evaluation of the same
+graph (see the comment in main()).  ``.cuda()`` is a no-op here (no GPU in the build container).
 
 Run in the build container: ``python tests/golden/make_golden_i3d_train.py``."""
 import importlib.util
@@ -85,6 +86,25 @@ def main():
         sd = net.state_dict()
         out[tag + "_stem_running_mean"] = npy(sd["conv3d_1a_7x7.batch3d.running_mean"])
         out[tag + "_stem_running_var"] = npy(sd["conv3d_1a_7x7.batch3d.running_var"])
+        # The same graph in fp64 (the reference's own network classes cast to double; the loss assembly is the oracle's
+        # restatement, bit-identical to static_model.forward in fp32 -- static_model.forward itself forces .float()):
+        # the trunk's training-mode BatchNorm chain at batch 1 is ill-conditioned, the fp32 reference run above sits 2-3 %
+        # from this on the trunk / generator gradients, so device runs are judged by their distance to THIS, relative to
+        # the reference's own distance.
+        net64 = ref_i3d.I3D(c["num_classes"], modality="flow+mp4", dropout_prob=0, arch_estimator="DenseNetTiny",
+                            arch_d="Discriminator")
+        O.seeded_state_fill(net64, seed=c["seed_net"]).train().double()
+        hooks = hook_dropout(net64.discriminator, {k: v.double() for k, v in masks.items()})
+        logits64, losses64 = O.i3d_losses(net64, data.double(), target, stage=1, detach=detach)
+        sum(losses64).backward()
+        for h in hooks:
+            h.remove()
+        p64 = dict(net64.named_parameters())
+        out[tag + "_losses64"] = np.array([float(l) for l in losses64], dtype=np.float64)
+        out[tag + "_logits64"] = npy(logits64)
+        for k in GRADS:
+            g = p64[k].grad
+            out[tag + "_grad64_" + k] = npy(g) if g.numel() <= 8192 else npy(g.reshape(-1)[::sample_stride(g.numel())])
         print(tag, [float(loss), float(mse), float(loss_adv)], float(logits.abs().max()),
               {k: (None if params[k].grad is None else float(params[k].grad.abs().max())) for k in GRADS[:4]})
     out["keys"] = np.array(list(net.state_dict().keys()))

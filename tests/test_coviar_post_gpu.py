@@ -103,7 +103,7 @@ def test_accumulation_chain_step_api_and_batch_api_bit_exact(hw, n_frames):
     L.check(lib.dmc_residual(L.ptr(d_pics[0]), L.ptr(d_pics[1]), L.ptr(a), L._P(0), L.ptr(res), H, W, _stream()), "residual")
     assert np.array_equal(mv.cpu().numpy(), mv_want) and np.array_equal(res.cpu().numpy(), res_want)
 
-    allmv = _dev(np.concatenate(frames))
+    allmv = torch.cat([_dev(f) for f in frames])       # bytes: np.concatenate would re-pack the padded record dtype
     off = np.cumsum([0] + [len(f) for f in frames]).astype(np.int32)
     d_off = torch.from_numpy(off).cuda()
     d_chain = torch.tensor([0, n_frames], dtype=torch.int32, device="cuda")

@@ -148,6 +148,28 @@ def test_fused_forward_inference_keeps_no_features():
     ws, bs = [w.detach().contiguous() for w in ws], [b.detach().contiguous() for b in bs]
     out = torch.empty_like(y_eval)
     work = torch.empty(lib.dmc_gen_tiny_workspace_bytes() // 4, device=DEV)
+    # the success path of saved == NULL at the C ABI itself (a.feat == nullptr in gen_fused_kernel), bit for bit
+    out.fill_(float("nan"))
+    L.check(lib.dmc_gen_tiny_fwd(L.ptr(mv), L.ptr(res), L.ptr_array(ws), L.ptr_array(bs), L.ptr(out), ctypes.c_void_p(0), L.ptr(work),
+                                 3, 50, 224, 1, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "dmc_gen_tiny_fwd")
+    assert torch.equal(out, y_train.detach())
+    # ... and through ops: with TRAINABLE parameters, no_grad must not allocate the feature buffer (needs_input_grad alone reads
+    # True under no_grad; ops.gen_tiny passes the grad mode), grad mode must
+    calls = []
+    orig = dmcnet_amd.ops._floats
+    dmcnet_amd.ops._floats = lambda nbytes, dev: (calls.append(nbytes), orig(nbytes, dev))[1]
+    try:
+        assert all(p.requires_grad for p in m.parameters())
+        with torch.no_grad():
+            m.forward_mv_res(mv, res, add_mv=True)
+        eval_allocs = list(calls)
+        del calls[:]
+        m.forward_mv_res(mv, res, add_mv=True)
+        train_allocs = list(calls)
+    finally:
+        dmcnet_amd.ops._floats = orig
+    feat = lib.dmc_gen_tiny_saved_bytes(3, 50, 224)
+    assert feat not in eval_allocs and feat in train_allocs, (feat, eval_allocs, train_allocs)
     before = _set(b"gen_fused", 0)
     try:
         rc = lib.dmc_gen_tiny_fwd(L.ptr(mv), L.ptr(res), L.ptr_array(ws), L.ptr_array(bs), L.ptr(out), ctypes.c_void_p(0), L.ptr(work),

@@ -823,15 +823,17 @@ def _g11_run(g, detach, trunk_dtype):
 def test_i3d_training_losses_vs_reference_golden(golden, tag, detach):
     """G11 (the reference's own static_model.forward in TRAINING mode, code/dmcnet_I3D/train/model.py:135-188, around its own
     I3D): ``i3d.i3d_losses`` -- per-frame HIP generator, the three reductions on csrc/losses.hip, HIP discriminator --
-    with an fp32 trunk: losses and logits to 1e-4, the twelve named gradients to 2e-3 of their largest entry (fp32 sums
-    over 16 x 224 x 224 positions in another order than the CPU's); then the bf16 trunk (BASELINE config 5's setting)
+    with an fp32 trunk: losses and logits to 1e-4; the twelve named gradients CONDITIONED -- the trunk's training-mode
+    BatchNorm chain at batch 1 is ill-conditioned (the reference's own fp32 run is 2-3 % from an fp64 evaluation of the same
+    graph on trunk / generator gradients; G11 stores both), so the device run must be within 3 x the reference's own
+    distance to the fp64 gradients; then the bf16 trunk (BASELINE config 5's setting)
     against this fp32 run: generator / discriminator losses unchanged to 1e-5 (they do not pass the trunk), the
     classification loss and the trunk gradients at bf16's resolution."""
     from tests.test_oracle_golden import g11_compare
     g = golden("g11_i3d_train")
     net, logits, losses = _g11_run(g, detach, None)
-    worst = g11_compare(g, tag, logits, losses, dict(net.named_parameters()), 1e-4, 1e-4, 2e-3)
-    print("G11 fp32 trunk", tag, {k: "%.1e" % v for k, v in worst.items()})
+    worst = g11_compare(g, tag, logits, losses, dict(net.named_parameters()), 1e-4, 1e-4, cond=3.0)
+    print("G11 fp32 trunk", tag, {k: ("%.1e" % v if isinstance(v, float) else "%.1e (ref %.1e)" % v) for k, v in worst.items()})
     sd = net.state_dict()
     assert rel_err(sd["conv3d_1a_7x7.batch3d.running_mean"], g[tag + "_stem_running_mean"]) < 1e-4
     assert rel_err(sd["conv3d_1a_7x7.batch3d.running_var"], g[tag + "_stem_running_var"]) < 1e-4

@@ -241,6 +241,40 @@ def _phase_losses(net, x, flow, t, phase):
                 + F.cross_entropy(net.discriminator(g), torch.ones(len(x)).long()))
 
 
+def _ddp_buffers_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(500 + rank)
+    net = _ToyGan()
+    net.base_model.add_module("bn", torch.nn.BatchNorm1d(4))
+    net.gen_flow_model.weight.data = net.gen_flow_model.weight.data.contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():                         # rank 1 resumed from somewhere else: other statistics, a frozen bias
+        net.base_model.bn.running_mean.fill_(1.0 + rank)
+        net.base_model.bn.running_var.fill_(2.0 + rank)
+        net.base_model.bn.num_batches_tracked.fill_(10 * (rank + 1))
+    net.discriminator[2].bias.requires_grad_(False)
+    red = ddp.for_model(net)
+    torch.save({"state": {k: v.clone() for k, v in net.state_dict().items()},
+                "cl": net.gen_flow_model.weight.is_contiguous(memory_format=torch.channels_last),
+                "in_buckets": sum(len(e) for _, e in red.buckets)}, os.path.join(out_dir, "buf_r%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_reducer_broadcasts_buffers_and_frozen_parameters(tmp_path):
+    """ddp.for_model: every rank starts from rank 0's parameters (trainable or frozen) AND buffers -- BatchNorm running
+    statistics and num_batches_tracked that differ on rank 1 (a resume on one rank only) are overwritten; memory formats
+    survive; frozen parameters are broadcast although they are in no bucket."""
+    port = _free_port()
+    mp.spawn(_ddp_buffers_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp_path, "buf_r%d.pt" % r)) for r in (0, 1))
+    assert list(r0["state"]) == list(r1["state"])
+    for k in r0["state"]:
+        assert torch.equal(r0["state"][k], r1["state"][k]), k
+    assert float(r1["state"]["base_model.bn.running_mean"][0]) == 1.0 and int(r1["state"]["base_model.bn.num_batches_tracked"]) == 10
+    assert r0["cl"] and r1["cl"]
+    assert r0["in_buckets"] == len(r0["state"]) - 3 - 1          # 3 buffers and the frozen bias are in no bucket
+
+
 def _ddp_plan_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)

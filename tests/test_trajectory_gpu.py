@@ -50,6 +50,7 @@ def test_gan_six_pairs_as_close_to_fp64_as_the_oracle():
     for both: a property of the game, not of either kernel.  What the kernels must get right is the next test.)"""
     import trajectory_check as TC
     recs = TC.run("gan", steps=12, batch=4, seed=700, fp64=True)
+    unshifted = 0.0
     for i, r in enumerate(recs):
         for k, gap in r["rel64_hip"].items():
             horizon = [q["rel64_ref"][k] for q in recs[:i + 3] if k in q["rel64_ref"]]
@@ -59,6 +60,15 @@ def test_gan_six_pairs_as_close_to_fp64_as_the_oracle():
             # floor: the first steps, where the oracle's own gap to fp64 is at rounding level
             bar = max(10.0 * worst_ref, 5e-4 * (i + 1))
             assert gap <= bar, (i, k, gap, bar, r["rel64_ref"][k])
+            # The look-ahead above depends on the oracle's LATER divergence; so that a genuine loss of accuracy of ~20x per pair
+            # cannot pass as chaos, the un-shifted ratio (device gap : the oracle's worst gap up to THIS step) is bounded too:
+            # recorded 6.8x (layer-by-layer forward) / 17.7x (one-launch forward) at their worst step, 1x - 3x elsewhere.
+            same_step = max(q["rel64_ref"][k] for q in recs[:i + 1] if k in q["rel64_ref"])
+            if gap > 5e-4 * (i + 1):
+                unshifted = max(unshifted, gap / max(same_step, 1e-12))
+    print("free-running GAN: worst un-shifted ratio to the oracle's gap %.1fx" % unshifted)
+    assert unshifted <= 25.0, unshifted
+    for i, r in enumerate(recs):
         # the first D step and the first G step are plain one-step parity (2e-4, as test_gan_step_pair_full_batch_vs_oracle)
         if i < 2:
             assert all(v <= 2e-4 for v in r["rel"].values()), (i, r["rel"])

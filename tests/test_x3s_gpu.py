@@ -584,6 +584,43 @@ def test_side_stream_with_a_weight_used_three_times_in_one_backward(monkeypatch)
     assert not ops._WGRAD_MAIN                               # cleared when the pass ends
 
 
+def test_side_stream_with_two_shared_weights_used_alternately(monkeypatch):
+    """Two shared convolutions A and B applied A, B, A, B: backward meets B, A, B, A -- B's second use joins the streams
+    mid-pass; A's first gradient went to the side stream BEFORE that join and A's second use comes after it.  The set of
+    weights seen in this pass survives the join, so A's second gradient is produced on the main stream, where the engine
+    sums the two.  Bitwise the one-stream result, repeatedly; exactly two launches (the first sighting of each) leave
+    the main stream."""
+    monkeypatch.setattr(resnet, "OWN_CONV", True)
+    torch.manual_seed(15)
+    ca = torch.nn.Conv2d(64, 64, 3, 1, 1, bias=False).to(DEV).to(memory_format=CL)
+    cb = torch.nn.Conv2d(64, 64, 3, 1, 1, bias=False).to(DEV).to(memory_format=CL)
+    bns = [torch.nn.BatchNorm2d(64).to(DEV).train() for _ in range(4)]
+    x = rnd(522, (24, 64, 56, 56)).to(DEV).contiguous(memory_format=CL)
+
+    def run(side):
+        monkeypatch.setattr(ops, "WGRAD_STREAM", side)
+        for m in [ca, cb] + bns:
+            m.zero_grad(set_to_none=True)
+        xin = x.clone().requires_grad_(True)
+        y = resnet._conv_bn_act(ca, bns[0], xin, next_conv=cb)
+        y = resnet._conv_bn_act(cb, bns[1], y, next_conv=ca)
+        y = resnet._conv_bn_act(ca, bns[2], y, next_conv=cb)
+        z = resnet._conv_bn_act(cb, bns[3], y)
+        n0 = ops._WGRAD_COUNT[0]
+        with ops.wgrad_side_stream():
+            z.square().mean().backward()
+        torch.cuda.synchronize()
+        return ca.weight.grad.clone(), cb.weight.grad.clone(), xin.grad.clone(), ops._WGRAD_COUNT[0] - n0
+
+    a0, b0, x0, n_main = run(False)
+    assert n_main == 0
+    for _ in range(3):
+        a1, b1, x1, n_side = run(True)
+        assert n_side == 2
+        assert torch.equal(a1, a0) and torch.equal(b1, b0) and torch.equal(x1, x0)
+    assert not ops._WGRAD_MAIN and not ops._WGRAD_SEEN
+
+
 @pytest.mark.parametrize("case", [(6, 64, 14, 14, 128), (37, 64, 14, 14, 64), (5, 128, 7, 7, 64), (42, 64, 14, 14, 512)])
 def test_x3s_two_workgroups_per_cu_configuration(case):
     """Tile configuration 4 of the pre-split convolutions (128-pixel tiles, 4 waves, a patch of <= 224 pixels: 79,872 B of

@@ -18,7 +18,7 @@ run() {   # name, extra environment
       > $OUT/host_${N}ranks_$1.json 2> $OUT/host_${N}ranks_$1.err
 }
 run replicas DMC_BENCH_REPLICAS=1 29611
-run stub DMC_BENCH_STUB_ALLREDUCE=1 29612
+run stub "DMC_BENCH_STUB_ALLREDUCE=1 DMC_BENCH_TEST_HOOKS=1" 29612
 run gloo DMC_NOTHING=1 29613
 python - <<PY
 import json
