@@ -217,12 +217,26 @@ def bench_i3d(args, rank, world, dev):
         counter[0] += 1
         return out[0], out[1], out[2]
 
+    graph_note = "eager (one launch per kernel)"
+    if args.graph:
+        # forward + losses + backward of a micro-batch replayed from a hipGraph (one per phase kind: D, G), captured during the
+        # warm-up; learning-rate policy, gradient exchange and Adam stay eager.  The input buffers are the graphs' own.
+        trainer.enable_graphs(warmup=1)
+        for _ in range(4):
+            one()
+        if trainer.static_batch() is not None:
+            sdata, starget = trainer.static_batch()
+            sdata.copy_(data); starget.copy_(target)
+            data, target = sdata, starget
+            graph_note = ("hipGraph replay of forward + losses + backward per phase kind (%d graphs), policy / exchange / Adam eager; "
+                          "kernels_ms from HIP events in 6 eager micro-steps run right after the timed region" % len(trainer._graphs))
     for _ in range(args.warmup):
         one()
     from dmcnet_amd import train as _train
     _train.settle_host()                             # host GC pauses out of the timed region (as the training driver does)
     probe = ops.EventProbe(None if args.all_spans else ("gen_tiny_fwd", "gen_tiny_bwd"))
-    ops.PROBE = probe
+    if not args.graph:
+        ops.PROBE = probe
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -240,6 +254,11 @@ def bench_i3d(args, rank, world, dev):
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
+    if args.graph:                                   # events cannot be recorded inside a replay: eager micro-steps for the spans
+        ops.PROBE = probe                            # (with a probe installed the trainer runs a micro-step eagerly)
+        for _ in range(6):
+            one()
+        torch.cuda.synchronize()
     ops.PROBE = None
     spans = probe.summary()
     clean = []                                       # clean host cost: each micro-step enqueued on an empty queue (see main())
@@ -276,7 +295,7 @@ def bench_i3d(args, rank, world, dev):
         "roofline": {"kernel": "dmc_gen_tiny_fwd (%d frames)" % (b * args.clip_length), "bound": "mfma",
                      "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": None, "launch_ms": round(fwd_ms, 4)},
-        "kernels_ms": {k: round(v[0], 4) for k, v in spans.items()}, "comm": comm}))
+        "kernels_ms": {k: round(v[0], 4) for k, v in spans.items()}, "comm": comm, "launch": graph_note}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -295,8 +314,10 @@ def main():
                     help="1 (default) = cudnn.benchmark as the reference's train.py:118 sets it: MIOpen "
                          "picks solvers by search, answered from the find-db shipped in "
                          "dmc-net_amd/miopen_db; 0 = MIOpen's heuristic picks")
-    ap.add_argument("--graph", type=int, default=0,
-                    help="1 = capture the whole training step (forward, losses, backward, Adam) in a hipGraph after the "
+    ap.add_argument("--graph", type=int, default=-1,
+                    help="-1 (default) = 1 for --config i3d (its ~840 launches per micro-step keep the host busy for 13-15 ms: "
+                         "forward + losses + backward are replayed from a hipGraph per phase kind, I3DTrainer.enable_graphs; the "
+                         "policy and Adam stay eager), 0 for the others (measured: no gain, the host needs 4.4 of 11.4 ms).  1 = capture the whole training step (forward, losses, backward, Adam) in a hipGraph after the "
                          "warm-up and time graph replays (single GPU): removes the launch gaps between the ~290 kernels "
                          "of a step.  The generator kernels' durations are then taken from eager steps run right after "
                          "the timed region (events cannot be recorded inside a replay)")
@@ -314,6 +335,8 @@ def main():
                     help="library kernel-selection option for A/B runs (dmc_set_option), e.g. --option gen_x3=2; recorded in the "
                          "JSON line's config")
     args = ap.parse_args()
+    if args.graph < 0:
+        args.graph = 1 if args.config == "i3d" else 0
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -159,6 +159,92 @@ class I3DTrainer(object):
             from .ddp import broadcast_coalesced
             broadcast_coalesced([p.data for p in net.parameters()] + [b for b in net.buffers() if b.numel()], 0, group)
         self.exchanged = []          # [(optimizer attribute, bytes)] of the last stepping micro-batch
+        # hipGraph mode (enable_graphs): forward + losses + backward of a micro-batch replayed from a captured graph
+        self.graph_warmup = None
+        self._graphs, self._graph_seen, self._graph_pool = {}, {}, None
+        self._static = None          # (data, target): the graphs' input buffers, shared by every captured phase
+        self._acc = {}               # parameter -> persistent gradient buffer (never graph memory)
+
+    # --------------------------------------------------------------------------------------- hipGraph mode
+    def enable_graphs(self, warmup=1):
+        """Replay forward + losses + backward of a micro-batch from a hipGraph, one graph per phase kind (D; G with the
+        classification loss x 0; G) captured the first time a kind comes up after ``warmup`` eager occurrences.  The I3D
+        micro-step is ~840 kernel launches of ~20 us: eager, the host needs 13-15 ms to issue them (and more when eight ranks
+        share a host); a replay costs it microseconds.  What stays eager is the POLICY -- which optimizer steps, with which
+        learning rate, the gradient exchange, Adam -- so the trainer's behaviour (golden G10) does not depend on the mode.
+        Gradients: a replay writes the micro-batch's gradients into the graph's own memory; they are copied / added into
+        persistent buffers exactly as autograd's AccumulateGrad would (``old + new``, same addends), so accumulation over
+        ``iter_size`` micro-batches and over phases (a phase zeroes only ITS optimizers' gradients) is unchanged.
+        Inputs are copied into static buffers (``static_batch()``: a loader can fill them directly and pass them in)."""
+        self.graph_warmup = int(warmup)
+
+    def static_batch(self):
+        """(data, target) input buffers of the captured graphs, or None before the first capture; passing these very tensors
+        to ``step`` skips the copy."""
+        return self._static
+
+    def _capture(self, key, data, target, stage, combine):
+        net = self.net
+        if self._static is None:
+            self._static = (data.clone(), target.clone())
+            self._graph_pool = torch.cuda.graph_pool_handle()
+        sdata, starget = self._static
+        if sdata.shape != data.shape or starget.shape != target.shape:
+            raise ValueError("hipGraph mode: the micro-batch shape changed (%s -> %s); graphs are captured for one shape"
+                             % (tuple(sdata.shape), tuple(data.shape)))
+        params = [p for p in net.parameters() if p.requires_grad]
+        stash = [p.grad for p in params]
+        for p in params:
+            p.grad = None
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        try:
+            with torch.cuda.graph(graph, pool=self._graph_pool):
+                out, losses = self.losses_fn(net, sdata, starget, stage=stage, detach=False)
+                with ops.wgrad_side_stream():
+                    combine(losses).backward()
+            produced = [(p, p.grad) for p in params if p.grad is not None]
+        finally:
+            for p, t in zip(params, stash):
+                p.grad = t
+        ent = {"graph": graph, "out": out, "losses": losses, "params": [p for p, _ in produced], "grads": [g for _, g in produced]}
+        self._graphs[key] = ent
+        return ent
+
+    def _fwd_bwd(self, key, data, target, stage, combine):
+        """Forward + losses + backward of one micro-batch; returns (logits, losses).  Eager, or -- graph mode, CUDA, after
+        the warm-up occurrences of this phase kind -- one replay."""
+        ent = self._graphs.get(key) if self.graph_warmup is not None else None
+        if ent is None:
+            seen = self._graph_seen.get(key, 0)
+            if self.graph_warmup is None or not data.is_cuda or seen < self.graph_warmup or ops.PROBE is not None:
+                self._graph_seen[key] = seen + 1
+                out, losses = self.losses_fn(self.net, data, target, stage=stage, detach=False)
+                self._backward(combine(losses))
+                return out, losses
+            ent = self._capture(key, data, target, stage, combine)
+        sdata, starget = self._static
+        if data is not sdata:
+            sdata.copy_(data, non_blocking=True)
+        if target is not starget:
+            starget.copy_(target, non_blocking=True)
+        ent["graph"].replay()
+        # AccumulateGrad, outside the graph: fresh gradients are copied into persistent buffers, or added to what is there
+        fresh_p, fresh_g, add_old, add_new = [], [], [], []
+        for p, g in zip(ent["params"], ent["grads"]):
+            if p.grad is None:
+                buf = self._acc.get(p)
+                if buf is None or buf.shape != g.shape or buf.stride() != g.stride():
+                    buf = self._acc[p] = torch.empty_like(g)
+                fresh_p.append(buf); fresh_g.append(g)
+                p.grad = buf
+            else:
+                add_old.append(p.grad); add_new.append(g)
+        if fresh_p:
+            torch._foreach_copy_(fresh_p, fresh_g)
+        if add_old:
+            torch._foreach_add_(add_old, add_new)
+        return ent["out"], ent["losses"]
 
     # ---------------------------------------------------------------------------------------
     def _exchange(self, name, opt):
@@ -250,15 +336,22 @@ class I3DTrainer(object):
         stage1 = i_epoch + 1 <= self.epoch_thre
         self.exchanged = []
         stepped = False
-        if joint:
-            # (fit() never forwards its ``detach`` flag to the network, :355,:414-416: the classifier always
-            # sees the undetached cue; ``detach`` only zeroes the trunk's stage-1 learning rate below)
-            out, losses = self.losses_fn(net, data, target, stage="D" if gan else None, detach=False)
-        else:
+        adv = self.adv
+        if not joint:
             out = net(data)
             losses = [torch.nn.functional.cross_entropy(out, target)]
+            self._backward(losses[0])
+        elif d_phase:
+            # (fit() never forwards its ``detach`` flag to the network, :355,:414-416: the classifier always
+            # sees the undetached cue; ``detach`` only zeroes the trunk's stage-1 learning rate below)
+            out, losses = self._fwd_bwd(("D", adv), data, target, "D", lambda l: l[0] + adv * l[2])
+        elif not gan:
+            out, losses = self._fwd_bwd(("G2",), data, target, None, lambda l: l[0] + l[1])
+        elif i_epoch < 1:
+            out, losses = self._fwd_bwd(("G0", adv), data, target, "D", lambda l: 0.0 * l[0] + l[1] + adv * l[2])
+        else:
+            out, losses = self._fwd_bwd(("G", adv), data, target, "D", lambda l: l[0] + l[1] + adv * l[2])
         if d_phase:
-            self._backward(losses[0] + self.adv * losses[2])
             if joint:
                 if stage1:
                     self.lr = self.lr_scheduler.update()
@@ -282,15 +375,7 @@ class I3DTrainer(object):
                 self.optimizer_3.step(); self.optimizer_3.zero_grad()
                 self.i, stepped = 0, True
             return out.detach(), [l.detach() for l in losses], "D", stepped
-        # ---- G phase (or the only phase without a discriminator) ----
-        if len(losses) == 1:
-            self._backward(losses[0])
-        elif not gan:
-            self._backward(losses[0] + losses[1])
-        elif i_epoch < 1:
-            self._backward(0.0 * losses[0] + losses[1] + self.adv * losses[2])
-        else:
-            self._backward(losses[0] + losses[1] + self.adv * losses[2])
+        # ---- G phase (or the only phase without a discriminator): its backward ran above ----
         if joint:
             if stage1:
                 if not gan:

@@ -855,6 +855,48 @@ def test_i3d_training_losses_vs_reference_golden(golden, tag, detach):
     print("G11 bf16 trunk vs fp32", tag, {k: "%.1e" % v for k, v in rep.items()})
 
 
+@pytest.mark.parametrize("iter_size", [1, 2])
+def test_i3d_trainer_graph_mode_equals_eager(iter_size):
+    """I3DTrainer.enable_graphs(): forward + losses + backward replayed from a hipGraph per phase kind, the policy (learning
+    rates, which optimizer steps, Adam) eager -- against the eager trainer from the same state on the same micro-batches,
+    eight micro-steps (D and G phases, gradient accumulation over ``iter_size`` and ACROSS phases, epoch 0 and epoch 1 G
+    kinds): every loss and every parameter after every micro-step.  Dropout off / masks fixed (a replay draws from the
+    graph's own Philox offsets, so random masks differ between the modes by construction); bf16 trunk as in BASELINE
+    config 5.  Reference: model.fit, code/dmcnet_I3D/train/model.py:345-491."""
+    from dmcnet_amd import i3d, i3d_train
+
+    def build():
+        torch.manual_seed(5)
+        net = i3d.I3D(51, modality="flow+mp4", dropout_prob=0, arch_estimator="DenseNetTiny", arch_d="Discriminator")
+        O.seeded_state_fill(net, seed=87)
+        net.to(DEV).train()
+        net.trunk_dtype = torch.bfloat16
+        net.discriminator.forced_masks = {k: v.to(DEV) for k, v in O.seeded_dropout_masks(88, net.discriminator, 32).items()}
+        return net, i3d_train.recipe_trainer(net, batch_size=1, iter_size=iter_size, epoch_thre=1)
+
+    (ne, te), (ng, tg) = build(), build()
+    tg.enable_graphs(warmup=1)
+    batches = [(rnd(900 + i, (1, 7, 16, 224, 224)).to(DEV), torch.tensor([i % 51], device=DEV)) for i in range(3)]
+    worst, replays = 0.0, 0
+    for k in range(12):
+        epoch = 0 if k < 8 else 1                      # the G kind changes at epoch 1 (classification loss no longer x 0)
+        data, tgt = batches[k % 3]
+        oe, le, pe, se = te.step(data, tgt, epoch, k)
+        og, lg, pg, sg = tg.step(data, tgt, epoch, k)
+        assert (pe, se) == (pg, sg)
+        for a, b in zip(le, lg):
+            worst = max(worst, abs(float(a) - float(b)) / max(abs(float(a)), 1e-12))
+        for (ka, a), (_, b) in zip(ne.named_parameters(), ng.named_parameters()):
+            d = float((a - b).abs().max())
+            if d > 0:
+                worst = max(worst, d / max(float(a.abs().max()), 1e-12))
+        for (ka, a), (_, b) in zip(ne.named_buffers(), ng.named_buffers()):
+            assert torch.equal(a, b) or rel_err(b.float(), a.float()) < 1e-5, ka
+    assert len(tg._graphs) >= 2 and tg.static_batch() is not None
+    print("graph vs eager, iter_size %d: worst relative difference %.2e over 12 micro-steps, %d graphs" % (iter_size, worst, len(tg._graphs)))
+    assert worst <= 1e-5, worst
+
+
 def test_i3d_train_step_phases():
     from dmcnet_amd import i3d
     torch.manual_seed(0)
