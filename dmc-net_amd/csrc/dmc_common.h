@@ -63,6 +63,14 @@ constexpr bool MEASURE_BUILD = true;
 constexpr bool MEASURE_BUILD = false;
 #endif
 constexpr bool measure_only(int o) { return o == OPT_GEN_ABLATE || o == OPT_CONV_ABLATE || o == OPT_GEN_STAGGER; }
+// Kernel variants that LOST their A/B measurement are compiled into the -DDMC_MEASURE build only (round 6): the product library
+// refuses the option values that select them -- the one-launch generator data gradient (gen_fused bit 1, gen_fused_bwd.hip),
+// the generator layer variants (ii) / (iii)-on-layer-3 / all-three-stage (gen_layer_path 3, 4, 5), the weight-gradient
+// predecessors (gen_wgrad_path 0 .. 3).
+constexpr bool product_value(int o, int v) {
+    return o == OPT_GEN_FUSED ? (v == 0 || v == 1) : o == OPT_GEN_LAYER_PATH ? (v == 0 || v == 1)
+         : o == OPT_GEN_WGRAD_PATH ? (v == 4 || v == 5) : true;
+}
 
 // ---- EstimatorDenseNetTiny geometry (code/dmcnet/model.py:172-194) --------------------------
 // Physical channel order used by every kernel: [mv0 mv1 r0 r1 r2 | y0(8) | y1(8) | y2(6) | y3(4)

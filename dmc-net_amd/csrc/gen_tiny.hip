@@ -2377,12 +2377,12 @@ int launch_layer(LayerArgs a, int n0, int N, hipStream_t s) {
         ra.ntiles = ra.tiles_y * N;
         const int wgs = ra.ntiles < num_cus() ? ra.ntiles : num_cus();
         if constexpr (GATHER_FORM) gen_layer_gather_kernel<MODE, K><<<wgs, G_THREADS, 0, s>>>(ra);
-    } else if (MODE == 0 && ((path == 1 && K == 2) || (path == 4 && (K == 2 || K == 3))) && a.W % 4 == 0 && a.W <= P_MAXW) {
+    } else if (MODE == 0 && ((path == 1 && K == 2) || (MEASURE_BUILD && path == 4 && (K == 2 || K == 3))) && a.W % 4 == 0 && a.W <= P_MAXW) {
         // variant (iii): the default tile with a two-stage ring, two 8-wave workgroups per CU.  Forward layer 2 (the most
         // matrix-bound layer) gains 7.5 % from the second resident workgroup (214.7 -> 198.5 us, matrix pipe busy 0.534 ->
         // 0.573) and takes it by default; layer 3 (HBM-bound, needs 3-channel chunks to fit) loses 1.7 %: option value 4 only.
         // Option value 5 = every layer on the three-stage single-workgroup kernel (the default before)
-        if constexpr (MODE == 0 && (K == 2 || K == 3)) {
+        if constexpr (MODE == 0 && (K == 2 || (MEASURE_BUILD && K == 3))) {
             RingArgs ra;
             ra.a = a;
             ra.tiles_y = (a.H + PT_H - 1) / PT_H;
@@ -2391,9 +2391,9 @@ int launch_layer(LayerArgs a, int n0, int N, hipStream_t s) {
             const int wgs = ra.ntiles < 2 * num_cus() ? ra.ntiles : 2 * num_cus();
             gen_layer_mfma_kernel<MODE, K, 2><<<wgs, LTHREADS, 0, s>>>(ra);
         }
-    } else if (path == 3 && MODE == 0 && (K == 2 || K == 3) && a.W % 4 == 0 && a.W <= P_MAXW) {
-        // measurement variant (round-2 verdict, variant ii): 4-row tiles, two 8-wave workgroups per CU
-        if constexpr (MODE == 0 && (K == 2 || K == 3)) {
+    } else if (MEASURE_BUILD && path == 3 && MODE == 0 && (K == 2 || K == 3) && a.W % 4 == 0 && a.W <= P_MAXW) {
+        // measurement variant (round-2 verdict, variant ii): 4-row tiles, two 8-wave workgroups per CU -- -DDMC_MEASURE build only
+        if constexpr (MEASURE_BUILD && MODE == 0 && (K == 2 || K == 3)) {
             RingArgs ra;
             ra.a = a;
             ra.tiles_y = (a.H + RingGeo<1>::ROWS - 1) / RingGeo<1>::ROWS;
@@ -2571,9 +2571,14 @@ int dmc_gen_tiny_bwd(const float* mv, const float* res, const float* const* w, c
     la.pk = workspace; la.out = nullptr; la.H = H; la.W = W; la.add_mv = 0;
     la.mse_flow = nullptr; la.mse_part = nullptr;
     const int step = frames_per_pass(N, H, W);
-    // option gen_fused bit 1 (default): the five data-gradient groups as ONE launch (gen_fused_bwd.hip)
+    // option gen_fused bit 1: the five data-gradient groups as ONE launch (gen_fused_bwd.hip) -- measured slower than the five
+    // launches (0.75 vs 0.60 ms): the kernel and the option value exist in the -DDMC_MEASURE build only
+#ifdef DMC_MEASURE
     const bool fused_data = (option(OPT_GEN_FUSED) & 2) && gen_fused_supported(H, W);
     if (fused_data && (rc = gen_fused_bwd_data(grad_out, saved, gbuf, workspace, N, H, W, s))) return rc;
+#else
+    const bool fused_data = false;
+#endif
     for (int n0 = 0; n0 < N && !fused_data; n0 += step) {
         const int nn = (N - n0) < step ? (N - n0) : step;
         if ((rc = launch_layer<2, 4>(la, n0, nn, s))) return rc;
@@ -2596,14 +2601,24 @@ int dmc_gen_tiny_bwd(const float* mv, const float* res, const float* const* w, c
         if ((rc = gen_wgrad_rs(mv, res, saved, grad_out, gbuf, workspace + PACKED_TOTAL, partials, N, H, W, groups, s))) return rc;
     } else if (W % 4 == 0 && wpath >= 1) {
         a.tiles_y = (H + PW_H - 1) / PW_H;
-        if (wpath >= 4) gen_bwd_weight_pc_kernel<3><<<groups, 512, 0, s>>>(a);
-        else if (wpath == 3) gen_bwd_weight_pc_kernel<2><<<groups, 512, 0, s>>>(a);
-        else if (wpath == 2) gen_bwd_weight_pc_kernel<1><<<groups, 512, 0, s>>>(a);
-        else gen_bwd_weight_pc_kernel<0><<<groups, 512, 0, s>>>(a);
+        // paths 1 .. 3 (fp32 producer / consumer, earlier bf16x3 forms): slower predecessors of path 4, -DDMC_MEASURE build only
+        if (!MEASURE_BUILD || wpath >= 4) gen_bwd_weight_pc_kernel<3><<<groups, 512, 0, s>>>(a);
+        else if constexpr (MEASURE_BUILD) {
+            if (wpath == 3) gen_bwd_weight_pc_kernel<2><<<groups, 512, 0, s>>>(a);
+            else if (wpath == 2) gen_bwd_weight_pc_kernel<1><<<groups, 512, 0, s>>>(a);
+            else gen_bwd_weight_pc_kernel<0><<<groups, 512, 0, s>>>(a);
+        }
     } else {
         a.tiles_y = (H + WT_H - 1) / WT_H;
-        if (W % 4 == 0) gen_bwd_weight_kernel<true><<<groups, 512, 0, s>>>(a, workspace + PACKED_TOTAL);
-        else gen_bwd_weight_kernel<false><<<groups, 512, 0, s>>>(a, workspace + PACKED_TOTAL);
+        // (W % 4 == 0 reaches this branch only with gen_wgrad_path 0, a -DDMC_MEASURE value)
+        bool done = false;
+        if constexpr (MEASURE_BUILD) {
+            if (W % 4 == 0) {
+                gen_bwd_weight_kernel<true><<<groups, 512, 0, s>>>(a, workspace + PACKED_TOTAL);
+                done = true;
+            }
+        }
+        if (!done) gen_bwd_weight_kernel<false><<<groups, 512, 0, s>>>(a, workspace + PACKED_TOTAL);
     }
     if ((rc = check_launch("gen_bwd_weight"))) return rc;
     const int wpart = layout3 ? WPART3 : WPART;

@@ -213,10 +213,14 @@ int dmc_set_option(const char* name, int value) {
     if (i < 0) return fail(DMC_E_INVALID, "dmc_set_option: unknown option '%s'", name ? name : "(null)");
     if (!MEASURE_BUILD && measure_only(i))
         return fail(DMC_E_INVALID, "dmc_set_option: '%s' switches parts of a kernel off (results wrong) and exists only in the -DDMC_MEASURE build", name);
+    if (!MEASURE_BUILD && !product_value(i, value))
+        return fail(DMC_E_INVALID, "dmc_set_option: %s = %d selects a kernel variant that lost its A/B measurement; it is compiled into the "
+                    "-DDMC_MEASURE build only", name, value);
     g_options[i].store(value, std::memory_order_relaxed);
     return DMC_OK;
 }
 int dmc_get_option(const char* name) {
+    if (name && !strcmp(name, "measure_build")) return MEASURE_BUILD ? 1 : 0;      // read-only: which build this library is
     const int i = option_index(name);
     return i < 0 ? -1 : (!MEASURE_BUILD && measure_only(i)) ? 0 : g_options[i].load(std::memory_order_relaxed);
 }

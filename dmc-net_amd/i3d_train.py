@@ -214,10 +214,11 @@ class I3DTrainer(object):
     def _fwd_bwd(self, key, data, target, stage, combine):
         """Forward + losses + backward of one micro-batch; returns (logits, losses).  Eager, or -- graph mode, CUDA, after
         the warm-up occurrences of this phase kind -- one replay."""
-        ent = self._graphs.get(key) if self.graph_warmup is not None else None
+        use_graph = self.graph_warmup is not None and data.is_cuda and ops.PROBE is None    # (HIP-event spans need eager launches)
+        ent = self._graphs.get(key) if use_graph else None
         if ent is None:
             seen = self._graph_seen.get(key, 0)
-            if self.graph_warmup is None or not data.is_cuda or seen < self.graph_warmup or ops.PROBE is not None:
+            if not use_graph or seen < self.graph_warmup:
                 self._graph_seen[key] = seen + 1
                 out, losses = self.losses_fn(self.net, data, target, stage=stage, detach=False)
                 self._backward(combine(losses))
