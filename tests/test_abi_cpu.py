@@ -137,6 +137,16 @@ def test_classifier_conv_entry_points_host_side_without_gpu():
         assert lib.dmc_get_option(name) == 0
         assert lib.dmc_set_option(name, 1) != 0 and b"DMC_MEASURE" in lib.dmc_last_error()
         assert lib.dmc_get_option(name) == 0
+    # kernel variants that lost their A/B measurement are compiled into the -DDMC_MEASURE build only (round 6): the product
+    # library refuses the option VALUES that select them and keeps the value it had
+    assert lib.dmc_get_option(b"measure_build") == 0
+    for name, bad, good in ((b"gen_fused", (2, 3), 1), (b"gen_layer_path", (3, 4, 5), 1), (b"gen_wgrad_path", (0, 1, 2, 3), 5)):
+        for v in bad:
+            assert lib.dmc_set_option(name, v) != 0 and b"DMC_MEASURE" in lib.dmc_last_error(), (name, v)
+            assert lib.dmc_get_option(name) == good
+        assert lib.dmc_set_option(name, good) == 0
+    assert lib.dmc_set_option(b"gen_wgrad_path", 4) == 0 and lib.dmc_set_option(b"gen_wgrad_path", 5) == 0
+    assert lib.dmc_set_option(b"gen_fused", 0) == 0 and lib.dmc_set_option(b"gen_fused", 1) == 0
     assert lib.dmc_get_option(b"no_such_option") == -1 and lib.dmc_set_option(b"no_such_option", 1) != 0
     for cin, cout, want in [(64, 64, 1), (64, 128, 1), (512, 512, 1), (256, 64, 1), (3, 64, 0), (16, 32, 0), (96, 64, 0)]:
         assert lib.dmc_conv_nhwc_presplit_supported(cin, cout) == want, (cin, cout)

@@ -210,6 +210,8 @@ def test_generator_full_batch_generic_weights(seed, frames, backward_mask):
     lib = dmcnet_amd._lib.load()
     before, fused_before = lib.dmc_get_option(b"gen_wino"), lib.dmc_get_option(b"gen_fused")
     if backward_mask < 0:          # the five data-gradient groups as one launch (csrc/gen_fused_bwd.hip, option gen_fused bit 1)
+        if lib.dmc_get_option(b"measure_build") != 1:
+            pytest.skip("the one-launch data gradient lost its measurement: -DDMC_MEASURE build only (DMC_HIP_LIB)")
         dmcnet_amd._lib.check(lib.dmc_set_option(b"gen_fused", 3), "dmc_set_option")
     else:
         dmcnet_amd._lib.check(lib.dmc_set_option(b"gen_wino", backward_mask), "dmc_set_option")

@@ -3,7 +3,8 @@
 O=$1; shift; OUT=$GRAFT_REPO_ROOT/gpurun_out/$O; mkdir -p $OUT
 R=$GRAFT_REPO_ROOT
 # option sets that name gen_ablate / conv_ablate / gen_stagger need the measurement build (python dmc-net_amd/build.py --measure):
-case "$*" in *ablate*|*stagger*) export DMC_HIP_LIB=$R/dmc-net_amd/libdmcnet_hip_measure.so;; esac
+# ... and so do the values that select variants which lost their measurement (gen_fused 2 / 3, gen_layer_path 3 .. 5, gen_wgrad_path 0 .. 3)
+case "$*" in *ablate*|*stagger*|*gen_fused=[23]*|*gen_layer_path=[345]*|*gen_wgrad_path=[0123]*) export DMC_HIP_LIB=$R/dmc-net_amd/libdmcnet_hip_measure.so;; esac
 cd /tmp && export TMPDIR=/tmp
 i=0
 for m in "$@"; do
