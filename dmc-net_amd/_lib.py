@@ -119,6 +119,7 @@ SIGNATURES = {
     "dmc_conv3d_bf16_wpack_bytes": (_Z, [_I] * 5),
     "dmc_conv3d_bf16_pack": (_I, [_P, _L, _L, _L, _P, _P] + [_I] * 5 + [_P]),
     "dmc_conv3d_bf16_stat_blocks": (_I, [_I] * 5),
+    "dmc_conv3d_bf16_stat_blocks_k": (_I, [_I] * 9),
     "dmc_conv3d_bf16_fwd": (_I, [_P, _P, _L, _L, _L, _P, _P, _P] + [_I] * 9 + [_P]),
     "dmc_conv3d_bf16_dgrad": (_I, [_P, _P, _L, _L, _L, _P, _P] + [_I] * 9 + [_P]),
     "dmc_conv3d_bf16_wgrad_bytes": (_Z, [_I] * 9),

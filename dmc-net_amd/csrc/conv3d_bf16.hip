@@ -720,6 +720,13 @@ C3dWgradPlan c3d_wgrad_plan(long M, int Cin, int Cout, int KD, int KH, int KW) {
     return p;
 }
 
+// index of (row r, tap t, contraction channel c) in the MFMA-fragment-order copy of a 27-tap weight array:
+// [r / 32][c / 32][t][k-block (c / 16) % 2][lane = 32 ((c / 8) % 2) + r % 32][c % 8]  (same element count as [rows_pad][27][Cp])
+__device__ __forceinline__ long frag_index(int r, int t, int c, int Cp) {
+    const int nch = Cp >> 5;
+    return ((((long)(r >> 5) * nch + (c >> 5)) * 27 + t) * 2 + ((c >> 4) & 1)) * 512 + (((c >> 3) & 1) * 32 + (r & 31)) * 8 + (c & 7);
+}
+
 // fp32 weights (any strides) -> packed bf16 [rows_pad][T][Cp], zero padded; tap index mirrored for the data gradient
 __global__ __launch_bounds__(256) void conv3d_pack_w_kernel(const float* __restrict__ w, bf16_t* __restrict__ wp, int rows,
                                                             int rows_pad, int cols, int Cp, int T, long s_row, long s_col,
@@ -732,6 +739,7 @@ __global__ __launch_bounds__(256) void conv3d_pack_w_kernel(const float* __restr
         unsigned v = 0;
         if (r < rows && c < cols) v = f2bf(w[r * s_row + c * s_col + (mirror ? T - 1 - t : t) * s_tap]);
         wp[i] = (bf16_t)v;
+        if (T == 27) wp[total + frag_index(r, t, c, Cp)] = (bf16_t)v;       // the patch-resident kernel's fragment-order copy
     }
 }
 
@@ -751,7 +759,267 @@ __global__ __launch_bounds__(256) void conv3d_pack_w2_kernel(const float* __rest
         unsigned v = 0;
         if (r < rows && c < cols) v = f2bf(w[r * s_row + c * s_col + (bwd ? T - 1 - t : t) * s_tap]);
         wp[i] = (bf16_t)v;
+        if (T == 27) wp[total + frag_index(r, t, c, Cp)] = (bf16_t)v;       // the patch-resident kernel's fragment-order copy
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// 3 x 3 x 3, stride 1: PATCH-RESIDENT form (round 6).  The tap-stepping kernel above re-fetches the pixel rows of every
+// tap from L2 (27 transfers of the same data) and meets a barrier every 2 - 8 MFMAs per wave.  Here a workgroup owns
+// P = 32 TM consecutive positions of ONE (n, d) plane in PADDED flat coordinates f = hp (W + 2) + wp -- so that every
+// in-plane tap is the constant offset (ky - 1) (W + 2) + (kx - 1) -- and 128 output channels, 32 per wave: every wave
+// multiplies ALL P positions (TM accumulator tiles: a weight fragment is loaded once per TM MFMAs).  Per 32-channel chunk
+// of the contraction the workgroup loads the patch ONCE: the rows [t P, t P + P + 2 (W + 2) + 2) of the three depth planes
+// d - 1, d, d + 1 (LDS-DMA, 16 bytes per lane; rows outside the volume are never written and stay zero from a one-off
+// clear), then runs all 27 taps x 2 k-blocks on it: 54 TM MFMAs per wave between two barriers.
+// LDS rows have a pitch of 80 bytes (64 of data + 16 of padding): 20 banks per row, so the sixteen lanes of a
+// ds_read_b128 group -- rows b + {0..3, 12..15, 20..27}, every residue mod 16 once -- hit disjoint banks for ANY base
+// row b: no swizzle, the address of a tap is one scalar added to a per-lane constant.  The weight fragments come
+// straight from global memory (L2-resident), from a copy of the packed weights in MFMA-fragment order
+// [32-row tile][chunk][tap][k-block][lane][8] -- one contiguous KB per wave-load -- prefetched one tap ahead in registers.
+// The patch is single-buffered: the workgroups resident on a CU (up to three at W = 28: 48 KB of LDS each) cover each
+// other's load phases.  Pad positions (wp = 0, W + 1) are computed and dropped: W / (W + 2) of the MFMAs are useful.
+// Workgroups that share a patch (the channel blocks of one tile) are mapped to the same XCD, one after the other.
+struct P3Args {
+    const bf16_t* x; const bf16_t* wfrag; bf16_t* y; float* stat_part;
+    int N, D, H, W, Cin, Cout, Cp;
+    int Wp, R, tiles_pp, nx, ny, ni;         // ni: DMA instructions per chunk (12 patch rows each)
+    unsigned magic_R, magic_Wp;              // floor(2^32 / d) + 1: n / d = umulhi(n, magic) for the small n used here
+    int ablate;                              // -DDMC_MEASURE build only (option conv_ablate): 16 = patch transfers of chunk 0 only, 32 = one weight fragment for every tap
+};
+
+constexpr int P3_PITCH = 80;
+constexpr int P3_MAXK = 22;                  // DMA instructions per depth plane and chunk (12 patch rows each): R <= 264
+constexpr int P3_THREADS = 320;              // waves 0 .. 3: one 32-channel tile each; wave 4: the loader
+
+__device__ __forceinline__ void p3_dma16(unsigned long long src, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)) : "memory");
+}
+
+// PERSISTENT: gridDim.x workgroups (one per CU) walk the (position tile, channel block) jobs with stride gridDim.x; the
+// loader streams the chunks of job after job, so the first chunk of the next job lands while the epilogue of this one runs.
+template <int TM>
+__global__ __launch_bounds__(P3_THREADS) void conv3d_p3_kernel(P3Args a) {
+    constexpr int P = 32 * TM;
+    extern __shared__ __attribute__((aligned(1024))) char p3_lds[];      // two patch buffers of ni x 960 bytes
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave == 4;
+    const unsigned lds0 = lds_addr_of(p3_lds);
+    const int bufsz = a.ni * 960;
+    const int nch = a.Cp >> 5;
+    const int total = ((a.nx + 7) / 8) * 8 * a.ny;
+    const int npi = a.R / 12;
+
+    if (loader) {
+        // ---- the loader wave: one instruction moves 12 patch rows (60 lanes: row 12 k + lane / 5, quad lane % 5; quad 4 is
+        // the row's padding and lanes 60 .. 63 idle) = 960 contiguous bytes of LDS.  Every depth plane of the patch starts at
+        // an instruction boundary (R is a multiple of 12), so ONE plan of R / 12 offsets serves the three planes, which differ
+        // by a scalar; the plan walks the rows incrementally (no division per row).  Rows outside the volume and channels
+        // beyond Cin are fetched from a page of zeros: every slot a consumer reads is rewritten by every chunk. ----
+        const int quad = lane % 5, rsub = lane / 5;
+        const bool lane_on = lane < 60 && quad < 4;
+        const unsigned long long zeros = (unsigned long long)g_zeros3d;
+        const size_t plane_bytes = (size_t)a.H * a.W * a.Cin * 2;
+        int job = 0;
+        for (int id = blockIdx.x; id < total; id += gridDim.x) {
+            const int slot = id >> 3;
+            const int bx = (slot / a.ny) * 8 + (id & 7);
+            if (bx >= a.nx) continue;
+            const int plane = bx / a.tiles_pp, t = bx - plane * a.tiles_pp;
+            const int n = plane / a.D, d = plane - n * a.D;
+            unsigned off[P3_MAXK];
+            {
+                const unsigned f0 = (unsigned)(t * P + rsub);
+                unsigned hp = __umulhi(f0, a.magic_Wp);
+                int wp = (int)(f0 - hp * a.Wp);
+#pragma unroll
+                for (int k = 0; k < P3_MAXK; ++k) {
+                    off[k] = 0xffffffffu;                                  // = the page of zeros
+                    if (k < npi && hp >= 1u && (int)hp <= a.H && wp >= 1 && wp <= a.W)
+                        off[k] = (unsigned)((((int)(hp - 1) * a.W + (wp - 1)) * a.Cin + quad * 8) * 2);
+                    wp += 12;
+                    if (wp >= a.Wp) { wp -= a.Wp; ++hp; }
+                    if (wp >= a.Wp) { wp -= a.Wp; ++hp; }                  // (W + 2 >= 6)
+                }
+            }
+            for (int c = 0; c < nch; ++c, ++job) {
+                // chunk job -> buffer job & 1, while the other four waves multiply the previous one (its readers left this
+                // buffer at the barrier that closed the job before that)
+                if (lane_on && !(DMC_ABL(a.ablate & 16) && job > 0)) {
+                    const bool cok = c * 32 + quad * 8 < a.Cin;
+                    const unsigned cbytes = (unsigned)c * 64u;
+                    for (int z = 0; z < 3; ++z) {
+                        const int dz = d + z - 1;
+                        const bool zok = cok && dz >= 0 && dz < a.D;
+                        const unsigned long long xb = (unsigned long long)a.x + (size_t)(n * a.D + (zok ? dz : 0)) * plane_bytes + cbytes;
+                        const unsigned dst = lds0 + (job & 1) * bufsz + z * npi * 960;
+#pragma unroll
+                        for (int k = 0; k < P3_MAXK; ++k)
+                            if (k < npi) p3_dma16(zok && off[k] != 0xffffffffu ? xb + off[k] : zeros, dst + k * 960);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();                                           // this chunk has landed / the previous one is consumed
+            }
+        }
+        __syncthreads();                                                   // (the consumers' last chunk)
+        return;
+    }
+
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int lb = l31 * P3_PITCH + khalf * 16;                        // B fragment: row of this lane's position, quad khalf (+ 2 kb)
+    int job = 0;
+    __syncthreads();                                                       // the first chunk has landed
+    for (int id = blockIdx.x; id < total; id += gridDim.x) {
+        const int slot = id >> 3;
+        const int bx = (slot / a.ny) * 8 + (id & 7), by = slot % a.ny;
+        if (bx >= a.nx) continue;
+        const int plane = bx / a.tiles_pp, t = bx - plane * a.tiles_pp;  // plane = n * D + d
+        const int co0 = by * 128 + wave * 32;                             // this wave's 32 output channels
+        const bool active = co0 < a.Cout;
+        // A fragments of this wave's channel tile: [chunk][tap][kb][lane][8]
+        const bf16_t* wl = a.wfrag + ((size_t)(active ? co0 >> 5 : 0) * nch * 27 * 2 * 64 + lane) * 8;
+
+        f32x16 acc[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+        for (int c = 0; c < nch; ++c, ++job) {
+            if (active) {
+                // Software pipeline, pinned with scheduling barriers (left alone, the scheduler sinks every load to just in
+                // front of its first use and each MFMA waits out a full LDS / L2 latency): while the MFMAs of tap t run, the
+                // position fragments of tap t + 1 (LDS) and the weight fragments of tap t + 2 (global) are in flight.
+                const bf16_t* wc = wl + (size_t)c * 27 * 2 * 64 * 8;
+                const char* pb = p3_lds + (job & 1) * bufsz + lb;
+                auto lda = [&](int tap, u32x4 (&dst)[2]) {
+                    const bf16_t* wt = wc + (size_t)tap * 2 * 64 * 8;
+                    dst[0] = *reinterpret_cast<const u32x4*>(wt);
+                    dst[1] = *reinterpret_cast<const u32x4*>(wt + 64 * 8);
+                };
+                auto ldb = [&](int tap, u32x4 (&dst)[2][TM]) {
+                    const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+                    const char* bt = pb + (kz * a.R + ky * a.Wp + kx) * P3_PITCH;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) dst[kb][i] = *reinterpret_cast<const u32x4*>(bt + i * 32 * P3_PITCH + kb * 32);
+                };
+                u32x4 af[3][2], bf[2][2][TM];
+                lda(0, af[0]);
+                if (!DMC_ABL(a.ablate & 32)) lda(1, af[1]);
+                ldb(0, bf[0]);
+#pragma unroll
+                for (int tap = 0; tap < 27; ++tap) {
+                    if (tap + 2 < 27 && !DMC_ABL(a.ablate & 32)) lda(tap + 2, af[(tap + 2) % 3]);
+                    if (tap + 1 < 27 && !DMC_ABL(a.ablate & 64)) ldb(tap + 1, bf[(tap + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int ai = DMC_ABL(a.ablate & 32) ? 0 : tap % 3;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf16x8, af[ai][kb]),
+                                __builtin_bit_cast(bf16x8, bf[DMC_ABL(a.ablate & 64) ? 0 : tap & 1][kb][i]), acc[i], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (c + 1 < nch) __syncthreads();                              // this chunk is consumed / the next one has landed
+        }
+
+        // ---- epilogue (before the job's closing barrier: the loader is already fetching the next job's first chunk): lane
+        // holds position 32 i + l31, channels 8 gq + 4 khalf + e of this wave's tile in acc[i][4 gq + e] ----
+        if (active) {
+            float s1[16], s2[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const unsigned f = (unsigned)(t * P + a.Wp + 1 + 32 * i + l31);
+                const unsigned hp = __umulhi(f, a.magic_Wp);
+                const int wp = (int)(f - hp * a.Wp);
+                const bool ok = hp >= 1u && (int)hp <= a.H && wp >= 1 && wp <= a.W;
+                const size_t m = ((size_t)plane * a.H + (hp - 1)) * a.W + (wp - 1);
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int co = co0 + 8 * gq + 4 * khalf;
+                    if (co >= a.Cout || !ok) continue;
+                    unsigned h[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        h[e] = f2bf(acc[i][4 * gq + e]);
+                        const float r = bf2f(h[e]);
+                        s1[4 * gq + e] += r; s2[4 * gq + e] += r * r;
+                    }
+                    *reinterpret_cast<uint2*>(a.y + m * a.Cout + co) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                }
+            }
+            if (a.stat_part) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float d1 = s1[e], d2 = s2[e];
+#pragma unroll
+                    for (int o = 1; o < 32; o <<= 1) {
+                        d1 += __shfl_xor(d1, o, 64);
+                        d2 += __shfl_xor(d2, o, 64);
+                    }
+                    const int co = co0 + 8 * (e >> 2) + 4 * khalf + (e & 3);
+                    if (l31 == 0 && co < a.Cout) {
+                        float* dst = a.stat_part + ((size_t)bx * a.Cout + co) * 2;
+                        dst[0] = d1; dst[1] = d2;
+                    }
+                }
+            }
+        }
+        __syncthreads();                                                   // the job's last chunk is consumed / the next job's first has landed
+    }
+}
+
+// geometry of the patch-resident kernel for a 3 x 3 x 3 layer with K contraction channels; tm = 0: not served
+struct P3Plan { int tm, Wp, R, tiles_pp, nx, ny, ni, lds; };
+P3Plan p3_plan(int N, int D, int H, int W, int K, int Cout, int KD, int KH, int KW) {
+    P3Plan p{};
+    const int cfg = option(OPT_CONV_CFG);
+    if ((cfg >= 1 && cfg <= 6) || !(KD == 3 && KH == 3 && KW == 3) || K % 8 != 0) return p;   // conv_cfg 1 .. 5: a tap-stepping tile, 6: its automatic choice (A/B)
+    if ((long)N * D * H * W * K * 2 >= 0x7fffffffL || (long)(H + 2) * (W + 2) + 130 >= (1L << 16)) return p;   // 32-bit offsets; exact magic division
+    p.Wp = W + 2;
+    p.ny = (Cout + 127) / 128;
+    const int count = (H - 1) * p.Wp + W;                  // flat positions first real .. last real
+    for (int tm = 4; tm >= 2; tm -= 2) {
+        const int P = 32 * tm, R = (P + 2 * p.Wp + 2 + 11) / 12 * 12;   // rows per depth plane, a whole number of 12-row transfers
+        const int ni = 3 * R / 12;
+        if (R / 12 > P3_MAXK || p.Wp < 6) continue;
+        const int tiles = (count + P - 1) / P;
+        if (tm == 4 && cfg != 7 && (cfg == 8 || count <= 64)) continue;   // one 64-position tile covers a 7 x 7 plane; conv_cfg 7 / 8: always 128 / 64 (A/B)
+        p.tm = tm; p.R = R; p.tiles_pp = tiles; p.nx = N * D * tiles; p.ni = ni; p.lds = 2 * ni * 960 + 64;
+        return p;
+    }
+    return p;
+}
+
+int launch_p3(const C3dArgs& a, const P3Plan& p, hipStream_t s) {
+    P3Args q;
+    const int T = 27;
+    q.x = a.x; q.y = a.y; q.stat_part = a.stat_part;
+    q.wfrag = a.w + (size_t)((a.Cout + 127) / 128 * 128) * T * a.Cp;     // behind the [rows_pad][T][Cp] copy
+    q.N = a.N; q.D = a.D; q.H = a.H; q.W = a.W; q.Cin = a.Cin; q.Cout = a.Cout; q.Cp = a.Cp;
+    q.Wp = p.Wp; q.R = p.R; q.tiles_pp = p.tiles_pp; q.nx = p.nx; q.ny = p.ny; q.ni = p.ni;
+    q.magic_R = (unsigned)(0x100000000ull / (unsigned)p.R) + 1u;
+    q.magic_Wp = (unsigned)(0x100000000ull / (unsigned)p.Wp) + 1u;
+    q.ablate = option(OPT_CONV_ABLATE);
+    const unsigned total = (unsigned)(((p.nx + 7) / 8) * 8 * p.ny);
+    const unsigned grid = total < 256u ? total : 256u;                    // persistent: one workgroup per CU (a multiple of 8: XCD mapping)
+    static LdsLimit lim4, lim2;
+    hipError_t e = p.tm == 4 ? lim4.raise(reinterpret_cast<const void*>(&conv3d_p3_kernel<4>), 160 * 1024)
+                             : lim2.raise(reinterpret_cast<const void*>(&conv3d_p3_kernel<2>), 160 * 1024);
+    if (e != hipSuccess) return fail(DMC_E_LAUNCH, "conv3d_p3: dynamic LDS limit: %s", hipGetErrorString(e));
+    if (p.tm == 4) conv3d_p3_kernel<4><<<grid, P3_THREADS, p.lds, s>>>(q);
+    else conv3d_p3_kernel<2><<<grid, P3_THREADS, p.lds, s>>>(q);
+    return check_launch("conv3d_p3");
 }
 
 template <int BM, int BN, int WM, int WN, int NS>
@@ -780,6 +1048,8 @@ int c3d_block_pixels(int cout, long M) {
 
 int launch_conv3d(const C3dArgs& a, hipStream_t s) {
     if (a.M <= 0) return DMC_OK;
+    const P3Plan p3 = p3_plan(a.N, a.D, a.H, a.W, a.Cin, a.Cout, a.KD, a.KH, a.KW);
+    if (p3.tm) return launch_p3(a, p3, s);
     switch (c3d_choice(a.Cout, a.M)) {
         // transfer-ring depth: 4 where every wave issues the same number of transfers and 4 stages fit the static LDS
         // (8 / 5 stages for the two small tiles: 20.11 vs 19.90 ms per I3D micro-step, three same-box pairs -- the LDS they take
@@ -813,7 +1083,7 @@ int dmc_conv3d_bf16_supported(int N, int D, int H, int W, int Cin, int Cout, int
 size_t dmc_conv3d_bf16_wpack_bytes(int Cin, int Cout, int KD, int KH, int KW) {
     const size_t T = (size_t)KD * KH * KW;
     const size_t f = (size_t)pad_to(Cout, 128) * T * pad_to(Cin, 32), b = (size_t)pad_to(Cin, 128) * T * pad_to(Cout, 32);
-    return 2 * (f > b ? f : b) + 16;
+    return (T == 27 ? 4 : 2) * (f > b ? f : b) + 16;      // 3 x 3 x 3: a second copy in MFMA-fragment order behind the first
 }
 
 // pack the weights for the forward (wpack_f) and the data gradient (wpack_b) in one launch; each workspace has
@@ -829,11 +1099,16 @@ int dmc_conv3d_bf16_pack(const float* w, long w_s_co, long w_s_ci, long w_s_tap,
     return check_launch("conv3d_pack_w2");
 }
 
-// number of [Cout][2] float partial rows the forward writes when asked for statistics
+// number of [Cout][2] float partial rows the forward writes when asked for statistics: the 1 x 1 x 1 / general kernels ...
 int dmc_conv3d_bf16_stat_blocks(int N, int D, int H, int W, int Cout) {
     const long M = (long)N * D * H * W;
     const int bm = c3d_block_pixels(Cout, M);
     return (int)((M + bm - 1) / bm);
+}
+// ... and for a given layer (the 3 x 3 x 3 layers take the patch-resident kernel: one row per position tile)
+int dmc_conv3d_bf16_stat_blocks_k(int N, int D, int H, int W, int Cin, int Cout, int KD, int KH, int KW) {
+    const P3Plan p3 = p3_plan(N, D, H, W, Cin, Cout, KD, KH, KW);
+    return p3.tm ? p3.nx : dmc_conv3d_bf16_stat_blocks(N, D, H, W, Cout);
 }
 
 // y [N,D,H,W,Cout] bf16 = conv3d(x [N,D,H,W,Cin] bf16, w fp32 [Cout][Cin][KD][KH][KW] given by its element strides),

@@ -19,7 +19,7 @@ size_t up256(size_t b) { return (b + 255) / 256 * 256; }
 struct FwdLayout { size_t part, wpack_f, wpack_b, stats, total; int nblk; };
 FwdLayout fwd_layout(int N, int D, int H, int W, int Cin, int Cout, int KD, int KH, int KW) {
     FwdLayout l;
-    l.nblk = dmc_conv3d_bf16_stat_blocks(N, D, H, W, Cout);
+    l.nblk = dmc_conv3d_bf16_stat_blocks_k(N, D, H, W, Cin, Cout, KD, KH, KW);
     const size_t wp = up256(dmc_conv3d_bf16_wpack_bytes(Cin, Cout, KD, KH, KW));
     l.part = 0;
     l.wpack_f = up256((size_t)l.nblk * Cout * 2 * sizeof(float));

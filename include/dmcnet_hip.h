@@ -534,6 +534,9 @@ size_t dmc_conv3d_bf16_wpack_bytes(int Cin, int Cout, int KD, int KH, int KW);
 int dmc_conv3d_bf16_pack(const float* w, long w_s_co, long w_s_ci, long w_s_tap, void* wpack_f, void* wpack_b, int Cin, int Cout,
                          int KD, int KH, int KW, dmc_stream_t stream);
 int dmc_conv3d_bf16_stat_blocks(int N, int D, int H, int W, int Cout);
+/* rows of stat_partials dmc_conv3d_bf16_fwd writes for THIS layer (the 3x3x3 layers run a patch-resident kernel whose
+ * workgroups are position tiles of one (n, d) plane; everything else: dmc_conv3d_bf16_stat_blocks) */
+int dmc_conv3d_bf16_stat_blocks_k(int N, int D, int H, int W, int Cin, int Cout, int KD, int KH, int KW);
 int dmc_conv3d_bf16_fwd(const void* x, const float* w, long w_s_co, long w_s_ci, long w_s_tap, void* wpack, void* y,
                         float* stat_partials, int N, int D, int H, int W, int Cin, int Cout, int KD, int KH, int KW,
                         dmc_stream_t stream);

@@ -91,9 +91,10 @@ def test_conv3d_bf16_fwd_dgrad_wgrad_vs_fp64(case):
     assert torch.equal(y1, y2) and torch.equal(g1, wg.grad) and torch.equal(d1, xg.grad)
 
 
-@pytest.mark.parametrize("conv_cfg", [1, 2, 3, 4, 5], indirect=True)
+@pytest.mark.parametrize("conv_cfg", [1, 2, 3, 4, 5, 6, 7, 8], indirect=True)
 def test_conv3d_bf16_every_tile_configuration(conv_cfg):
-    """Each forward tile configuration (option conv_cfg) on a shape with ragged pixel and channel edges."""
+    """Each forward tile configuration (option conv_cfg: 1 .. 5 the tap-stepping tiles, 6 their automatic choice, 7 / 8 the
+    patch-resident 3 x 3 x 3 kernel with 128- / 64-position tiles) on a shape with ragged pixel and channel edges."""
     n, cin, d, h, w, cout, k = 2, 48, 3, 11, 9, 160, 3
     x = rnd(311, (n, cin, d, h, w)).bfloat16()
     wt = rnd(312, (cout, cin, k, k, k)) * 0.05
