@@ -797,6 +797,121 @@ __device__ __forceinline__ void p3_dma16(unsigned long long src, unsigned lds_by
                  :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)) : "memory");
 }
 
+// one consumer wave's share of a job: TMW position tiles (32 positions each) starting at tile i0 of the workgroup's P = 32 TM
+// positions, the 32 output channels from co0; `job` counts chunk jobs (buffer parity) and is advanced by nch
+template <int TM, int TMW>
+__device__ __forceinline__ void p3_consume(const P3Args& a, const char* p3_lds, int bufsz, int nch, int bx, int co0, int i0, bool active,
+                                           int& job) {
+    constexpr int P = 32 * TM;
+    const int lane = threadIdx.x & 63;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int lb = (32 * i0 + l31) * P3_PITCH + khalf * 16;            // B fragment: row of this lane's position, quad khalf (+ 2 kb)
+    const int plane = bx / a.tiles_pp, t = bx - plane * a.tiles_pp;      // plane = n * D + d
+    // A fragments of this wave's channel tile: [chunk][tap][kb][lane][8]
+    const bf16_t* wl = a.wfrag + ((size_t)(active ? co0 >> 5 : 0) * nch * 27 * 2 * 64 + lane) * 8;
+
+    f32x16 acc[TMW];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    for (int c = 0; c < nch; ++c, ++job) {
+        if (active) {
+            // Software pipeline, pinned with scheduling barriers (left alone, the scheduler sinks every load to just in
+            // front of its first use and each MFMA waits out a full LDS / L2 latency): while the MFMAs of tap t run, the
+            // position fragments of tap t + 1 (LDS) and the weight fragments of tap t + 2 (global) are in flight.
+            const bf16_t* wc = wl + (size_t)c * 27 * 2 * 64 * 8;
+            const char* pb = p3_lds + (job & 1) * bufsz + lb;
+            u32x4 af[3][2], bf[2][2][TMW];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                af[0][kb] = *reinterpret_cast<const u32x4*>(wc + kb * 64 * 8);
+                if (!DMC_ABL(a.ablate & 32)) af[1][kb] = *reinterpret_cast<const u32x4*>(wc + (2 + kb) * 64 * 8);
+#pragma unroll
+                for (int i = 0; i < TMW; ++i) bf[0][kb][i] = *reinterpret_cast<const u32x4*>(pb + i * 32 * P3_PITCH + kb * 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tap = 0; tap < 27; ++tap) {
+                const int ai = DMC_ABL(a.ablate & 32) ? 0 : tap % 3;
+                const int kzn = (tap + 1) / 9, kyn = ((tap + 1) / 3) % 3, kxn = (tap + 1) % 3;
+                const char* btn = pb + (kzn * a.R + kyn * a.Wp + kxn) * P3_PITCH;
+                const bf16_t* wtn = wc + (size_t)(tap + 2) * 2 * 64 * 8;
+                // one load behind every MFMA (the wave issues in order: a block of loads in front of the MFMAs would leave
+                // the matrix pipe idle while it issues): position fragment (kb, i) of tap + 1, and behind the first MFMA of
+                // each k-block a weight fragment of tap + 2
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < TMW; ++i) {
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, af[ai][kb]),
+                            __builtin_bit_cast(bf16x8, bf[DMC_ABL(a.ablate & 64) ? 0 : tap & 1][kb][i]), acc[i], 0, 0, 0);
+                        if (tap + 1 < 27 && !DMC_ABL(a.ablate & 64))
+                            bf[(tap + 1) & 1][kb][i] = *reinterpret_cast<const u32x4*>(btn + i * 32 * P3_PITCH + kb * 32);
+                        if (i == 0 && tap + 2 < 27 && !DMC_ABL(a.ablate & 32))
+                            af[(tap + 2) % 3][kb] = *reinterpret_cast<const u32x4*>(wtn + kb * 64 * 8);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            }
+        }
+        if (c + 1 < nch) __syncthreads();                                  // this chunk is consumed / the next one has landed
+    }
+
+    // ---- epilogue (before the job's closing barrier: the loader is already fetching the next job's first chunk): lane
+    // holds position 32 (i0 + i) + l31, channels 8 gq + 4 khalf + e of this wave's tile in acc[i][4 gq + e] ----
+    if (active) {
+        float s1[16], s2[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < TMW; ++i) {
+            const unsigned f = (unsigned)(t * P + a.Wp + 1 + 32 * (i0 + i) + l31);
+            const unsigned hp = __umulhi(f, a.magic_Wp);
+            const int wp = (int)(f - hp * a.Wp);
+            const bool ok = hp >= 1u && (int)hp <= a.H && wp >= 1 && wp <= a.W;
+            const size_t m = ((size_t)plane * a.H + (hp - 1)) * a.W + (wp - 1);
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int co = co0 + 8 * gq + 4 * khalf;
+                if (co >= a.Cout || !ok) continue;
+                unsigned h[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    h[e] = f2bf(acc[i][4 * gq + e]);
+                    const float r = bf2f(h[e]);
+                    s1[4 * gq + e] += r; s2[4 * gq + e] += r * r;
+                }
+                *reinterpret_cast<uint2*>(a.y + m * a.Cout + co) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            }
+        }
+        if (a.stat_part) {
+            // TM rows of partials per position tile bx (one per 32 positions); this wave owns rows i0 .. i0 + TMW - 1 of its
+            // channels: its sums go to the first, zeros to the rest -- every (row, channel) is written exactly once
+            // whichever way the job was shared among the waves
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float d1 = s1[e], d2 = s2[e];
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) {
+                    d1 += __shfl_xor(d1, o, 64);
+                    d2 += __shfl_xor(d2, o, 64);
+                }
+                const int co = co0 + 8 * (e >> 2) + 4 * khalf + (e & 3);
+                if (l31 == 0 && co < a.Cout) {
+#pragma unroll
+                    for (int q = 0; q < TMW; ++q) {
+                        float* dst = a.stat_part + (((size_t)bx * TM + i0 + q) * a.Cout + co) * 2;
+                        dst[0] = q == 0 ? d1 : 0.f; dst[1] = q == 0 ? d2 : 0.f;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();                                                       // the job's last chunk is consumed / the next job's first has landed
+}
+
 // PERSISTENT: gridDim.x workgroups (one per CU) walk the (position tile, channel block) jobs with stride gridDim.x; the
 // loader streams the chunks of job after job, so the first chunk of the next job lands while the epilogue of this one runs.
 template <int TM>
@@ -868,114 +983,21 @@ __global__ __launch_bounds__(P3_THREADS) void conv3d_p3_kernel(P3Args a) {
         return;
     }
 
-    const int l31 = lane & 31, khalf = lane >> 5;
-    const int lb = l31 * P3_PITCH + khalf * 16;                        // B fragment: row of this lane's position, quad khalf (+ 2 kb)
+    // ---- the four consumer waves.  A job has nt = 1 .. 4 tiles of 32 output channels; the waves share them so that none
+    // idles: nt = 4 (or 3): one tile each, all P positions; nt = 2: two waves per tile, half of the positions each; nt = 1:
+    // four waves on the one tile, a quarter of the positions each (a weight fragment then serves fewer MFMAs, but the
+    // alternative is an idle SIMD for the whole job). ----
     int job = 0;
     __syncthreads();                                                       // the first chunk has landed
     for (int id = blockIdx.x; id < total; id += gridDim.x) {
         const int slot = id >> 3;
         const int bx = (slot / a.ny) * 8 + (id & 7), by = slot % a.ny;
         if (bx >= a.nx) continue;
-        const int plane = bx / a.tiles_pp, t = bx - plane * a.tiles_pp;  // plane = n * D + d
-        const int co0 = by * 128 + wave * 32;                             // this wave's 32 output channels
-        const bool active = co0 < a.Cout;
-        // A fragments of this wave's channel tile: [chunk][tap][kb][lane][8]
-        const bf16_t* wl = a.wfrag + ((size_t)(active ? co0 >> 5 : 0) * nch * 27 * 2 * 64 + lane) * 8;
-
-        f32x16 acc[TM];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-
-        for (int c = 0; c < nch; ++c, ++job) {
-            if (active) {
-                // Software pipeline, pinned with scheduling barriers (left alone, the scheduler sinks every load to just in
-                // front of its first use and each MFMA waits out a full LDS / L2 latency): while the MFMAs of tap t run, the
-                // position fragments of tap t + 1 (LDS) and the weight fragments of tap t + 2 (global) are in flight.
-                const bf16_t* wc = wl + (size_t)c * 27 * 2 * 64 * 8;
-                const char* pb = p3_lds + (job & 1) * bufsz + lb;
-                auto lda = [&](int tap, u32x4 (&dst)[2]) {
-                    const bf16_t* wt = wc + (size_t)tap * 2 * 64 * 8;
-                    dst[0] = *reinterpret_cast<const u32x4*>(wt);
-                    dst[1] = *reinterpret_cast<const u32x4*>(wt + 64 * 8);
-                };
-                auto ldb = [&](int tap, u32x4 (&dst)[2][TM]) {
-                    const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
-                    const char* bt = pb + (kz * a.R + ky * a.Wp + kx) * P3_PITCH;
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                        for (int i = 0; i < TM; ++i) dst[kb][i] = *reinterpret_cast<const u32x4*>(bt + i * 32 * P3_PITCH + kb * 32);
-                };
-                u32x4 af[3][2], bf[2][2][TM];
-                lda(0, af[0]);
-                if (!DMC_ABL(a.ablate & 32)) lda(1, af[1]);
-                ldb(0, bf[0]);
-#pragma unroll
-                for (int tap = 0; tap < 27; ++tap) {
-                    if (tap + 2 < 27 && !DMC_ABL(a.ablate & 32)) lda(tap + 2, af[(tap + 2) % 3]);
-                    if (tap + 1 < 27 && !DMC_ABL(a.ablate & 64)) ldb(tap + 1, bf[(tap + 1) & 1]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    const int ai = DMC_ABL(a.ablate & 32) ? 0 : tap % 3;
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                        for (int i = 0; i < TM; ++i)
-                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                __builtin_bit_cast(bf16x8, af[ai][kb]),
-                                __builtin_bit_cast(bf16x8, bf[DMC_ABL(a.ablate & 64) ? 0 : tap & 1][kb][i]), acc[i], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            if (c + 1 < nch) __syncthreads();                              // this chunk is consumed / the next one has landed
-        }
-
-        // ---- epilogue (before the job's closing barrier: the loader is already fetching the next job's first chunk): lane
-        // holds position 32 i + l31, channels 8 gq + 4 khalf + e of this wave's tile in acc[i][4 gq + e] ----
-        if (active) {
-            float s1[16], s2[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const unsigned f = (unsigned)(t * P + a.Wp + 1 + 32 * i + l31);
-                const unsigned hp = __umulhi(f, a.magic_Wp);
-                const int wp = (int)(f - hp * a.Wp);
-                const bool ok = hp >= 1u && (int)hp <= a.H && wp >= 1 && wp <= a.W;
-                const size_t m = ((size_t)plane * a.H + (hp - 1)) * a.W + (wp - 1);
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const int co = co0 + 8 * gq + 4 * khalf;
-                    if (co >= a.Cout || !ok) continue;
-                    unsigned h[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        h[e] = f2bf(acc[i][4 * gq + e]);
-                        const float r = bf2f(h[e]);
-                        s1[4 * gq + e] += r; s2[4 * gq + e] += r * r;
-                    }
-                    *reinterpret_cast<uint2*>(a.y + m * a.Cout + co) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-                }
-            }
-            if (a.stat_part) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float d1 = s1[e], d2 = s2[e];
-#pragma unroll
-                    for (int o = 1; o < 32; o <<= 1) {
-                        d1 += __shfl_xor(d1, o, 64);
-                        d2 += __shfl_xor(d2, o, 64);
-                    }
-                    const int co = co0 + 8 * (e >> 2) + 4 * khalf + (e & 3);
-                    if (l31 == 0 && co < a.Cout) {
-                        float* dst = a.stat_part + ((size_t)bx * a.Cout + co) * 2;
-                        dst[0] = d1; dst[1] = d2;
-                    }
-                }
-            }
-        }
-        __syncthreads();                                                   // the job's last chunk is consumed / the next job's first has landed
+        const int nt = min(4, (a.Cout - by * 128 + 31) / 32);
+        if (nt >= 3) p3_consume<TM, TM>(a, p3_lds, bufsz, nch, bx, by * 128 + wave * 32, 0, wave < nt, job);
+        else if (nt == 2) p3_consume<TM, TM / 2>(a, p3_lds, bufsz, nch, bx, by * 128 + (wave & 1) * 32, (wave >> 1) * (TM / 2), true, job);
+        else if constexpr (TM >= 4) p3_consume<TM, TM / 4>(a, p3_lds, bufsz, nch, bx, by * 128, wave * (TM / 4), true, job);
+        else p3_consume<TM, TM / 2>(a, p3_lds, bufsz, nch, bx, by * 128, (wave & 1) * (TM / 2), wave < 2, job);
     }
 }
 
@@ -1108,7 +1130,7 @@ int dmc_conv3d_bf16_stat_blocks(int N, int D, int H, int W, int Cout) {
 // ... and for a given layer (the 3 x 3 x 3 layers take the patch-resident kernel: one row per position tile)
 int dmc_conv3d_bf16_stat_blocks_k(int N, int D, int H, int W, int Cin, int Cout, int KD, int KH, int KW) {
     const P3Plan p3 = p3_plan(N, D, H, W, Cin, Cout, KD, KH, KW);
-    return p3.tm ? p3.nx : dmc_conv3d_bf16_stat_blocks(N, D, H, W, Cout);
+    return p3.tm ? p3.nx * p3.tm : dmc_conv3d_bf16_stat_blocks(N, D, H, W, Cout);
 }
 
 // y [N,D,H,W,Cout] bf16 = conv3d(x [N,D,H,W,Cin] bf16, w fp32 [Cout][Cin][KD][KH][KW] given by its element strides),
