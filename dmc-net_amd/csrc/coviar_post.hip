@@ -24,16 +24,19 @@ using namespace dmc;
 struct MvRec {
     int w, h, sx, sy, dx, dy, source;
 };
+// records are 8-byte aligned (sizeof 24 / 40): the 14 bytes that matter are read as four dwords (one 16-byte load; a scalar
+// load when the index is wave-uniform) instead of seven byte / short loads
 __device__ __forceinline__ MvRec load_mv(const unsigned char* __restrict__ mvs, int stride, int i) {
-    const unsigned char* p = mvs + (size_t)i * stride;
+    const uint2* p = reinterpret_cast<const uint2*>(mvs + (size_t)i * stride);
+    const uint2 lo = p[0], hi = p[1];
     MvRec r;
-    r.source = *reinterpret_cast<const int*>(p);
-    r.w = p[4];
-    r.h = p[5];
-    r.sx = *reinterpret_cast<const short*>(p + 6);
-    r.sy = *reinterpret_cast<const short*>(p + 8);
-    r.dx = *reinterpret_cast<const short*>(p + 10);
-    r.dy = *reinterpret_cast<const short*>(p + 12);
+    r.source = (int)lo.x;
+    r.w = (int)(lo.y & 0xffu);
+    r.h = (int)((lo.y >> 8) & 0xffu);
+    r.sx = (short)(lo.y >> 16);
+    r.sy = (short)(hi.x & 0xffffu);
+    r.dx = (short)(hi.x >> 16);
+    r.dy = (short)(hi.y & 0xffffu);
     return r;
 }
 
@@ -44,7 +47,10 @@ __global__ __launch_bounds__(256) void mv_owner_kernel(const unsigned char* __re
                                                        const int* __restrict__ frame_off, int n_frames, int n_mv,
                                                        int* __restrict__ owner, int H, int W, int* __restrict__ bad_source) {
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // wave-uniform on purpose: the record and the frame_off probes below become scalar loads (one per wave, scalar cache)
+    // instead of 64 identical vector loads with an L2 round trip per probe (owner pass 270 -> 240 us on the 120-chain batch of
+    // tools/coviar_post_bench.py; what remains is the 105 M global atomicMax themselves)
+    const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (i >= n_mv) return;
     const MvRec m = load_mv(mvs, stride, i);
     if (m.source != -1 && bad_source != nullptr && lane == 0) atomicAdd(bad_source, 1);   // the reference asserts, :86
@@ -54,7 +60,7 @@ __global__ __launch_bounds__(256) void mv_owner_kernel(const unsigned char* __re
         int lo = 0, hi = n_frames;
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
-            if (frame_off[mid] <= i) lo = mid; else hi = mid;
+            if (__builtin_amdgcn_readfirstlane(frame_off[mid]) <= i) lo = mid; else hi = mid;
         }
         f = lo;
     }
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(256) void gop_trace_kernel(const unsigned char* __r
 
 int check_dims(const char* who, int H, int W, int stride) {
     if (H <= 0 || W <= 0 || (long)H * W > (1l << 28)) return fail(DMC_E_INVALID, "%s: bad frame size %d x %d", who, H, W);
-    if (stride < 14 || (stride & 1)) return fail(DMC_E_INVALID, "%s: mv_stride %d is not a sizeof(AVMotionVector) (24 or 40)", who, stride);
+    if (stride < 16 || (stride & 7)) return fail(DMC_E_INVALID, "%s: mv_stride %d is not a sizeof(AVMotionVector) (24 or 40: a multiple of 8, >= 16)", who, stride);
     return DMC_OK;
 }
 

@@ -60,7 +60,7 @@ def test_bad_source_is_counted_and_arguments_are_checked():
     d = _dev(mvs)
     L.check(lib.dmc_mv_rasterise(L.ptr(d), 40, len(mvs), L.ptr(owner), L.ptr(out), L.ptr(bad), H, W, _stream()), "rasterise")
     assert int(bad.item()) == 5
-    assert lib.dmc_mv_rasterise(L.ptr(d), 13, len(mvs), L.ptr(owner), L.ptr(out), L.ptr(bad), H, W, _stream()) == -1
+    assert lib.dmc_mv_rasterise(L.ptr(d), 20, len(mvs), L.ptr(owner), L.ptr(out), L.ptr(bad), H, W, _stream()) == -1
     assert lib.dmc_mv_rasterise(L.ptr(d), 40, len(mvs), L._P(0), L.ptr(out), L.ptr(bad), H, W, _stream()) == -1
     assert lib.dmc_mv_accumulate(L.ptr(d), 40, len(mvs), L.ptr(owner), L.ptr(out), L.ptr(out), L.ptr(bad), H, W, _stream()) == -1
     assert lib.dmc_residual(L.ptr(out), L.ptr(out), L._P(0), L._P(0), L.ptr(out), H, W, _stream()) == -1
