@@ -40,39 +40,49 @@ __device__ __forceinline__ MvRec load_mv(const unsigned char* __restrict__ mvs, 
     return r;
 }
 
-// One wave per vector; lanes over the block's pixels.  frame_off [n_frames + 1]: vector index ranges per frame (the
-// owner plane of frame f is owner + f * H * W, row-major [y][x]).  The loop bounds are the reference's
-// (-1 * w / 2 .. w / 2: C integer division, so an odd w covers 2 * (w / 2) columns), :91-92.
+// One wave per MV_PER_WAVE consecutive vectors (a wave per vector was bound by the dispatcher: 410 k waves of four
+// atomics each); lanes over a block's pixels.  frame_off [n_frames + 1]: vector index ranges per frame (the owner plane of
+// frame f is owner + f * H * W, row-major [y][x]).  The loop bounds are the reference's (-1 * w / 2 .. w / 2: C integer
+// division, so an odd w covers 2 * (w / 2) columns), :91-92.  Everything per vector is wave-uniform: the record and the
+// frame_off probes are scalar loads.
+constexpr int MV_PER_WAVE = 16;
 __global__ __launch_bounds__(256) void mv_owner_kernel(const unsigned char* __restrict__ mvs, int stride,
                                                        const int* __restrict__ frame_off, int n_frames, int n_mv,
                                                        int* __restrict__ owner, int H, int W, int* __restrict__ bad_source) {
     const int lane = threadIdx.x & 63;
-    // wave-uniform on purpose: the record and the frame_off probes below become scalar loads (one per wave, scalar cache)
-    // instead of 64 identical vector loads with an L2 round trip per probe (owner pass 270 -> 240 us on the 120-chain batch of
-    // tools/coviar_post_bench.py; what remains is the 105 M global atomicMax themselves)
-    const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (i >= n_mv) return;
-    const MvRec m = load_mv(mvs, stride, i);
-    if (m.source != -1 && bad_source != nullptr && lane == 0) atomicAdd(bad_source, 1);   // the reference asserts, :86
-    if (m.dx - m.sx == 0 && m.dy - m.sy == 0) return;                                       // :88
-    int f = 0;
-    if (frame_off != nullptr) {                       // last f with frame_off[f] <= i
+    const int i0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (threadIdx.x >> 6)) * MV_PER_WAVE);
+    if (i0 >= n_mv) return;
+    int f = 0, f_end = n_mv;                          // frame of vector i0: last f with frame_off[f] <= i0
+    if (frame_off != nullptr) {
         int lo = 0, hi = n_frames;
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
-            if (__builtin_amdgcn_readfirstlane(frame_off[mid]) <= i) lo = mid; else hi = mid;
+            if (__builtin_amdgcn_readfirstlane(frame_off[mid]) <= i0) lo = mid; else hi = mid;
         }
         f = lo;
+        f_end = __builtin_amdgcn_readfirstlane(frame_off[f + 1]);
     }
-    int* __restrict__ plane = owner + (size_t)f * H * W;
-    const int hw = m.w / 2, hh = m.h / 2;
-    const int bw = 2 * hw, npx = bw * 2 * hh;
-    for (int q = lane; q < npx; q += 64) {
-        const int oy = q / bw - hh, ox = q % bw - hw;
-        const int pdx = m.dx + ox, pdy = m.dy + oy, psx = m.sx + ox, psy = m.sy + oy;
-        if (pdy >= 0 && pdy < H && pdx >= 0 && pdx < W && psy >= 0 && psy < H && psx >= 0 && psx < W)   // :100-103
-            atomicMax(plane + pdy * W + pdx, i);
+    const int i1 = i0 + MV_PER_WAVE < n_mv ? i0 + MV_PER_WAVE : n_mv;
+    int nbad = 0;
+    for (int i = i0; i < i1; ++i) {
+        while (frame_off != nullptr && i >= f_end) {  // (empty frames are skipped)
+            ++f;
+            f_end = __builtin_amdgcn_readfirstlane(frame_off[f + 1]);
+        }
+        const MvRec m = load_mv(mvs, stride, i);
+        nbad += m.source != -1;                                                             // the reference asserts, :86
+        if (m.dx - m.sx == 0 && m.dy - m.sy == 0) continue;                                  // :88
+        int* __restrict__ plane = owner + (size_t)f * H * W;
+        const int hw = m.w / 2, hh = m.h / 2;
+        const int bw = 2 * hw, npx = bw * 2 * hh;
+        for (int q = lane; q < npx; q += 64) {
+            const int oy = q / bw - hh, ox = q % bw - hw;
+            const int pdx = m.dx + ox, pdy = m.dy + oy, psx = m.sx + ox, psy = m.sy + oy;
+            if (pdy >= 0 && pdy < H && pdx >= 0 && pdx < W && psy >= 0 && psy < H && psx >= 0 && psx < W)   // :100-103
+                atomicMax(plane + pdy * W + pdx, i);
+        }
     }
+    if (nbad != 0 && bad_source != nullptr && lane == 0) atomicAdd(bad_source, nbad);
 }
 
 // non-accumulating branch, :111-113: covered pixels get (dst - src) of their owner, the others keep what mv_out holds
@@ -188,7 +198,7 @@ int owner_pass(const char* who, const void* mvs, int stride, const int* frame_of
     hipError_t e = hipMemsetAsync(owner, 0xFF, (size_t)n_frames * H * W * sizeof(int), s);   // -1 everywhere
     if (e != hipSuccess) return fail(DMC_E_LAUNCH, "%s: hipMemsetAsync: %s", who, hipGetErrorString(e));
     if (n_mv > 0) {
-        mv_owner_kernel<<<(n_mv + 3) / 4, 256, 0, s>>>(static_cast<const unsigned char*>(mvs), stride, frame_off, n_frames, n_mv,
+        mv_owner_kernel<<<(n_mv + 4 * MV_PER_WAVE - 1) / (4 * MV_PER_WAVE), 256, 0, s>>>(static_cast<const unsigned char*>(mvs), stride, frame_off, n_frames, n_mv,
                                                         owner, H, W, bad_source);
         return check_launch(who);
     }
