@@ -1034,7 +1034,8 @@ int launch_p3(const C3dArgs& a, const P3Plan& p, hipStream_t s) {
     q.magic_Wp = (unsigned)(0x100000000ull / (unsigned)p.Wp) + 1u;
     q.ablate = option(OPT_CONV_ABLATE);
     const unsigned total = (unsigned)(((p.nx + 7) / 8) * 8 * p.ny);
-    const unsigned grid = total < 256u ? total : 256u;                    // persistent: one workgroup per CU (a multiple of 8: XCD mapping)
+    const unsigned cus = (unsigned)persistent_cus(256);                   // persistent: one workgroup per CU (a multiple of 8: XCD mapping)
+    const unsigned grid = total < cus ? total : cus;
     static LdsLimit lim4, lim2;
     hipError_t e = p.tm == 4 ? lim4.raise(reinterpret_cast<const void*>(&conv3d_p3_kernel<4>), 160 * 1024)
                              : lim2.raise(reinterpret_cast<const void*>(&conv3d_p3_kernel<2>), 160 * 1024);

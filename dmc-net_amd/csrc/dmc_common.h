@@ -50,8 +50,17 @@ struct LdsLimit {
 // A/B measurements; the defaults are the fastest measured path.  They are relaxed atomics read
 // once per entry-point call -- the only process-wide state of the library.
 enum Option { OPT_GEN_LAYER_PATH = 0, OPT_GEN_GATHER, OPT_GEN_FUSE45, OPT_GEN_WGRAD_PATH, OPT_GEN_FUSE_FWD,
-              OPT_GEN_FUSE_BWD, OPT_GEN_FRAMES, OPT_CONV_PATH, OPT_CONV_CFG, OPT_CONV_ABLATE, OPT_GEN_ABLATE, OPT_CONV_ARITH, OPT_CONV3D_WGRAD, OPT_GEN_X3, OPT_GEN_WINO, OPT_GEN_STAGGER, OPT_GEN_FUSED, OPT_COUNT };
+              OPT_GEN_FUSE_BWD, OPT_GEN_FRAMES, OPT_CONV_PATH, OPT_CONV_CFG, OPT_CONV_ABLATE, OPT_GEN_ABLATE, OPT_CONV_ARITH, OPT_CONV3D_WGRAD, OPT_GEN_X3, OPT_GEN_WINO, OPT_GEN_STAGGER, OPT_GEN_FUSED, OPT_GRID_RESERVE_CUS, OPT_COUNT };
 int option(Option o);
+// CUs a PERSISTENT grid (one workgroup per CU walking a work list: gen_fused, the generator ring / gather / Winograd kernels,
+// gen_wgrad_rs, conv3d_p3) may fill, out of `hw`: option "grid_reserve_cus" (default 0) leaves that many idle -- room for RCCL's
+// channel kernels when gradients are exchanged while the backward pass runs; a multiple of 8 stays (one CU per XCD granularity).
+inline int persistent_cus(int hw) {
+    const int r = option(OPT_GRID_RESERVE_CUS);
+    int n = hw - (r > 0 ? r : 0);
+    n -= n % 8;
+    return n < 8 ? (hw < 8 ? hw : 8) : n;
+}
 // Measurement-only options ("gen_ablate", "conv_ablate", "gen_stagger": parts of a kernel switched off, RESULTS WRONG) exist only
 // in a -DDMC_MEASURE build (dmc-net_amd/build.py --measure -> libdmcnet_hip_measure.so, which tools/ load through DMC_HIP_LIB):
 // the product library refuses to set them, reads them as 0, and DMC_ABL() folds every ablated path out of its kernels.

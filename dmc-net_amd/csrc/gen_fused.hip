@@ -468,7 +468,7 @@ namespace dmc {
 
 bool gen_fused_supported(int H, int W) { return H >= 1 && W >= 1 && W <= 2 * (FZ_MAXSW - FZ_HALO); }
 
-int gen_fused_max_partials() { return 2 * fz_num_cus(); }
+int gen_fused_max_partials() { return 2 * fz_num_cus_hw(); }
 
 int gen_fused_fwd(const float* mv, const float* res, float* feat, float* out, const ParamPtrs& prm, const float* flow,
                   double* mse_part, int* nparts, int N, int H, int W, int add_mv, hipStream_t s) {

@@ -95,7 +95,7 @@ __device__ __forceinline__ Half half_of(const Args& a, const Strip& st, int hf, 
     return h;
 }
 
-inline int fz_num_cus() {
+inline int fz_num_cus_hw() {
     static const int n = [] {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
@@ -105,6 +105,8 @@ inline int fz_num_cus() {
     }();
     return n;
 }
+// the CUs a persistent grid fills (option grid_reserve_cus); buffer SIZES use fz_num_cus_hw()
+inline int fz_num_cus() { return dmc::persistent_cus(fz_num_cus_hw()); }
 
 
 // strip geometry of a launch: one strip up to FZ_MAXSW columns, else two strips with `halo` recomputed columns on the interior side

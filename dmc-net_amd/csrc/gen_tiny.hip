@@ -2311,7 +2311,7 @@ int wgrad_groups(int N, int H, int W) {
 // measured slower: under-filled grids).
 int frames_per_pass(int N, int, int) { const int f = option(OPT_GEN_FRAMES); return f > 0 && f < N ? f : N; }
 
-int num_cus() {
+int num_cus_hw() {
     static const int n = [] {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
@@ -2321,6 +2321,7 @@ int num_cus() {
     }();
     return n;
 }
+int num_cus() { return persistent_cus(num_cus_hw()); }       // what a persistent grid fills (option grid_reserve_cus)
 
 template <int MODE, int K>
 int launch_layer(LayerArgs a, int n0, int N, hipStream_t s) {
@@ -2531,7 +2532,7 @@ int dmc_gen_tiny_fwd(const float* mv, const float* res, const float* const* w,
 }
 
 size_t dmc_gen_tiny_mse_partials_bytes(void) {
-    const int fparts = num_cus() * P_CONS > gen_fused_max_partials() ? num_cus() * P_CONS : gen_fused_max_partials();
+    const int fparts = num_cus_hw() * P_CONS > gen_fused_max_partials() ? num_cus_hw() * P_CONS : gen_fused_max_partials();
     const size_t fused = (size_t)fparts * sizeof(double), plain = dmc_flow_mse_partials_bytes();
     return fused > plain ? fused : plain;
 }

@@ -143,8 +143,8 @@ __global__ __launch_bounds__(1024) void consensus_ce_kernel(const float* __restr
 }
 
 const char* const OPTION_NAMES[OPT_COUNT] = {"gen_layer_path", "gen_gather", "gen_fuse45", "gen_wgrad_path",
-                                             "gen_fuse_fwd", "gen_fuse_bwd", "gen_frames", "conv_path", "conv_cfg", "conv_ablate", "gen_ablate", "conv_arith", "conv3d_wgrad", "gen_x3", "gen_wino", "gen_stagger", "gen_fused"};
-std::atomic<int> g_options[OPT_COUNT] = {{1}, {1}, {1}, {5}, {1}, {1}, {0}, {1}, {0}, {0}, {0}, {1}, {2}, {2}, {768}, {0}, {1}};
+                                             "gen_fuse_fwd", "gen_fuse_bwd", "gen_frames", "conv_path", "conv_cfg", "conv_ablate", "gen_ablate", "conv_arith", "conv3d_wgrad", "gen_x3", "gen_wino", "gen_stagger", "gen_fused", "grid_reserve_cus"};
+std::atomic<int> g_options[OPT_COUNT] = {{1}, {1}, {1}, {5}, {1}, {1}, {0}, {1}, {0}, {0}, {0}, {1}, {2}, {2}, {768}, {0}, {1}, {0}};
 int option_index(const char* name) {
     if (!name) return -1;
     for (int i = 0; i < OPT_COUNT; ++i)
@@ -213,6 +213,8 @@ int dmc_set_option(const char* name, int value) {
     if (i < 0) return fail(DMC_E_INVALID, "dmc_set_option: unknown option '%s'", name ? name : "(null)");
     if (!MEASURE_BUILD && measure_only(i))
         return fail(DMC_E_INVALID, "dmc_set_option: '%s' switches parts of a kernel off (results wrong) and exists only in the -DDMC_MEASURE build", name);
+    if (i == OPT_GRID_RESERVE_CUS && (value < 0 || value > 128))
+        return fail(DMC_E_INVALID, "dmc_set_option: grid_reserve_cus = %d (0 .. 128 CUs may be left to other streams)", value);
     if (!MEASURE_BUILD && !product_value(i, value))
         return fail(DMC_E_INVALID, "dmc_set_option: %s = %d selects a kernel variant that lost its A/B measurement; it is compiled into the "
                     "-DDMC_MEASURE build only", name, value);

@@ -147,6 +147,16 @@ def test_classifier_conv_entry_points_host_side_without_gpu():
         assert lib.dmc_set_option(name, good) == 0
     assert lib.dmc_set_option(b"gen_wgrad_path", 4) == 0 and lib.dmc_set_option(b"gen_wgrad_path", 5) == 0
     assert lib.dmc_set_option(b"gen_fused", 0) == 0 and lib.dmc_set_option(b"gen_fused", 1) == 0
+    # grid_reserve_cus (round 6): CUs every persistent grid leaves idle (room for RCCL's channel kernels during the backward
+    # pass).  Host side: the value is validated, buffer-size queries do NOT shrink with it (a buffer sized before the option
+    # changed stays large enough), the default is 0.
+    assert lib.dmc_get_option(b"grid_reserve_cus") == 0
+    sizes = (lib.dmc_gen_tiny_mse_partials_bytes(), lib.dmc_gen_tiny_partials_bytes(120, 224, 224), lib.dmc_gen_tiny_workspace_bytes())
+    for bad in (-1, 129, 1000):
+        assert lib.dmc_set_option(b"grid_reserve_cus", bad) != 0 and lib.dmc_get_option(b"grid_reserve_cus") == 0
+    assert lib.dmc_set_option(b"grid_reserve_cus", 32) == 0 and lib.dmc_get_option(b"grid_reserve_cus") == 32
+    assert sizes == (lib.dmc_gen_tiny_mse_partials_bytes(), lib.dmc_gen_tiny_partials_bytes(120, 224, 224), lib.dmc_gen_tiny_workspace_bytes())
+    assert lib.dmc_set_option(b"grid_reserve_cus", 0) == 0
     assert lib.dmc_get_option(b"no_such_option") == -1 and lib.dmc_set_option(b"no_such_option", 1) != 0
     for cin, cout, want in [(64, 64, 1), (64, 128, 1), (512, 512, 1), (256, 64, 1), (3, 64, 0), (16, 32, 0), (96, 64, 0)]:
         assert lib.dmc_conv_nhwc_presplit_supported(cin, cout) == want, (cin, cout)

@@ -187,3 +187,34 @@ def test_fused_forward_inference_keeps_no_features():
         assert rc != 0 and b"saved == NULL" in lib.dmc_last_error()
     finally:
         _set(b"gen_fused", before)
+
+
+def test_grid_reserve_cus_changes_no_result():
+    """Option grid_reserve_cus (CUs the persistent grids leave to other streams, e.g. RCCL's channel kernels): the generator's
+    one-launch forward, its backward (ring / Winograd / row-sliding weight-gradient kernels, all persistent) and the
+    patch-resident 3-D convolution give the same values on 256 and on 192 CUs -- every output element is produced by one
+    workgroup whichever way the work list is dealt; sums over workgroups (weight gradients, the fused MSE) may group their
+    partials differently and are compared to fp32 rounding."""
+    from dmcnet_amd import ops
+    o, m = tiny_pair(17)
+    mv, res, flow = rnd(41, (6, 2, 224, 224)).to(DEV), rnd(42, (6, 3, 224, 224)).to(DEV), rnd(43, (6, 2, 224, 224)).to(DEV)
+    x3 = rnd(44, (2, 48, 4, 28, 28)).bfloat16().to(DEV).contiguous(memory_format=torch.channels_last_3d)
+    w3 = (rnd(45, (96, 48, 3, 3, 3)) * 0.05).to(DEV)
+    runs = []
+    for reserve in (0, 64):
+        before = _set(b"grid_reserve_cus", reserve)
+        try:
+            m.zero_grad()
+            y, loss = m.forward_mv_res_mse(mv, res, flow, add_mv=True)
+            (y.sum() * 1e-3 + loss).backward()
+            with torch.no_grad():
+                y3 = ops.conv3d_bf16(x3, w3)
+            runs.append((y.detach().clone(), float(loss), [p.grad.clone() for p in m.parameters()], y3.clone()))
+        finally:
+            _set(b"grid_reserve_cus", before)
+    a, b = runs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[3], b[3])
+    assert abs(a[1] - b[1]) <= 1e-6 * abs(a[1])
+    for ga, gb in zip(a[2], b[2]):
+        assert rel_err(gb, ga) < 1e-5
+
