@@ -207,6 +207,15 @@ def bench_i3d(args, rank, world, dev):
     # the shipped recipe's optimizers / schedulers / two-stage policy; iter_size 1: every micro-step steps
     # (and, with --gpus N, exchanges the stepping optimizers' gradients) -- the recipe's 32 would amortise both
     trainer = i3d_train.recipe_trainer(net, batch_size=b, world_size=world, iter_size=1)
+    # the measurement hooks of tools/host_contention.sh (see main()): independent replicas / a stubbed collective
+    stubbed = False
+    if world > 1 and os.environ.get("DMC_BENCH_REPLICAS") == "1":
+        trainer.world = 1                             # no gradient exchange at all
+    elif world > 1 and os.environ.get("DMC_BENCH_STUB_ALLREDUCE") == "1":
+        if os.environ.get("DMC_BENCH_TEST_HOOKS") != "1":
+            raise SystemExit("DMC_BENCH_STUB_ALLREDUCE=1 disables the gradient exchange: refused unless DMC_BENCH_TEST_HOOKS=1 is set as well")
+        stubbed = True
+        i3d_train.dist.all_reduce = lambda *a, **k: None          # the trainer's exchange is blocking: nothing to wait for
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     data = torch.randn((b, 7, args.clip_length, 224, 224), generator=g, device=dev)
     target = torch.randint(0, args.num_class, (b,), generator=g, device=dev)
@@ -273,7 +282,12 @@ def bench_i3d(args, rank, world, dev):
     host_clean_ms = sorted(clean)[len(clean) // 2]
     comm = {"backend": None, "world_size": 1, "note": "single process: no gradient exchange"}
     if world > 1:
-        comm = add_rank_spread(trainer.comm_summary(), world, dev, elapsed_rank / args.steps * 1e3, None, host_clean_ms)
+        comm = trainer.comm_summary()
+        if stubbed:
+            comm["allreduce"] = "stubbed"
+        if trainer.world == 1:
+            comm["note"] = "DMC_BENCH_REPLICAS=1: independent replicas, no gradient exchange (host-contention measurement)"
+        comm = add_rank_spread(comm, world, dev, elapsed_rank / args.steps * 1e3, None, host_clean_ms)
     if rank != 0:
         dist.destroy_process_group()
         return

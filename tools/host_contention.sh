@@ -7,14 +7,16 @@
 #   stub       the gradient reducer ON (74 post-accumulate hooks, bucket copies, side-stream joins, waits) with all_reduce
 #              returning a completed Work at once: the reducer's HOST cost without gloo's host-memory transport
 #   gloo       the reducer ON over gloo (45 MB per rank and step through host memory: an upper bound no RCCL run pays)
-#   tools/host_contention.sh <out-subdir-of-gpurun_out> [ranks=8] [batch=2]
+#   tools/host_contention.sh <out-subdir-of-gpurun_out> [ranks=8] [batch=2] [further bench.py arguments, e.g. --config i3d --clip-length 64]
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; mkdir -p $OUT
 N=${2:-8}; B=${3:-2}
+shift; shift; shift
+EXTRA="$@"
 cd $GRAFT_REPO_ROOT
-python bench.py --no-cpu-baseline --batch $B --steps 20 --warmup 5 > $OUT/host_1rank.json 2> $OUT/host_1rank.err
+python bench.py --no-cpu-baseline --batch $B --steps 20 --warmup 5 $EXTRA > $OUT/host_1rank.json 2> $OUT/host_1rank.err
 run() {   # name, extra environment
   env $2 DMC_FORCE_DEVICE=0 DMC_DIST_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N \
-      --master-addr 127.0.0.1 --master-port $3 bench.py --gpus $N --batch $B --steps 20 --warmup 5 --no-cpu-baseline \
+      --master-addr 127.0.0.1 --master-port $3 bench.py --gpus $N --batch $B --steps 20 --warmup 5 --no-cpu-baseline $EXTRA \
       > $OUT/host_${N}ranks_$1.json 2> $OUT/host_${N}ranks_$1.err
 }
 run replicas DMC_BENCH_REPLICAS=1 29611
@@ -28,7 +30,7 @@ def last_json(path):        # gloo prints its rendezvous lines to stdout: take t
         if i >= 0:
             return json.loads(line[i:])
 a = last_json("$OUT/host_1rank.json")
-out = {"one_rank": {k: a[k] for k in ("host_clean_ms_per_step", "host_enqueue_ms_per_step", "ms_per_step")}, "ranks": $N, "batch_per_rank": $B}
+out = {"one_rank": {k: a[k] for k in ("host_clean_ms_per_step", "host_enqueue_ms_per_step", "ms_per_step")}, "ranks": $N, "batch_per_rank": $B, "bench_args": "$EXTRA"}
 print("1 rank : clean host %.3f ms/step, GPU step %.3f ms (batch $B)" % (a["host_clean_ms_per_step"], a["ms_per_step"]))
 for name in ("replicas", "stub", "gloo"):
     b = last_json("$OUT/host_${N}ranks_%s.json" % name)
