@@ -132,6 +132,109 @@ __global__ __launch_bounds__(256) void pool3d_fwd_kernel(Pool3dArgs a) {
     }
 }
 
+// Forward, key form (round 6; kw <= 3, stride 1 or 2 along W).  The scan above spends ~6 vector instructions per (tap,
+// channel) on compare / select pairs (value and tap code) and is bound by them, not by memory (57 us for a 29 MB tensor).
+// Here every candidate becomes ONE 32-bit key, (order-preserving 16-bit image of the bf16 value) << 16 | (255 - tap), and the
+// window's winner is an unsigned max: the larger value wins, among equal values the EARLIER tap (nn.MaxPool3d's strict >
+// in scan order), in 2 instructions per (tap, channel) plus 6 per loaded word for the image:
+//   x >= +0:  x | 0x8000          x < 0 (sign bit set):  (0 - x) mod 2^16     (-0 and +0 share 0x8000; -inf -> 0x0080; +NaN on top)
+// Padding positions inside the padded extent are candidates with the value +0; whether the winning tap was one of them
+// (code 255: the gradient goes nowhere) is read from a per-output bit mask of the taps that lie in the volume.
+// Deviation from the scan kernel: a NaN with the sign bit set orders below everything instead of winning (the hardware's
+// default NaN, and torch's, is positive), and a winning -0 is returned as +0.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned p3k_image(unsigned v) {            // two bf16 -> two order-preserving 16-bit images
+    const unsigned neg = __builtin_bit_cast(unsigned, (u16x2)(-__builtin_bit_cast(u16x2, v)));
+    const unsigned m = ((v >> 15) & 0x00010001u) * 0xffffu;
+    return (neg & m) | ((v | 0x80008000u) & ~m);
+}
+__device__ __forceinline__ unsigned p3k_value(unsigned k16) {          // image -> bf16 bits
+    return (k16 & 0x8000u) ? (k16 & 0x7fffu) : ((0x10000u - k16) & 0xffffu);
+}
+
+template <int SW>
+__global__ __launch_bounds__(256) void pool3d_fwd_key_kernel(Pool3dArgs a) {
+    const int C8 = a.C >> 3;
+    const int OWG = (a.OW + P3_OWT - 1) / P3_OWT;
+    const long total = (long)a.N * a.OD * a.OH * OWG * C8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c8 = (int)(i % C8);
+        long p = i / C8;
+        const int owg = (int)(p % OWG); p /= OWG;
+        const int oh = (int)(p % a.OH); p /= a.OH;
+        const int od = (int)(p % a.OD);
+        const int n = (int)(p / a.OD);
+        const int ow0 = owg * P3_OWT;
+        unsigned best[P3_OWT][8], inm[P3_OWT];
+#pragma unroll
+        for (int o = 0; o < P3_OWT; ++o) {
+            inm[o] = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) best[o][e] = 0;
+        }
+        const int ncol = (P3_OWT - 1) * SW + a.kw;
+        for (int kz = 0; kz < a.kd; ++kz)
+            for (int ky = 0; ky < a.kh; ++ky) {
+                const int z = od * a.sd + kz, yv = oh * a.sh + ky;
+                if (z >= a.PD || yv >= a.PH) continue;                             // beyond the padded extent (ceil_mode)
+                const int iz = z - a.fd, iy = yv - a.fh;
+                const bool row_in = iz >= 0 && iz < a.D && iy >= 0 && iy < a.H;
+                const bf16_t* rowp = a.x + (((long)n * a.D + (row_in ? iz : 0)) * a.H + (row_in ? iy : 0)) * a.W * a.C + 8 * c8;
+                u32x4 col[P3_MAXCOL];
+                unsigned colin = 0;
+#pragma unroll
+                for (int q = 0; q < P3_MAXCOL; ++q) {
+                    col[q] = u32x4{0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};   // the image of +0 (padding)
+                    const int ix = ow0 * SW + q - a.fw;
+                    if (q < ncol && row_in && ix >= 0 && ix < a.W) {
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(rowp + (long)ix * a.C);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) col[q][e] = p3k_image(v[e]);
+                        colin |= 1u << q;
+                    }
+                }
+                const int tzy = (kz * a.kh + ky) * a.kw;
+#pragma unroll
+                for (int o = 0; o < P3_OWT; ++o) {
+                    if (ow0 + o >= a.OW) continue;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        if (kx >= a.kw || (ow0 + o) * SW + kx >= a.PW) continue;
+                        const int tap = tzy + kx;
+                        const unsigned T = 255u - (unsigned)tap;
+                        const u32x4 v = col[o * SW + kx];
+                        inm[o] |= ((colin >> (o * SW + kx)) & 1u) << tap;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned lo = (v[e] << 16) | T, hi = (v[e] & 0xffff0000u) | T;
+                            best[o][2 * e] = best[o][2 * e] > lo ? best[o][2 * e] : lo;
+                            best[o][2 * e + 1] = best[o][2 * e + 1] > hi ? best[o][2 * e + 1] : hi;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+        for (int o = 0; o < P3_OWT; ++o) {
+            if (ow0 + o >= a.OW) continue;
+            u32x4 ov;
+            unsigned cd[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned tap = 255u - (best[o][e] & 0xffu);
+                cd[e] = ((inm[o] >> tap) & 1u) ? tap : 255u;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[e] = p3k_value(best[o][2 * e] >> 16) | (p3k_value(best[o][2 * e + 1] >> 16) << 16);
+            const long off = ((((long)n * a.OD + od) * a.OH + oh) * a.OW + ow0 + o) * a.C + 8 * c8;
+            *reinterpret_cast<u32x4*>(a.y + off) = ov;
+            u32x2 cc;
+            cc[0] = cd[0] | (cd[1] << 8) | (cd[2] << 16) | (cd[3] << 24);
+            cc[1] = cd[4] | (cd[5] << 8) | (cd[6] << 16) | (cd[7] << 24);
+            *reinterpret_cast<u32x2*>(a.code + off) = cc;
+        }
+    }
+}
+
 __device__ __forceinline__ int ceil_div_floor0(int a, int b) { return a <= 0 ? 0 : (a + b - 1) / b; }
 
 __global__ __launch_bounds__(256) void pool3d_bwd_kernel(Pool3dArgs a) {
@@ -286,7 +389,12 @@ int dmc_maxpool3d_tf_bf16_fwd(const void* x, void* y, void* code, int N, int D, 
     if (!pool_args(a, N, D, H, W, C, kd, kh, kw, sd, sh, sw)) return fail(DMC_E_INVALID, "dmc_maxpool3d_tf_bf16_fwd: unsupported shape");
     a.x = (const bf16_t*)x; a.y = (bf16_t*)y; a.code = (unsigned char*)code; a.dx = nullptr;
     const int grid = grid_for((long)N * a.OD * a.OH * ((a.OW + P3_OWT - 1) / P3_OWT) * (C / 8));
-    if (kw <= 3 && sw == 1) pool3d_fwd_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    const bool keys = kd * kh * kw <= 27 && option(OPT_CONV_CFG) != 9;   // (the mask of in-volume taps has 32 bits; conv_cfg 9: the scan kernels, A/B)
+    // measured (tools/pool3d_microbench.py, us, key / scan): 3x3x3 s1 @28^2 x192 79 / 96, @14^2 x480 39 / 46; 1x3x3 s2 @112^2 72 / 60,
+    // 3x3x3 s2 @28^2 51 / 51 -- the key form serves the stride-1 pools (the nine Mixed blocks), the scan form the rest
+    if (kw <= 3 && sw == 1 && keys) pool3d_fwd_key_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    else if (kw <= 3 && sw == 2 && keys && option(OPT_CONV_CFG) == 10) pool3d_fwd_key_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(a);   // (A/B)
+    else if (kw <= 3 && sw == 1) pool3d_fwd_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(a);
     else if (kw <= 3 && sw == 2) pool3d_fwd_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(a);
     else pool3d_fwd_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(a);
     return check_launch("pool3d_fwd");

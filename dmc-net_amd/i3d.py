@@ -192,11 +192,13 @@ class I3D(nn.Module):
     def generate(self, inp):
         """[b,5,T,H,W] -> the DMC cue [b,2,T,H,W] (generator applied to every frame)."""
         b, c, t, h, w = inp.shape
-        frames = inp.transpose(1, 2).reshape(-1, c, h, w)
         if isinstance(self.gen_flow_model, _m.EstimatorDenseNetTiny):
-            g = self.gen_flow_model.forward_mv_res(frames[:, :2].contiguous(), frames[:, 2:].contiguous())
+            # frame-major MV / residual planes straight from the clip-major input: two strided copies (5 channels once),
+            # not a 5-channel frame-major copy that is then sliced and copied again
+            ft = inp.transpose(1, 2)                                      # [b, T, 5, H, W] view
+            g = self.gen_flow_model.forward_mv_res(ft[:, :, :2].reshape(-1, 2, h, w), ft[:, :, 2:].reshape(-1, c - 2, h, w))
         else:
-            g = self.gen_flow_model(frames)
+            g = self.gen_flow_model(inp.transpose(1, 2).reshape(-1, c, h, w))
         return g.reshape(b, t, 2, h, w).transpose(1, 2)
 
     def forward(self, inp, node="logit", detach=False):

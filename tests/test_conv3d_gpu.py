@@ -163,6 +163,31 @@ def test_maxpool3d_tf_matches_the_stock_module_bit_for_bit(kernel, stride, shape
     assert torch.equal(xo.grad.float(), xs.grad.bfloat16().float())
 
 
+@pytest.mark.parametrize("kernel,stride,shape", POOLS[:6])
+def test_maxpool3d_tf_signed_inputs_and_negative_zero(kernel, stride, shape):
+    """The same pools on SIGNED inputs (the key-form forward orders bf16 bit patterns as integers: negative values, -0 next
+    to +0 and to the padding's +0, -inf, values below every padding zero): output and input gradient as the stock module's."""
+    pool = i3d.MaxPool3dTFPadding(kernel, stride)
+    x = rnd(331, shape)
+    x[x.abs() < 0.3] = 0.0
+    x.view(-1)[::7] *= -1.0                               # turns every 7th exact zero into -0.0, flips other signs
+    x.view(-1)[3::101] = float("-inf")
+    x = x.bfloat16().to(DEV)
+    i3d.OWN_CONV3D = False
+    try:
+        xs = x.clone().float().requires_grad_(True)
+        ys = pool(xs)
+        g = rnd(332, tuple(ys.shape)).bfloat16().to(DEV)
+        ys.backward(g.float())
+    finally:
+        i3d.OWN_CONV3D = True
+    xo = x.clone().contiguous(memory_format=CL3).requires_grad_(True)
+    yo = pool(xo)
+    yo.backward(g)
+    assert torch.equal(yo.float(), ys)                   # (-0 == +0 under torch.equal: the key form returns +0 for a winning -0)
+    assert torch.equal(xo.grad.float(), xs.grad.bfloat16().float())
+
+
 @pytest.mark.parametrize("shape,cout,k,relu", [((2, 64, 4, 14, 14), 192, 3, True), ((1, 192, 3, 7, 6), 16, 1, True),
                                                ((3, 48, 2, 9, 5), 208, 3, False), ((2, 832, 2, 7, 7), 384, 1, True)])
 def test_conv_bn_relu3d_vs_fp32_batchnorm_on_the_same_conv_output(shape, cout, k, relu):
