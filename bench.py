@@ -30,7 +30,7 @@ GEN_FLOP_PER_PX = 9108         # 4,554 MAC, SURVEY.md 8(d)
 GEN_BYTES_PER_PX = 28          # read 5 ch + write 2 ch fp32 (fused, inference-style)
 
 HP = dict(lr=0.01, weight_decay=1e-4, lr_cls_mult=0.01, lr_mse_mult=1.0)
-TRAFFIC_JSON = os.path.join("profiles", "r5_gen_traffic.json")
+TRAFFIC_JSON = os.path.join("profiles", "r6_gen_traffic.json")
 
 
 def measured_traffic(px):
