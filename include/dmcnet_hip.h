@@ -43,25 +43,35 @@ typedef void* dmc_stream_t; /* hipStream_t */
 int dmc_version(void);
 /* Text of the last error on this host thread ("" if none). */
 const char* dmc_last_error(void);
-/* Kernel-selection options for A/B measurements (tools/, bench.py); every default is the
- * fastest measured path.  Names: "gen_fused" (bit 0, set by default: the generator forward as ONE launch, gen_fused.hip -- strips
- * of <= 118 columns walked row by row, features line-buffered in LDS, the six layers pipelined across the waves of a
- * workgroup; any H, W <= 224; clear: the layer-by-layer kernels below, which also serve wider images.  Bit 1, opt-in: the
- * five data-gradient groups as ONE launch, gen_fused_bwd.hip -- same scheme, global memory touched by a staging and a
- * storing wave only; measured slower than the five layer launches at 120 frames), "gen_layer_path" (0: VALU layer kernels instead of the matrix-core
- * ones), "gen_gather" (0: push form for the Cout-8 layers), "gen_fuse45" (0: layers 4 and 5 as two
- * launches), "gen_wgrad_path" (0: all-waves-stage weight gradient; 1: fp32 producer/consumer; 2 / 3: bf16x3; 4: bf16x3 tile kernel with wide LDS reads; 5, the default: the row-sliding kernel of gen_wgrad.hip, operands split once into LDS -- W % 4 == 0, else path 4's rules), "gen_fuse_fwd" / "gen_fuse_bwd"
- * (0: the layer-by-layer forward / data-gradient launches instead of the fused groups), "gen_x3" (bit K: hidden
- * layer K of the generator forward, K = 0 .. 2, in bf16x3 arithmetic on the 16x16x32 matrix instruction, gen_x3.hip;
- * default 2 = layer 1), "gen_wino" (bit K: hidden layer K of the generator forward, K = 0 .. 3; bit 8 + K: data-gradient
- * group K, K = 0 .. 4, on the Winograd F(2x2, 3x3) ring kernel, gen_tiny.hip gen_wino_kernel -- fp32 arithmetic with 2.25x
- * fewer multiplications, results within rounding of the direct kernels', not bit-identical to them; shapes with W % 4 == 0,
- * 64 <= W <= 224; a set bit overrides "gen_x3" for that layer; default 768 = gradient groups 0 and 1; layer 1 of the forward
- * (bit 1) is faster on it too but stays on "gen_x3": DESIGN 4.10), "gen_ablate" / "conv_ablate" (parts of a kernel switched off, results wrong) and
- * "gen_stagger" (start delay between workgroups of gen_wino_kernel, 10 ns ticks per step): MEASUREMENT BUILD ONLY
- * (-DDMC_MEASURE, dmc-net_amd/build.py --measure -> libdmcnet_hip_measure.so): in the product library dmc_set_option refuses
- * them (DMC_E_INVALID), they read 0 and the ablated paths are not compiled into its kernels.
- * dmc_set_option returns DMC_E_INVALID for an unknown name; dmc_get_option returns -1 for one. */
+/* Kernel-selection options for A/B measurements (tools/, bench.py); every default is the fastest measured path.
+ *   "gen_fused"       1 (default): the generator forward as ONE launch (gen_fused.hip: strips of <= 118 columns walked row by row,
+ *                     features line-buffered in LDS, the six layers pipelined across the waves of a workgroup; any H, W <= 224);
+ *                     0: the layer-by-layer kernels, which also serve wider images.  [2 / 3 = also the one-launch data gradient,
+ *                     gen_fused_bwd.hip: measured slower, -DDMC_MEASURE build only]
+ *   "gen_layer_path"  1 (default) / 0: matrix-core / VALU layer kernels of the layer-by-layer forward and the data gradient.
+ *                     [3, 4, 5: tile variants that lost their measurement, -DDMC_MEASURE build only]
+ *   "gen_gather"      0: push form for the Cout-8 layers.        "gen_fuse45"  0: layers 4 and 5 as two launches.
+ *   "gen_wgrad_path"  5 (default): the row-sliding weight gradient of gen_wgrad.hip (W % 4 == 0, else path 4's rules); 4: the bf16x3
+ *                     tile kernel.  [0 .. 3: predecessors, -DDMC_MEASURE build only]
+ *   "gen_fuse_fwd" / "gen_fuse_bwd"  0: the layer-by-layer forward / data-gradient launches instead of the fused groups.
+ *   "gen_x3"          bit K: hidden layer K (0 .. 2) of the layer-by-layer forward in bf16x3 arithmetic (gen_x3.hip); default 2.
+ *   "gen_wino"        bit K: hidden layer K (0 .. 3) of the layer-by-layer forward, bit 8 + K: data-gradient group K (0 .. 4), on the
+ *                     Winograd F(2x2, 3x3) ring kernel (fp32, results within rounding of the direct kernels'; W % 4 == 0,
+ *                     64 <= W <= 224); default 768 = gradient groups 0 and 1.
+ *   "conv_path" / "conv_arith" / "conv_cfg"  classifier / discriminator / I3D convolutions: second-generation kernels (1), bf16x3
+ *                     arithmetic (1) or fp32 MFMA (0), and a forced tile configuration (0 = automatic; 1 .. 5 tiles of the
+ *                     tap-stepping 3-D kernel, 6 = never the patch-resident 3x3x3 kernel, 7 / 8 = its 128- / 64-position tiles,
+ *                     9 = the scan form of the 3-D max pool, 101 .. 305 = 2-D tile choices named in the kernels).
+ *   "conv3d_wgrad"    2 (default): row-ring weight gradient for 3x3x3 and 1x1x1; 1: 3x3x3 only; 0: tap-stepping kernels.
+ *   "grid_reserve_cus" 0 (default) .. 128: CUs every PERSISTENT grid (gen_fused, the generator's ring / gather / Winograd kernels,
+ *                     gen_wgrad_rs, conv3d_p3) leaves idle -- room for RCCL's channel kernels while gradients are exchanged
+ *                     during the backward pass; buffer-size queries do not depend on it; no result changes.
+ *   "gen_ablate" / "conv_ablate" (parts of a kernel switched off, results wrong), "gen_stagger": MEASUREMENT BUILD ONLY
+ *                     (-DDMC_MEASURE, dmc-net_amd/build.py --measure -> libdmcnet_hip_measure.so): the product library refuses
+ *                     them, they read 0 and the ablated paths are not compiled into its kernels.
+ * The product library also refuses the option VALUES in [brackets] above (kernel variants that lost their A/B measurement are
+ * compiled into the measurement build only).  dmc_get_option("measure_build") reads 1 in that build, 0 in the product library.
+ * dmc_set_option returns DMC_E_INVALID for an unknown name or a refused value; dmc_get_option returns -1 for an unknown name. */
 int dmc_set_option(const char* name, int value);
 int dmc_get_option(const char* name);
 /* Launches an empty kernel named dmc_profile_mark_kernel on `stream`: a marker that brackets
