@@ -1,5 +1,8 @@
-import sys, torch
-sys.path.insert(0,'/root/repo')
+#!/usr/bin/env python3
+"""HIP-event timing of MaxPool3dTFPadding's forward on the I3D trunk's pool shapes: the key form (conv_cfg 0, stride-1 pools) against
+the scan form (conv_cfg 9).   python tools/pool3d_microbench.py"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dmcnet_amd
 from dmcnet_amd import i3d, ops
 lib=dmcnet_amd._lib.load()
