@@ -785,12 +785,14 @@ struct P3Args {
     int N, D, H, W, Cin, Cout, Cp;
     int Wp, R, tiles_pp, nx, ny, ni;         // ni: DMA instructions per chunk (12 patch rows each)
     unsigned magic_R, magic_Wp;              // floor(2^32 / d) + 1: n / d = umulhi(n, magic) for the small n used here
-    int ablate;                              // -DDMC_MEASURE build only (option conv_ablate): 16 = patch transfers of chunk 0 only, 32 = one weight fragment for every tap
+    int ablate;                              // -DDMC_MEASURE build only (option conv_ablate): 16 = patch transfers of chunk 0 only, 32 = one weight fragment for every tap,
+                                             // 64 = one position fragment per tap, 128 = s_memtime clocks per phase written over stat_part
 };
 
 constexpr int P3_PITCH = 80;
 constexpr int P3_MAXK = 22;                  // DMA instructions per depth plane and chunk (12 patch rows each): R <= 264
-constexpr int P3_THREADS = 320;              // waves 0 .. 3: one 32-channel tile each; wave 4: the loader
+constexpr int P3_LOADERS = 4;
+constexpr int P3_THREADS = 256 + 64 * P3_LOADERS;   // waves 0 .. 3: the consumers; the rest: loaders (transfer instruction k of a plane -> loader k % P3_LOADERS)
 
 __device__ __forceinline__ void p3_dma16(unsigned long long src, unsigned lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
@@ -801,7 +803,15 @@ __device__ __forceinline__ void p3_dma16(unsigned long long src, unsigned lds_by
 // positions, the 32 output channels from co0; `job` counts chunk jobs (buffer parity) and is advanced by nch
 template <int TM, int TMW>
 __device__ __forceinline__ void p3_consume(const P3Args& a, const char* p3_lds, int bufsz, int nch, int bx, int co0, int i0, bool active,
-                                           int& job) {
+                                           int& job, long long (&tim)[3]) {
+    [[maybe_unused]] long long tq = DMC_ABL(a.ablate & 128) ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    auto lap = [&](int slot) {                                         // measurement build, conv_ablate bit 7: clocks per phase
+        if (DMC_ABL(a.ablate & 128)) {
+            const long long now = (long long)__builtin_amdgcn_s_memtime();
+            tim[slot] += now - tq;
+            tq = now;
+        }
+    };
     constexpr int P = 32 * TM;
     const int lane = threadIdx.x & 63;
     const int l31 = lane & 31, khalf = lane >> 5;
@@ -823,40 +833,51 @@ __device__ __forceinline__ void p3_consume(const P3Args& a, const char* p3_lds, 
             // position fragments of tap t + 1 (LDS) and the weight fragments of tap t + 2 (global) are in flight.
             const bf16_t* wc = wl + (size_t)c * 27 * 2 * 64 * 8;
             const char* pb = p3_lds + (job & 1) * bufsz + lb;
-            u32x4 af[3][2], bf[2][2][TMW];
+            // prefetch distances in taps: position fragments (LDS, ~130 - 300 clocks) PB ahead, weight fragments (L2, 500+ clocks
+            // under load) PA ahead; one wave per SIMD has registers to spare (LDS bounds the occupancy, not the register file)
+            constexpr int PB = 2, PA = 4;
+            u32x4 af[PA + 1][2], bf[PB + 1][2][TMW];
+            auto lda1 = [&](int tap, int kb) {
+                af[tap % (PA + 1)][kb] = *reinterpret_cast<const u32x4*>(wc + ((size_t)tap * 2 + kb) * 64 * 8);
+            };
+            auto ldb1 = [&](int tap, int kb, int i) {
+                const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+                bf[tap % (PB + 1)][kb][i] = *reinterpret_cast<const u32x4*>(pb + (kz * a.R + ky * a.Wp + kx) * P3_PITCH + i * 32 * P3_PITCH + kb * 32);
+            };
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                af[0][kb] = *reinterpret_cast<const u32x4*>(wc + kb * 64 * 8);
-                if (!DMC_ABL(a.ablate & 32)) af[1][kb] = *reinterpret_cast<const u32x4*>(wc + (2 + kb) * 64 * 8);
+            for (int tap = 0; tap < PA; ++tap)
 #pragma unroll
-                for (int i = 0; i < TMW; ++i) bf[0][kb][i] = *reinterpret_cast<const u32x4*>(pb + i * 32 * P3_PITCH + kb * 32);
-            }
+                for (int kb = 0; kb < 2; ++kb)
+                    if (tap == 0 || !DMC_ABL(a.ablate & 32)) lda1(tap, kb);
+#pragma unroll
+            for (int tap = 0; tap < PB; ++tap)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < TMW; ++i)
+                        if (tap == 0 || !DMC_ABL(a.ablate & 64)) ldb1(tap, kb, i);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tap = 0; tap < 27; ++tap) {
-                const int ai = DMC_ABL(a.ablate & 32) ? 0 : tap % 3;
-                const int kzn = (tap + 1) / 9, kyn = ((tap + 1) / 3) % 3, kxn = (tap + 1) % 3;
-                const char* btn = pb + (kzn * a.R + kyn * a.Wp + kxn) * P3_PITCH;
-                const bf16_t* wtn = wc + (size_t)(tap + 2) * 2 * 64 * 8;
                 // one load behind every MFMA (the wave issues in order: a block of loads in front of the MFMAs would leave
-                // the matrix pipe idle while it issues): position fragment (kb, i) of tap + 1, and behind the first MFMA of
-                // each k-block a weight fragment of tap + 2
+                // the matrix pipe idle while it issues): position fragment (kb, i) of tap + PB, and behind the first MFMA of
+                // each k-block a weight fragment of tap + PA
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int i = 0; i < TMW; ++i) {
                         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8, af[ai][kb]),
-                            __builtin_bit_cast(bf16x8, bf[DMC_ABL(a.ablate & 64) ? 0 : tap & 1][kb][i]), acc[i], 0, 0, 0);
-                        if (tap + 1 < 27 && !DMC_ABL(a.ablate & 64))
-                            bf[(tap + 1) & 1][kb][i] = *reinterpret_cast<const u32x4*>(btn + i * 32 * P3_PITCH + kb * 32);
-                        if (i == 0 && tap + 2 < 27 && !DMC_ABL(a.ablate & 32))
-                            af[(tap + 2) % 3][kb] = *reinterpret_cast<const u32x4*>(wtn + kb * 64 * 8);
+                            __builtin_bit_cast(bf16x8, af[DMC_ABL(a.ablate & 32) ? 0 : tap % (PA + 1)][kb]),
+                            __builtin_bit_cast(bf16x8, bf[DMC_ABL(a.ablate & 64) ? 0 : tap % (PB + 1)][kb][i]), acc[i], 0, 0, 0);
+                        if (tap + PB < 27 && !DMC_ABL(a.ablate & 64)) ldb1(tap + PB, kb, i);
+                        if (i == 0 && tap + PA < 27 && !DMC_ABL(a.ablate & 32)) lda1(tap + PA, kb);
                         __builtin_amdgcn_sched_barrier(0);
                     }
             }
         }
+        lap(0);                                                            // compute
         if (c + 1 < nch) __syncthreads();                                  // this chunk is consumed / the next one has landed
+        lap(1);                                                            // waiting for the loaders / the other waves
     }
 
     // ---- epilogue (before the job's closing barrier: the loader is already fetching the next job's first chunk): lane
@@ -872,18 +893,33 @@ __device__ __forceinline__ void p3_consume(const P3Args& a, const char* p3_lds, 
             const int wp = (int)(f - hp * a.Wp);
             const bool ok = hp >= 1u && (int)hp <= a.H && wp >= 1 && wp <= a.W;
             const size_t m = ((size_t)plane * a.H + (hp - 1)) * a.W + (wp - 1);
+            // 16-byte stores: a lane holds channels 8 gq + 4 khalf .. + 3 of its position; lanes l and l + 32 (the two khalf)
+            // swap halves so that each stores 8 consecutive channels for two of the four gq (eight dwordx4 stores per lane and
+            // tile set instead of sixteen dwordx2: the store tail of a job is issue-bound)
+            unsigned pk[4][2];
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                const int co = co0 + 8 * gq + 4 * khalf;
-                if (co >= a.Cout || !ok) continue;
                 unsigned h[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     h[e] = f2bf(acc[i][4 * gq + e]);
                     const float r = bf2f(h[e]);
-                    s1[4 * gq + e] += r; s2[4 * gq + e] += r * r;
+                    if (ok && co0 + 8 * gq + 4 * khalf < a.Cout) { s1[4 * gq + e] += r; s2[4 * gq + e] += r * r; }
                 }
-                *reinterpret_cast<uint2*>(a.y + m * a.Cout + co) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                pk[gq][0] = h[0] | (h[1] << 16);
+                pk[gq][1] = h[2] | (h[3] << 16);
+            }
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                // this lane stores gq = 2 pr + khalf and hands gq = 2 pr + 1 - khalf to its partner (selects, not indexed registers)
+                const unsigned t0 = khalf ? pk[2 * pr][0] : pk[2 * pr + 1][0], t1 = khalf ? pk[2 * pr][1] : pk[2 * pr + 1][1];
+                const unsigned m0 = khalf ? pk[2 * pr + 1][0] : pk[2 * pr][0], m1 = khalf ? pk[2 * pr + 1][1] : pk[2 * pr][1];
+                const unsigned r0 = __shfl_xor(t0, 32, 64), r1 = __shfl_xor(t1, 32, 64);
+                const int co = co0 + 8 * (2 * pr + khalf);
+                if (co < a.Cout && ok) {
+                    const u32x4 v = khalf ? u32x4{r0, r1, m0, m1} : u32x4{m0, m1, r0, r1};
+                    *reinterpret_cast<u32x4*>(a.y + m * a.Cout + co) = v;
+                }
             }
         }
         if (a.stat_part) {
@@ -909,7 +945,9 @@ __device__ __forceinline__ void p3_consume(const P3Args& a, const char* p3_lds, 
             }
         }
     }
+    lap(2);                                                                // epilogue
     __syncthreads();                                                       // the job's last chunk is consumed / the next job's first has landed
+    lap(1);
 }
 
 // PERSISTENT: gridDim.x workgroups (one per CU) walk the (position tile, channel block) jobs with stride gridDim.x; the
@@ -920,7 +958,7 @@ __global__ __launch_bounds__(P3_THREADS) void conv3d_p3_kernel(P3Args a) {
     extern __shared__ __attribute__((aligned(1024))) char p3_lds[];      // two patch buffers of ni x 960 bytes
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = wave == 4;
+    const bool loader = wave >= 4;
     const unsigned lds0 = lds_addr_of(p3_lds);
     const int bufsz = a.ni * 960;
     const int nch = a.Cp >> 5;
@@ -928,7 +966,7 @@ __global__ __launch_bounds__(P3_THREADS) void conv3d_p3_kernel(P3Args a) {
     const int npi = a.R / 12;
 
     if (loader) {
-        // ---- the loader wave: one instruction moves 12 patch rows (60 lanes: row 12 k + lane / 5, quad lane % 5; quad 4 is
+        // ---- the loader waves: one instruction moves 12 patch rows (60 lanes: row 12 k + lane / 5, quad lane % 5; quad 4 is
         // the row's padding and lanes 60 .. 63 idle) = 960 contiguous bytes of LDS.  Every depth plane of the patch starts at
         // an instruction boundary (R is a multiple of 12), so ONE plan of R / 12 offsets serves the three planes, which differ
         // by a scalar; the plan walks the rows incrementally (no division per row).  Rows outside the volume and channels
@@ -970,9 +1008,11 @@ __global__ __launch_bounds__(P3_THREADS) void conv3d_p3_kernel(P3Args a) {
                         const bool zok = cok && dz >= 0 && dz < a.D;
                         const unsigned long long xb = (unsigned long long)a.x + (size_t)(n * a.D + (zok ? dz : 0)) * plane_bytes + cbytes;
                         const unsigned dst = lds0 + (job & 1) * bufsz + z * npi * 960;
+                        // (one wave issues a transfer every ~100 clocks: 63 of them per chunk at W = 56 took longer than the
+                        // consumers' 216 MFMAs -- P3_LOADERS waves share them)
 #pragma unroll
                         for (int k = 0; k < P3_MAXK; ++k)
-                            if (k < npi) p3_dma16(zok && off[k] != 0xffffffffu ? xb + off[k] : zeros, dst + k * 960);
+                            if (k < npi && k % P3_LOADERS == wave - 4) p3_dma16(zok && off[k] != 0xffffffffu ? xb + off[k] : zeros, dst + k * 960);
                     }
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -988,16 +1028,23 @@ __global__ __launch_bounds__(P3_THREADS) void conv3d_p3_kernel(P3Args a) {
     // four waves on the one tile, a quarter of the positions each (a weight fragment then serves fewer MFMAs, but the
     // alternative is an idle SIMD for the whole job). ----
     int job = 0;
+    long long tim[3] = {0, 0, 0};
+    const long long t_begin = DMC_ABL(a.ablate & 128) ? (long long)__builtin_amdgcn_s_memtime() : 0;
     __syncthreads();                                                       // the first chunk has landed
     for (int id = blockIdx.x; id < total; id += gridDim.x) {
         const int slot = id >> 3;
         const int bx = (slot / a.ny) * 8 + (id & 7), by = slot % a.ny;
         if (bx >= a.nx) continue;
         const int nt = min(4, (a.Cout - by * 128 + 31) / 32);
-        if (nt >= 3) p3_consume<TM, TM>(a, p3_lds, bufsz, nch, bx, by * 128 + wave * 32, 0, wave < nt, job);
-        else if (nt == 2) p3_consume<TM, TM / 2>(a, p3_lds, bufsz, nch, bx, by * 128 + (wave & 1) * 32, (wave >> 1) * (TM / 2), true, job);
-        else if constexpr (TM >= 4) p3_consume<TM, TM / 4>(a, p3_lds, bufsz, nch, bx, by * 128, wave * (TM / 4), true, job);
-        else p3_consume<TM, TM / 2>(a, p3_lds, bufsz, nch, bx, by * 128, (wave & 1) * (TM / 2), wave < 2, job);
+        if (nt >= 3) p3_consume<TM, TM>(a, p3_lds, bufsz, nch, bx, by * 128 + wave * 32, 0, wave < nt, job, tim);
+        else if (nt == 2) p3_consume<TM, TM / 2>(a, p3_lds, bufsz, nch, bx, by * 128 + (wave & 1) * 32, (wave >> 1) * (TM / 2), true, job, tim);
+        else if constexpr (TM >= 4) p3_consume<TM, TM / 4>(a, p3_lds, bufsz, nch, bx, by * 128, wave * (TM / 4), true, job, tim);
+        else p3_consume<TM, TM / 2>(a, p3_lds, bufsz, nch, bx, by * 128, (wave & 1) * (TM / 2), wave < 2, job, tim);
+    }
+    if (DMC_ABL(a.ablate & 128) && a.stat_part != nullptr && lane == 0) {  // measurement build: clocks per phase of this wave, over the statistics
+        float* d = a.stat_part + (blockIdx.x * 4 + wave) * 4;
+        d[0] = (float)tim[0]; d[1] = (float)tim[1]; d[2] = (float)tim[2];
+        d[3] = (float)((long long)__builtin_amdgcn_s_memtime() - t_begin);
     }
 }
 
