@@ -794,6 +794,12 @@ constexpr int P3_MAXK = 22;                  // DMA instructions per depth plane
 constexpr int P3_LOADERS = 4;
 constexpr int P3_THREADS = 256 + 64 * P3_LOADERS;   // waves 0 .. 3: the consumers; the rest: loaders (transfer instruction k of a plane -> loader k % P3_LOADERS)
 
+typedef __bf16 p3_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float p3_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned p3_cvt2(float lo, float hi) {     // two fp32 -> packed bf16, round to nearest even (v_cvt_pk_bf16_f32)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(p3_f32x2{lo, hi}, p3_bf16x2));
+}
+
 __device__ __forceinline__ void p3_dma16(unsigned long long src, unsigned lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                  :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)) : "memory");
@@ -899,15 +905,16 @@ __device__ __forceinline__ void p3_consume(const P3Args& a, const char* p3_lds, 
             unsigned pk[4][2];
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                unsigned h[4];
+                // v_cvt_pk_bf16_f32 (round to nearest even, as f2bf): one instruction per two values
+                pk[gq][0] = p3_cvt2(acc[i][4 * gq + 0], acc[i][4 * gq + 1]);
+                pk[gq][1] = p3_cvt2(acc[i][4 * gq + 2], acc[i][4 * gq + 3]);
+                if (a.stat_part && ok && co0 + 8 * gq + 4 * khalf < a.Cout) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    h[e] = f2bf(acc[i][4 * gq + e]);
-                    const float r = bf2f(h[e]);
-                    if (ok && co0 + 8 * gq + 4 * khalf < a.Cout) { s1[4 * gq + e] += r; s2[4 * gq + e] += r * r; }
+                    for (int e = 0; e < 4; ++e) {
+                        const float r = bf2f((e & 1) ? pk[gq][e >> 1] >> 16 : pk[gq][e >> 1] & 0xffffu);
+                        s1[4 * gq + e] += r; s2[4 * gq + e] += r * r;
+                    }
                 }
-                pk[gq][0] = h[0] | (h[1] << 16);
-                pk[gq][1] = h[2] | (h[3] << 16);
             }
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
