@@ -2,10 +2,11 @@
 // data loader, code/dmcnet/data_loader/coviar_data_loader.c:71-175, on arrays the decoder hands over.
 //
 // The reference walks the AVMotionVector list in order and writes the pixels of every block; where blocks overlap the
-// LATER vector wins.  On the device that order becomes a per-pixel "owner": every (vector, block pixel) pair that passes
-// the reference's four bounds tests does atomicMax(owner[pixel], vector index) -- the maximum of a set does not depend
-// on the order of the updates, so the result is the sequential loop's, bit for bit.  A second pass reads each pixel's
-// owner and does what the reference's innermost statement does for it.
+// LATER vector wins.  On the device that order becomes a per-pixel "owner": the largest index among the vectors whose
+// block covers the pixel and passes the reference's four bounds tests -- the maximum of a set does not depend on the
+// order of the updates, so the result is the sequential loop's, bit for bit.  The owner maps are resolved tile by tile
+// in LDS (mv_owner_tile_kernel below); a second pass reads each pixel's owner and does what the reference's innermost
+// statement does for it.
 //
 // A whole accumulated chain needs no ping-pong between frames: accu_t[p] = accu_{t-1}[p + (src - dst) of p's owner in
 // frame t] (or accu_{t-1}[p] when no vector covers p; :101-105 reads accu_src_old, writes accu_src, and :125-127 copies
@@ -40,49 +41,74 @@ __device__ __forceinline__ MvRec load_mv(const unsigned char* __restrict__ mvs, 
     return r;
 }
 
-// One wave per MV_PER_WAVE consecutive vectors (a wave per vector was bound by the dispatcher: 410 k waves of four
-// atomics each); lanes over a block's pixels.  frame_off [n_frames + 1]: vector index ranges per frame (the owner plane of
-// frame f is owner + f * H * W, row-major [y][x]).  The loop bounds are the reference's (-1 * w / 2 .. w / 2: C integer
-// division, so an odd w covers 2 * (w / 2) columns), :91-92.  Everything per vector is wave-uniform: the record and the
-// frame_off probes are scalar loads.
-constexpr int MV_PER_WAVE = 16;
-__global__ __launch_bounds__(256) void mv_owner_kernel(const unsigned char* __restrict__ mvs, int stride,
-                                                       const int* __restrict__ frame_off, int n_frames, int n_mv,
-                                                       int* __restrict__ owner, int H, int W, int* __restrict__ bad_source) {
-    const int lane = threadIdx.x & 63;
-    const int i0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (threadIdx.x >> 6)) * MV_PER_WAVE);
-    if (i0 >= n_mv) return;
-    int f = 0, f_end = n_mv;                          // frame of vector i0: last f with frame_off[f] <= i0
-    if (frame_off != nullptr) {
-        int lo = 0, hi = n_frames;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (__builtin_amdgcn_readfirstlane(frame_off[mid]) <= i0) lo = mid; else hi = mid;
-        }
-        f = lo;
-        f_end = __builtin_amdgcn_readfirstlane(frame_off[f + 1]);
-    }
-    const int i1 = i0 + MV_PER_WAVE < n_mv ? i0 + MV_PER_WAVE : n_mv;
+// Owner pass, tile by tile in LDS.  (The first form did one GLOBAL atomicMax per (vector, block pixel) into owner maps that do
+// not fit the L2 -- 105 M read-modify-writes against HBM for the 120-chain batch, 240 us plus a 38 us clear.)  A workgroup owns
+// one 32 x 128 pixel tile of one frame (16 KB of LDS; 0.278 ms per batch against 0.291 for 64 x 64, 0.332 for 64 x 32 and 0.367 for
+// 32 x 32: fewer tiles re-read the vector list, and 340 columns waste less of a 32-wide tile): its four waves walk the frame's vector list 64 vectors at a time (one record per lane;
+// vectors that miss the tile are dropped by a ballot), then the lanes of a wave cover the pixels of each block that hits the
+// tile and do the atomicMax in LDS, and the finished tile -- -1 where no vector
+// landed -- is written out with coalesced stores: every owner word is written once, nothing is cleared, no global atomics.
+// A vector is looked at by every tile of its frame (22 tiles at 340 x 256) and
+// rasterised by the 1 - 4 tiles it overlaps.  frame_off [n_frames + 1]: vector index ranges per frame (NULL: one frame, all
+// n_mv vectors); the owner plane of frame f is owner + f * H * W, row-major [y][x].  The block bounds are the reference's
+// (-1 * w / 2 .. w / 2: C integer division, so an odd w covers 2 * (w / 2) columns), :91-92.
+#ifndef DMC_OT_W
+#define DMC_OT_W 32
+#define DMC_OT_H 128
+#endif
+constexpr int OT_W = DMC_OT_W, OT_H = DMC_OT_H;
+__global__ __launch_bounds__(256) void mv_owner_tile_kernel(const unsigned char* __restrict__ mvs, int stride,
+                                                            const int* __restrict__ frame_off, int n_mv, int* __restrict__ owner,
+                                                            int H, int W, int tiles_x, int* __restrict__ bad_source) {
+    __shared__ int tile[OT_W * OT_H];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int f = blockIdx.y;
+    const int x0 = (blockIdx.x % tiles_x) * OT_W, y0 = (blockIdx.x / tiles_x) * OT_H;
+    const int i0 = frame_off != nullptr ? __builtin_amdgcn_readfirstlane(frame_off[f]) : 0;
+    const int i1 = frame_off != nullptr ? __builtin_amdgcn_readfirstlane(frame_off[f + 1]) : n_mv;
+    for (int k = tid; k < OT_W * OT_H; k += 256) tile[k] = -1;
+    __syncthreads();
+    // the scan is vectorised: a wave tests 64 vectors at a time, one per lane (a scalar walk spent ~200 clocks per vector on
+    // its dependent record load: 1.25 ms per batch), and rasterises the few that hit the tile one after the other
     int nbad = 0;
-    for (int i = i0; i < i1; ++i) {
-        while (frame_off != nullptr && i >= f_end) {  // (empty frames are skipped)
-            ++f;
-            f_end = __builtin_amdgcn_readfirstlane(frame_off[f + 1]);
-        }
-        const MvRec m = load_mv(mvs, stride, i);
-        nbad += m.source != -1;                                                             // the reference asserts, :86
-        if (m.dx - m.sx == 0 && m.dy - m.sy == 0) continue;                                  // :88
-        int* __restrict__ plane = owner + (size_t)f * H * W;
+    for (int base = i0 + wave * 64; base < i1; base += 256) {
+        const int i = base + lane;
+        const bool valid = i < i1;
+        MvRec m = load_mv(mvs, stride, valid ? i : i0);
+        nbad += valid && m.source != -1;                                                    // the reference asserts, :86
         const int hw = m.w / 2, hh = m.h / 2;
-        const int bw = 2 * hw, npx = bw * 2 * hh;
-        for (int q = lane; q < npx; q += 64) {
-            const int oy = q / bw - hh, ox = q % bw - hw;
-            const int pdx = m.dx + ox, pdy = m.dy + oy, psx = m.sx + ox, psy = m.sy + oy;
-            if (pdy >= 0 && pdy < H && pdx >= 0 && pdx < W && psy >= 0 && psy < H && psx >= 0 && psx < W)   // :100-103
-                atomicMax(plane + pdy * W + pdx, i);
+        const bool hit = valid && !(m.dx - m.sx == 0 && m.dy - m.sy == 0) &&                 // :88
+                         m.dx + hw > x0 && m.dx - hw < x0 + OT_W && m.dy + hh > y0 && m.dy - hh < y0 + OT_H;
+        unsigned long long todo = __ballot(hit);
+        while (todo) {
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int vi = base + src;
+            const int vdx = __builtin_amdgcn_readlane(m.dx, src), vdy = __builtin_amdgcn_readlane(m.dy, src);
+            const int vsx = __builtin_amdgcn_readlane(m.sx, src), vsy = __builtin_amdgcn_readlane(m.sy, src);
+            const int vhw = __builtin_amdgcn_readlane(hw, src), vhh = __builtin_amdgcn_readlane(hh, src);
+            // the part of the block inside this tile (scalar bounds), walked 16 columns x 4 rows per step: no division per pixel
+            const int ox_lo = max(-vhw, x0 - vdx), ox_hi = min(vhw, x0 + OT_W - vdx);
+            const int oy_lo = max(-vhh, y0 - vdy), oy_hi = min(vhh, y0 + OT_H - vdy);
+            for (int oy0 = oy_lo; oy0 < oy_hi; oy0 += 4)
+                for (int ox0 = ox_lo; ox0 < ox_hi; ox0 += 16) {
+                    const int ox = ox0 + (lane & 15), oy = oy0 + (lane >> 4);
+                    const int pdx = vdx + ox, pdy = vdy + oy, psx = vsx + ox, psy = vsy + oy;
+                    if (ox < ox_hi && oy < oy_hi &&
+                        pdy >= 0 && pdy < H && pdx >= 0 && pdx < W && psy >= 0 && psy < H && psx >= 0 && psx < W)   // :100-103
+                        atomicMax(&tile[(pdy - y0) * OT_W + (pdx - x0)], vi);
+                }
         }
     }
-    if (nbad != 0 && bad_source != nullptr && lane == 0) atomicAdd(bad_source, nbad);
+    for (int o = 32; o > 0; o >>= 1) nbad += __shfl_xor(nbad, o, 64);
+    if (nbad != 0 && bad_source != nullptr && blockIdx.x == 0 && lane == 0) atomicAdd(bad_source, nbad);
+    __syncthreads();
+    int* __restrict__ plane = owner + (size_t)f * H * W;
+    for (int k = tid; k < OT_W * OT_H; k += 256) {
+        const int px = x0 + k % OT_W, py = y0 + k / OT_W;
+        if (px < W && py < H) plane[py * W + px] = tile[k];
+    }
 }
 
 // non-accumulating branch, :111-113: covered pixels get (dst - src) of their owner, the others keep what mv_out holds
@@ -195,14 +221,11 @@ int check_dims(const char* who, int H, int W, int stride) {
 
 int owner_pass(const char* who, const void* mvs, int stride, const int* frame_off, int n_frames, int n_mv, int* owner, int H, int W,
                int* bad_source, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(owner, 0xFF, (size_t)n_frames * H * W * sizeof(int), s);   // -1 everywhere
-    if (e != hipSuccess) return fail(DMC_E_LAUNCH, "%s: hipMemsetAsync: %s", who, hipGetErrorString(e));
-    if (n_mv > 0) {
-        mv_owner_kernel<<<(n_mv + 4 * MV_PER_WAVE - 1) / (4 * MV_PER_WAVE), 256, 0, s>>>(static_cast<const unsigned char*>(mvs), stride, frame_off, n_frames, n_mv,
-                                                        owner, H, W, bad_source);
-        return check_launch(who);
-    }
-    return DMC_OK;
+    const int tiles_x = (W + OT_W - 1) / OT_W, tiles_y = (H + OT_H - 1) / OT_H;
+    if (n_frames > 65535) return fail(DMC_E_INVALID, "%s: at most 65535 frames per call", who);
+    mv_owner_tile_kernel<<<dim3(tiles_x * tiles_y, n_frames), 256, 0, s>>>(static_cast<const unsigned char*>(mvs), stride, frame_off, n_mv,
+                                                                            owner, H, W, tiles_x, bad_source);
+    return check_launch(who);
 }
 
 }  // namespace
@@ -227,8 +250,8 @@ int dmc_mv_rasterise(const void* mvs, int mv_stride, int n_mv, int32_t* owner_ws
         return fail(DMC_E_INVALID, "dmc_mv_rasterise: null pointer or negative count");
     if (int rc = check_dims("dmc_mv_rasterise", H, W, mv_stride)) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (int rc = owner_pass("dmc_mv_rasterise", mvs, mv_stride, nullptr, 1, n_mv, owner_ws, H, W, bad_source, s)) return rc;
     if (n_mv == 0) return DMC_OK;
+    if (int rc = owner_pass("dmc_mv_rasterise", mvs, mv_stride, nullptr, 1, n_mv, owner_ws, H, W, bad_source, s)) return rc;
     mv_rasterise_kernel<<<(H * W + 255) / 256, 256, 0, s>>>(static_cast<const unsigned char*>(mvs), mv_stride, owner_ws, mv_out, H, W);
     return check_launch("dmc_mv_rasterise");
 }
