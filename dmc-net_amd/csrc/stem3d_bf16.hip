@@ -337,6 +337,281 @@ __global__ __launch_bounds__(256) void stem3d_wgrad_reduce_kernel(const float* _
 }
 
 // ------------------------------------------------------------------------------------------
+// Weight gradient of the stem, second form (round 6): the kernel above spends its time on the 2-byte LDS scatter that turns every
+// 32-pixel segment into a [784][32 px] operand (112 ds_write_b16 per thread and segment against 28 matrix instructions per
+// wave: matrix pipe 9.5 % busy, 0.94 ms for the 3 x 64-frame micro-step).  Here nothing is scattered:
+//   * the cue is prepared as PLANES, xp [n][z][y][c][parity p][128] bf16 with plane[i] = x[2 i + p - 2] (stem3d_prep_planes_kernel):
+//     the operand row of tap (kz, ky, kx = 2 u + p, c) for output row (od, oh) is plane (c, p) of input row (2 od + kz, 2 oh + ky)
+//     SHIFTED by u -- dw[kz,ky,2u+p,c][co] = sum_i plane[i] * dy[i - u][co] -- so the four taps u share ONE operand, the
+//     1 KB input row as it lies in memory, and the shift moves to dy.  GEMM per output row: M = 49 input rows x 4 planes
+//     = 196 (7 tiles of 32), N = 64, K = OW + 3 <= 128 positions i;
+//   * a workgroup walks consecutive output rows of one (n, od) plane and keeps the 7 x 7 input rows of the current output row in
+//     a ring of 16 slots per kz (LDS, filled by global_load_lds: no registers, no scatter): the next output row needs TWO new
+//     input rows per kz -- 14 KB instead of 49 KB -- and they land while the current row is multiplied;
+//   * dy rows are transposed once into dyT [co][i] (pixel pairs as dwords: 16 conflict-free ds_write_b32 per thread and row),
+//     double-buffered; wave u takes its fragment for positions i - u from two aligned reads and a funnel shift by the
+//     compile-time u.
+// Wave u owns taps kx = 2 u, 2 u + 1: 7 M tiles x 2 column tiles = 14 accumulators (224 registers); one barrier per output row.
+// Partials [workgroup][u][224][64] fp32, summed in workgroup order by stem3d_w2_reduce_kernel (deterministic).
+// ------------------------------------------------------------------------------------------
+constexpr int W2_SLOTS = 16;
+constexpr int W2_A_BYTES = 7 * W2_SLOTS * 1024;            // 114,688: [kz][slot][c][p][128 i] bf16
+constexpr int W2_BPITCH = 272;                             // dyT row: 16 zero bytes (i = -8 .. -1) + 128 positions; 272 = 16 (mod 32): fragment reads conflict-free
+constexpr int W2_B_BYTES = 64 * W2_BPITCH;                 // 17,408
+constexpr int W2_LDS = W2_A_BYTES + 2 * W2_B_BYTES;        // 149,504
+constexpr int W2_MROWS = 224;
+
+// x fp32 [N][2][T][H][W] -> xp [N][Tp][Hp][c][p][128] bf16: xp[..][c][p][i] = x[c][z - 2][y - 2][2 i + p - 2], zero outside
+__global__ __launch_bounds__(256) void stem3d_prep_planes_kernel(const float* __restrict__ x, unsigned* __restrict__ xp, int N, int T, int H,
+                                                                 int W, int Tp, int Hp) {
+    const int rows = N * Tp * Hp;
+    const long plane = (long)T * H * W;
+    const int e0 = 2 * threadIdx.x;                        // two consecutive i of one (c, p) plane per thread
+    const int c = e0 >> 8, par = (e0 >> 7) & 1, i = e0 & 127;
+    const int w0 = 2 * i + par - 2, w1 = w0 + 2;
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+        const int yy = r % Hp, q = r / Hp;
+        const int zz = q % Tp, n = q / Tp;
+        const int t = zz - 2, h = yy - 2;
+        unsigned v = 0;
+        if (t >= 0 && t < T && h >= 0 && h < H) {
+            const float* src = x + ((long)n * 2 + c) * plane + ((long)t * H + h) * W;
+            if (w0 >= 0 && w0 < W) v = f2bf(src[w0]);
+            if (w1 >= 0 && w1 < W) v |= f2bf(src[w1]) << 16;
+        }
+        xp[(long)r * 256 + threadIdx.x] = v;
+    }
+}
+
+struct Stem3dW2Args {
+    const bf16_t* xp;      // [N][Tp][Hp][2][2][128]
+    const bf16_t* dy;      // [N][OD][OH][OW][64]
+    float* part;           // [gridDim.x][4][224][64]
+    int N, OD, OH, OW, Tp, Hp, ksteps;
+    long nrows, per_wg;
+};
+
+__device__ __forceinline__ void w2_dma16(const void* src, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"((unsigned long long)src), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)) : "memory");
+}
+
+template <int U>
+__device__ __forceinline__ void w2_wave(const Stem3dW2Args& a, char* lds) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int l31 = lane & 31, half = lane >> 5;
+    const unsigned lds0 = lds_addr_of(lds);
+    char* bT = lds + W2_A_BYTES;
+
+    f32x16 acc[7][2];
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // operand rows of this lane: M row 32 mt + l31 = (kz * 7 + ky) * 4 + (c, p); rows >= 196 (tile 6) read row 192 + (c, p): never stored
+    int kz_[7], ky_[7];
+#pragma unroll
+    for (int mt = 0; mt < 7; ++mt) {
+        int kzky = 8 * mt + (l31 >> 2);
+        if (kzky > 48) kzky = 48;
+        kz_[mt] = kzky / 7;
+        ky_[mt] = kzky - 7 * kz_[mt];
+    }
+    const int cp = l31 & 3;
+    // transfers: lane -> plane lane >> 4 of the 1 KB input row, 16-byte unit lane & 15 of it
+    const int dcp = lane >> 4, dpos = lane & 15;
+    // dy transposition: thread -> pixel pair (tid >> 1) & 63, channel octets (tid & 1) + 4 (tid >> 7) + 2 it, it = 0, 1
+    const int pair = (tid >> 1) & 63, oct0 = (tid & 1) + 4 * (tid >> 7);
+    const int npairs = (a.OW + 1) >> 1;
+
+    long r = (long)blockIdx.x * a.per_wg;
+    long r_end = r + a.per_wg;
+    if (r_end > a.nrows) r_end = a.nrows;
+    if (r >= r_end) return;                                // (whole workgroup: the grid is sized so that this does not happen)
+
+    auto row_base = [&](long row) -> const bf16_t* {       // input row (2 od, 2 oh) of output row `row`
+        const int oh = (int)(row % a.OH);
+        const long nd = row / a.OH;
+        const int od = (int)(nd % a.OD), n = (int)(nd / a.OD);
+        return a.xp + (((long)n * a.Tp + 2 * od) * a.Hp + 2 * oh) * 512;
+    };
+    auto dma = [&](const bf16_t* base, int kz, int ky, int S) {   // input row (kz, ky) of the output row at `base` into slot S of ring kz
+        const int swz = (((S - kz) & 3) << 2) | dcp;
+        const bf16_t* src = base + ((long)kz * a.Hp + ky) * 512 + dcp * 128 + ((dpos ^ swz) << 3);
+        w2_dma16(src, lds0 + (unsigned)((kz * W2_SLOTS + (S & (W2_SLOTS - 1))) * 1024));
+    };
+    u32x4 de[2], dd[2];                                    // dy of pixels 2 pair, 2 pair + 1, two octets
+    auto dy_load = [&](long row) {
+        const bf16_t* src = a.dy + row * a.OW * S3_CO;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int oct = oct0 + 2 * it;
+            de[it] = u32x4{0u, 0u, 0u, 0u};
+            dd[it] = u32x4{0u, 0u, 0u, 0u};
+            if (pair < npairs) {
+                de[it] = *reinterpret_cast<const u32x4*>(src + (2 * pair) * S3_CO + 8 * oct);
+                if (2 * pair + 1 < a.OW) dd[it] = *reinterpret_cast<const u32x4*>(src + (2 * pair + 1) * S3_CO + 8 * oct);
+            }
+        }
+    };
+    auto dy_store = [&](char* buf) {
+        if (pair >= npairs) return;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int oct = oct0 + 2 * it;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned e = de[it][j >> 1], o = dd[it][j >> 1];
+                const unsigned v = (j & 1) ? ((e >> 16) | (o & 0xffff0000u)) : ((e & 0xffffu) | (o << 16));
+                *reinterpret_cast<unsigned*>(buf + (8 * oct + j) * W2_BPITCH + 16 + 4 * pair) = v;
+            }
+        }
+    };
+
+    // ---- first output row of the run: its 49 input rows, its dy ----
+    int sb = 0;
+    {
+        const bf16_t* base = row_base(r);
+#pragma unroll 1
+        for (int q = U; q < 49; q += 4) {
+            const int kz = q / 7, ky = q - 7 * kz;
+            dma(base, kz, ky, sb + ky);
+        }
+        dy_load(r);
+        dy_store(bT);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (; r < r_end; ++r) {
+        const int buf = (int)((r - (long)blockIdx.x * a.per_wg) & 1);
+        const bool more = r + 1 < r_end;
+        const bool same_plane = (r + 1) % a.OH != 0;
+        if (more) {
+            const bf16_t* base = row_base(r + 1);
+            if (same_plane) {                              // input rows 2 (oh + 1) + 5, + 6 of every kz: slots sb + 7, sb + 8
+#pragma unroll 1
+                for (int q = U; q < 14; q += 4) dma(base, q >> 1, 5 + (q & 1), sb + 7 + (q & 1));
+            } else {
+#pragma unroll 1
+                for (int q = U; q < 49; q += 4) {
+                    const int kz = q / 7, ky = q - 7 * kz;
+                    dma(base, kz, ky, sb + 7 + ky);
+                }
+            }
+            dy_load(r + 1);
+        }
+        // this row's operand addresses
+        int arow[7], axor[7];
+#pragma unroll
+        for (int mt = 0; mt < 7; ++mt) {
+            const int S = sb + ky_[mt];
+            arow[mt] = (kz_[mt] * W2_SLOTS + (S & (W2_SLOTS - 1))) * 1024 + cp * 256;
+            axor[mt] = ((((S - kz_[mt]) & 3) << 2) | cp) << 4;
+        }
+        const char* bb = bT + buf * W2_B_BYTES + l31 * W2_BPITCH + 16 + half * 16;
+        u32x4 af[2][7], bf[2][2];
+        auto frags = [&](int ks, u32x4 (&A)[7], u32x4 (&B)[2]) {
+#pragma unroll
+            for (int mt = 0; mt < 7; ++mt) A[mt] = *reinterpret_cast<const u32x4*>(lds + arow[mt] + (((2 * ks + half) << 4) ^ axor[mt]));
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const char* p = bb + nt * 32 * W2_BPITCH + ks * 32;
+                const u32x4 c = *reinterpret_cast<const u32x4*>(p);
+                if (U == 0) B[nt] = c;
+                else if (U == 2) {
+                    const unsigned p3 = *reinterpret_cast<const unsigned*>(p - 4);
+                    B[nt] = u32x4{p3, c[0], c[1], c[2]};
+                } else if (U == 1) {
+                    const unsigned p3 = *reinterpret_cast<const unsigned*>(p - 4);
+                    B[nt] = u32x4{__builtin_amdgcn_alignbit(c[0], p3, 16), __builtin_amdgcn_alignbit(c[1], c[0], 16),
+                                  __builtin_amdgcn_alignbit(c[2], c[1], 16), __builtin_amdgcn_alignbit(c[3], c[2], 16)};
+                } else {
+                    const u32x2 pq = *reinterpret_cast<const u32x2*>(p - 8);
+                    B[nt] = u32x4{__builtin_amdgcn_alignbit(pq[1], pq[0], 16), __builtin_amdgcn_alignbit(c[0], pq[1], 16),
+                                  __builtin_amdgcn_alignbit(c[1], c[0], 16), __builtin_amdgcn_alignbit(c[2], c[1], 16)};
+                }
+            }
+        };
+        auto mfmas = [&](const u32x4 (&A)[7], const u32x4 (&B)[2]) {
+#pragma unroll
+            for (int mt = 0; mt < 7; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[mt]), __builtin_bit_cast(bf16x8, B[nt]),
+                                                                          acc[mt][nt], 0, 0, 0);
+        };
+        frags(0, af[0], bf[0]);
+#pragma unroll 1
+        for (int ks = 0; ks < a.ksteps; ks += 2) {
+            if (ks + 1 < a.ksteps) frags(ks + 1, af[1], bf[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(af[0], bf[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < a.ksteps) {
+                if (ks + 2 < a.ksteps) frags(ks + 2, af[0], bf[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(af[1], bf[1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (more) dy_store(bT + (buf ^ 1) * W2_B_BYTES);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        sb = (sb + (same_plane ? 2 : 7)) & (W2_SLOTS - 1);
+    }
+
+    // partial: lane holds column l31 (co) of column tile nt, rows 8 g + 4 half + e of row tile mt
+    float* part = a.part + ((size_t)blockIdx.x * 4 + U) * W2_MROWS * S3_CO;
+#pragma unroll
+    for (int mt = 0; mt < 7; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = 32 * mt + 8 * (e >> 2) + 4 * half + (e & 3);
+                part[(size_t)row * S3_CO + 32 * nt + l31] = acc[mt][nt][e];
+            }
+}
+
+__global__ __launch_bounds__(256) void stem3d_w2_kernel(Stem3dW2Args a) {
+    extern __shared__ __attribute__((aligned(1024))) char w2_lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // dyT buffers: zero once (the zero unit in front of every row and the positions >= OW are never written)
+    for (int i = threadIdx.x; i < 2 * W2_B_BYTES / 16; i += 256) reinterpret_cast<u32x4*>(w2_lds + W2_A_BYTES)[i] = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    if (wave == 0) w2_wave<0>(a, w2_lds);
+    else if (wave == 1) w2_wave<1>(a, w2_lds);
+    else if (wave == 2) w2_wave<2>(a, w2_lds);
+    else w2_wave<3>(a, w2_lds);
+}
+
+// dw [64][2][7][7][7] = sum over workgroups of part[g][u][(kz * 7 + ky) * 4 + 2 c + p][co] with kx = 2 u + p, fixed order
+__global__ __launch_bounds__(256) void stem3d_w2_reduce_kernel(const float* __restrict__ part, int groups, float* __restrict__ dw) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S3_CO * 686) return;
+    const int co = i & (S3_CO - 1), rj = i / S3_CO;         // rj = kb * 14 + (2 kx + c)
+    const int kb = rj / 14, j = rj - kb * 14, kx = j >> 1, c = j & 1;
+    const size_t off = ((size_t)(kx >> 1) * W2_MROWS + kb * 4 + 2 * c + (kx & 1)) * S3_CO + co;
+    const size_t gs = (size_t)4 * W2_MROWS * S3_CO;
+    float s = 0.f;
+    int g = 0;
+    for (; g + 16 <= groups; g += 16) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = part[(size_t)(g + k) * gs + off];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += v[k];
+    }
+    for (; g < groups; ++g) s += part[(size_t)g * gs + off];
+    dw[(size_t)co * 686 + c * 343 + kb * 7 + kx] = s;
+}
+
+// ------------------------------------------------------------------------------------------
 // Data gradient of the stem (the gradient of the 2-channel cue): per input row (n, t, h)
 //     Q[ow][(kx, c)] = sum over the (kz, ky) whose stride-2 window reaches (t, h), and over co, of dy[od][oh][ow][co] * w[co][c][kz][ky][kx]
 //     dx[t][h][w][c] = sum over kx = w (mod 2) of Q[(w + 2 - kx) / 2][(kx, c)]
@@ -580,10 +855,12 @@ int dmc_stem3d_bf16_fwd(const float* x, const float* w, void* workspace, void* y
     return check_launch("stem3d_fwd");
 }
 
-// bytes of the weight gradient's workspace (padded volume + partials)
+// bytes of the weight gradient's workspace (prepared cue + partials; the larger of the two forms)
 size_t dmc_stem3d_bf16_wgrad_workspace_bytes(int N, int T, int H, int W) {
     const long Wp = (W + 5 + 1 + 3) / 4 * 4;
-    return (size_t)N * (T + 5) * (H + 5) * Wp * 4 + (size_t)256 * S3_ROWS * S3_CO * sizeof(float) + 64;
+    const size_t v1 = (size_t)N * (T + 5) * (H + 5) * Wp * 4 + (size_t)256 * S3_ROWS * S3_CO * sizeof(float) + 64;
+    const size_t v2 = (size_t)N * (T + 5) * (H + 5) * 1024 + (size_t)256 * 4 * W2_MROWS * S3_CO * sizeof(float) + 64;
+    return v1 > v2 ? v1 : v2;
 }
 
 // dw [64,2,7,7,7] fp32 contiguous from x [N,2,T,H,W] fp32 (rounded to bf16 as in the forward) and dy [N,OD,OH,OW,64] bf16
@@ -593,6 +870,31 @@ int dmc_stem3d_bf16_wgrad(const float* x, const void* dy, float* dw, void* works
     if (N <= 0 || T < 2 || H < 2 || W < 2) return fail(DMC_E_INVALID, "dmc_stem3d_bf16_wgrad: bad shape");
     hipStream_t s = (hipStream_t)stream;
     const int Tp = T + 5, Hp = H + 5, Wp = (W + 5 + 1 + 3) / 4 * 4;
+    const int OWn = (W + 5 - 7) / 2 + 1;
+    if (OWn + 3 <= 128 && option(OPT_CONV_CFG) != 11) {   // the plane form (rows of up to 125 output pixels); conv_cfg 11: the first form, for A/B
+        unsigned* xp = (unsigned*)workspace;
+        float* part2 = (float*)((char*)workspace + (size_t)N * Tp * Hp * 1024);
+        const int rows = N * Tp * Hp;
+        stem3d_prep_planes_kernel<<<rows > 16384 ? 16384 : rows, 256, 0, s>>>(x, xp, N, T, H, W, Tp, Hp);
+        int rc2 = check_launch("stem3d_prep_planes");
+        if (rc2) return rc2;
+        Stem3dW2Args b;
+        b.xp = (const bf16_t*)xp; b.dy = (const bf16_t*)dy; b.part = part2;
+        b.N = N; b.OD = (T + 5 - 7) / 2 + 1; b.OH = (H + 5 - 7) / 2 + 1; b.OW = OWn;
+        b.Tp = Tp; b.Hp = Hp; b.ksteps = (OWn + 3 + 15) / 16;
+        b.nrows = (long)N * b.OD * b.OH;
+        const int cus = persistent_cus(256);
+        const int groups2 = (int)(b.nrows < cus ? b.nrows : cus);
+        b.per_wg = (b.nrows + groups2 - 1) / groups2;
+        const int used2 = (int)((b.nrows + b.per_wg - 1) / b.per_wg);
+        static LdsLimit lim_w2;
+        const hipError_t attr = lim_w2.raise(reinterpret_cast<const void*>(&stem3d_w2_kernel), W2_LDS);
+        if (attr != hipSuccess) return fail(DMC_E_LAUNCH, "stem3d wgrad: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
+        stem3d_w2_kernel<<<used2, 256, W2_LDS, s>>>(b);
+        if ((rc2 = check_launch("stem3d_w2"))) return rc2;
+        stem3d_w2_reduce_kernel<<<(S3_CO * 686 + 255) / 256, 256, 0, s>>>(part2, used2, dw);
+        return check_launch("stem3d_w2_reduce");
+    }
     unsigned* xq = (unsigned*)workspace;
     float* part = (float*)((char*)workspace + (((size_t)N * Tp * Hp * Wp * 4 + 63) / 64) * 64);
     const long total = (long)N * Tp * Hp * Wp;
