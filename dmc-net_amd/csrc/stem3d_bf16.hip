@@ -427,25 +427,25 @@ __device__ __forceinline__ void w2_wave(const Stem3dW2Args& a, char* lds) {
     const int pair = (tid >> 1) & 63, oct0 = (tid & 1) + 4 * (tid >> 7);
     const int npairs = (a.OW + 1) >> 1;
 
-    long r = (long)blockIdx.x * a.per_wg;
-    long r_end = r + a.per_wg;
-    if (r_end > a.nrows) r_end = a.nrows;
-    if (r >= r_end) return;                                // (whole workgroup: the grid is sized so that this does not happen)
-
-    auto row_base = [&](long row) -> const bf16_t* {       // input row (2 od, 2 oh) of output row `row`
-        const int oh = (int)(row % a.OH);
-        const long nd = row / a.OH;
-        const int od = (int)(nd % a.OD), n = (int)(nd / a.OD);
-        return a.xp + (((long)n * a.Tp + 2 * od) * a.Hp + 2 * oh) * 512;
+    const int r0 = blockIdx.x * (int)a.per_wg;
+    int r_end = r0 + (int)a.per_wg;
+    if (r_end > (int)a.nrows) r_end = (int)a.nrows;
+    if (r0 >= r_end) return;                               // (whole workgroup: the grid is sized so that this does not happen)
+    int oh = r0 % a.OH;                                    // the row's coordinates advance with it (no division per row)
+    int nd = r0 / a.OH;                                    // n * OD + od
+    auto row_base = [&](int nd_, int oh_) -> const bf16_t* {   // input row (2 od, 2 oh) of output row (nd_, oh_)
+        const int od = nd_ % a.OD, n = nd_ / a.OD;
+        return a.xp + (((long)n * a.Tp + 2 * od) * a.Hp + 2 * oh_) * 512;
     };
+    const bf16_t* base = row_base(nd, oh);
     auto dma = [&](const bf16_t* base, int kz, int ky, int S) {   // input row (kz, ky) of the output row at `base` into slot S of ring kz
         const int swz = (((S - kz) & 3) << 2) | dcp;
         const bf16_t* src = base + ((long)kz * a.Hp + ky) * 512 + dcp * 128 + ((dpos ^ swz) << 3);
         w2_dma16(src, lds0 + (unsigned)((kz * W2_SLOTS + (S & (W2_SLOTS - 1))) * 1024));
     };
     u32x4 de[2], dd[2];                                    // dy of pixels 2 pair, 2 pair + 1, two octets
-    auto dy_load = [&](long row) {
-        const bf16_t* src = a.dy + row * a.OW * S3_CO;
+    auto dy_load = [&](int row) {
+        const bf16_t* src = a.dy + (long)row * a.OW * S3_CO;
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int oct = oct0 + 2 * it;
@@ -471,28 +471,105 @@ __device__ __forceinline__ void w2_wave(const Stem3dW2Args& a, char* lds) {
         }
     };
 
+#ifdef W2_TIMING
+    long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = (long long)__builtin_amdgcn_s_memtime();
+#define W2_LAP(k) { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); tm[k] += now_ - tq; tq = now_; }
+#else
+#define W2_LAP(k)
+#endif
     // ---- first output row of the run: its 49 input rows, its dy ----
     int sb = 0;
     {
-        const bf16_t* base = row_base(r);
 #pragma unroll 1
         for (int q = U; q < 49; q += 4) {
             const int kz = q / 7, ky = q - 7 * kz;
             dma(base, kz, ky, sb + ky);
         }
-        dy_load(r);
+        dy_load(r0);
         dy_store(bT);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
     __syncthreads();
+    W2_LAP(0)
 
 #pragma unroll 1
-    for (; r < r_end; ++r) {
-        const int buf = (int)((r - (long)blockIdx.x * a.per_wg) & 1);
+    for (int r = r0; r < r_end; ++r) {
+        const int buf = (r - r0) & 1;
         const bool more = r + 1 < r_end;
-        const bool same_plane = (r + 1) % a.OH != 0;
+        const bool same_plane = oh + 1 < a.OH;
+        if (same_plane) { ++oh; base += 1024; }
+        else { oh = 0; ++nd; if (more) base = row_base(nd, 0); }
+        if (more) dy_load(r + 1);
+        W2_LAP(6)
+        // this row's operand addresses
+        int arow[7], axor[7];
+#pragma unroll
+        for (int mt = 0; mt < 7; ++mt) {
+            const int S = sb + ky_[mt];
+            arow[mt] = (kz_[mt] * W2_SLOTS + (S & (W2_SLOTS - 1))) * 1024 + cp * 256;
+            axor[mt] = ((((S - kz_[mt]) & 3) << 2) | cp) << 4;
+        }
+        const char* bb = bT + buf * W2_B_BYTES + l31 * W2_BPITCH + 16 + half * 16;
+        // One register set for the operand fragments: the read of tile mt for the NEXT k-step is issued right behind the two matrix
+        // instructions that use tile mt in this one (it then has the other twelve to land), and the next step's dy fragment -- raw
+        // reads first, funnel shift after the fifth tile -- goes into the other of two sets.  With one wave per SIMD nothing else
+        // fills the matrix pipe: every other instruction has to sit BETWEEN matrix instructions, not in a block before them
+        // (a block of ~20 reads and address instructions in front of 14 matrix instructions cost ~170 of 620 clocks per k-step).
+        auto readA = [&](int ks, int mt) -> u32x4 {
+            return *reinterpret_cast<const u32x4*>(lds + arow[mt] + (((2 * ks + half) << 4) ^ axor[mt]));
+        };
+        auto readB = [&](int ks, u32x4 (&C)[2], u32x2 (&P)[2]) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const char* p = bb + nt * 32 * W2_BPITCH + ks * 32;
+                C[nt] = *reinterpret_cast<const u32x4*>(p);
+                if (U == 1 || U == 2) P[nt] = u32x2{0u, *reinterpret_cast<const unsigned*>(p - 4)};
+                else if (U == 3) P[nt] = *reinterpret_cast<const u32x2*>(p - 8);
+                else P[nt] = u32x2{0u, 0u};
+            }
+        };
+        auto shifted = [&](const u32x4& c, const u32x2& pq) -> u32x4 {
+            if (U == 0) return c;
+            if (U == 2) return u32x4{pq[1], c[0], c[1], c[2]};
+            if (U == 1)
+                return u32x4{__builtin_amdgcn_alignbit(c[0], pq[1], 16), __builtin_amdgcn_alignbit(c[1], c[0], 16),
+                             __builtin_amdgcn_alignbit(c[2], c[1], 16), __builtin_amdgcn_alignbit(c[3], c[2], 16)};
+            return u32x4{__builtin_amdgcn_alignbit(pq[1], pq[0], 16), __builtin_amdgcn_alignbit(c[0], pq[1], 16),
+                         __builtin_amdgcn_alignbit(c[1], c[0], 16), __builtin_amdgcn_alignbit(c[2], c[1], 16)};
+        };
+        u32x4 af[7], b0[2], b1[2];
+        auto step = [&](int ksn, const u32x4 (&B)[2], u32x4 (&Bn)[2]) {   // k-step with fragments (af, B); fetches k-step ksn into (af, Bn)
+            u32x4 C[2];
+            u32x2 P[2];
+#pragma unroll
+            for (int mt = 0; mt < 7; ++mt) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mt]), __builtin_bit_cast(bf16x8, B[nt]),
+                                                                          acc[mt][nt], 0, 0, 0);
+                af[mt] = readA(ksn, mt);
+                if (mt == 0) readB(ksn, C, P);
+                if (mt == 5) {
+                    Bn[0] = shifted(C[0], P[0]);
+                    Bn[1] = shifted(C[1], P[1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);         // source order, group by group (the scheduler otherwise bunches the reads)
+            }
+        };
+        {
+            u32x4 C[2];
+            u32x2 P[2];
+#pragma unroll
+            for (int mt = 0; mt < 7; ++mt) af[mt] = readA(0, mt);
+            readB(0, C, P);
+            b0[0] = shifted(C[0], P[0]);
+            b0[1] = shifted(C[1], P[1]);
+        }
+        // The next row's transfers go out HERE, behind the wait for the first fragments: global_load_lds counts in lgkmcnt as well
+        // as vmcnt (measured: any lgkmcnt(0) behind them waits for the data, ~1,100 clocks), so nothing that drains lgkmcnt may
+        // follow them closely -- the k-steps' waits are all lgkmcnt(>= 5)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (more) {
-            const bf16_t* base = row_base(r + 1);
             if (same_plane) {                              // input rows 2 (oh + 1) + 5, + 6 of every kz: slots sb + 7, sb + 8
 #pragma unroll 1
                 for (int q = U; q < 14; q += 4) dma(base, q >> 1, 5 + (q & 1), sb + 7 + (q & 1));
@@ -503,65 +580,23 @@ __device__ __forceinline__ void w2_wave(const Stem3dW2Args& a, char* lds) {
                     dma(base, kz, ky, sb + 7 + ky);
                 }
             }
-            dy_load(r + 1);
         }
-        // this row's operand addresses
-        int arow[7], axor[7];
-#pragma unroll
-        for (int mt = 0; mt < 7; ++mt) {
-            const int S = sb + ky_[mt];
-            arow[mt] = (kz_[mt] * W2_SLOTS + (S & (W2_SLOTS - 1))) * 1024 + cp * 256;
-            axor[mt] = ((((S - kz_[mt]) & 3) << 2) | cp) << 4;
-        }
-        const char* bb = bT + buf * W2_B_BYTES + l31 * W2_BPITCH + 16 + half * 16;
-        u32x4 af[2][7], bf[2][2];
-        auto frags = [&](int ks, u32x4 (&A)[7], u32x4 (&B)[2]) {
-#pragma unroll
-            for (int mt = 0; mt < 7; ++mt) A[mt] = *reinterpret_cast<const u32x4*>(lds + arow[mt] + (((2 * ks + half) << 4) ^ axor[mt]));
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const char* p = bb + nt * 32 * W2_BPITCH + ks * 32;
-                const u32x4 c = *reinterpret_cast<const u32x4*>(p);
-                if (U == 0) B[nt] = c;
-                else if (U == 2) {
-                    const unsigned p3 = *reinterpret_cast<const unsigned*>(p - 4);
-                    B[nt] = u32x4{p3, c[0], c[1], c[2]};
-                } else if (U == 1) {
-                    const unsigned p3 = *reinterpret_cast<const unsigned*>(p - 4);
-                    B[nt] = u32x4{__builtin_amdgcn_alignbit(c[0], p3, 16), __builtin_amdgcn_alignbit(c[1], c[0], 16),
-                                  __builtin_amdgcn_alignbit(c[2], c[1], 16), __builtin_amdgcn_alignbit(c[3], c[2], 16)};
-                } else {
-                    const u32x2 pq = *reinterpret_cast<const u32x2*>(p - 8);
-                    B[nt] = u32x4{__builtin_amdgcn_alignbit(pq[1], pq[0], 16), __builtin_amdgcn_alignbit(c[0], pq[1], 16),
-                                  __builtin_amdgcn_alignbit(c[1], c[0], 16), __builtin_amdgcn_alignbit(c[2], c[1], 16)};
-                }
-            }
-        };
-        auto mfmas = [&](const u32x4 (&A)[7], const u32x4 (&B)[2]) {
-#pragma unroll
-            for (int mt = 0; mt < 7; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[mt]), __builtin_bit_cast(bf16x8, B[nt]),
-                                                                          acc[mt][nt], 0, 0, 0);
-        };
-        frags(0, af[0], bf[0]);
+        W2_LAP(1)
+        // k-steps in pairs, no branch inside (an odd count runs one more step: its dy positions are zero, its operand bytes valid)
 #pragma unroll 1
         for (int ks = 0; ks < a.ksteps; ks += 2) {
-            if (ks + 1 < a.ksteps) frags(ks + 1, af[1], bf[1]);
             __builtin_amdgcn_sched_barrier(0);
-            mfmas(af[0], bf[0]);
+            step(ks + 1, b0, b1);
             __builtin_amdgcn_sched_barrier(0);
-            if (ks + 1 < a.ksteps) {
-                if (ks + 2 < a.ksteps) frags(ks + 2, af[0], bf[0]);
-                __builtin_amdgcn_sched_barrier(0);
-                mfmas(af[1], bf[1]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            step(ks + 2 < 8 ? ks + 2 : 7, b1, b0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        W2_LAP(2)
         if (more) dy_store(bT + (buf ^ 1) * W2_B_BYTES);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        W2_LAP(3)
         __syncthreads();
+        W2_LAP(4)
         sb = (sb + (same_plane ? 2 : 7)) & (W2_SLOTS - 1);
     }
 
@@ -574,8 +609,13 @@ __device__ __forceinline__ void w2_wave(const Stem3dW2Args& a, char* lds) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = 32 * mt + 8 * (e >> 2) + 4 * half + (e & 3);
-                part[(size_t)row * S3_CO + 32 * nt + l31] = acc[mt][nt][e];
+                if (U == 3 && (e & 1)) continue;           // kx = 7 does not exist: the reduce never reads these rows
+                if (row < 196) part[(size_t)row * S3_CO + 32 * nt + l31] = acc[mt][nt][e];
             }
+#ifdef W2_TIMING
+    if (lane == 0)
+        for (int k = 0; k < 8; ++k) part[k] = (float)tm[k];
+#endif
 }
 
 __global__ __launch_bounds__(256) void stem3d_w2_kernel(Stem3dW2Args a) {
