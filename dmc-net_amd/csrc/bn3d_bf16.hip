@@ -222,6 +222,7 @@ int dmc_bn3d_bf16_fwd(const void* y, const float* partials, int nblk, const floa
     if (!y || !partials || !gamma || !beta || !stats || !out || nblk <= 0) return fail(DMC_E_INVALID, "dmc_bn3d_bf16_fwd: bad argument");
     if (!bn3_ok(M, C)) return fail(DMC_E_INVALID, "dmc_bn3d_bf16_fwd: unsupported shape M=%ld C=%d", M, C);
     hipStream_t s = (hipStream_t)stream;
+    if (!DMC_ABL(option(OPT_CONV_ABLATE) & 1024))   // measurement build: the per-channel finalisation launches
     bn3d_stats_final_kernel<<<C, 256, 0, s>>>(partials, nblk, C, M, stats, running_mean, running_var, eps, momentum);
     int rc = check_launch("bn3d_stats_final");
     if (rc) return rc;
@@ -243,6 +244,7 @@ int dmc_bn3d_bf16_bwd(const void* dout, long dout_ld, const void* y, const float
     bn3d_bwd_partial_kernel<<<nblk, 256, 0, s>>>((const bf16_t*)dout, (const bf16_t*)y, stats, gamma, beta, scratch, M, C, relu, dout_ld);
     int rc = check_launch("bn3d_bwd_partial");
     if (rc) return rc;
+    if (!DMC_ABL(option(OPT_CONV_ABLATE) & 1024))
     bn3d_bwd_final_kernel<<<C, 256, 0, s>>>(scratch, nblk, C, M, dgamma, dbeta, coef);
     if ((rc = check_launch("bn3d_bwd_final"))) return rc;
     bn3d_bwd_apply_kernel<<<nblk, 256, 0, s>>>((const bf16_t*)dout, (const bf16_t*)y, stats, gamma, beta, coef, (bf16_t*)dy, M, C, relu, dout_ld);

@@ -1172,6 +1172,7 @@ int dmc_conv3d_bf16_pack(const float* w, long w_s_co, long w_s_ci, long w_s_tap,
     const long tf = (long)pad_to(Cout, 128) * T * pad_to(Cin, 32), tb = (long)pad_to(Cin, 128) * T * pad_to(Cout, 32);
     const long total = tf > tb ? tf : tb;
     dim3 grid((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256), 2);
+    if (DMC_ABL(option(OPT_CONV_ABLATE) & 256)) return DMC_OK;   // measurement build: what the per-layer pack launches cost a step
     conv3d_pack_w2_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(w, (bf16_t*)wpack_f, (bf16_t*)wpack_b, Cout, Cin, T, w_s_co, w_s_ci, w_s_tap);
     return check_launch("conv3d_pack_w2");
 }
@@ -1268,6 +1269,7 @@ int dmc_conv3d_bf16_wgrad(const void* x, const void* dy, float* dw, float* works
         if (rc) return rc;
         const int T = k3 ? 27 : 1;
         const long total = (long)Cout * T * Cin;
+        if (DMC_ABL(option(OPT_CONV_ABLATE) & 512)) return DMC_OK;   // measurement build: the partial-sum launches
         conv3d_wgrad_reduce_kernel<<<(int)((total + 63) / 64 > 8192 ? 8192 : (total + 63) / 64), 256, 0, s>>>(
             workspace, dw, rp.groups, Cout, T, Cin);
         return check_launch("conv3d_wgrad_reduce");
@@ -1285,6 +1287,7 @@ int dmc_conv3d_bf16_wgrad(const void* x, const void* dy, float* dw, float* works
     if (rc) return rc;
     const int T = KD * KH * KW;
     const long total = (long)Cout * T * Cin;
+    if (DMC_ABL(option(OPT_CONV_ABLATE) & 512)) return DMC_OK;
     conv3d_wgrad_reduce_kernel<<<(int)((total + 63) / 64 > 8192 ? 8192 : (total + 63) / 64), 256, 0, s>>>(
         workspace, dw, p.splits, Cout, T, Cin);
     return check_launch("conv3d_wgrad_reduce");

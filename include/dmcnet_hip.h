@@ -61,7 +61,8 @@ const char* dmc_last_error(void);
  *   "conv_path" / "conv_arith" / "conv_cfg"  classifier / discriminator / I3D convolutions: second-generation kernels (1), bf16x3
  *                     arithmetic (1) or fp32 MFMA (0), and a forced tile configuration (0 = automatic; 1 .. 5 tiles of the
  *                     tap-stepping 3-D kernel, 6 = never the patch-resident 3x3x3 kernel, 7 / 8 = its 128- / 64-position tiles,
- *                     9 = the scan form of the 3-D max pool, 101 .. 305 = 2-D tile choices named in the kernels).
+ *                     9 = the scan form of the 3-D max pool, 11 = the first (LDS-scatter) form of the I3D stem's weight gradient,
+ *                     101 .. 305 = 2-D tile choices named in the kernels).
  *   "conv3d_wgrad"    2 (default): row-ring weight gradient for 3x3x3 and 1x1x1; 1: 3x3x3 only; 0: tap-stepping kernels.
  *   "grid_reserve_cus" 0 (default) .. 128: CUs every PERSISTENT grid (gen_fused, the generator's ring / gather / Winograd kernels,
  *                     gen_wgrad_rs, conv3d_p3) leaves idle -- room for RCCL's channel kernels while gradients are exchanged
@@ -619,8 +620,8 @@ int dmc_stem3d_bf16_stat_blocks(int N, int T, int H, int W);
 int dmc_stem3d_bf16_fwd(const float* x, const float* w, void* workspace, void* y, float* stat_partials, int N, int T, int H, int W,
                         dmc_stream_t stream);
 /* weight gradient of the same convolution: dw [64,2,7,7,7] fp32 contiguous from x (rounded to bf16 as in the forward) and
- * dy [N,OD,OH,OW,64] bf16 NDHWC; GEMM over pixels on the bf16 matrix cores, deterministic split-K reduction; workspace:
- * dmc_stem3d_bf16_wgrad_workspace_bytes(). */
+ * dy [N,OD,OH,OW,64] bf16 NDHWC; GEMM over pixels on the bf16 matrix cores (plane form for rows of up to 125 output pixels:
+ * csrc/stem3d_bf16.hip, stem3d_w2_kernel), deterministic split-K reduction; workspace: dmc_stem3d_bf16_wgrad_workspace_bytes(). */
 size_t dmc_stem3d_bf16_wgrad_workspace_bytes(int N, int T, int H, int W);
 int dmc_stem3d_bf16_wgrad(const float* x, const void* dy, float* dw, void* workspace, int N, int T, int H, int W, dmc_stream_t stream);
 /* data gradient of the same convolution (the gradient of the cue): dx [N,2,T,H,W] fp32 from dy [N,OD,OH,OW,64] bf16 NDHWC and

@@ -252,6 +252,36 @@ def test_conv_bn_relu3d_reads_a_concatenation_slice_gradient_in_place():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("shape", [(2, 2, 8, 32, 24), (1, 2, 6, 10, 224), (1, 2, 5, 9, 250), (1, 2, 4, 10, 256)])
+def test_i3d_stem_weight_gradient_forms_agree(shape):
+    """The stem's weight gradient has two forms: the plane form (rows of up to 125 output pixels: the default, several output rows
+    per workgroup so that the input-row ring turns over, odd extents) and the first LDS-scatter form (wider rows, or conv_cfg 11).
+    Both against fp64 autograd on the same bf16-rounded operands; W = 256 takes the first form by itself."""
+    torch.manual_seed(5)
+    lib = dmcnet_amd._lib.load()
+    n, _, t, h, w = shape
+    x = torch.randn(*shape, device=DEV)
+    od, oh, ow = (t - 2) // 2 + 1, (h - 2) // 2 + 1, (w - 2) // 2 + 1
+    g = torch.randn(n, 64, od, oh, ow, device=DEV).bfloat16()
+    wo = torch.zeros(64, 2, 7, 7, 7, device=DEV, dtype=torch.float64, requires_grad=True)
+    (F.conv3d(F.pad(x.bfloat16().double(), (2, 3, 2, 3, 2, 3)), wo, None, 2, 0) * g.double()).sum().backward()
+    gcl = g.contiguous(memory_format=CL3)
+    ws = torch.empty(lib.dmc_stem3d_bf16_wgrad_workspace_bytes(n, t, h, w), dtype=torch.uint8, device=DEV)
+    out = []
+    try:
+        for cfg in (0, 11):
+            dmcnet_amd._lib.check(lib.dmc_set_option(b"conv_cfg", cfg), "dmc_set_option")
+            dw = torch.empty((64, 2, 7, 7, 7), dtype=torch.float32, device=DEV)
+            dmcnet_amd._lib.check(lib.dmc_stem3d_bf16_wgrad(dmcnet_amd._lib.ptr(x), dmcnet_amd._lib.ptr(gcl), dmcnet_amd._lib.ptr(dw),
+                                                            dmcnet_amd._lib.ptr(ws), n, t, h, w, None), "dmc_stem3d_bf16_wgrad")
+            err = float((dw.double() - wo.grad).abs().max() / wo.grad.abs().max())
+            assert err < 2e-5, (cfg, err)
+            out.append(dw)
+    finally:
+        dmcnet_amd._lib.check(lib.dmc_set_option(b"conv_cfg", 0), "dmc_set_option")
+    assert float((out[0] - out[1]).abs().max() / out[1].abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("shape", [(2, 2, 8, 32, 24), (1, 2, 4, 18, 70), (1, 2, 16, 64, 64), (1, 2, 4, 10, 224), (2, 2, 2, 6, 224)])
 def test_i3d_stem_forward_and_unit_vs_stock(shape):
     """conv3d_1a_7x7 (2 -> 64, 7x7x7, stride 2, TF-"SAME"): dmc_stem3d_bf16_fwd against an fp64 evaluation of the

@@ -23,3 +23,5 @@ m = part.mean(0)
 for u in range(4):
     print("wave", u, {names[k]: int(m[u, k]) for k in range(8)}, "total", int(m[u].sum()))
 print("(s_memtime ticks at 100 MHz: x ~21-24 for shader clocks; 42 rows per workgroup)")
+# build that library on the GPU box:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DW2_TIMING -I include -I dmc-net_amd/csrc \
+#   -c dmc-net_amd/csrc/stem3d_bf16.hip -o /tmp/s3t.o && hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/lib_w2t.so /tmp/s3t.o <the other objects>
