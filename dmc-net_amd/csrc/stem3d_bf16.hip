@@ -845,6 +845,216 @@ __global__ __launch_bounds__(S3_DG_WAVES * 64) void stem3d_dgrad4_kernel(Stem3dD
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Data gradient of the stem, block form (round 6).  The row kernels above read both operands of every matrix instruction from
+// global memory (two 1 KB loads per 16-clock instruction: matrix pipe 8.5 % busy, 0.60 ms for the 3 x 64-frame micro-step).
+// Here a workgroup owns a BLOCK of the cue's gradient -- 4 frames t x 8 rows h, full width: wave w owns frame 4 tb + w and keeps
+// its eight rows' Q[ow][(kx, c)] in accumulators (8 x 7 tiles of 16 x 16 = 224 registers) -- all 49 weight blocks
+// [(kx, c)][co] sit in LDS for the whole (persistent) launch, and the dy rows the block needs (od = 2 tb - 2 .. 2 tb + 2,
+// oh = 4 hb - 2 .. 4 hb + 4: at most 35) pass through a double-buffered LDS row, staged by all four waves (global -> registers ->
+// ds_write_b128: vmcnt only, no lgkmcnt coupling) while the previous row is multiplied.  A staged row serves every (frame,
+// row) pair of the block it reaches: wave w uses it with kz = w + 6 - 2 od_l (if that is a tap) and, for its row h_l, with
+// ky = h_l + 6 - 2 oh_l -- both static in the unrolled code, so accumulator indices are compile-time.  A dy row is read from
+// L2 once per ~0.9 rows of dx (the row kernel: 2.6 GB through the L2 per launch, here 0.55 GB).  Pixel rows and weight rows
+// are 144 bytes apart in LDS (128 + 16): a ds_read_b128 of 16 consecutive rows touches every bank once.  The fold of Q
+// into dx goes through slots in LDS (see below).  OW <= 112.
+// ------------------------------------------------------------------------------------------
+constexpr int D3_PITCH = 144;
+constexpr int D3_W_BYTES = S3_KB * 16 * D3_PITCH;          // 112,896
+constexpr int D3_ROW_BYTES = 128 * D3_PITCH;               // 18,432 (128 pixels)
+constexpr int D3_LDS = D3_W_BYTES + 2 * D3_ROW_BYTES;      // 149,760: weights | two dy rows (the fold's rows, 4 x 7,424, at a block's end)
+constexpr int D3_MT = 7;
+
+__global__ __launch_bounds__(256) void stem3d_dgrad_blk_kernel(Stem3dDgArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char d3_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kg = lane >> 4;
+    for (int i = tid; i < S3_KB * 16 * 8; i += 256) {      // the packed weights [49][16][64] -> rows of 144 bytes
+        const int row = i >> 3, piece = i & 7;
+        *reinterpret_cast<u32x4*>(d3_lds + row * D3_PITCH + piece * 16) = *reinterpret_cast<const u32x4*>(a.wq + row * S3_CO + piece * 8);
+    }
+    char* rows = d3_lds + D3_W_BYTES;
+    for (int i = tid; i < 2 * D3_ROW_BYTES / 16; i += 256) reinterpret_cast<u32x4*>(rows)[i] = u32x4{0u, 0u, 0u, 0u};   // pixels >= OW stay zero
+    const int tblocks = (a.T + 3) >> 2, hblocks = (a.H + 7) >> 3;
+    const int total = a.N * tblocks * hblocks;
+    const int pieces = a.OW * 8;                           // 16-byte pieces of a dy row
+    const long plane = (long)a.T * a.H * a.W;
+    const int wfrag = l15 * D3_PITCH + kg * 16;            // this lane's 16 bytes of a weight block / of a 16-pixel tile (+ 64 per k-step)
+    __syncthreads();
+#ifdef D3_TIMING
+    long long tm[6] = {0, 0, 0, 0, 0, 0}, tq = (long long)__builtin_amdgcn_s_memtime();
+#define D3_LAP(k) { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); tm[k] += now_ - tq; tq = now_; }
+#else
+#define D3_LAP(k)
+#endif
+
+#pragma unroll 1
+    for (int blk = blockIdx.x; blk < total; blk += gridDim.x) {
+        const int hb = blk % hblocks, q = blk / hblocks;
+        const int tb = q % tblocks, n = q / tblocks;
+        const int t = 4 * tb + wave;
+        s3_f32x4 acc[8][D3_MT];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int m = 0; m < D3_MT; ++m) acc[r][m] = s3_f32x4{0.f, 0.f, 0.f, 0.f};
+
+        auto row_ok = [&](int od_l, int oh_l) -> bool {
+            const int od = 2 * tb - 2 + od_l, oh = 4 * hb - 2 + oh_l;
+            return od_l < 5 && od >= 0 && od < a.OD && oh >= 0 && oh < a.OH;
+        };
+        // Staging: row s + 3 is requested at the top of step s into register set s & 1 and written to LDS two steps later (a load
+        // takes ~2 us under this traffic, a step ~0.5: with one register set, loaded and stored within a step, every step waited
+        // for memory).  Eight steps per od_l (the eighth is empty) keep the parities compile-time.
+        u32x4 sv[2][4];
+        // (unconditional, coordinates clamped into the volume: with loads under a branch the compiler cannot count what is in flight
+        // and waits with vmcnt(0), which is the one-step coverage again; a row outside the volume is staged and not used)
+        auto g_load = [&](int od_l, int oh_l, u32x4 (&R)[4]) {
+            int od = 2 * tb - 2 + od_l, oh = 4 * hb - 2 + oh_l;
+            od = od < 0 ? 0 : (od >= a.OD ? a.OD - 1 : od);
+            oh = oh < 0 ? 0 : (oh >= a.OH ? a.OH - 1 : oh);
+            const bf16_t* src = a.dy + ((((long)n * a.OD + od) * a.OH + oh) * a.OW) * S3_CO;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int p = tid + 256 * k;
+                p = p < pieces ? p : pieces - 1;           // (beyond the row: the last piece again, no branch)
+                R[k] = *reinterpret_cast<const u32x4*>(src + (long)p * 8);
+            }
+        };
+        auto l_store = [&](int buf, const u32x4 (&R)[4]) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int p = tid + 256 * k;
+                p = p < pieces ? p : pieces - 1;
+                *reinterpret_cast<u32x4*>(rows + buf * D3_ROW_BYTES + (p >> 3) * D3_PITCH + (p & 7) * 16) = R[k];
+            }
+        };
+        g_load(0, 0, sv[0]);
+        l_store(0, sv[0]);
+        g_load(0, 1, sv[0]);                               // row 1 -> set 0, row 2 -> set 1 (written to LDS at the top of steps 0 and 1)
+        g_load(0, 2, sv[1]);
+        __syncthreads();
+        D3_LAP(0)
+#pragma unroll 1
+        for (int od_l = 0; od_l < 5; ++od_l) {
+            const int kz = wave + 6 - 2 * od_l;
+            const bool wave_on = kz >= 0 && kz < S3_K && t < a.T;
+            const char* wkz = d3_lds + kz * (S3_K * 16 * D3_PITCH) + wfrag;
+#pragma unroll
+            for (int oh_l = 0; oh_l < 8; ++oh_l) {
+                const int buf = oh_l & 1;
+                // row s + 1 (requested two steps ago) into the other buffer; then request row s + 3 into the freed registers
+                l_store(buf ^ 1, sv[oh_l & 1]);
+                g_load(oh_l + 3 < 8 ? od_l : od_l + 1, (oh_l + 3) & 7, sv[oh_l & 1]);
+                D3_LAP(1)
+                if (oh_l < 7 && wave_on && row_ok(od_l, oh_l)) {
+                    const char* rb = rows + buf * D3_ROW_BYTES + wfrag;
+                    // all of the step's weight fragments and the first k-step's pixel fragments up front (one exposed LDS round trip
+                    // per step instead of one per group of seven matrix instructions: with one wave per SIMD nothing else covers it);
+                    // the second k-step's pixel fragments are read between the first's matrix instructions
+                    u32x4 bf[8][2], af0[D3_MT], af1[D3_MT];
+#pragma unroll
+                    for (int m = 0; m < D3_MT; ++m) af0[m] = *reinterpret_cast<const u32x4*>(rb + m * 16 * D3_PITCH);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const int ky = r + 6 - 2 * oh_l;           // compile-time
+                        if (ky < 0 || ky >= S3_K) continue;
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) bf[r][ks] = *reinterpret_cast<const u32x4*>(wkz + ky * 16 * D3_PITCH + ks * 64);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    int nread = 0;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const int ky = r + 6 - 2 * oh_l;
+                        if (ky < 0 || ky >= S3_K) continue;
+#pragma unroll
+                        for (int m = 0; m < D3_MT; ++m) {
+                            acc[r][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af0[m]),
+                                                                                 __builtin_bit_cast(bf16x8, bf[r][0]), acc[r][m], 0, 0, 0);
+                            if ((m & 1) == 0 && nread < D3_MT) {
+                                af1[nread] = *reinterpret_cast<const u32x4*>(rb + nread * 16 * D3_PITCH + 64);
+                                ++nread;
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (; nread < D3_MT; ++nread) af1[nread] = *reinterpret_cast<const u32x4*>(rb + nread * 16 * D3_PITCH + 64);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const int ky = r + 6 - 2 * oh_l;
+                        if (ky < 0 || ky >= S3_K) continue;
+#pragma unroll
+                        for (int m = 0; m < D3_MT; ++m)
+                            acc[r][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af1[m]),
+                                                                                 __builtin_bit_cast(bf16x8, bf[r][1]), acc[r][m], 0, 0, 0);
+                    }
+                }
+                D3_LAP(2)
+                __syncthreads();
+                D3_LAP(3)
+            }
+        }
+        // Fold: dx[w][c] = sum over kx = w (mod 2) of Q[(w + 2 - kx) / 2][(kx, c)].  A lane holds column (kx, c) = l15 of Q for 28
+        // output pixels ow = 16 m + 4 kg + q, and its value is term u = kx / 2 of dx pixel w = 2 ow + kx - 2: it is WRITTEN to slot
+        // (c, w, u) of a [2][232][4] float row in LDS (one base address per lane + compile-time offsets, every slot has one
+        // writer), and an output pixel is one ds_read_b128 and three additions in the row kernels' order (kx ascending).  Slots no
+        // pixel writes (ow < 0 or >= 112 at the two ends of a row) are zeroed once per block; columns 14 / 15 carry zero weights.
+        // (The row kernels' fold -- per output pixel four conditional LDS reads and an integer division -- is latency that
+        // other waves hide there; with ONE wave per SIMD it was 46 % of this kernel.  ds_add_f32 into one float per pixel was worse
+        // still: ~780 clocks per instruction.)  The rows live in the (then idle) dy buffers.
+        int lane_f = lane;                                 // (opaque: the fold's 56 row / column addresses are NOT to be computed -- and
+        asm volatile("" : "+v"(lane_f));                   // spilled -- in front of the staging loop, where the compiler hoists them)
+        float* F = reinterpret_cast<float*>(rows) + wave * (2 * 232 * 4);
+        float* fw = F + ((l15 & 1) * 232 + 8 * kg + (l15 >> 1)) * 4 + (l15 >> 2);   // slot (c, w, u) at F[((c * 232) + 2 + w) * 4 + u]
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int k = lane + 64 * j;                   // 2 planes x (8 + 12) edge pixels x 4 slots
+            const int c = k / 80, rem = k - 80 * c, e = rem >> 2;
+            if (k < 160) F[((c * 232) + (e < 8 ? e : 212 + e)) * 4 + (rem & 3)] = 0.f;
+        }
+        if (t < a.T) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int h = 8 * hb + r;
+                if (h >= a.H) break;
+#pragma unroll
+                for (int m = 0; m < D3_MT; ++m)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) fw[(32 * m + 2 * qq) * 4] = acc[r][m][qq];
+                __builtin_amdgcn_wave_barrier();
+                float* dst = a.dx + ((long)n * 2 * a.T + t) * a.H * a.W + (long)h * a.W;
+#pragma unroll
+                for (int it = 0; it < 7; ++it) {                   // 2 W <= 448 = 7 x 64
+                    int i = lane_f + 64 * it;
+                    i = i < 2 * a.W ? i : 2 * a.W - 1;             // (beyond the row: the last element again -- the same value to the same
+                                                                   // address; under a branch the compiler sinks the read into it and the seven
+                                                                   // LDS round trips of a row happen one after the other)
+                    const int c = i >= a.W ? 1 : 0, w = i - c * a.W;
+                    const float4 v = *reinterpret_cast<const float4*>(F + ((c * 232) + 2 + w) * 4);
+                    dst[c * plane + w] = ((v.x + v.y) + v.z) + v.w;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * (112 - a.OW) * 9; i += 256) {    // narrow frames: pixels OW .. 111 of the dy buffers are zeros again
+            const int bufi = i / ((112 - a.OW) * 9), rem = i - bufi * (112 - a.OW) * 9;
+            *reinterpret_cast<u32x4*>(rows + bufi * D3_ROW_BYTES + (a.OW + rem / 9) * D3_PITCH + (rem % 9) * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+        D3_LAP(4)
+        __syncthreads();                                   // the dy buffers are the next block's again
+        D3_LAP(5)
+    }
+#ifdef D3_TIMING
+    if (lane == 0)
+        for (int k = 0; k < 6; ++k) a.dx[(blockIdx.x * 4 + wave) * 8 + k] = (float)tm[k];
+#endif
+}
+
 int s3_wg_groups(long nseg) { return (int)(nseg < 256 ? nseg : 256); }
 
 int s3_blocks(long tiles) {
@@ -976,6 +1186,15 @@ int dmc_stem3d_bf16_dgrad(const void* dy, const float* w, float* dx, void* works
     long blocks = (rows + S3_DG_WAVES - 1) / S3_DG_WAVES;
     if (blocks > 2048) blocks = 2048;
     const int mt = (OW + 15) / 16;
+    if (mt <= D3_MT && option(OPT_CONV_CFG) != 12) {          // the block form (conv_cfg 12: the row kernels, for A/B)
+        const int total = N * ((T + 3) / 4) * ((H + 7) / 8);
+        const int cus = persistent_cus(256);
+        static LdsLimit lim_d3;
+        const hipError_t attr = lim_d3.raise(reinterpret_cast<const void*>(&stem3d_dgrad_blk_kernel), D3_LDS);
+        if (attr != hipSuccess) return fail(DMC_E_LAUNCH, "stem3d dgrad: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
+        stem3d_dgrad_blk_kernel<<<total < cus ? total : cus, 256, D3_LDS, s>>>(a);
+        return check_launch("stem3d_dgrad_blk");
+    }
     if (mt == 7 && option(OPT_CONV3D_WGRAD) != 10) {          // 224-wide frames: four input rows per wave (option value 10: one row, A/B)
         long b4 = ((long)N * T * ((H + 3) / 4) + S3_DG_WAVES - 1) / S3_DG_WAVES;
         if (b4 > 2048) b4 = 2048;
