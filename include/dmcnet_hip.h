@@ -61,7 +61,7 @@ const char* dmc_last_error(void);
  *   "conv_path" / "conv_arith" / "conv_cfg"  classifier / discriminator / I3D convolutions: second-generation kernels (1), bf16x3
  *                     arithmetic (1) or fp32 MFMA (0), and a forced tile configuration (0 = automatic; 1 .. 5 tiles of the
  *                     tap-stepping 3-D kernel, 6 = never the patch-resident 3x3x3 kernel, 7 / 8 = its 128- / 64-position tiles,
- *                     9 = the scan form of the 3-D max pool, 11 = the first (LDS-scatter) form of the I3D stem's weight gradient,
+ *                     9 = the scan form of the 3-D max pool, 11 / 12 = the first forms of the I3D stem's weight / data gradient (LDS scatter; one or four rows per wave),
  *                     101 .. 305 = 2-D tile choices named in the kernels).
  *   "conv3d_wgrad"    2 (default): row-ring weight gradient for 3x3x3 and 1x1x1; 1: 3x3x3 only; 0: tap-stepping kernels.
  *   "grid_reserve_cus" 0 (default) .. 128: CUs every PERSISTENT grid (gen_fused, the generator's ring / gather / Winograd kernels,

@@ -282,6 +282,38 @@ def test_i3d_stem_weight_gradient_forms_agree(shape):
     assert float((out[0] - out[1]).abs().max() / out[1].abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 2, 8, 32, 24), (1, 2, 6, 10, 224), (1, 2, 7, 13, 100), (1, 2, 5, 9, 250), (1, 2, 9, 20, 64)])
+def test_i3d_stem_data_gradient_forms_agree(shape):
+    """The stem's data gradient has two forms: the block form (4 frames x 8 rows of the cue's gradient per workgroup, frames of up
+    to 225 columns; here with frame / row counts that are not multiples of the block, narrow frames -- the staged rows' pixels
+    beyond OW must read as zeros after a fold used the buffers --, several blocks per workgroup) and the row kernels (wider frames,
+    or conv_cfg 12).  Both against fp64 autograd, and twice for determinism."""
+    torch.manual_seed(6)
+    lib = dmcnet_amd._lib.load()
+    n, _, t, h, w = shape
+    od, oh, ow = (t - 2) // 2 + 1, (h - 2) // 2 + 1, (w - 2) // 2 + 1
+    wt = torch.randn(64, 2, 7, 7, 7, device=DEV) * 0.05
+    g = torch.randn(n, 64, od, oh, ow, device=DEV).bfloat16()
+    xo = torch.zeros(n, 2, t, h, w, device=DEV, dtype=torch.float64, requires_grad=True)
+    (F.conv3d(F.pad(xo, (2, 3, 2, 3, 2, 3)), wt.bfloat16().double(), None, 2, 0) * g.double()).sum().backward()
+    gcl = g.contiguous(memory_format=CL3)
+    wsd = torch.empty(lib.dmc_stem3d_bf16_dgrad_workspace_bytes(), dtype=torch.uint8, device=DEV)
+    out = []
+    try:
+        for cfg in (0, 0, 12):
+            dmcnet_amd._lib.check(lib.dmc_set_option(b"conv_cfg", cfg), "dmc_set_option")
+            dx = torch.full((n, 2, t, h, w), float("nan"), dtype=torch.float32, device=DEV)
+            dmcnet_amd._lib.check(lib.dmc_stem3d_bf16_dgrad(dmcnet_amd._lib.ptr(gcl), dmcnet_amd._lib.ptr(wt), dmcnet_amd._lib.ptr(dx),
+                                                            dmcnet_amd._lib.ptr(wsd), n, t, h, w, None), "dmc_stem3d_bf16_dgrad")
+            err = float((dx.double() - xo.grad).abs().max() / xo.grad.abs().max())
+            assert err < 2e-5, (cfg, err)
+            out.append(dx)
+    finally:
+        dmcnet_amd._lib.check(lib.dmc_set_option(b"conv_cfg", 0), "dmc_set_option")
+    assert torch.equal(out[0], out[1])
+    assert float((out[0] - out[2]).abs().max() / out[2].abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("shape", [(2, 2, 8, 32, 24), (1, 2, 4, 18, 70), (1, 2, 16, 64, 64), (1, 2, 4, 10, 224), (2, 2, 2, 6, 224)])
 def test_i3d_stem_forward_and_unit_vs_stock(shape):
     """conv3d_1a_7x7 (2 -> 64, 7x7x7, stride 2, TF-"SAME"): dmc_stem3d_bf16_fwd against an fp64 evaluation of the
