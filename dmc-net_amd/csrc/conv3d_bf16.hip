@@ -49,6 +49,23 @@ __device__ __forceinline__ unsigned f2bf(float v) {        // round to nearest e
 }
 __device__ __forceinline__ float bf2f(unsigned h) { return __uint_as_float(h << 16); }
 
+// Sum over the 32 lanes of a half wave (the pixel columns of an accumulator tile) on the VALU's data-parallel primitives: four
+// rotations within the rows of 16 and one broadcast of a row's lane 15 into the next row; lanes 16 .. 31 (48 .. 63) end up with
+// the sum of lanes 0 .. 31 (32 .. 63).  (A butterfly of __shfl_xor is five ds_bpermute_b32 per value -- 160 LDS-crossbar round
+// trips for the 2 x 16 statistics of a tile, each waited for: half of a 1 x 1 x 1 launch, 11-26 % of a 3 x 3 x 3 job.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float c3d_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float c3d_sum32(float v) {
+    v += c3d_dpp<0x128, 0xf>(v);                           // row_ror:8
+    v += c3d_dpp<0x124, 0xf>(v);                           // row_ror:4
+    v += c3d_dpp<0x122, 0xf>(v);                           // row_ror:2
+    v += c3d_dpp<0x121, 0xf>(v);                           // row_ror:1
+    v += c3d_dpp<0x142, 0xa>(v);                           // row_bcast:15 into rows 1 and 3
+    return v;
+}
+
 struct C3dArgs {
     const bf16_t* x;       // [N][D][H][W][Cin]
     const bf16_t* w;       // packed [rows_pad][T][Cp]
@@ -64,27 +81,36 @@ struct C3dArgs {
 // (~1 us each: 108 steps = 100 us for a 3x3x3 layer of 128 channels on a 9,408-pixel map, 83 such launches per I3D
 // micro-step).  With NS stages NS - 1 steps are in flight and a step only waits for the OLDEST of them
 // (s_waitcnt vmcnt(<transfers of the NS - 2 younger steps>)).
+constexpr int C3D_NL = 4;                                  // loader waves (one alone issues a transfer every ~100 clocks: 12-24 per step are too many)
+// The transfers are issued by LOADER waves of their own (waves NW .. NW + 3; round 6): global_load_lds counts in lgkmcnt as well as vmcnt, so a
+// wave that issued a step's transfers waited at its next fragment read -- the compiler's lgkmcnt(0) -- until they had landed, every
+// step: the ring was NS deep on paper and one deep in fact (15-step 1 x 1 x 1 GEMMs took 15 memory round trips).  The consumer
+// waves now only read fragments and multiply; the loader only issues and waits (vmcnt, oldest step).
 template <int BM, int BN, int WM, int WN, int NS>
-__global__ __launch_bounds__(WM * WN * 64) void conv3d_bf16_kernel(C3dArgs a) {
+__global__ __launch_bounds__((WM * WN + C3D_NL) * 64) void conv3d_bf16_kernel(C3dArgs a) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     static_assert(BM % (32 * WM) == 0 && BN % (32 * WN) == 0 && BM % 16 == 0 && BN % 16 == 0, "tile layout");
     constexpr int IP = BM / 16, IW = BN / 16;              // DMA instructions per step: pixel rows, weight rows
-    constexpr int NDP = (IP + NW - 1) / NW, NDW = (IW + NW - 1) / NW;
+    constexpr int NDP = (IP + C3D_NL - 1) / C3D_NL, NDW = (IW + C3D_NL - 1) / C3D_NL;   // ... per loader wave (the waves count their
+                                                           // transfers: where IP or IW is no multiple of 4 a wave repeats a row)
     constexpr int PIXB = BM * 64, BUF = (BM + BN) * 64;
-    static_assert(NS == 2 || (IP % NW == 0 && IW % NW == 0), "a deeper ring counts transfers per wave: every wave must issue the same number");
     static_assert(NS * BUF <= 64 * 1024, "static LDS");
-    constexpr int PER_STEP = NDP + NDW;                     // transfers per wave and step
+    constexpr int PER_STEP = NDP + NDW;                     // transfers per loader wave and step
+    static_assert(PER_STEP * (NS - 2) <= 63, "vmcnt is six bits");
     __shared__ __attribute__((aligned(1024))) char lds[NS * BUF];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave % WM, wn = wave / WM;
+    const bool loader = wave >= NW;
+    const int li = wave - NW;                              // loader wave li moves tile rows 16 e .. 16 e + 15 for e = li (mod 4)
+    const int wm = wave % WM, wn = (wave / WM) % WN;
     const long m0 = (long)blockIdx.x * BM;
     const int co0 = blockIdx.y * BN;
     const unsigned lds0 = lds_addr_of(lds);
     const unsigned long long zeros = (unsigned long long)g_zeros3d;
     const int T = a.KD * a.KH * a.KW;
+    const int T_steps = T * (a.Cp >> 5);
 
     // ---- transfers: instruction e moves tile rows 16 e .. 16 e + 15; lane -> (row 16 e + lane / 4, slot lane % 4),
     // source quad = slot ^ ((row >> 2) & 3) = (lane & 3) ^ ((lane >> 4) & 3) ----
@@ -94,10 +120,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_bf16_kernel(C3dArgs a) {
     unsigned p_mask[NDP];
 #pragma unroll
     for (int j = 0; j < NDP; ++j) {
-        const int e = wave + NW * j;
+        const int e = (li + C3D_NL * j) % IP;
         const long m = m0 + 16 * e + rr;
         p_mask[j] = 0; p_addr[j] = zeros;
-        if (e < IP && m < a.M) {
+        if (loader && m < a.M) {
             const long hw = (long)a.H * a.W;
             const long nd = m / hw;
             const int rem = (int)(m - nd * hw);
@@ -115,10 +141,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_bf16_kernel(C3dArgs a) {
     }
     unsigned long long w_addr[NDW];
 #pragma unroll
-    for (int j = 0; j < NDW; ++j) {
-        const int e = wave + NW * j;
-        w_addr[j] = (unsigned long long)a.w + ((unsigned long long)(co0 + 16 * e + rr) * T * a.Cp + 8 * q) * 2;
-    }
+    for (int j = 0; j < NDW; ++j) w_addr[j] = (unsigned long long)a.w + ((unsigned long long)(co0 + 16 * ((li + C3D_NL * j) % IW) + rr) * T * a.Cp + 8 * q) * 2;
 
     // step state of the transfers being issued: tap (kz, ky, kx) = index tap_n, channel chunk ci_n; all scalar
     int tap_n = 0, kz_n = 0, ky_n = 0, kx_n = 0, ci_n = 0;
@@ -129,16 +152,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_bf16_kernel(C3dArgs a) {
         const unsigned base = lds0 + buf * BUF;
 #pragma unroll
         for (int j = 0; j < NDP; ++j) {
-            if (IP % NW != 0 && wave + NW * j >= IP) continue;
             const bool ok = ((p_mask[j] >> tap_n) & 1) && cok;
             const unsigned long long src = ok ? p_addr[j] + (unsigned long long)toff : zeros;
-            dma16(reinterpret_cast<const void*>(src), base + (wave + NW * j) * 1024);
+            dma16(reinterpret_cast<const void*>(src), base + ((li + C3D_NL * j) % IP) * 1024);
         }
 #pragma unroll
-        for (int j = 0; j < NDW; ++j) {
-            if (IW % NW != 0 && wave + NW * j >= IW) continue;
-            dma16(reinterpret_cast<const void*>(w_addr[j] + (unsigned long long)woff), base + PIXB + (wave + NW * j) * 1024);
-        }
+        for (int j = 0; j < NDW; ++j) dma16(reinterpret_cast<const void*>(w_addr[j] + (unsigned long long)woff), base + PIXB + ((li + C3D_NL * j) % IW) * 1024);
     };
     auto advance = [&]() {
         ci_n += 32;
@@ -147,6 +166,27 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_bf16_kernel(C3dArgs a) {
             if (++kx_n == a.KW) { kx_n = 0; if (++ky_n == a.KH) { ky_n = 0; ++kz_n; } }
         }
     };
+
+    if (loader) {                                          // one barrier per step, as the consumers
+#pragma unroll
+        for (int p = 0; p < NS - 1; ++p)
+            if (p < T_steps) { issue(p); advance(); }
+        if (NS - 1 <= T_steps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER_STEP * (NS - 2)) : "memory");   // step 0 has landed
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int nbuf = NS - 1;                                 // ring slot of the step issued in iteration t
+#pragma unroll 1
+        for (int t = 0; t < T_steps; ++t) {
+            const bool more = t + NS - 1 < T_steps;
+            if (more) { issue(nbuf); advance(); }
+            // step t + 1 must have landed: the NS - 2 steps younger than it may stay in flight while the ring is full
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER_STEP * (NS - 2)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
+        }
+        return;
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -167,18 +207,17 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_bf16_kernel(C3dArgs a) {
         wfo[kb] = PIXB + (crow0 + l31) * 64 + slot;
     }
 
-    const int T_steps = T * (a.Cp >> 5);
-#pragma unroll
-    for (int p = 0; p < NS - 1; ++p)
-        if (p < T_steps) { issue(p); advance(); }
-    if (NS - 1 <= T_steps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER_STEP * (NS - 2)) : "memory");   // step 0 has landed
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    int buf = 0, nbuf = NS - 1;                              // ring slots of step t / of the step issued in iteration t
+#ifdef C3D_TIMING
+    long long tm[4] = {0, 0, 0, 0}, tq = (long long)__builtin_amdgcn_s_memtime();
+#define C3D_LAP(k) { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); tm[k] += now_ - tq; tq = now_; }
+#else
+#define C3D_LAP(k)
+#endif
+    __builtin_amdgcn_s_barrier();                            // step 0 has landed
+    C3D_LAP(0)
+    int buf = 0;                                             // ring slot of step t
 #pragma unroll 1
     for (int t = 0; t < T_steps; ++t) {
-        const bool more = t + NS - 1 < T_steps;
-        if (more) { issue(nbuf); advance(); }
         const char* base = lds + buf * BUF;
         u32x4 xf[2][TM], wf[2][TN];
 #pragma unroll
@@ -196,12 +235,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_bf16_kernel(C3dArgs a) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[kb][j]),
                                                                         __builtin_bit_cast(bf16x8, xf[kb][i]), acc[i][j], 0, 0, 0);
-        // step t + 1 must have landed: the NS - 2 steps younger than it may stay in flight while the ring is full
-        if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(PER_STEP * (NS - 2)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the fragments are in registers: the slot may be refilled)
+        C3D_LAP(1)
         __builtin_amdgcn_s_barrier();
+        C3D_LAP(2)
         buf = buf + 1 == NS ? 0 : buf + 1;
-        nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
     }
 
     // ---- epilogue: lane holds pixel column l31 of tile i, channels 8 gq + 4 khalf + e of tile j in acc[4 gq + e] ----
@@ -233,13 +271,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_bf16_kernel(C3dArgs a) {
         if (a.stat_part) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                float d1 = s1[e], d2 = s2[e];
-#pragma unroll
-                for (int o = 1; o < 32; o <<= 1) {
-                    d1 += __shfl_xor(d1, o, 64);
-                    d2 += __shfl_xor(d2, o, 64);
-                }
-                if (l31 == 0) {
+                const float d1 = c3d_sum32(s1[e]), d2 = c3d_sum32(s2[e]);
+                if (l31 == 31) {
                     const int c = crow0 + 32 * j + 8 * (e >> 2) + 4 * khalf + (e & 3);
                     red[(wm * BN + c) * 2 + 0] = d1;
                     red[(wm * BN + c) * 2 + 1] = d2;
@@ -258,6 +291,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_bf16_kernel(C3dArgs a) {
                 dst[0] = d1; dst[1] = d2;
             }
     }
+#ifdef C3D_TIMING
+    C3D_LAP(3)
+    __syncthreads();
+    if (tid == 0 && a.stat_part)
+        for (int k = 0; k < 4; ++k) a.stat_part[(size_t)blockIdx.x * a.Cout * 2 + blockIdx.y * 8 + k] = (float)tm[k];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -935,14 +974,9 @@ __device__ __forceinline__ void p3_consume(const P3Args& a, const char* p3_lds, 
             // whichever way the job was shared among the waves
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                float d1 = s1[e], d2 = s2[e];
-#pragma unroll
-                for (int o = 1; o < 32; o <<= 1) {
-                    d1 += __shfl_xor(d1, o, 64);
-                    d2 += __shfl_xor(d2, o, 64);
-                }
+                const float d1 = c3d_sum32(s1[e]), d2 = c3d_sum32(s2[e]);
                 const int co = co0 + 8 * (e >> 2) + 4 * khalf + (e & 3);
-                if (l31 == 0 && co < a.Cout) {
+                if (l31 == 31 && co < a.Cout) {
 #pragma unroll
                     for (int q = 0; q < TMW; ++q) {
                         float* dst = a.stat_part + (((size_t)bx * TM + i0 + q) * a.Cout + co) * 2;
@@ -1102,7 +1136,7 @@ int launch_p3(const C3dArgs& a, const P3Plan& p, hipStream_t s) {
 template <int BM, int BN, int WM, int WN, int NS>
 int launch_c3d(const C3dArgs& a, hipStream_t s) {
     dim3 grid((unsigned)((a.M + BM - 1) / BM), (a.Cout + BN - 1) / BN);
-    conv3d_bf16_kernel<BM, BN, WM, WN, NS><<<grid, WM * WN * 64, 0, s>>>(a);
+    conv3d_bf16_kernel<BM, BN, WM, WN, NS><<<grid, (WM * WN + C3D_NL) * 64, 0, s>>>(a);
     return check_launch("conv3d_bf16");
 }
 
