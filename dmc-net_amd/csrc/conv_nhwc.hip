@@ -249,12 +249,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvArgs a) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                double d1 = (double)s1[j][e], d2 = (double)s2[j][e];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    d1 += __shfl_xor(d1, o, 64);
-                    d2 += __shfl_xor(d2, o, 64);
-                }
+                const double d1 = row16_sum((double)s1[j][e]), d2 = row16_sum((double)s2[j][e]);
                 if (i16 == 0) {
                     const int c = wn * (BN / WN) + 16 * j + 4 * kq + e;
                     red[(wm * BN + c) * 2 + 0] = d1;
@@ -359,13 +354,8 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvArgs& a, f32x16 (&a
             // per-channel sums of this workgroup's tile: 32 pixel lanes -> waves (WM) -> one store per channel
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                double d1 = (double)s1[e], d2 = (double)s2[e];
-#pragma unroll
-                for (int o = 1; o < 32; o <<= 1) {
-                    d1 += __shfl_xor(d1, o, 64);
-                    d2 += __shfl_xor(d2, o, 64);
-                }
-                if (l31 == 0) {
+                const double d1 = half32_sum_hi((double)s1[e]), d2 = half32_sum_hi((double)s2[e]);
+                if (l31 == 31) {
                     const int c = wn * (BN / WN) + 32 * j + 8 * (e >> 2) + 4 * khalf + (e & 3);
                     red[(wm * BN + c) * 2 + 0] = d1;
                     red[(wm * BN + c) * 2 + 1] = d2;

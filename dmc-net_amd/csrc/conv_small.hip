@@ -222,11 +222,8 @@ __global__ __launch_bounds__(Csm<C>::NW * 64) void csm_conv_kernel(CsmArgs a) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int m = 1; m < 16; m <<= 1) {
-                ssum[mt][i] += __shfl_xor(ssum[mt][i], m, 64);
-                ssq[mt][i] += __shfl_xor(ssq[mt][i], m, 64);
-            }
+            ssum[mt][i] = row16_sum(ssum[mt][i]);
+            ssq[mt][i] = row16_sum(ssq[mt][i]);
             if (n == 0) {
                 red[wave][mt * 16 + 4 * kq + i][0] = ssum[mt][i];
                 red[wave][mt * 16 + 4 * kq + i][1] = ssq[mt][i];
@@ -437,11 +434,8 @@ __global__ __launch_bounds__(Csm2::NW * 64) void csm_conv_s2_kernel(Csm2Args a) 
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int m = 1; m < 16; m <<= 1) {
-                ssum[mt][i] += __shfl_xor(ssum[mt][i], m, 64);
-                ssq[mt][i] += __shfl_xor(ssq[mt][i], m, 64);
-            }
+            ssum[mt][i] = row16_sum(ssum[mt][i]);
+            ssq[mt][i] = row16_sum(ssq[mt][i]);
             if (n == 0) {
                 red[wave][mt * 16 + 4 * kq + i][0] = ssum[mt][i];
                 red[wave][mt * 16 + 4 * kq + i][1] = ssq[mt][i];

@@ -163,6 +163,34 @@ __device__ __forceinline__ void lds_dma16(unsigned long long sbase, unsigned vof
 }
 }  // namespace dmc
 
+// ---- lane sums on the VALU's data-parallel primitives (DPP) -----------------------------------------------
+// A butterfly of __shfl_xor is one ds_bpermute_b32 per dword and level -- an LDS-crossbar round trip each, waited for: the fp64
+// BatchNorm sums of an accumulator tile (32 values x 5 levels x 2 dwords) cost more than a short convolution's main loop.
+// Rotations within a row of 16 lanes (row_ror) and the broadcast of a row's lane 15 into the next row (row_bcast:15) are plain
+// vector instructions.  The order of the additions is fixed (not the butterfly's).
+namespace dmc {
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// every lane of a row of 16 (lanes 16 k .. 16 k + 15) gets the row's sum
+__device__ __forceinline__ double row16_sum(double v) {
+    v += dpp_f64<0x128, 0xf>(v);                           // row_ror:8
+    v += dpp_f64<0x124, 0xf>(v);                           // row_ror:4
+    v += dpp_f64<0x122, 0xf>(v);                           // row_ror:2
+    v += dpp_f64<0x121, 0xf>(v);                           // row_ror:1
+    return v;
+}
+// lanes 16 .. 31 (48 .. 63) get the sum of lanes 0 .. 31 (32 .. 63); the other lanes hold their row's sum
+__device__ __forceinline__ double half32_sum_hi(double v) {
+    v = row16_sum(v);
+    v += dpp_f64<0x142, 0xa>(v);                           // row_bcast:15 into rows 1 and 3 (rows 0 and 2 add 0)
+    return v;
+}
+}  // namespace dmc
+
 // ---- bf16x3 slice tensors (conv_x3s.hip and their producers in bn_act.hip) -------------------------------
 // An fp32 value is the exact sum of three bf16 values: s0 = its upper 16 bits, s1 = the upper 16 bits of the exact
 // remainder, s2 = the second remainder.  A slice tensor of a [M][C] fp32 activation is bf16 [3][C / 16][M][16].
