@@ -81,36 +81,27 @@ struct C3dArgs {
 // (~1 us each: 108 steps = 100 us for a 3x3x3 layer of 128 channels on a 9,408-pixel map, 83 such launches per I3D
 // micro-step).  With NS stages NS - 1 steps are in flight and a step only waits for the OLDEST of them
 // (s_waitcnt vmcnt(<transfers of the NS - 2 younger steps>)).
-constexpr int C3D_NL = 4;                                  // loader waves (one alone issues a transfer every ~100 clocks: 12-24 per step are too many)
-// The transfers are issued by LOADER waves of their own (waves NW .. NW + 3; round 6): global_load_lds counts in lgkmcnt as well as vmcnt, so a
-// wave that issued a step's transfers waited at its next fragment read -- the compiler's lgkmcnt(0) -- until they had landed, every
-// step: the ring was NS deep on paper and one deep in fact (15-step 1 x 1 x 1 GEMMs took 15 memory round trips).  The consumer
-// waves now only read fragments and multiply; the loader only issues and waits (vmcnt, oldest step).
 template <int BM, int BN, int WM, int WN, int NS>
-__global__ __launch_bounds__((WM * WN + C3D_NL) * 64) void conv3d_bf16_kernel(C3dArgs a) {
+__global__ __launch_bounds__(WM * WN * 64) void conv3d_bf16_kernel(C3dArgs a) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     static_assert(BM % (32 * WM) == 0 && BN % (32 * WN) == 0 && BM % 16 == 0 && BN % 16 == 0, "tile layout");
     constexpr int IP = BM / 16, IW = BN / 16;              // DMA instructions per step: pixel rows, weight rows
-    constexpr int NDP = (IP + C3D_NL - 1) / C3D_NL, NDW = (IW + C3D_NL - 1) / C3D_NL;   // ... per loader wave (the waves count their
-                                                           // transfers: where IP or IW is no multiple of 4 a wave repeats a row)
+    constexpr int NDP = (IP + NW - 1) / NW, NDW = (IW + NW - 1) / NW;
     constexpr int PIXB = BM * 64, BUF = (BM + BN) * 64;
+    static_assert(NS == 2 || (IP % NW == 0 && IW % NW == 0), "a deeper ring counts transfers per wave: every wave must issue the same number");
     static_assert(NS * BUF <= 64 * 1024, "static LDS");
-    constexpr int PER_STEP = NDP + NDW;                     // transfers per loader wave and step
-    static_assert(PER_STEP * (NS - 2) <= 63, "vmcnt is six bits");
+    constexpr int PER_STEP = NDP + NDW;                     // transfers per wave and step
     __shared__ __attribute__((aligned(1024))) char lds[NS * BUF];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = wave >= NW;
-    const int li = wave - NW;                              // loader wave li moves tile rows 16 e .. 16 e + 15 for e = li (mod 4)
-    const int wm = wave % WM, wn = (wave / WM) % WN;
+    const int wm = wave % WM, wn = wave / WM;
     const long m0 = (long)blockIdx.x * BM;
     const int co0 = blockIdx.y * BN;
     const unsigned lds0 = lds_addr_of(lds);
     const unsigned long long zeros = (unsigned long long)g_zeros3d;
     const int T = a.KD * a.KH * a.KW;
-    const int T_steps = T * (a.Cp >> 5);
 
     // ---- transfers: instruction e moves tile rows 16 e .. 16 e + 15; lane -> (row 16 e + lane / 4, slot lane % 4),
     // source quad = slot ^ ((row >> 2) & 3) = (lane & 3) ^ ((lane >> 4) & 3) ----
@@ -120,10 +111,10 @@ __global__ __launch_bounds__((WM * WN + C3D_NL) * 64) void conv3d_bf16_kernel(C3
     unsigned p_mask[NDP];
 #pragma unroll
     for (int j = 0; j < NDP; ++j) {
-        const int e = (li + C3D_NL * j) % IP;
+        const int e = wave + NW * j;
         const long m = m0 + 16 * e + rr;
         p_mask[j] = 0; p_addr[j] = zeros;
-        if (loader && m < a.M) {
+        if (e < IP && m < a.M) {
             const long hw = (long)a.H * a.W;
             const long nd = m / hw;
             const int rem = (int)(m - nd * hw);
@@ -141,7 +132,10 @@ __global__ __launch_bounds__((WM * WN + C3D_NL) * 64) void conv3d_bf16_kernel(C3
     }
     unsigned long long w_addr[NDW];
 #pragma unroll
-    for (int j = 0; j < NDW; ++j) w_addr[j] = (unsigned long long)a.w + ((unsigned long long)(co0 + 16 * ((li + C3D_NL * j) % IW) + rr) * T * a.Cp + 8 * q) * 2;
+    for (int j = 0; j < NDW; ++j) {
+        const int e = wave + NW * j;
+        w_addr[j] = (unsigned long long)a.w + ((unsigned long long)(co0 + 16 * e + rr) * T * a.Cp + 8 * q) * 2;
+    }
 
     // step state of the transfers being issued: tap (kz, ky, kx) = index tap_n, channel chunk ci_n; all scalar
     int tap_n = 0, kz_n = 0, ky_n = 0, kx_n = 0, ci_n = 0;
@@ -152,12 +146,16 @@ __global__ __launch_bounds__((WM * WN + C3D_NL) * 64) void conv3d_bf16_kernel(C3
         const unsigned base = lds0 + buf * BUF;
 #pragma unroll
         for (int j = 0; j < NDP; ++j) {
+            if (IP % NW != 0 && wave + NW * j >= IP) continue;
             const bool ok = ((p_mask[j] >> tap_n) & 1) && cok;
             const unsigned long long src = ok ? p_addr[j] + (unsigned long long)toff : zeros;
-            dma16(reinterpret_cast<const void*>(src), base + ((li + C3D_NL * j) % IP) * 1024);
+            dma16(reinterpret_cast<const void*>(src), base + (wave + NW * j) * 1024);
         }
 #pragma unroll
-        for (int j = 0; j < NDW; ++j) dma16(reinterpret_cast<const void*>(w_addr[j] + (unsigned long long)woff), base + PIXB + ((li + C3D_NL * j) % IW) * 1024);
+        for (int j = 0; j < NDW; ++j) {
+            if (IW % NW != 0 && wave + NW * j >= IW) continue;
+            dma16(reinterpret_cast<const void*>(w_addr[j] + (unsigned long long)woff), base + PIXB + (wave + NW * j) * 1024);
+        }
     };
     auto advance = [&]() {
         ci_n += 32;
@@ -166,27 +164,6 @@ __global__ __launch_bounds__((WM * WN + C3D_NL) * 64) void conv3d_bf16_kernel(C3
             if (++kx_n == a.KW) { kx_n = 0; if (++ky_n == a.KH) { ky_n = 0; ++kz_n; } }
         }
     };
-
-    if (loader) {                                          // one barrier per step, as the consumers
-#pragma unroll
-        for (int p = 0; p < NS - 1; ++p)
-            if (p < T_steps) { issue(p); advance(); }
-        if (NS - 1 <= T_steps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER_STEP * (NS - 2)) : "memory");   // step 0 has landed
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        int nbuf = NS - 1;                                 // ring slot of the step issued in iteration t
-#pragma unroll 1
-        for (int t = 0; t < T_steps; ++t) {
-            const bool more = t + NS - 1 < T_steps;
-            if (more) { issue(nbuf); advance(); }
-            // step t + 1 must have landed: the NS - 2 steps younger than it may stay in flight while the ring is full
-            if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER_STEP * (NS - 2)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
-        }
-        return;
-    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -207,17 +184,25 @@ __global__ __launch_bounds__((WM * WN + C3D_NL) * 64) void conv3d_bf16_kernel(C3
         wfo[kb] = PIXB + (crow0 + l31) * 64 + slot;
     }
 
+    const int T_steps = T * (a.Cp >> 5);
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < T_steps) { issue(p); advance(); }
 #ifdef C3D_TIMING
     long long tm[4] = {0, 0, 0, 0}, tq = (long long)__builtin_amdgcn_s_memtime();
 #define C3D_LAP(k) { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); tm[k] += now_ - tq; tq = now_; }
 #else
 #define C3D_LAP(k)
 #endif
-    __builtin_amdgcn_s_barrier();                            // step 0 has landed
+    if (NS - 1 <= T_steps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER_STEP * (NS - 2)) : "memory");   // step 0 has landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     C3D_LAP(0)
-    int buf = 0;                                             // ring slot of step t
+    int buf = 0, nbuf = NS - 1;                              // ring slots of step t / of the step issued in iteration t
 #pragma unroll 1
     for (int t = 0; t < T_steps; ++t) {
+        const bool more = t + NS - 1 < T_steps;
+        if (more) { issue(nbuf); advance(); }
         const char* base = lds + buf * BUF;
         u32x4 xf[2][TM], wf[2][TN];
 #pragma unroll
@@ -235,11 +220,14 @@ __global__ __launch_bounds__((WM * WN + C3D_NL) * 64) void conv3d_bf16_kernel(C3
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[kb][j]),
                                                                         __builtin_bit_cast(bf16x8, xf[kb][i]), acc[i][j], 0, 0, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the fragments are in registers: the slot may be refilled)
+        // step t + 1 must have landed: the NS - 2 steps younger than it may stay in flight while the ring is full
         C3D_LAP(1)
+        if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(PER_STEP * (NS - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         C3D_LAP(2)
         buf = buf + 1 == NS ? 0 : buf + 1;
+        nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
     }
 
     // ---- epilogue: lane holds pixel column l31 of tile i, channels 8 gq + 4 khalf + e of tile j in acc[4 gq + e] ----
@@ -1136,7 +1124,7 @@ int launch_p3(const C3dArgs& a, const P3Plan& p, hipStream_t s) {
 template <int BM, int BN, int WM, int WN, int NS>
 int launch_c3d(const C3dArgs& a, hipStream_t s) {
     dim3 grid((unsigned)((a.M + BM - 1) / BM), (a.Cout + BN - 1) / BN);
-    conv3d_bf16_kernel<BM, BN, WM, WN, NS><<<grid, (WM * WN + C3D_NL) * 64, 0, s>>>(a);
+    conv3d_bf16_kernel<BM, BN, WM, WN, NS><<<grid, WM * WN * 64, 0, s>>>(a);
     return check_launch("conv3d_bf16");
 }
 
