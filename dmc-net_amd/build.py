@@ -15,13 +15,51 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wall", "-Wno-unused-function"]
 
 
+MANIFEST = os.path.join(PKG, "libdmcnet_hip.manifest.json")
+
+
+def _sha(path):
+    import hashlib
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def source_hashes():
+    """sha256 of everything the library is built from (every file of csrc/ that is not an object, the public header, this recipe)."""
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith((".o", ".hipfb")))
+    deps += [os.path.join(ROOT, "include", "dmcnet_hip.h"), os.path.abspath(__file__)]
+    return {os.path.relpath(d, ROOT): _sha(d) for d in deps}
+
+
+def read_manifest():
+    import json
+    try:
+        with open(MANIFEST) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
 def _stale():
+    """True unless the library on disk is the one the manifest describes AND the manifest's source hashes are the tree's.
+    (Content, not modification times: a prebuilt library that travelled with a snapshot is recognised -- or refused -- by what
+    it was built from.)"""
     if not os.path.exists(LIB):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + \
-           [os.path.join(ROOT, "include", "dmcnet_hip.h"), os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    m = read_manifest()
+    return m is None or m.get("library_sha256") != _sha(LIB) or m.get("sources") != source_hashes()
+
+
+def _write_manifest(compiled):
+    import json
+    import time
+    with open(MANIFEST, "w") as f:
+        json.dump({"library": os.path.relpath(LIB, ROOT), "library_sha256": _sha(LIB), "built_at": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
+                   "compiled_objects": compiled, "hipcc": HIPCC, "flags": FLAGS, "sources": source_hashes()}, f, indent=1, sort_keys=True)
+
+
+#: what the last build_library() call of this process did: "up to date" or the list of objects it compiled (recorded for the driver's log)
+LAST_BUILD = {"action": None}
 
 
 MEASURE_LIB = os.path.join(PKG, "libdmcnet_hip_measure.so")
@@ -36,8 +74,9 @@ def build_library(force=False, verbose=False, measure=False):
     if measure:
         return _build_measure(verbose)
     if not force and not _stale():
+        LAST_BUILD["action"] = "up to date (sources and library match the manifest's hashes)"
         return LIB
-    objs = []
+    objs, compiled = [], []
     for src in SOURCES:
         path = os.path.join(CSRC, src)
         if not os.path.exists(path):
@@ -52,10 +91,13 @@ def build_library(force=False, verbose=False, measure=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        compiled.append(src)
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    _write_manifest(compiled)
+    LAST_BUILD["action"] = "compiled %d of %d sources and linked: %s" % (len(compiled), len(objs), ", ".join(compiled) or "(objects were current)")
     return LIB
 
 

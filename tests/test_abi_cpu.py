@@ -271,3 +271,20 @@ def test_small_channel_conv_dispatch_host_side_without_gpu():
         assert lib.dmc_conv_nhwc_stat_blocks(240, 112, 112, 16, 16, 3, 1, 1) == (240 * 112 * 112 + 255) // 256
     finally:
         _lib.check(lib.dmc_set_option(b"conv_cfg", 0), "dmc_set_option")
+
+
+def test_build_manifest_describes_the_library_on_disk():
+    """build() decides by CONTENT: the manifest next to the library holds the sha256 of every source it was built from and of the
+    library itself; an unchanged tree is recognised as up to date (no compiler run), and the record says which it was."""
+    import importlib.util
+    import __graft_entry__ as G
+    G.build()
+    spec = importlib.util.spec_from_file_location("_dmc_build_t", os.path.join(G.ROOT, "dmc-net_amd", "build.py"))
+    B = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(B)
+    m = B.read_manifest()
+    assert m is not None and m["sources"] == B.source_hashes() and m["library_sha256"] == B._sha(B.LIB)
+    assert any(k.endswith("coviar_post.hip") for k in m["sources"]) and "include/dmcnet_hip.h" in m["sources"]
+    assert not B._stale()
+    B.build_library()
+    assert B.LAST_BUILD["action"].startswith("up to date")
