@@ -856,13 +856,18 @@ __global__ __launch_bounds__(S3_DG_WAVES * 64) void stem3d_dgrad4_kernel(Stem3dD
 // row) pair of the block it reaches: wave w uses it with kz = w + 6 - 2 od_l (if that is a tap) and, for its row h_l, with
 // ky = h_l + 6 - 2 oh_l -- both static in the unrolled code, so accumulator indices are compile-time.  A dy row is read from
 // L2 once per ~0.9 rows of dx (the row kernel: 2.6 GB through the L2 per launch, here 0.55 GB).  Pixel rows and weight rows
-// are 144 bytes apart in LDS (128 + 16): a ds_read_b128 of 16 consecutive rows touches every bank once.  The fold of Q
+// are 128 bytes with their 16-byte pieces XOR-swizzled (d3_swz): fragment reads and staging stores touch every bank once.  The fold of Q
 // into dx goes through slots in LDS (see below).  OW <= 112.
 // ------------------------------------------------------------------------------------------
-constexpr int D3_PITCH = 144;
-constexpr int D3_W_BYTES = S3_KB * 16 * D3_PITCH;          // 112,896
-constexpr int D3_ROW_BYTES = 128 * D3_PITCH;               // 18,432 (128 pixels)
-constexpr int D3_LDS = D3_W_BYTES + 2 * D3_ROW_BYTES;      // 149,760: weights | two dy rows (the fold's rows, 4 x 7,424, at a block's end)
+constexpr int D3_PITCH = 128;                              // rows of 128 bytes = eight 16-byte pieces; piece p of row r lives in piece p ^ d3_swz(r)
+constexpr int D3_W_BYTES = S3_KB * 16 * D3_PITCH;          // 100,352
+constexpr int D3_ROW_BYTES = 128 * D3_PITCH;               // 16,384 (128 pixels)
+constexpr int D3_LDS = D3_W_BYTES + 2 * D3_ROW_BYTES;      // 133,120: weights | two dy rows (the fold's rows, 4 x 7,424, at a block's end)
+// The 16 lanes a ds_read_b128 serves together are {0-3, 12-15, 20-27} (+ 4 / + 32 / + 36 for the other three groups): in a
+// 16 x 16 x 32 fragment read, rows 0-3 and 12-15 of one k-group and rows 4-11 of the next.  With 128-byte rows (bank = 8 (r & 1) +
+// piece) the XOR below sends them to sixteen different 16-byte bank groups, and the staging stores (8 pieces of 8 pixels per wave) as
+// well; a 144-byte pitch was conflict-free within a k-group only (LDS bank-conflict share 0.45, profiles/r6_pmc_i3d_kernels.csv).
+__device__ __forceinline__ int d3_swz(int row) { return ((row >> 1) & 3) << 1; }
 constexpr int D3_MT = 7;
 
 __global__ __launch_bounds__(256) void stem3d_dgrad_blk_kernel(Stem3dDgArgs a) {
@@ -872,7 +877,7 @@ __global__ __launch_bounds__(256) void stem3d_dgrad_blk_kernel(Stem3dDgArgs a) {
     const int l15 = lane & 15, kg = lane >> 4;
     for (int i = tid; i < S3_KB * 16 * 8; i += 256) {      // the packed weights [49][16][64] -> rows of 144 bytes
         const int row = i >> 3, piece = i & 7;
-        *reinterpret_cast<u32x4*>(d3_lds + row * D3_PITCH + piece * 16) = *reinterpret_cast<const u32x4*>(a.wq + row * S3_CO + piece * 8);
+        *reinterpret_cast<u32x4*>(d3_lds + row * D3_PITCH + (piece ^ d3_swz(row)) * 16) = *reinterpret_cast<const u32x4*>(a.wq + row * S3_CO + piece * 8);
     }
     char* rows = d3_lds + D3_W_BYTES;
     for (int i = tid; i < 2 * D3_ROW_BYTES / 16; i += 256) reinterpret_cast<u32x4*>(rows)[i] = u32x4{0u, 0u, 0u, 0u};   // pixels >= OW stay zero
@@ -880,7 +885,8 @@ __global__ __launch_bounds__(256) void stem3d_dgrad_blk_kernel(Stem3dDgArgs a) {
     const int total = a.N * tblocks * hblocks;
     const int pieces = a.OW * 8;                           // 16-byte pieces of a dy row
     const long plane = (long)a.T * a.H * a.W;
-    const int wfrag = l15 * D3_PITCH + kg * 16;            // this lane's 16 bytes of a weight block / of a 16-pixel tile (+ 64 per k-step)
+    const int wfrag = l15 * D3_PITCH + (kg ^ d3_swz(l15)) * 16;   // this lane's 16 bytes of a weight block / of a 16-pixel tile, first k-step
+    const int dk = (d3_swz(l15) & 4) ? -64 : 64;           // ... to the second k-step (piece ^ 4)
     __syncthreads();
 #ifdef D3_TIMING
     long long tm[6] = {0, 0, 0, 0, 0, 0}, tq = (long long)__builtin_amdgcn_s_memtime();
@@ -927,7 +933,7 @@ __global__ __launch_bounds__(256) void stem3d_dgrad_blk_kernel(Stem3dDgArgs a) {
             for (int k = 0; k < 4; ++k) {
                 int p = tid + 256 * k;
                 p = p < pieces ? p : pieces - 1;
-                *reinterpret_cast<u32x4*>(rows + buf * D3_ROW_BYTES + (p >> 3) * D3_PITCH + (p & 7) * 16) = R[k];
+                *reinterpret_cast<u32x4*>(rows + buf * D3_ROW_BYTES + (p >> 3) * D3_PITCH + ((p & 7) ^ d3_swz(p >> 3)) * 16) = R[k];
             }
         };
         g_load(0, 0, sv[0]);
@@ -961,7 +967,7 @@ __global__ __launch_bounds__(256) void stem3d_dgrad_blk_kernel(Stem3dDgArgs a) {
                         const int ky = r + 6 - 2 * oh_l;           // compile-time
                         if (ky < 0 || ky >= S3_K) continue;
 #pragma unroll
-                        for (int ks = 0; ks < 2; ++ks) bf[r][ks] = *reinterpret_cast<const u32x4*>(wkz + ky * 16 * D3_PITCH + ks * 64);
+                        for (int ks = 0; ks < 2; ++ks) bf[r][ks] = *reinterpret_cast<const u32x4*>(wkz + ky * 16 * D3_PITCH + ks * dk);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     int nread = 0;
@@ -974,14 +980,14 @@ __global__ __launch_bounds__(256) void stem3d_dgrad_blk_kernel(Stem3dDgArgs a) {
                             acc[r][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af0[m]),
                                                                                  __builtin_bit_cast(bf16x8, bf[r][0]), acc[r][m], 0, 0, 0);
                             if ((m & 1) == 0 && nread < D3_MT) {
-                                af1[nread] = *reinterpret_cast<const u32x4*>(rb + nread * 16 * D3_PITCH + 64);
+                                af1[nread] = *reinterpret_cast<const u32x4*>(rb + nread * 16 * D3_PITCH + dk);
                                 ++nread;
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         }
                     }
 #pragma unroll
-                    for (; nread < D3_MT; ++nread) af1[nread] = *reinterpret_cast<const u32x4*>(rb + nread * 16 * D3_PITCH + 64);
+                    for (; nread < D3_MT; ++nread) af1[nread] = *reinterpret_cast<const u32x4*>(rb + nread * 16 * D3_PITCH + dk);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int r = 0; r < 8; ++r) {
@@ -1041,9 +1047,9 @@ __global__ __launch_bounds__(256) void stem3d_dgrad_blk_kernel(Stem3dDgArgs a) {
             }
         }
         __syncthreads();
-        for (int i = tid; i < 2 * (112 - a.OW) * 9; i += 256) {    // narrow frames: pixels OW .. 111 of the dy buffers are zeros again
-            const int bufi = i / ((112 - a.OW) * 9), rem = i - bufi * (112 - a.OW) * 9;
-            *reinterpret_cast<u32x4*>(rows + bufi * D3_ROW_BYTES + (a.OW + rem / 9) * D3_PITCH + (rem % 9) * 16) = u32x4{0u, 0u, 0u, 0u};
+        for (int i = tid; i < 2 * (112 - a.OW) * 8; i += 256) {    // narrow frames: pixels OW .. 111 of the dy buffers are zeros again
+            const int bufi = i / ((112 - a.OW) * 8), rem = i - bufi * (112 - a.OW) * 8;
+            *reinterpret_cast<u32x4*>(rows + bufi * D3_ROW_BYTES + (a.OW + (rem >> 3)) * D3_PITCH + (rem & 7) * 16) = u32x4{0u, 0u, 0u, 0u};
         }
         D3_LAP(4)
         __syncthreads();                                   // the dy buffers are the next block's again
