@@ -41,6 +41,12 @@ __device__ __forceinline__ MvRec load_mv(const unsigned char* __restrict__ mvs, 
     return r;
 }
 
+// a pixel's entry in the maps the owner pass writes: the displacement (src - dst) of the LAST vector that covers it
+constexpr int DISP_NONE = (int)0x80008000u;                // (-32768, -32768): no displacement between two in-frame positions
+__device__ __forceinline__ int pack_disp(int ddx, int ddy) { return (int)(((unsigned)ddx & 0xffffu) | ((unsigned)ddy << 16)); }
+__device__ __forceinline__ int disp_x(int d) { return (int)(short)(d & 0xffff); }
+__device__ __forceinline__ int disp_y(int d) { return d >> 16; }
+
 // Owner pass, tile by tile in LDS.  (The first form did one GLOBAL atomicMax per (vector, block pixel) into owner maps that do
 // not fit the L2 -- 105 M read-modify-writes against HBM for the 120-chain batch, 240 us plus a 38 us clear.)  A workgroup owns
 // one 32 x 128 pixel tile of one frame (16 KB of LDS; 0.278 ms per batch against 0.291 for 64 x 64, 0.332 for 64 x 32 and 0.367 for
@@ -104,10 +110,21 @@ __global__ __launch_bounds__(256) void mv_owner_tile_kernel(const unsigned char*
     for (int o = 32; o > 0; o >>= 1) nbad += __shfl_xor(nbad, o, 64);
     if (nbad != 0 && bad_source != nullptr && blockIdx.x == 0 && lane == 0) atomicAdd(bad_source, nbad);
     __syncthreads();
+    // What goes out is not the owner's index but what every consumer wants of it: its displacement (src - dst), two int16 in one
+    // word (both positions lie inside the frame, :100-103, so it fits), DISP_NONE where no vector landed.  The walk through a
+    // chain then makes ONE dependent load per frame instead of two (owner, then its record): MV + residual 0.367 -> 0.334 ms per batch.
     int* __restrict__ plane = owner + (size_t)f * H * W;
     for (int k = tid; k < OT_W * OT_H; k += 256) {
         const int px = x0 + k % OT_W, py = y0 + k / OT_W;
-        if (px < W && py < H) plane[py * W + px] = tile[k];
+        if (px < W && py < H) {
+            const int o = tile[k];
+            int d = DISP_NONE;
+            if (o >= 0) {
+                const MvRec m = load_mv(mvs, stride, o);
+                d = pack_disp(m.sx - m.dx, m.sy - m.dy);
+            }
+            plane[py * W + px] = d;
+        }
     }
 }
 
@@ -116,10 +133,9 @@ __global__ __launch_bounds__(256) void mv_rasterise_kernel(const unsigned char* 
                                                            const int* __restrict__ owner, int* __restrict__ mv_out, int H, int W) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= H * W) return;
-    const int o = owner[p];
-    if (o < 0) return;
-    const MvRec m = load_mv(mvs, stride, o);
-    reinterpret_cast<int2*>(mv_out)[p] = make_int2(m.dx - m.sx, m.dy - m.sy);
+    const int d = owner[p];
+    if (d == DISP_NONE) return;
+    reinterpret_cast<int2*>(mv_out)[p] = make_int2(-disp_x(d), -disp_y(d));
 }
 
 // accumulating branch, :105-110, one frame: accu_new[dst] = accu_old[src] for covered pixels, accu_old[dst] for the
@@ -131,12 +147,11 @@ __global__ __launch_bounds__(256) void mv_accumulate_kernel(const unsigned char*
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= H * W) return;
     const int x = q / H, y = q % H;
-    const int o = owner[y * W + x];
+    const int d = owner[y * W + x];
     int sx = x, sy = y;
-    if (o >= 0) {
-        const MvRec m = load_mv(mvs, stride, o);
-        sx = x + m.sx - m.dx;
-        sy = y + m.sy - m.dy;
+    if (d != DISP_NONE) {
+        sx = x + disp_x(d);
+        sy = y + disp_y(d);
     }
     reinterpret_cast<int2*>(accu_new)[q] = reinterpret_cast<const int2*>(accu_old)[sx * H + sy];
 }
@@ -181,35 +196,52 @@ __global__ __launch_bounds__(256) void residual_kernel(const unsigned char* __re
 // Whole batch: one thread per (chain, pixel) walks back through the chain's owner planes.  chain_off [n_chains + 1]
 // indexes frames; emit [n_chains] (nullable = all 1): 0 leaves the chain's outputs untouched (the reference's
 // `cur_pos > 0` / `if (sd)` gates, :128 and :363).
+// TRACE_PPT pixels per thread, their walks interleaved (a walk is a chain of dependent gathers, one per frame).  Measured on the
+// 120-chain batch: 1 pixel 0.278 ms, 2 pixels 0.274-0.284, 4 pixels 0.305 -- the kernel is not short of gathers in flight; 1 it is.
+constexpr int TRACE_PPT = 1;
 __global__ __launch_bounds__(256) void gop_trace_kernel(const unsigned char* __restrict__ mvs, int stride, const int* __restrict__ chain_off,
                                                         const int* __restrict__ emit, const int* __restrict__ owner,
                                                         const unsigned char* __restrict__ ref, const unsigned char* __restrict__ cur,
                                                         int* __restrict__ accu_out, int* __restrict__ mv_out, int* __restrict__ res_out,
                                                         int H, int W) {
     const int c = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= H * W) return;
     if (emit != nullptr && emit[c] == 0) return;
-    const int x0 = p % W, y0 = p / W;
-    int x = x0, y = y0;
+    const int npx = H * W;
+    int p[TRACE_PPT], x[TRACE_PPT], y[TRACE_PPT];
+#pragma unroll
+    for (int j = 0; j < TRACE_PPT; ++j) {
+        p[j] = (blockIdx.x * TRACE_PPT + j) * 256 + threadIdx.x;
+        const int q = p[j] < npx ? p[j] : npx - 1;         // (beyond the frame: the last pixel's walk again, nothing stored)
+        x[j] = q % W;
+        y[j] = q / W;
+    }
     const int f0 = chain_off[c], f1 = chain_off[c + 1];
     const size_t hw = (size_t)H * W;
     for (int f = f1 - 1; f >= f0; --f) {
-        const int o = owner[f * hw + (size_t)y * W + x];
-        if (o >= 0) {
-            const MvRec m = load_mv(mvs, stride, o);
-            x += m.sx - m.dx;
-            y += m.sy - m.dy;
-        }
-    }
-    if (accu_out != nullptr) reinterpret_cast<int2*>(accu_out + (size_t)c * hw * 2)[x0 * H + y0] = make_int2(x, y);
-    if (mv_out != nullptr) reinterpret_cast<int2*>(mv_out + (size_t)c * hw * 2)[p] = make_int2(x0 - x, y0 - y);
-    if (res_out != nullptr) {
-        const unsigned char* __restrict__ r = ref + (size_t)c * hw * 3 + ((size_t)y * W + x) * 3;
-        const unsigned char* __restrict__ k = cur + (size_t)c * hw * 3 + (size_t)p * 3;
-        int* __restrict__ out = res_out + (size_t)c * hw * 3 + (size_t)p * 3;
+        const int* __restrict__ plane = owner + f * hw;
+        int d[TRACE_PPT];
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) out[ch] = (int)k[ch] - (int)r[ch];
+        for (int j = 0; j < TRACE_PPT; ++j) d[j] = plane[y[j] * W + x[j]];
+#pragma unroll
+        for (int j = 0; j < TRACE_PPT; ++j)
+            if (d[j] != DISP_NONE) {
+                x[j] += disp_x(d[j]);
+                y[j] += disp_y(d[j]);
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < TRACE_PPT; ++j) {
+        if (p[j] >= npx) continue;
+        const int x0 = p[j] % W, y0 = p[j] / W;
+        if (accu_out != nullptr) reinterpret_cast<int2*>(accu_out + (size_t)c * hw * 2)[x0 * H + y0] = make_int2(x[j], y[j]);
+        if (mv_out != nullptr) reinterpret_cast<int2*>(mv_out + (size_t)c * hw * 2)[p[j]] = make_int2(x0 - x[j], y0 - y[j]);
+        if (res_out != nullptr) {
+            const unsigned char* __restrict__ r = ref + (size_t)c * hw * 3 + ((size_t)y[j] * W + x[j]) * 3;
+            const unsigned char* __restrict__ k = cur + (size_t)c * hw * 3 + (size_t)p[j] * 3;
+            int* __restrict__ out = res_out + (size_t)c * hw * 3 + (size_t)p[j] * 3;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) out[ch] = (int)k[ch] - (int)r[ch];
+        }
     }
 }
 
@@ -299,7 +331,7 @@ int dmc_mv_gop_batch(const void* mvs, int mv_stride, int n_mv, const int32_t* fr
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (n_frames > 0)
         if (int rc = owner_pass("dmc_mv_gop_batch", mvs, mv_stride, frame_off, n_frames, n_mv, owner_ws, H, W, bad_source, s)) return rc;
-    gop_trace_kernel<<<dim3((H * W + 255) / 256, n_chains), 256, 0, s>>>(static_cast<const unsigned char*>(mvs), mv_stride, chain_off, emit,
+    gop_trace_kernel<<<dim3((H * W + 256 * TRACE_PPT - 1) / (256 * TRACE_PPT), n_chains), 256, 0, s>>>(static_cast<const unsigned char*>(mvs), mv_stride, chain_off, emit,
                                                                          owner_ws, bgr_ref, bgr_cur, accu_out, mv_out, res_out, H, W);
     return check_launch("dmc_mv_gop_batch");
 }

@@ -639,8 +639,8 @@ int dmc_stem3d_bf16_dgrad(const void* dy, const float* w, float* dx, void* works
  * Accumulators use the reference's TRANSPOSED layout, accu[x * H * 2 + y * 2 + c] (:107-108); MV planes are int32
  * [H][W][2] and residuals int32 [H][W][3] as its numpy arrays (:292-309); BGR frames uint8 [H][W][3].
  * Overlapping blocks: the LATER vector of the list wins, as in the sequential loop (realised as the per-pixel maximum of
- * the covering vectors' indices, resolved tile by tile in LDS and written to
- * owner_ws, int32 [H][W]: order-independent, bit-exact).  Vectors with zero displacement are skipped (:88); a (block pixel) is written only when destination AND source are inside the frame (:100-103).
+ * the covering vectors' indices, resolved tile by tile in LDS; owner_ws, int32 [H][W], receives the winner's displacement
+ * (src - dst) as two int16: order-independent, bit-exact).  Vectors with zero displacement are skipped (:88); a (block pixel) is written only when destination AND source are inside the frame (:100-103).
  * bad_source (nullable): device int32 incremented once per vector whose `source` is not -1 (the reference asserts, :86).
  *
  *   dmc_mv_accu_init   :311-318  accu = identity (x, y)
