@@ -134,10 +134,12 @@ SIGNATURES = {
     "dmc_bn3d_bf16_supported": (_I, [_L, _I]),
     "dmc_bn3d_bf16_scratch_bytes": (_Z, [_I]),
     "dmc_bn3d_bf16_fwd": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _F, _P]),
+    "dmc_bn3d_bf16_fwd_ld": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _F, _F, _P]),
     "dmc_bn3d_bf16_bwd": (_I, [_P, _L] + [_P] * 8 + [_L, _I, _I, _P]),
     "dmc_unit3d_bf16_fwd_workspace_bytes": (_Z, [_I] * 9),
     "dmc_unit3d_bf16_bwd_workspace_bytes": (_Z, [_I] * 9),
     "dmc_unit3d_bf16_fwd": (_I, [_P] * 9 + [_I] * 10 + [_F, _F, _P]),
+    "dmc_unit3d_bf16_fwd_into": (_I, [_P] * 9 + [_L] + [_I] * 10 + [_F, _F, _P]),
     "dmc_unit3d_bf16_bwd": (_I, [_P, _L] + [_P] * 11 + [_I] * 10 + [_P]),
     "dmc_maxpool3d_tf_out_shape": (_I, [_I] * 10 + [_P] * 3),
     "dmc_maxpool3d_tf_bf16_fwd": (_I, [_P] * 3 + [_I] * 11 + [_P]),

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void bn3d_stats_final_kernel(const float* __re
 
 __global__ __launch_bounds__(256) void bn3d_apply_kernel(const bf16_t* __restrict__ y, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         bf16_t* __restrict__ out, long M, int C, int relu) {
+                                                         bf16_t* __restrict__ out, long M, int C, int relu, long out_ld) {
     const int C8 = C >> 3, P = 256 / C8;
     const int chunk = threadIdx.x % C8, pl = threadIdx.x / C8;
     if (pl >= P) return;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void bn3d_apply_kernel(const bf16_t* __restric
             f[e] = f[e] * sc[e] + sh[e];
             if (relu) f[e] = f[e] > 0.f ? f[e] : 0.f;
         }
-        *reinterpret_cast<u32x4*>(out + m * C + 8 * chunk) = pack8(f);
+        *reinterpret_cast<u32x4*>(out + m * out_ld + 8 * chunk) = pack8(f);
     }
 }
 
@@ -216,18 +216,26 @@ size_t dmc_bn3d_bf16_scratch_bytes(int C) { return ((size_t)BN3_MAXBLK * C * 2 +
 
 // stats [2*C] = (mean, invstd) from the convolution's partials [nblk][C][2] (dmc_conv3d_bf16_fwd with stat_partials);
 // running_mean / running_var updated as nn.BatchNorm3d does (NULL to skip); then out = relu?(bn(y)) in bf16
-int dmc_bn3d_bf16_fwd(const void* y, const float* partials, int nblk, const float* gamma, const float* beta, float* stats,
-                      float* running_mean, float* running_var, void* out, long M, int C, int relu, float eps, float momentum,
-                      dmc_stream_t stream) {
+// out_ld: elements between consecutive pixels of `out` (C for a dense tensor; the width of the concatenated tensor when `out` is a
+// channel slice of an Inception block's output, which is then written in place -- no torch.cat afterwards)
+int dmc_bn3d_bf16_fwd_ld(const void* y, const float* partials, int nblk, const float* gamma, const float* beta, float* stats,
+                         float* running_mean, float* running_var, void* out, long out_ld, long M, int C, int relu, float eps,
+                         float momentum, dmc_stream_t stream) {
     if (!y || !partials || !gamma || !beta || !stats || !out || nblk <= 0) return fail(DMC_E_INVALID, "dmc_bn3d_bf16_fwd: bad argument");
     if (!bn3_ok(M, C)) return fail(DMC_E_INVALID, "dmc_bn3d_bf16_fwd: unsupported shape M=%ld C=%d", M, C);
+    if (out_ld < C || out_ld % 8 != 0 || ((size_t)out & 15)) return fail(DMC_E_INVALID, "dmc_bn3d_bf16_fwd: out_ld=%ld / out must keep 16-byte pixel rows (C=%d)", out_ld, C);
     hipStream_t s = (hipStream_t)stream;
     if (!DMC_ABL(option(OPT_CONV_ABLATE) & 1024))   // measurement build: the per-channel finalisation launches
     bn3d_stats_final_kernel<<<C, 256, 0, s>>>(partials, nblk, C, M, stats, running_mean, running_var, eps, momentum);
     int rc = check_launch("bn3d_stats_final");
     if (rc) return rc;
-    bn3d_apply_kernel<<<bn3_blocks(M, C), 256, 0, s>>>((const bf16_t*)y, stats, gamma, beta, (bf16_t*)out, M, C, relu);
+    bn3d_apply_kernel<<<bn3_blocks(M, C), 256, 0, s>>>((const bf16_t*)y, stats, gamma, beta, (bf16_t*)out, M, C, relu, out_ld);
     return check_launch("bn3d_apply");
+}
+int dmc_bn3d_bf16_fwd(const void* y, const float* partials, int nblk, const float* gamma, const float* beta, float* stats,
+                      float* running_mean, float* running_var, void* out, long M, int C, int relu, float eps, float momentum,
+                      dmc_stream_t stream) {
+    return dmc_bn3d_bf16_fwd_ld(y, partials, nblk, gamma, beta, stats, running_mean, running_var, out, C, M, C, relu, eps, momentum, stream);
 }
 
 // dy (gradient of the convolution output), dgamma, dbeta from dout; scratch: dmc_bn3d_bf16_scratch_bytes(C).

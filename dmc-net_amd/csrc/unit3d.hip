@@ -41,9 +41,10 @@ size_t dmc_unit3d_bf16_bwd_workspace_bytes(int N, int D, int H, int W, int Cin, 
     return up256(dmc_bn3d_bf16_scratch_bytes(Cout)) + up256(dmc_conv3d_bf16_wgrad_bytes(N, D, H, W, Cin, Cout, KD, KH, KW));
 }
 
-int dmc_unit3d_bf16_fwd(const void* x, const float* w, const float* gamma, const float* beta, float* running_mean,
-                        float* running_var, void* workspace, void* y, void* out, int N, int D, int H, int W, int Cin, int Cout,
-                        int KD, int KH, int KW, int relu, float eps, float momentum, dmc_stream_t stream) {
+// out_ld: elements between consecutive pixels of `out` (Cout: a dense tensor; more: a channel slice of a wider NDHWC tensor)
+int dmc_unit3d_bf16_fwd_into(const void* x, const float* w, const float* gamma, const float* beta, float* running_mean,
+                             float* running_var, void* workspace, void* y, void* out, long out_ld, int N, int D, int H, int W, int Cin,
+                             int Cout, int KD, int KH, int KW, int relu, float eps, float momentum, dmc_stream_t stream) {
     if (!x || !w || !gamma || !beta || !workspace || !y || !out) return fail(DMC_E_INVALID, "dmc_unit3d_bf16_fwd: null pointer");
     const FwdLayout l = fwd_layout(N, D, H, W, Cin, Cout, KD, KH, KW);
     char* ws = static_cast<char*>(workspace);
@@ -53,8 +54,15 @@ int dmc_unit3d_bf16_fwd(const void* x, const float* w, const float* gamma, const
     rc = dmc_conv3d_bf16_fwd(x, nullptr, (long)Cin * T, T, 1, ws + l.wpack_f, y, reinterpret_cast<float*>(ws + l.part), N, D, H, W,
                              Cin, Cout, KD, KH, KW, stream);
     if (rc) return rc;
-    return dmc_bn3d_bf16_fwd(y, reinterpret_cast<const float*>(ws + l.part), l.nblk, gamma, beta, reinterpret_cast<float*>(ws + l.stats),
-                             running_mean, running_var, out, (long)N * D * H * W, Cout, relu, eps, momentum, stream);
+    return dmc_bn3d_bf16_fwd_ld(y, reinterpret_cast<const float*>(ws + l.part), l.nblk, gamma, beta, reinterpret_cast<float*>(ws + l.stats),
+                                running_mean, running_var, out, out_ld, (long)N * D * H * W, Cout, relu, eps, momentum, stream);
+}
+
+int dmc_unit3d_bf16_fwd(const void* x, const float* w, const float* gamma, const float* beta, float* running_mean,
+                        float* running_var, void* workspace, void* y, void* out, int N, int D, int H, int W, int Cin, int Cout,
+                        int KD, int KH, int KW, int relu, float eps, float momentum, dmc_stream_t stream) {
+    return dmc_unit3d_bf16_fwd_into(x, w, gamma, beta, running_mean, running_var, workspace, y, out, Cout, N, D, H, W, Cin, Cout, KD, KH,
+                                    KW, relu, eps, momentum, stream);
 }
 
 int dmc_unit3d_bf16_bwd(const void* dout, long dout_ld, const void* x, const void* y, const void* fwd_workspace, const float* gamma,

@@ -24,6 +24,8 @@ OWN_CONV3D = _os.environ.get("DMC_OWN_CONV3D", "1") != "0"
 
 #: True (default): the branches of an Inception block run on concurrent HIP streams (Mixed.forward); DMC_I3D_BRANCH_STREAMS=0: one stream
 BRANCH_STREAMS = _os.environ.get("DMC_I3D_BRANCH_STREAMS", "1") != "0"
+#: an Inception block's branches write their channels straight into the block's output (DMC_I3D_JOIN_IN_PLACE=0: torch.cat)
+JOIN_IN_PLACE = _os.environ.get("DMC_I3D_JOIN_IN_PLACE", "1") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -67,7 +69,9 @@ class Unit3Dpy(nn.Module):
             self.batch3d = nn.BatchNorm3d(out_channels)
         self.use_bn = use_bn
 
-    def forward(self, x):
+    def forward(self, x, into=None):
+        """``into`` (optional): a channel slice of a wider NDHWC tensor that may receive the result in place; whether it did is
+        ``result.data_ptr() == into.data_ptr()`` (only the fused training-mode op does, Mixed.forward)."""
         c = self.conv3d
         if (OWN_CONV3D and self.pad is not None and self.use_bn and not self.squeeze and c.kernel_size == (7, 7, 7)
                 and ops.stem3d_supported(x, c, self.batch3d)):
@@ -79,7 +83,7 @@ class Unit3Dpy(nn.Module):
                and ops.conv3d_bf16_supported(x, c.weight, c.stride, c.padding))
         if own and self.use_bn and not self.squeeze and ops.conv_bn_relu3d_supported(x, c, self.batch3d):
             # conv (batch statistics in its epilogue) -> BatchNorm3d -> ReLU as one op on the bf16 kernels
-            return ops.conv_bn_relu3d(x, c, self.batch3d, self.relu)
+            return ops.conv_bn_relu3d(x, c, self.batch3d, self.relu, into)
         if own:
             x = ops.conv3d_bf16(x, c.weight)            # bf16 NDHWC implicit GEMM on the matrix cores
         else:
@@ -121,8 +125,32 @@ class Mixed(nn.Module):
         self.branch_3 = nn.Sequential(MaxPool3dTFPadding((3, 3, 3), (1, 1, 1)),
                                       Unit3Dpy(in_channels, o[5]))
 
+    def _branches(self):
+        """(modules before the last unit, last unit) per branch"""
+        return ((None, self.branch_0), (self.branch_1[0], self.branch_1[1]), (self.branch_2[0], self.branch_2[1]),
+                (self.branch_3[0], self.branch_3[1]))
+
     def forward(self, x):
-        if BRANCH_STREAMS and OWN_CONV3D and x.is_cuda and x.dtype == torch.bfloat16:
+        own = OWN_CONV3D and x.is_cuda and x.dtype == torch.bfloat16
+        # Each branch's last unit writes its channels straight into the block's output (ops.conv_bn_relu3d(..., into=slice)): no
+        # torch.cat -- 9 concatenations of 4 strided copies each, 0.34 ms per micro-step on the chain between two blocks.
+        # (Only the fused training-mode op writes in place; anything else falls back to the concatenation.)
+        buf, slices = None, [None] * 4
+        if own and JOIN_IN_PLACE and torch.is_grad_enabled() and x.dim() == 5 and x.is_contiguous(memory_format=torch.channels_last_3d):
+            widths = [u.conv3d.out_channels for _, u in self._branches()]
+            if all(wd % 8 == 0 for wd in widths):
+                buf = torch.empty((x.shape[0], sum(widths)) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device,
+                                  memory_format=torch.channels_last_3d)
+                c0 = 0
+                for k, wd in enumerate(widths):
+                    slices[k] = buf[:, c0:c0 + wd]
+                    c0 += wd
+
+        def run(k):
+            head, last = self._branches()[k]
+            return last(x if head is None else head(x), into=slices[k])
+
+        if BRANCH_STREAMS and own:
             # The four branches are independent and, from mixed_4b on, small (9,408 or 1,176 pixels: every kernel a
             # fraction of the chip, bounded by its own latency): branches 1-3 run on side streams next to branch 0 and
             # join before the concatenation.  Autograd replays each node on its forward stream, so the backward
@@ -131,15 +159,20 @@ class Mixed(nn.Module):
             sides = _side_streams(x.device)
             outs = [None] * 4
             fork = main.record_event()               # x is ready; the side pools' blocks are free of earlier main-stream readers
-            outs[0] = self.branch_0(x)               # (autograd nodes are created in the one-stream order: the same gradient sums)
-            for k, (branch, st) in enumerate(zip((self.branch_1, self.branch_2, self.branch_3), sides)):
+            outs[0] = run(0)                         # (autograd nodes are created in the one-stream order: the same gradient sums)
+            for k, st in enumerate(sides):
                 st.wait_event(fork)
+                if buf is not None:
+                    buf.record_stream(st)
                 with torch.cuda.stream(st):
-                    outs[k + 1] = branch(x)
+                    outs[k + 1] = run(k + 1)
             for st in sides:
                 main.wait_stream(st)
-            return torch.cat(outs, 1)
-        return torch.cat((self.branch_0(x), self.branch_1(x), self.branch_2(x), self.branch_3(x)), 1)
+        else:
+            outs = [run(k) for k in range(4)]
+        if buf is not None and all(o.data_ptr() == sl.data_ptr() and o.shape == sl.shape for o, sl in zip(outs, slices)):
+            return ops.join_slices(buf, outs)
+        return torch.cat(outs, 1)
 
 
 _MIXED = (("mixed_3b", 192, (64, 96, 128, 16, 32, 32)), ("mixed_3c", 256, (128, 128, 192, 32, 96, 64)),

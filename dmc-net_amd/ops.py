@@ -1928,7 +1928,7 @@ class _ConvBnRelu3d(torch.autograd.Function):
     the backward runs the ReLU + BatchNorm backward in two passes and feeds the data / weight gradient kernels."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, eps, momentum, relu):
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, eps, momentum, relu, into=None):
         lib = _lib.load()
         if not (x.is_cuda and weight.is_cuda):
             raise _lib.DmcHipError("conv_bn_relu3d runs on the HIP extension only (no CPU fallback)")
@@ -1943,12 +1943,21 @@ class _ConvBnRelu3d(torch.autograd.Function):
         # ONE foreign call (pack + convolution with the statistics in its epilogue + BatchNorm / ReLU pass) and one
         # workspace: the trunk is bound by the host that issues its ~940 launches per micro-step (csrc/unit3d.hip)
         y = torch.empty((n, cout, d, h, w), dtype=torch.bfloat16, device=x.device, memory_format=_CL3)
-        out = torch.empty_like(y)
+        # `into`: a channel slice of a wider NDHWC tensor (an Inception block's output) that receives the result in place --
+        # the block then needs no torch.cat; autograd sees a view of it as this op's output (the buffer itself has no history)
+        if into is not None:
+            ld = into.stride(4)
+            if not (into.dtype == torch.bfloat16 and tuple(into.shape) == (n, cout, d, h, w) and ld >= cout and ld % 8 == 0
+                    and into.storage_offset() % 8 == 0 and into.stride() == (d * h * w * ld, 1, h * w * ld, w * ld, ld)):
+                raise ValueError("conv_bn_relu3d: `into` must be a channel slice of a channels_last_3d bf16 tensor of this op's shape")
+            out = into
+        else:
+            out, ld = torch.empty_like(y), cout
         ws = torch.empty(lib.dmc_unit3d_bf16_fwd_workspace_bytes(*geom), dtype=torch.uint8, device=x.device)
         with _span("conv3d_bf16_fwd"):
-            _lib.check(lib.dmc_unit3d_bf16_fwd(_lib.ptr(x), _lib.ptr(wc), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean),
-                                               _lib.ptr(running_var), _lib.ptr(ws), _lib.ptr(y), _lib.ptr(out), *geom, int(relu),
-                                               float(eps), float(momentum), _stream()), "dmc_unit3d_bf16_fwd")
+            _lib.check(lib.dmc_unit3d_bf16_fwd_into(_lib.ptr(x), _lib.ptr(wc), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean),
+                                                    _lib.ptr(running_var), _lib.ptr(ws), _lib.ptr(y), _lib.ptr(out), ld, *geom, int(relu),
+                                                    float(eps), float(momentum), _stream()), "dmc_unit3d_bf16_fwd_into")
         ctx.save_for_backward(x, weight, y, gamma, beta, ws)
         ctx.relu, ctx.geom = bool(relu), geom
         return out
@@ -1989,7 +1998,7 @@ class _ConvBnRelu3d(torch.autograd.Function):
                 dw = _on_wgrad_stream(weight, (x, dy), launch)
         if dx is not None and not ctx.x_was_cl3:
             dx = dx.contiguous()
-        return dx, dw, dgamma, dbeta, None, None, None, None, None
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, None
 
 
 def conv_bn_relu3d_supported(x, conv, bn):
@@ -2002,16 +2011,39 @@ def conv_bn_relu3d_supported(x, conv, bn):
     return bool(_lib.load().dmc_bn3d_bf16_supported(n * d * h * w, conv.out_channels))
 
 
-def conv_bn_relu3d(x, conv, bn, relu=True):
+def conv_bn_relu3d(x, conv, bn, relu=True, into=None):
     """relu?(bn(conv(x))) for a bf16 ``x`` (see conv_bn_relu3d_supported); updates the running statistics and
-    ``num_batches_tracked`` as nn.BatchNorm3d does."""
+    ``num_batches_tracked`` as nn.BatchNorm3d does.  ``into``: see _ConvBnRelu3d.forward."""
     if bn.num_batches_tracked is not None:
         if _PENDING_COUNTERS is not None:
             _PENDING_COUNTERS.append(bn.num_batches_tracked)
         else:
             bn.num_batches_tracked.add_(1)
     return _ConvBnRelu3d.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum,
-                               bool(relu))
+                               bool(relu), into)
+
+
+class _JoinSlices(torch.autograd.Function):
+    """The concatenation that already happened: ``parts`` are channel slices of ``buf`` that their producers wrote in place
+    (conv_bn_relu3d(..., into=...)).  Forward hands out ``buf``; backward hands each producer its slice of the gradient -- what
+    torch.cat's backward does, without the forward copies."""
+
+    @staticmethod
+    def forward(ctx, buf, *parts):
+        ctx.widths = [p.shape[1] for p in parts]
+        return buf.view(buf.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, c = [], 0
+        for wd in ctx.widths:
+            outs.append(g[:, c:c + wd])
+            c += wd
+        return (None,) + tuple(outs)
+
+
+def join_slices(buf, parts):
+    return _JoinSlices.apply(buf, *parts)
 
 
 class _Stem3dBnRelu(torch.autograd.Function):

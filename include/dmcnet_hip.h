@@ -587,6 +587,11 @@ size_t dmc_bn3d_bf16_scratch_bytes(int C);
 int dmc_bn3d_bf16_fwd(const void* y, const float* partials, int nblk, const float* gamma, const float* beta, float* stats,
                       float* running_mean, float* running_var, void* out, long M, int C, int relu, float eps, float momentum,
                       dmc_stream_t stream);
+/* the same with `out` a channel slice of a wider NDHWC tensor: out_ld = elements between consecutive pixels of `out` (a multiple
+ * of 8, >= C; `out` 16-byte aligned) -- an Inception branch writes its part of the block's output in place (no concatenation) */
+int dmc_bn3d_bf16_fwd_ld(const void* y, const float* partials, int nblk, const float* gamma, const float* beta, float* stats,
+                         float* running_mean, float* running_var, void* out, long out_ld, long M, int C, int relu, float eps,
+                         float momentum, dmc_stream_t stream);
 int dmc_bn3d_bf16_bwd(const void* dout, long dout_ld, const void* y, const float* stats, const float* gamma, const float* beta,
                       float* scratch, void* dy, float* dgamma, float* dbeta, long M, int C, int relu, dmc_stream_t stream);
 
@@ -603,6 +608,10 @@ size_t dmc_unit3d_bf16_bwd_workspace_bytes(int N, int D, int H, int W, int Cin, 
 int dmc_unit3d_bf16_fwd(const void* x, const float* w, const float* gamma, const float* beta, float* running_mean,
                         float* running_var, void* workspace, void* y, void* out, int N, int D, int H, int W, int Cin, int Cout,
                         int KD, int KH, int KW, int relu, float eps, float momentum, dmc_stream_t stream);
+/* dmc_unit3d_bf16_fwd with `out` a channel slice of a wider NDHWC tensor (see dmc_bn3d_bf16_fwd_ld) */
+int dmc_unit3d_bf16_fwd_into(const void* x, const float* w, const float* gamma, const float* beta, float* running_mean,
+                             float* running_var, void* workspace, void* y, void* out, long out_ld, int N, int D, int H, int W, int Cin,
+                             int Cout, int KD, int KH, int KW, int relu, float eps, float momentum, dmc_stream_t stream);
 int dmc_unit3d_bf16_bwd(const void* dout, long dout_ld, const void* x, const void* y, const void* fwd_workspace, const float* gamma,
                         const float* beta, void* bwd_workspace, void* dy, void* dx, float* dw, float* dgamma, float* dbeta, int N,
                         int D, int H, int W, int Cin, int Cout, int KD, int KH, int KW, int relu, dmc_stream_t stream);

@@ -543,3 +543,27 @@ def test_i3d_trunk_conditioned_gradients_vs_fp32():
         c_own, c_stock = cos(g_own[k], g_32[k]), cos(g_stock[k], g_32[k])
         print("  conditioned grad cos vs fp32  %-40s own %.4f  stock bf16 %.4f" % (k, c_own, c_stock))
         assert c_own >= 0.9 and c_own >= c_stock - 0.03, (k, c_own, c_stock)
+
+
+@pytest.mark.parametrize("streams", [False, True])
+def test_inception_block_in_place_join_equals_concatenation(streams, monkeypatch):
+    """Mixed.forward with each branch's last unit writing its channels into the block's output (ops.conv_bn_relu3d(..., into=slice) +
+    ops.join_slices) against the same block with torch.cat: output, the input's gradient, every parameter gradient and the BatchNorm
+    running statistics BIT FOR BIT, on one stream and on branch streams; a second block behind it (its four data gradients are the
+    sums the first block's join receives)."""
+    res = []
+    for in_place in (False, True):
+        monkeypatch.setattr(i3d, "JOIN_IN_PLACE", in_place)
+        monkeypatch.setattr(i3d, "BRANCH_STREAMS", streams)
+        torch.manual_seed(21)
+        blocks = torch.nn.Sequential(i3d.Mixed(64, (32, 48, 64, 16, 24, 24)), i3d.Mixed(144, (48, 32, 40, 8, 16, 16))).to(DEV).train()
+        x = torch.randn(2, 64, 4, 14, 14, device=DEV).bfloat16().contiguous(memory_format=CL3).requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = blocks(x)
+        assert tuple(y.shape) == (2, 120, 4, 14, 14) and y.is_contiguous(memory_format=CL3)
+        g = torch.randn_like(y)
+        y.backward(g)
+        torch.cuda.synchronize()
+        res.append([y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in blocks.parameters()] + [b.clone() for b in blocks.buffers()])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
