@@ -134,6 +134,7 @@ SIGNATURES = {
     "dmc_bn3d_bf16_supported": (_I, [_L, _I]),
     "dmc_bn3d_bf16_scratch_bytes": (_Z, [_I]),
     "dmc_bn3d_bf16_fwd": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _F, _P]),
+    "dmc_add4_bf16": (_I, [_P] * 5 + [_L, _P]),
     "dmc_bn3d_bf16_fwd_ld": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _F, _F, _P]),
     "dmc_bn3d_bf16_bwd": (_I, [_P, _L] + [_P] * 8 + [_L, _I, _I, _P]),
     "dmc_unit3d_bf16_fwd_workspace_bytes": (_Z, [_I] * 9),

@@ -196,6 +196,22 @@ __global__ __launch_bounds__(256) void bn3d_bwd_apply_kernel(const bf16_t* __res
     }
 }
 
+// out = ((a + b) + c) + d, every sum rounded to bf16 -- what three torch additions of bf16 tensors produce, in one pass (the gradient
+// of an Inception block's input is the sum of its four branches' data gradients: 27 additions per micro-step, 9 launches here)
+__global__ __launch_bounds__(256) void add4_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, const bf16_t* __restrict__ c,
+                                                        const bf16_t* __restrict__ d, bf16_t* __restrict__ out, long n8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        float fa[8], fb[8], fc[8], fd[8];
+        unpack8(reinterpret_cast<const u32x4*>(a)[i], fa);
+        unpack8(reinterpret_cast<const u32x4*>(b)[i], fb);
+        unpack8(reinterpret_cast<const u32x4*>(c)[i], fc);
+        unpack8(reinterpret_cast<const u32x4*>(d)[i], fd);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fa[e] = bf2f(f2bf(bf2f(f2bf(fa[e] + fb[e])) + fc[e])) + fd[e];
+        reinterpret_cast<u32x4*>(out)[i] = pack8(fa);
+    }
+}
+
 bool bn3_ok(long M, int C) { return M > 0 && C > 0 && C % 8 == 0 && C <= 2048; }
 int bn3_blocks(long M, int C) {
     const int P = 256 / (C / 8);
@@ -257,6 +273,17 @@ int dmc_bn3d_bf16_bwd(const void* dout, long dout_ld, const void* y, const float
     if ((rc = check_launch("bn3d_bwd_final"))) return rc;
     bn3d_bwd_apply_kernel<<<nblk, 256, 0, s>>>((const bf16_t*)dout, (const bf16_t*)y, stats, gamma, beta, coef, (bf16_t*)dy, M, C, relu, dout_ld);
     return check_launch("bn3d_bwd_apply");
+}
+
+// out = ((a + b) + c) + d on bf16 tensors of n elements (n % 8 == 0, 16-byte aligned), each sum rounded to bf16 as torch's additions are
+int dmc_add4_bf16(const void* a, const void* b, const void* c, const void* d, void* out, long n, dmc_stream_t stream) {
+    if (!a || !b || !c || !d || !out || n <= 0 || n % 8 != 0 || (((size_t)a | (size_t)b | (size_t)c | (size_t)d | (size_t)out) & 15))
+        return fail(DMC_E_INVALID, "dmc_add4_bf16: null / unaligned pointer or n %% 8 != 0");
+    const long n8 = n / 8;
+    const long blocks = (n8 + 255) / 256;
+    add4_bf16_kernel<<<(int)(blocks > 4096 ? 4096 : blocks), 256, 0, (hipStream_t)stream>>>((const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)c,
+                                                                                           (const bf16_t*)d, (bf16_t*)out, n8);
+    return check_launch("add4_bf16");
 }
 
 }  // extern "C"

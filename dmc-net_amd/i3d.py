@@ -26,6 +26,8 @@ OWN_CONV3D = _os.environ.get("DMC_OWN_CONV3D", "1") != "0"
 BRANCH_STREAMS = _os.environ.get("DMC_I3D_BRANCH_STREAMS", "1") != "0"
 #: an Inception block's branches write their channels straight into the block's output (DMC_I3D_JOIN_IN_PLACE=0: torch.cat)
 JOIN_IN_PLACE = _os.environ.get("DMC_I3D_JOIN_IN_PLACE", "1") != "0"
+#: the four data gradients of a block's input summed by one kernel (DMC_I3D_FANOUT_ADD=0: the autograd engine's three additions)
+FANOUT_ADD = _os.environ.get("DMC_I3D_FANOUT_ADD", "1") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -146,9 +148,12 @@ class Mixed(nn.Module):
                     slices[k] = buf[:, c0:c0 + wd]
                     c0 += wd
 
+        # the four consumers of x: their data gradients are summed in one pass (ops.fanout4) instead of three additions
+        xs = ops.fanout4(x) if (own and FANOUT_ADD and torch.is_grad_enabled() and x.requires_grad) else (x, x, x, x)
+
         def run(k):
             head, last = self._branches()[k]
-            return last(x if head is None else head(x), into=slices[k])
+            return last(xs[k] if head is None else head(xs[k]), into=slices[k])
 
         if BRANCH_STREAMS and own:
             # The four branches are independent and, from mixed_4b on, small (9,408 or 1,176 pixels: every kernel a

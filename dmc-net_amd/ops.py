@@ -2046,6 +2046,35 @@ def join_slices(buf, parts):
     return _JoinSlices.apply(buf, *parts)
 
 
+class _Fanout4(torch.autograd.Function):
+    """x handed to four consumers; backward adds their four gradients in ONE pass (dmc_add4_bf16) instead of the engine's three
+    additions -- in the engine's order (the consumer created last delivers first) and with its bf16 rounding after every sum, so
+    the result is bit for bit the engine's."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return tuple(x.view(x.shape) for _ in range(4))
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2, g3):
+        gs = [g for g in (g3, g2, g1, g0) if g is not None]
+        if (len(gs) == 4 and all(g.is_cuda and g.dtype == torch.bfloat16 and g.shape == gs[0].shape and g.stride() == gs[0].stride()
+                                 and g.storage_offset() % 8 == 0 for g in gs)
+                and gs[0].numel() % 8 == 0 and (gs[0].is_contiguous() or gs[0].is_contiguous(memory_format=_CL3))):
+            out = torch.empty_like(gs[0])
+            _lib.check(_lib.load().dmc_add4_bf16(_lib.ptr(gs[0]), _lib.ptr(gs[1]), _lib.ptr(gs[2]), _lib.ptr(gs[3]), _lib.ptr(out),
+                                                 out.numel(), _stream()), "dmc_add4_bf16")
+            return out
+        r = None
+        for g in gs:
+            r = g if r is None else r + g
+        return r
+
+
+def fanout4(x):
+    return _Fanout4.apply(x)
+
+
 class _Stem3dBnRelu(torch.autograd.Function):
     """relu(BatchNorm3d(conv3d_1a_7x7(x))) of the I3D stem in a bf16 trunk (code/dmcnet_I3D/network/i3d.py:480-481,
     :390-398): forward on dmc_stem3d_bf16_fwd (statistics in its epilogue) + the fused BatchNorm3d / ReLU pass; the

@@ -592,6 +592,10 @@ int dmc_bn3d_bf16_fwd(const void* y, const float* partials, int nblk, const floa
 int dmc_bn3d_bf16_fwd_ld(const void* y, const float* partials, int nblk, const float* gamma, const float* beta, float* stats,
                          float* running_mean, float* running_var, void* out, long out_ld, long M, int C, int relu, float eps,
                          float momentum, dmc_stream_t stream);
+/* out = ((a + b) + c) + d on bf16 arrays of n elements (n % 8 == 0, pointers 16-byte aligned), every sum rounded to bf16 (nearest
+ * even) -- bit for bit what three additions of bf16 tensors give: the gradient of an Inception block's input
+ * (network/i3d.py:449-454: four branches read x) in one pass instead of three. */
+int dmc_add4_bf16(const void* a, const void* b, const void* c, const void* d, void* out, long n, dmc_stream_t stream);
 int dmc_bn3d_bf16_bwd(const void* dout, long dout_ld, const void* y, const float* stats, const float* gamma, const float* beta,
                       float* scratch, void* dy, float* dgamma, float* dbeta, long M, int C, int relu, dmc_stream_t stream);
 

@@ -248,8 +248,9 @@ def test_conv_bn_relu3d_reads_a_concatenation_slice_gradient_in_place():
         assert not g.is_contiguous(memory_format=CL3)
         out.backward(g.clone().contiguous(memory_format=CL3) if dense else g)
         res.append((xi.grad.clone(), unit.conv3d.weight.grad.clone(), unit.batch3d.weight.grad.clone(), unit.batch3d.bias.grad.clone()))
-    for a, b in zip(*res):
-        assert torch.equal(a, b)
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("shape", [(2, 2, 8, 32, 24), (1, 2, 6, 10, 224), (1, 2, 5, 9, 250), (1, 2, 4, 10, 256)])
@@ -550,10 +551,12 @@ def test_inception_block_in_place_join_equals_concatenation(streams, monkeypatch
     """Mixed.forward with each branch's last unit writing its channels into the block's output (ops.conv_bn_relu3d(..., into=slice) +
     ops.join_slices) against the same block with torch.cat: output, the input's gradient, every parameter gradient and the BatchNorm
     running statistics BIT FOR BIT, on one stream and on branch streams; a second block behind it (its four data gradients are the
-    sums the first block's join receives)."""
+    sums the first block's join receives); and the same with those four gradients summed by one kernel (ops.fanout4 / dmc_add4_bf16)
+    instead of the engine's three additions."""
     res = []
-    for in_place in (False, True):
+    for in_place, fan in ((False, False), (True, False), (True, True)):
         monkeypatch.setattr(i3d, "JOIN_IN_PLACE", in_place)
+        monkeypatch.setattr(i3d, "FANOUT_ADD", fan)
         monkeypatch.setattr(i3d, "BRANCH_STREAMS", streams)
         torch.manual_seed(21)
         blocks = torch.nn.Sequential(i3d.Mixed(64, (32, 48, 64, 16, 24, 24)), i3d.Mixed(144, (48, 32, 40, 8, 16, 16))).to(DEV).train()
@@ -565,5 +568,6 @@ def test_inception_block_in_place_join_equals_concatenation(streams, monkeypatch
         y.backward(g)
         torch.cuda.synchronize()
         res.append([y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in blocks.parameters()] + [b.clone() for b in blocks.buffers()])
-    for a, b in zip(*res):
-        assert torch.equal(a, b)
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)
