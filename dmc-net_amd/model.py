@@ -224,7 +224,13 @@ class _DiscriminatorBase(nn.Module):
             x = F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding)
             x = ops.disc_tail(x.contiguous(), keep, bn, self.training)
             nhwc = False
-        # flatten in the reference's NCHW order (the Linear's weight is laid out for it)
+        # flatten in the reference's NCHW order (the Linear's weight is laid out for it).  An NHWC (channels_last) activation is
+        # NOT copied into that order: the weight's columns are permuted to (h, w, c) instead -- 50 k values against 4.7 M (GAN) /
+        # 9.6 M (I3D) per step each way; autograd carries the weight gradient back through the same permutation.
+        if x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last):
+            n, c, h, w = x.shape
+            wp = self.adv_layer.weight.view(-1, c, h, w).permute(0, 2, 3, 1).reshape(self.adv_layer.out_features, -1)
+            return F.linear(x.permute(0, 2, 3, 1).reshape(n, -1), wp, self.adv_layer.bias)
         return self.adv_layer(x.contiguous().reshape(x.shape[0], -1))
 
 
