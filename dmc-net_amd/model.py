@@ -211,11 +211,23 @@ class _DiscriminatorBase(nn.Module):
         otherwise (Discriminator4's 8-channel blocks, CPU tensors) the convolution goes to
         PyTorch-ROCm and the tail to ``ops.disc_tail``."""
         nhwc = False
+        # the Dropout2d keep masks of ALL blocks from one draw (same p everywhere, as the reference's blocks have): 4 launches for the
+        # pass instead of 4 per block -- they are ~5 us kernels in front of every block of every discriminator pass
+        keeps = None
+        drops = [getattr(self, nm)[2] for nm in self.block_names]
+        if self.training and self.forced_masks is None and all(d.p == drops[0].p for d in drops) and __import__("os").environ.get("DMC_DISC_ONE_DRAW", "1") != "0":
+            widths = [getattr(self, nm)[0].out_channels for nm in self.block_names]
+            n = x.shape[0]
+            allk = (torch.rand(n * sum(widths), device=x.device) >= drops[0].p).float() / (1.0 - drops[0].p)
+            keeps, c0 = {}, 0
+            for nm, wd in zip(self.block_names, widths):
+                keeps[nm] = allk[c0:c0 + n * wd].view(n, wd)       # (contiguous pieces of the one draw: no copies)
+                c0 += n * wd
         for i, name in enumerate(self.block_names):
             blk = getattr(self, name)
             conv, drop = blk[0], blk[2]
             bn = blk[3] if len(blk) == 4 else None
-            keep = self._keep(name, x, drop)
+            keep = keeps[name] if keeps is not None else self._keep(name, x, drop)
             first = i == 0 and not nhwc
             if ops.disc_block_supported(x, conv, first) and (bn is None or not first):
                 x = ops.disc_block(x, conv, keep, bn, self.training, first=first)
